@@ -1,0 +1,283 @@
+/*
+ * nyx_hip.h — C-ABI of the MI355X-native batched propagation path.
+ *
+ * This is the drop-in boundary for ONE hot path of nyx-space/nyx: the adaptive
+ * Runge-Kutta integration of the SpacecraftDynamics force-model stack, batched
+ * over many dispersed Spacecraft states.  The reference has no FFI for this path
+ * (Propagator<D> is a monomorphised generic), so the cut is made at the level at
+ * which the reference itself parallelises:
+ *
+ *   - `MonteCarlo::run_until_epoch` -> rayon `par_iter` over initial states
+ *         nyx-core/src/mc/montecarlo.rs:233-253
+ *   - Python `Propagator.many_for_duration(spacecraft, duration)`
+ *         nyx-py/src/py_md.rs:275-321
+ *   - one trajectory = `Propagator::with(state, almanac).for_duration(d)`
+ *         nyx-core/src/propagators/propagator.rs:88-108, instance.rs:87-282
+ *
+ * Everything in here is plain data: no C++ types, no torch types, no ownership
+ * transfer.  The caller allocates and frees every array; the library owns only
+ * the device memory held inside a `nyx_hip_ctx`.  Functions return 0 on success
+ * and never unwind across the ABI; per-trajectory failures are reported through
+ * the `status` array (the analogue of `Run.result: Result<_, PropagationError>`,
+ * nyx-core/src/mc/results.rs:48-59), index-stable.
+ *
+ * Units follow the reference: km, km/s, kg, m^2, seconds; epochs are integer
+ * nanoseconds (hifitime's Duration grain) counted in TDB past J2000.
+ */
+#ifndef NYX_HIP_H
+#define NYX_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NYX_HIP_ABI_VERSION 1
+
+/* ---- IntegratorMethod: nyx-core/src/propagators/rk_methods/mod.rs:65-79 ---- */
+enum nyx_hip_method {
+    NYX_HIP_RK89 = 0,     /* RungeKutta89 (default), rk.rs:91-251       */
+    NYX_HIP_DP78 = 1,     /* DormandPrince78, dormand.rs:73-184         */
+    NYX_HIP_DP45 = 2,     /* DormandPrince45, dormand.rs:24-66          */
+    NYX_HIP_RK4 = 3,      /* RungeKutta4, rk.rs:66-81                   */
+    NYX_HIP_CASHKARP45 = 4, /* CashKarp45, rk.rs:24-58                  */
+    NYX_HIP_VERNER56 = 5  /* Verner56, verner.rs:26-79                  */
+};
+
+/* ---- ErrorControl: nyx-core/src/propagators/error_ctrl.rs:30-76 ---- */
+enum nyx_hip_error_ctrl {
+    NYX_HIP_RSS_CARTESIAN_STATE = 0,
+    NYX_HIP_RSS_CARTESIAN_STEP = 1, /* default */
+    NYX_HIP_RSS_STATE = 2,
+    NYX_HIP_RSS_STEP = 3,
+    NYX_HIP_LARGEST_ERROR = 4,
+    NYX_HIP_LARGEST_STATE = 5,
+    NYX_HIP_LARGEST_STEP = 6
+};
+
+/* ---- per-trajectory status (replaces Result<_, PropagationError>) ---- */
+enum nyx_hip_status {
+    NYX_HIP_OK = 0,
+    NYX_HIP_ERR_NAN = 1,            /* PropMathError, instance.rs:432-439          */
+    NYX_HIP_ERR_MASSLESS = 2,       /* MasslessSpacecraft, dynamics/spacecraft.rs:201-203 */
+    NYX_HIP_ERR_FUEL_EXHAUSTED = 3, /* FuelExhausted, dynamics/spacecraft.rs:163-168 */
+    NYX_HIP_ERR_EPHEM_RANGE = 4,    /* almanac lookup outside the loaded segments   */
+    NYX_HIP_ERR_UNSUPPORTED = 5     /* model combination the device path refuses   */
+};
+
+/* ---- library-level return codes ---- */
+enum nyx_hip_rc {
+    NYX_HIP_RC_OK = 0,
+    NYX_HIP_RC_BAD_ARG = 1,
+    NYX_HIP_RC_NO_DEVICE = 2,
+    NYX_HIP_RC_HIP_ERROR = 3,
+    NYX_HIP_RC_UNSUPPORTED = 4
+};
+
+/* IntegratorOptions: nyx-core/src/propagators/options.rs:42-61 (defaults :172-186).
+ * Durations are integer nanoseconds, exactly what hifitime stores. */
+typedef struct nyx_hip_integ_opts {
+    int64_t init_step_ns; /* 60 s   */
+    int64_t min_step_ns;  /* 1 ms   */
+    int64_t max_step_ns;  /* 2700 s */
+    double tolerance;     /* 1e-12  */
+    int32_t attempts;     /* u8 in the reference; 50 */
+    int32_t fixed_step;   /* bool */
+    int32_t error_ctrl;   /* enum nyx_hip_error_ctrl */
+    int32_t method;       /* enum nyx_hip_method (PropagatorConfig.method, sequence/config.rs:138-143) */
+} nyx_hip_integ_opts_t;
+
+/* One SPK-type-2-style Chebyshev segment: position of `target` w.r.t. `center`
+ * (replaces what `almanac.transform` reads from the BSP; call sites
+ * dynamics/orbital.rs:230-234, dynamics/solarpressure.rs:138-143).
+ * Record r covers [init_et_s + r*interval_s, +interval_s); each record is
+ * [mid_et_s, radius_s, X[n_coeffs], Y[n_coeffs], Z[n_coeffs]]. */
+typedef struct nyx_hip_cheby_segment {
+    double init_et_s;
+    double interval_s;
+    int32_t n_records;
+    int32_t n_coeffs;
+    const double *records; /* n_records * (2 + 3*n_coeffs) doubles */
+} nyx_hip_cheby_segment_t;
+
+#define NYX_HIP_MAX_CHAIN 4
+#define NYX_HIP_MAX_BODIES 8
+#define NYX_HIP_MAX_SEGMENTS 16
+
+/* A celestial body as the path needs it: GM, mean equatorial radius (eclipse),
+ * and its position relative to the integration centre as a signed sum of
+ * segments (the ephemeris-tree walk ANISE does, flattened by the host). */
+typedef struct nyx_hip_body {
+    int32_t naif_id;
+    int32_t n_chain;                       /* 0 => the integration centre itself */
+    int32_t chain_segment[NYX_HIP_MAX_CHAIN];
+    int32_t chain_sign[NYX_HIP_MAX_CHAIN]; /* +1 / -1 */
+    double mu_km3_s2;
+    double mean_radius_km;
+} nyx_hip_body_t;
+
+/* IAU-style body-fixed orientation w.r.t. the inertial integration frame
+ * (replaces almanac.transform_to / almanac.rotate at gravity_field.rs:150-154,
+ * 258-265): alpha = ra[0] + ra[1]*T + ra[2]*T^2 (deg, T in Julian centuries TDB),
+ * delta likewise, W = w[0] + w[1]*d + w[2]*d^2 (deg, d in days TDB);
+ * DCM(inertial->fixed) = R3(W) R1(90deg - delta) R3(90deg + alpha). */
+typedef struct nyx_hip_rotation {
+    double ra_deg[3];
+    double dec_deg[3];
+    double w_deg[3];
+} nyx_hip_rotation_t;
+
+/* GravityFieldData + frame constants: io/gravity.rs:90-96, gravity_field.rs:195-207.
+ * c_nm/s_nm are fully-normalised, packed lower-triangular: idx(n,m)=n(n+1)/2+m,
+ * n = 0..degree.  mu/R_eq are the FRAME's values (Appendix A.9 of SURVEY.md). */
+typedef struct nyx_hip_gravity_field {
+    int32_t degree;
+    int32_t order;
+    double mu_km3_s2;
+    double eq_radius_km;
+    const double *c_nm;
+    const double *s_nm;
+    nyx_hip_rotation_t rotation;
+} nyx_hip_gravity_field_t;
+
+/* SolarPressure + ShadowModel: dynamics/solarpressure.rs:40-48, cosmic/eclipse.rs:34-37 */
+typedef struct nyx_hip_srp {
+    double phi_w_m2;         /* 1367.0 */
+    int32_t estimate;        /* d a / d Cr into STM column 6 (solarpressure.rs:131-133) */
+    int32_t sun_body;        /* index into bodies[] */
+    int32_t n_shadow_bodies;
+    int32_t shadow_body[NYX_HIP_MAX_BODIES]; /* indices into bodies[] */
+} nyx_hip_srp_t;
+
+/* AtmDensity / Drag: dynamics/drag.rs:39-45,115-123 */
+enum nyx_hip_density { NYX_HIP_RHO_CONSTANT = 0, NYX_HIP_RHO_EXPONENTIAL = 1, NYX_HIP_RHO_STDATM = 2 };
+typedef struct nyx_hip_drag {
+    int32_t density;      /* enum nyx_hip_density */
+    int32_t _pad;
+    double rho0;          /* Constant(rho) or Exponential.rho0 */
+    double r0;            /* Exponential.r0 (metres, sic) */
+    double ref_alt_m;     /* Exponential.ref_alt_m */
+    double max_alt_m;     /* StdAtm.max_alt_m */
+    double eq_radius_km;  /* drag frame mean equatorial radius */
+    nyx_hip_rotation_t rotation; /* drag frame (IAU Earth) */
+} nyx_hip_drag_t;
+
+/* PropagatorConfig{dynamics, method, options}: dynamics/sequence/config.rs:96-169.
+ * Model order is the reference's `Dynamics::build` order: two-body, point
+ * masses, gravity field; then SRP, drag. */
+typedef struct nyx_hip_config {
+    uint32_t abi_version; /* NYX_HIP_ABI_VERSION */
+    uint32_t flags;       /* NYX_HIP_FLAG_* */
+    nyx_hip_integ_opts_t opts;
+
+    double central_mu_km3_s2; /* osc.frame.mu_km3_s2(), orbital.rs:86-92 */
+
+    int32_t n_segments;
+    int32_t n_bodies;
+    const nyx_hip_cheby_segment_t *segments;
+    const nyx_hip_body_t *bodies;
+
+    /* PointMasses.celestial_objects (orbital.rs:176-182), as indices into bodies[] */
+    int32_t n_point_masses;
+    int32_t point_mass_body[NYX_HIP_MAX_BODIES];
+
+    const nyx_hip_gravity_field_t *gravity; /* NULL => none */
+    const nyx_hip_srp_t *srp;               /* NULL => none */
+    const nyx_hip_drag_t *drag;             /* NULL => none */
+
+    double speed_of_light_km_s; /* anise::constants::SPEED_OF_LIGHT_KM_S (cosmic/mod.rs:179-180) */
+} nyx_hip_config_t;
+
+/* flags */
+#define NYX_HIP_FLAG_STM 0x1u          /* states carry a 9x9 STM (Spacecraft.stm = Some) */
+#define NYX_HIP_FLAG_STM_TEXTBOOK 0x2u /* integrate dPhi/dt = A Phi instead of the reference's Phi_ctx*A (spacecraft.rs:214) */
+
+/* Spacecraft batch, structure-of-arrays (one array per field, length n).
+ * Mirrors Spacecraft::to_vector / set (cosmic/spacecraft.rs:451-497) plus the
+ * constants carried by the struct (Mass, SRPData, DragData). */
+typedef struct nyx_hip_states {
+    int64_t n;
+    int64_t *epoch_ns;  /* TDB ns past J2000 */
+    double *x_km, *y_km, *z_km;
+    double *vx_km_s, *vy_km_s, *vz_km_s;
+    double *cr;            /* srp.coeff_reflectivity  (vector[6]) */
+    double *cd;            /* drag.coeff_drag         (vector[7]) */
+    double *prop_mass_kg;  /* mass.prop_mass_kg       (vector[8]) */
+    double *dry_mass_kg;
+    double *extra_mass_kg;
+    double *srp_area_m2;
+    double *drag_area_m2;
+    double *stm;           /* NULL or n*81, per trajectory column-major 9x9 (vector[9..90]) */
+    int64_t *step_ns;      /* NULL, or in: PropInstance.step_size to resume with (0 => opts.init_step);
+                              out: step_size after the call (instance.rs:464-473) */
+} nyx_hip_states_t;
+
+/* IntegrationDetails of the last step (propagators/mod.rs:49-56) + counters. All arrays length n, any may be NULL. */
+typedef struct nyx_hip_step_stats {
+    int32_t *status;        /* enum nyx_hip_status */
+    int64_t *last_step_ns;  /* details.step */
+    double *last_error;     /* details.error */
+    int32_t *last_attempts; /* details.attempts */
+    int64_t *n_accepted;    /* accepted steps (incl. the final fixed step) */
+    int64_t *n_rejected;    /* rejected attempts */
+    int64_t *n_evals;       /* eom calls = stages * attempts */
+} nyx_hip_step_stats_t;
+
+typedef struct nyx_hip_ctx nyx_hip_ctx;
+
+/* Number of visible HIP devices (0 if none / no runtime). */
+int32_t nyx_hip_device_count(void);
+
+/* Builds an immutable propagation context on `device`: validates the config,
+ * precomputes the recursion tables (GravityField::new, gravity_field.rs:52-132)
+ * and uploads every shared table once.  `Propagator::new` + `Arc<Almanac>` analogue. */
+int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t device, nyx_hip_ctx **out);
+void nyx_hip_ctx_destroy(nyx_hip_ctx *ctx);
+
+/* Propagates every state of `in` for `duration_ns` (may be negative) — the batch
+ * form of `prop.with(state, almanac).for_duration(duration)`.  `in` and `out`
+ * are HOST SoA batches (out may alias in); H2D/D2H is done inside. */
+int32_t nyx_hip_propagate_batch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t duration_ns,
+                                nyx_hip_states_t *out, nyx_hip_step_stats_t *stats);
+
+/* Same, but every pointer in `in`/`out`/`stats` is a DEVICE pointer and the
+ * launch is enqueued on `hip_stream` (a hipStream_t, NULL = default stream);
+ * returns without synchronising.  This is the entry bench.py times with inputs
+ * resident in HBM. */
+int32_t nyx_hip_propagate_batch_device(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t duration_ns,
+                                       nyx_hip_states_t *out, nyx_hip_step_stats_t *stats, void *hip_stream);
+
+/* Per-trajectory epochs variant of until_epoch (instance.rs:279-282): duration_i = end_epoch_ns - epoch_i. */
+int32_t nyx_hip_propagate_until_epoch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t end_epoch_ns,
+                                      nyx_hip_states_t *out, nyx_hip_step_stats_t *stats);
+
+/* Tuning knob: number of waves that split the spherical-harmonics columns of one
+ * 64-trajectory workgroup (0 = pick automatically from n). */
+int32_t nyx_hip_ctx_set_column_waves(nyx_hip_ctx *ctx, int32_t waves);
+
+/* Elapsed device time (ms) of the kernels launched by the last propagate call on
+ * this ctx, measured with HIP events on the launch stream; <0 if unavailable. */
+double nyx_hip_last_kernel_ms(nyx_hip_ctx *ctx);
+
+/* Thread-local, NUL-terminated description of the last failure on this thread. */
+const char *nyx_hip_last_error(void);
+
+/* ---- host-side helpers that belong to the path (io/gravity.rs) ---- */
+
+/* Parses a GMAT .cof (optionally gzipped) the way GravityFieldData::from_cof does
+ * (io/gravity.rs:150-367).  On success c_nm and s_nm receive malloc'ed packed
+ * lower-triangular arrays of (degree+1)(degree+2)/2 doubles that the caller frees
+ * with nyx_hip_free; out_degree and out_order receive the max degree/order SEEN in the
+ * file within the request (from_cof keeps those, io/gravity.rs:330-366). */
+int32_t nyx_hip_load_cof(const char *path, int32_t degree, int32_t order, int32_t gunzipped,
+                         int32_t *out_degree, int32_t *out_order, double **c_nm, double **s_nm);
+/* SHADR flavour (io/gravity.rs:370-501). */
+int32_t nyx_hip_load_shadr(const char *path, int32_t degree, int32_t order, int32_t gunzipped,
+                           int32_t *out_degree, int32_t *out_order, double **c_nm, double **s_nm);
+void nyx_hip_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NYX_HIP_H */

@@ -1,0 +1,6 @@
+"""nyx_amd — MI355X-native batched propagation path behind the interface of nyx-space/nyx's
+Propagator / MonteCarlo.  The numeric path is the HIP library
+``nyx_amd/libnyx_hip.so`` (C-ABI in include/nyx_hip.h); importing this package does not load it,
+any compute call does and fails loudly if it is missing."""
+from . import _abi  # noqa: F401
+from .propagator import *  # noqa: F401,F403

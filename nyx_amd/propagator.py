@@ -1,0 +1,703 @@
+"""Host-side mirror of the reference's operator interface for the batched propagation path.
+
+Same names, argument meaning and error behaviour as the reference so that the parity tests
+read like the reference's own tests:
+
+* ``IntegratorOptions``     -> nyx-core/src/propagators/options.rs:42-186
+* ``IntegratorMethod``      -> propagators/rk_methods/mod.rs:65-79
+* ``ErrorControl``          -> propagators/error_ctrl.rs:30-76
+* ``PointMasses``           -> dynamics/orbital.rs:174-198
+* ``GravityFieldData``      -> io/gravity.rs:90-128, 514-516
+* ``SolarPressure``         -> dynamics/solarpressure.rs:40-128
+* ``Drag``                  -> dynamics/drag.rs:115-160
+* ``OrbitalDynamics`` / ``SpacecraftDynamics`` -> dynamics/orbital.rs:43-71, dynamics/spacecraft.rs:44-107
+* ``Propagator`` / ``PropInstance``            -> propagators/propagator.rs:34-121, instance.rs:62-352
+* ``Propagator.many_for_duration``             -> nyx-py/src/py_md.rs:275-321
+
+Everything numeric happens behind the C-ABI (include/nyx_hip.h) on the GPU.  There is no CPU
+fallback in this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import enum
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _abi
+
+NS_PER_S = 1_000_000_000
+SPEED_OF_LIGHT_KM_S = 299_792.458  # anise::constants::SPEED_OF_LIGHT_KM_S (reference cosmic/mod.rs:179-180)
+
+# NAIF ids (anise::constants::celestial_objects)
+SUN, MOON, EARTH, EARTH_MOON_BARYCENTER, JUPITER_BARYCENTER, SSB = 10, 301, 399, 3, 5, 0
+
+
+def seconds(x: float) -> int:
+    """``x * Unit::Second`` -> integer-ns ``Duration`` (hifitime: f64*1e9 then `as i64`)."""
+    t = float(x) * 1e9
+    if t != t:
+        return 0
+    return int(t)  # truncation toward zero
+
+
+def to_seconds(ns: int) -> float:
+    """``Duration::to_seconds``."""
+    ns = int(ns)
+    npc = 3155760000 * NS_PER_S
+    cent, rem = divmod(ns, npc)
+    whole, sub = divmod(rem, NS_PER_S)
+    if cent == 0:
+        return float(whole) + float(sub) * 1e-9
+    return float(cent) * 3155760000.0 + float(whole) + float(sub) * 1e-9
+
+
+class IntegratorMethod(enum.IntEnum):
+    RungeKutta89 = _abi.RK89
+    DormandPrince78 = _abi.DP78
+    DormandPrince45 = _abi.DP45
+    RungeKutta4 = _abi.RK4
+    CashKarp45 = _abi.CASHKARP45
+    Verner56 = _abi.VERNER56
+
+    @classmethod
+    def from_str(cls, s: str) -> "IntegratorMethod":
+        """rk_methods/mod.rs:135-164 (case-insensitive)."""
+        for m in cls:
+            if m.name.lower() == s.lower():
+                return m
+        raise ValueError(f"unknow integration method `{s}`, must be one of " + ",".join(m.name for m in cls))
+
+
+class ErrorControl(enum.IntEnum):
+    RSSCartesianState = _abi.RSS_CARTESIAN_STATE
+    RSSCartesianStep = _abi.RSS_CARTESIAN_STEP
+    RSSState = _abi.RSS_STATE
+    RSSStep = _abi.RSS_STEP
+    LargestError = _abi.LARGEST_ERROR
+    LargestState = _abi.LARGEST_STATE
+    LargestStep = _abi.LARGEST_STEP
+
+
+@dataclass
+class IntegratorOptions:
+    """options.rs:42-61; defaults are GMAT's (options.rs:172-186). Durations are integer ns."""
+
+    init_step: int = 60 * NS_PER_S
+    min_step: int = NS_PER_S // 1000
+    max_step: int = 2700 * NS_PER_S
+    tolerance: float = 1e-12
+    attempts: int = 50
+    fixed_step: bool = False
+    error_ctrl: ErrorControl = ErrorControl.RSSCartesianStep
+
+    @classmethod
+    def with_adaptive_step(cls, min_step: int, max_step: int, tolerance: float, error_ctrl: ErrorControl):
+        return cls(init_step=max_step, min_step=min_step, max_step=max_step, tolerance=tolerance, attempts=50,
+                   fixed_step=False, error_ctrl=error_ctrl)
+
+    @classmethod
+    def with_adaptive_step_s(cls, min_step: float, max_step: float, tolerance: float, error_ctrl: ErrorControl):
+        return cls.with_adaptive_step(seconds(min_step), seconds(max_step), tolerance, error_ctrl)
+
+    @classmethod
+    def with_fixed_step(cls, step: int):
+        return cls(init_step=step, min_step=step, max_step=step, tolerance=0.0, fixed_step=True, attempts=0,
+                   error_ctrl=ErrorControl.RSSCartesianStep)
+
+    @classmethod
+    def with_fixed_step_s(cls, step: float):
+        return cls.with_fixed_step(seconds(step))
+
+    @classmethod
+    def with_tolerance(cls, tolerance: float):
+        o = cls()
+        o.tolerance = tolerance
+        return o
+
+    @classmethod
+    def with_max_step(cls, max_step: int):
+        o = cls()
+        o.set_max_step(max_step)
+        return o
+
+    def set_max_step(self, max_step: int):
+        if self.init_step > max_step:
+            self.init_step = max_step
+        self.max_step = max_step
+
+    def set_min_step(self, min_step: int):
+        if self.init_step < min_step:
+            self.init_step = min_step
+        self.min_step = min_step
+
+
+# --------------------------------------------------------------------------------------------
+# "Almanac": the plain data the path needs from ANISE (ephemeris segments, body constants,
+# body-fixed orientation).  The host flattens ANISE's ephemeris tree into signed chains.
+# --------------------------------------------------------------------------------------------
+
+
+@dataclass
+class ChebySegment:
+    """SPK-type-2-style segment: records[r] = [mid, radius, X.., Y.., Z..]."""
+
+    init_et_s: float
+    interval_s: float
+    records: np.ndarray  # (n_records, 2 + 3*n_coeffs)
+
+    @property
+    def n_coeffs(self) -> int:
+        return (self.records.shape[1] - 2) // 3
+
+
+@dataclass
+class Rotation:
+    """IAU polynomial orientation (PCK): alpha/delta in deg + deg/century, W in deg + deg/day."""
+
+    ra_deg: Sequence[float] = (0.0, 0.0, 0.0)
+    dec_deg: Sequence[float] = (90.0, 0.0, 0.0)
+    w_deg: Sequence[float] = (0.0, 0.0, 0.0)
+
+
+# pck00008 Earth (IAU 2000): alpha0 = 0 - 0.641 T, delta0 = 90 - 0.557 T, W = 190.147 + 360.9856235 d
+IAU_EARTH_ROTATION = Rotation((0.0, -0.641, 0.0), (90.0, -0.557, 0.0), (190.147, 360.9856235, 0.0))
+# pck00008 Moon, polynomial part only (the trig series is out of scope of the descriptor for now)
+IAU_MOON_ROTATION_POLY = Rotation((269.9949, 0.0031, 0.0), (66.5392, 0.0130, 0.0), (38.3213, 13.17635815, -1.4e-12))
+
+
+@dataclass
+class Frame:
+    """What the path reads from an ANISE ``Frame``: mu, mean equatorial radius, orientation."""
+
+    naif_id: int
+    mu_km3_s2: float
+    mean_equatorial_radius_km: float = 0.0
+    rotation: Optional[Rotation] = None  # None => inertial (J2000 orientation)
+
+    def with_mu_km3_s2(self, mu: float) -> "Frame":
+        return Frame(self.naif_id, mu, self.mean_equatorial_radius_km, self.rotation)
+
+
+class Almanac:
+    """Container of segments and body constants (values of data/02_config/full_seq.dhall:150-182)."""
+
+    def __init__(self):
+        self.segments: List[ChebySegment] = []
+        self.bodies = {}  # naif_id -> dict(mu, radius, chain=[(seg_idx, sign)])
+
+    def add_segment(self, seg: ChebySegment) -> int:
+        self.segments.append(seg)
+        return len(self.segments) - 1
+
+    def add_body(self, naif_id: int, mu_km3_s2: float, mean_radius_km: float, chain):
+        self.bodies[naif_id] = dict(mu=mu_km3_s2, radius=mean_radius_km, chain=list(chain))
+
+    def frame_info(self, naif_id: int, rotation: Optional[Rotation] = None) -> Frame:
+        b = self.bodies[naif_id]
+        return Frame(naif_id, b["mu"], b["radius"], rotation)
+
+
+@dataclass
+class PointMasses:
+    celestial_objects: List[int]
+
+
+@dataclass
+class GravityFieldData:
+    """io/gravity.rs:90-96. ``c_nm``/``s_nm`` packed lower-triangular, idx = n(n+1)/2+m."""
+
+    degree: int
+    order: int
+    c_nm: np.ndarray
+    s_nm: np.ndarray
+    frame: Frame
+
+    @classmethod
+    def from_j2(cls, j2: float, frame: Frame) -> "GravityFieldData":
+        """io/gravity.rs:117-128 — stores the (normalised) C20 as given."""
+        c = np.zeros(6)
+        c[3] = j2
+        return cls(2, 0, c, np.zeros(6), frame)
+
+    @classmethod
+    def from_cof(cls, path: str, degree: int, order: int, gunzipped: bool, frame: Frame) -> "GravityFieldData":
+        return cls._load(path, degree, order, gunzipped, frame, "nyx_hip_load_cof")
+
+    @classmethod
+    def from_shadr(cls, path: str, degree: int, order: int, gunzipped: bool, frame: Frame) -> "GravityFieldData":
+        return cls._load(path, degree, order, gunzipped, frame, "nyx_hip_load_shadr")
+
+    @classmethod
+    def _load(cls, path, degree, order, gunzipped, frame, fn):
+        lib = _abi.load_library()
+        od, oo = C.c_int32(), C.c_int32()
+        pc, ps = _abi.c_double_p(), _abi.c_double_p()
+        rc = getattr(lib, fn)(str(path).encode(), degree, order, int(gunzipped), C.byref(od), C.byref(oo), C.byref(pc), C.byref(ps))
+        if rc != 0:
+            raise IOError(f"FileUnreadable: {_abi.last_error()}")
+        n = (degree + 1) * (degree + 2) // 2
+        c = np.ctypeslib.as_array(pc, shape=(n,)).copy()
+        s = np.ctypeslib.as_array(ps, shape=(n,)).copy()
+        lib.nyx_hip_free(pc)
+        lib.nyx_hip_free(ps)
+        # from_cof keeps the max degree/order seen (io/gravity.rs:330-366); arrays stay sized for `degree`
+        d = od.value
+        nn = (d + 1) * (d + 2) // 2
+        return cls(d, oo.value, c[:nn].copy(), s[:nn].copy(), frame)
+
+    @classmethod
+    def from_packed_file(cls, path: str, frame: Frame, degree: Optional[int] = None, order: Optional[int] = None):
+        """Loads the converted fixture written by tools/convert_cof.py (float64 little-endian:
+        [degree, order, C packed..., S packed...])."""
+        raw = np.fromfile(path, dtype="<f8")
+        d0, o0 = int(raw[0]), int(raw[1])
+        n0 = (d0 + 1) * (d0 + 2) // 2
+        c0, s0 = raw[2:2 + n0], raw[2 + n0:2 + 2 * n0]
+        d = d0 if degree is None else min(degree, d0)
+        o = o0 if order is None else min(order, o0, d)
+        n = (d + 1) * (d + 2) // 2
+        c, s = c0[:n].copy(), s0[:n].copy()
+        for nn in range(d + 1):  # entries with m > order are never stored by the loaders
+            for m in range(o + 1, nn + 1):
+                c[nn * (nn + 1) // 2 + m] = 0.0
+                s[nn * (nn + 1) // 2 + m] = 0.0
+        return cls(d, o, c, s, frame)
+
+
+@dataclass
+class SolarPressure:
+    """solarpressure.rs:40-128 (`estimate` defaults to True for default_flux/new, :88-93)."""
+
+    shadow_bodies: List[int]
+    phi: float = 1367.0
+    estimate: bool = True
+    light_source: int = SUN
+
+    @classmethod
+    def default_flux(cls, shadow_body: int):
+        return cls([shadow_body])
+
+    @classmethod
+    def default_no_estimation(cls, shadow_bodies: List[int]):
+        return cls(list(shadow_bodies), estimate=False)
+
+    @classmethod
+    def with_flux(cls, flux_w_m2: float, shadow_bodies: List[int]):
+        return cls(list(shadow_bodies), phi=flux_w_m2)
+
+
+@dataclass
+class Drag:
+    """drag.rs:115-160. density: ('constant', rho) | ('exponential', rho0, r0, ref_alt_m) | ('stdatm', max_alt_m)."""
+
+    density: tuple
+    frame: Frame
+    estimate: bool = False
+
+    @classmethod
+    def earth_exp(cls, iau_earth: Frame):
+        return cls(("exponential", 3.614e-13, 700_000.0, 88_667.0), iau_earth)
+
+    @classmethod
+    def std_atm1976(cls, iau_earth: Frame):
+        return cls(("stdatm", 1_000_000.0), iau_earth)
+
+
+@dataclass
+class OrbitalDynamics:
+    accel_models: list = field(default_factory=list)
+
+    @classmethod
+    def two_body(cls):
+        return cls([])
+
+    @classmethod
+    def point_masses(cls, celestial_objects: List[int]):
+        return cls([PointMasses(list(celestial_objects))])
+
+    @classmethod
+    def from_model(cls, model):
+        return cls([model])
+
+
+@dataclass
+class SpacecraftDynamics:
+    orbital_dyn: OrbitalDynamics
+    force_models: list = field(default_factory=list)
+
+    @classmethod
+    def new(cls, orbital_dyn: OrbitalDynamics):
+        return cls(orbital_dyn, [])
+
+    @classmethod
+    def from_model(cls, orbital_dyn: OrbitalDynamics, force_model):
+        return cls(orbital_dyn, [force_model])
+
+    @classmethod
+    def from_models(cls, orbital_dyn: OrbitalDynamics, force_models):
+        return cls(orbital_dyn, list(force_models))
+
+
+@dataclass
+class Spacecraft:
+    """cosmic/spacecraft.rs:115-143, the fields this path reads."""
+
+    epoch_ns: int
+    rv: Sequence[float]  # x,y,z km, vx,vy,vz km/s in `frame`
+    frame: Frame
+    dry_mass_kg: float = 0.0
+    prop_mass_kg: float = 0.0
+    extra_mass_kg: float = 0.0
+    srp_area_m2: float = 0.0
+    cr: float = 1.8  # SRPData default (cosmic/spacecraft.rs:210-217 from_srp_defaults)
+    drag_area_m2: float = 0.0
+    cd: float = 2.2
+    stm: Optional[np.ndarray] = None  # 9x9
+
+    def with_stm(self) -> "Spacecraft":
+        s = Spacecraft(**{**self.__dict__})
+        s.stm = np.eye(9)
+        return s
+
+
+class PropagationError(RuntimeError):
+    def __init__(self, status: int, index: int = 0):
+        self.status = status
+        self.index = index
+        super().__init__(f"run {index}: {_abi.STATUS_NAMES[status]}")
+
+
+class CompiledConfig:
+    """C descriptor + the numpy arrays it points into (kept alive here)."""
+
+    def __init__(self, cfg: _abi.Config, keep: list, central: Frame):
+        self.cfg = cfg
+        self._keep = keep
+        self.central = central
+
+
+def compile_config(dynamics: SpacecraftDynamics, method: IntegratorMethod, opts: IntegratorOptions, almanac: Almanac,
+                   central: Frame, stm: bool = False, stm_textbook: bool = False) -> CompiledConfig:
+    """Flattens (dynamics, method, options, almanac) into ``nyx_hip_config_t`` — the analogue of
+    ``PropagatorConfig::build`` (dynamics/sequence/config.rs:145-151) run in reverse."""
+    keep: list = []
+    cfg = _abi.Config()
+    cfg.abi_version = _abi.ABI_VERSION
+    cfg.flags = (_abi.FLAG_STM if stm else 0) | (_abi.FLAG_STM_TEXTBOOK if stm_textbook else 0)
+    o = cfg.opts
+    o.init_step_ns, o.min_step_ns, o.max_step_ns = int(opts.init_step), int(opts.min_step), int(opts.max_step)
+    o.tolerance, o.attempts, o.fixed_step = float(opts.tolerance), int(opts.attempts), int(bool(opts.fixed_step))
+    o.error_ctrl, o.method = int(opts.error_ctrl), int(method)
+    cfg.central_mu_km3_s2 = float(central.mu_km3_s2)
+    cfg.speed_of_light_km_s = SPEED_OF_LIGHT_KM_S
+
+    # segments
+    segs = (_abi.ChebySegment * max(1, len(almanac.segments)))()
+    for i, s in enumerate(almanac.segments):
+        rec = np.ascontiguousarray(s.records, dtype=np.float64)
+        keep.append(rec)
+        segs[i].init_et_s, segs[i].interval_s = float(s.init_et_s), float(s.interval_s)
+        segs[i].n_records, segs[i].n_coeffs = rec.shape[0], s.n_coeffs
+        segs[i].records = rec.ctypes.data_as(_abi.c_double_p)
+    keep.append(segs)
+    cfg.n_segments = len(almanac.segments)
+    cfg.segments = C.cast(segs, C.POINTER(_abi.ChebySegment))
+
+    # bodies actually used, central body first
+    body_index = {}
+    body_list = []
+
+    def body_of(naif_id: int) -> int:
+        if naif_id in body_index:
+            return body_index[naif_id]
+        if naif_id == central.naif_id:
+            b = dict(mu=central.mu_km3_s2, radius=central.mean_equatorial_radius_km, chain=[])
+        else:
+            if naif_id not in almanac.bodies:
+                raise KeyError(f"planetary data from third body not loaded: {naif_id}")
+            b = almanac.bodies[naif_id]
+        body_index[naif_id] = len(body_list)
+        body_list.append((naif_id, b))
+        return body_index[naif_id]
+
+    body_of(central.naif_id)
+    pm = [m for m in dynamics.orbital_dyn.accel_models if isinstance(m, PointMasses)]
+    gf = [m for m in dynamics.orbital_dyn.accel_models if isinstance(m, GravityFieldData)]
+    srp = [m for m in dynamics.force_models if isinstance(m, SolarPressure)]
+    drag = [m for m in dynamics.force_models if isinstance(m, Drag)]
+    if len(pm) > 1 or len(gf) > 1 or len(srp) > 1 or len(drag) > 1:
+        raise NotImplementedError("the device path takes at most one model of each kind")
+    known = len(pm) + len(gf)
+    if known != len(dynamics.orbital_dyn.accel_models) or len(srp) + len(drag) != len(dynamics.force_models):
+        raise NotImplementedError("unsupported model on the device path (guidance/solid tides fall back to the CPU reference)")
+
+    cfg.n_point_masses = 0
+    if pm:
+        objs = [c for c in pm[0].celestial_objects]
+        if len(objs) > _abi.MAX_BODIES:
+            raise ValueError("too many point masses")
+        for k, nid in enumerate(objs):
+            cfg.point_mass_body[k] = body_of(nid)
+        cfg.n_point_masses = len(objs)
+
+    if srp:
+        s = _abi.Srp()
+        s.phi_w_m2, s.estimate = float(srp[0].phi), int(bool(srp[0].estimate))
+        s.sun_body = body_of(srp[0].light_source)
+        s.n_shadow_bodies = len(srp[0].shadow_bodies)
+        for k, nid in enumerate(srp[0].shadow_bodies):
+            s.shadow_body[k] = body_of(nid)
+        keep.append(s)
+        cfg.srp = C.pointer(s)
+
+    def fill_rot(dst, rot: Optional[Rotation]):
+        rot = rot or Rotation()
+        for k in range(3):
+            dst.ra_deg[k], dst.dec_deg[k], dst.w_deg[k] = float(rot.ra_deg[k]), float(rot.dec_deg[k]), float(rot.w_deg[k])
+
+    if gf:
+        g = gf[0]
+        if g.frame.naif_id != central.naif_id:
+            raise NotImplementedError("gravity field of a non-central body is not on the device path")
+        gs = _abi.GravityField()
+        gs.degree, gs.order = int(g.degree), int(g.order)
+        gs.mu_km3_s2, gs.eq_radius_km = float(g.frame.mu_km3_s2), float(g.frame.mean_equatorial_radius_km)
+        cn = np.ascontiguousarray(g.c_nm, dtype=np.float64)
+        sn = np.ascontiguousarray(g.s_nm, dtype=np.float64)
+        need = (g.degree + 1) * (g.degree + 2) // 2
+        assert cn.size >= need and sn.size >= need
+        keep += [cn, sn]
+        gs.c_nm, gs.s_nm = cn.ctypes.data_as(_abi.c_double_p), sn.ctypes.data_as(_abi.c_double_p)
+        fill_rot(gs.rotation, g.frame.rotation)
+        keep.append(gs)
+        cfg.gravity = C.pointer(gs)
+
+    if drag:
+        d = drag[0]
+        ds = _abi.Drag()
+        kind = d.density[0]
+        if kind == "constant":
+            ds.density, ds.rho0 = _abi.RHO_CONSTANT, float(d.density[1])
+        elif kind == "exponential":
+            ds.density = _abi.RHO_EXPONENTIAL
+            ds.rho0, ds.r0, ds.ref_alt_m = (float(x) for x in d.density[1:4])
+        elif kind == "stdatm":
+            ds.density, ds.max_alt_m = _abi.RHO_STDATM, float(d.density[1])
+        else:
+            raise ValueError(kind)
+        ds.eq_radius_km = float(d.frame.mean_equatorial_radius_km)
+        fill_rot(ds.rotation, d.frame.rotation)
+        keep.append(ds)
+        cfg.drag = C.pointer(ds)
+
+    if len(body_list) > _abi.MAX_BODIES:
+        raise ValueError("too many bodies")
+    bodies = (_abi.Body * len(body_list))()
+    for i, (nid, b) in enumerate(body_list):
+        bodies[i].naif_id = nid
+        bodies[i].mu_km3_s2 = float(b["mu"])
+        bodies[i].mean_radius_km = float(b["radius"])
+        ch = b["chain"]
+        if len(ch) > _abi.MAX_CHAIN:
+            raise ValueError("ephemeris chain too long")
+        bodies[i].n_chain = len(ch)
+        for k, (si, sg) in enumerate(ch):
+            bodies[i].chain_segment[k], bodies[i].chain_sign[k] = int(si), int(sg)
+    keep.append(bodies)
+    cfg.n_bodies = len(body_list)
+    cfg.bodies = C.cast(bodies, C.POINTER(_abi.Body))
+    return CompiledConfig(cfg, keep, central)
+
+
+def pack_spacecraft(states: Sequence[Spacecraft], with_stm: bool) -> _abi.StateBatch:
+    b = _abi.StateBatch(len(states), with_stm)
+    for i, s in enumerate(states):
+        b.epoch_ns[i] = int(s.epoch_ns)
+        rv = np.asarray(s.rv, dtype=np.float64)
+        b.x_km[i], b.y_km[i], b.z_km[i], b.vx_km_s[i], b.vy_km_s[i], b.vz_km_s[i] = rv
+        b.cr[i], b.cd[i] = s.cr, s.cd
+        b.prop_mass_kg[i], b.dry_mass_kg[i], b.extra_mass_kg[i] = s.prop_mass_kg, s.dry_mass_kg, s.extra_mass_kg
+        b.srp_area_m2[i], b.drag_area_m2[i] = s.srp_area_m2, s.drag_area_m2
+        if with_stm:
+            m = np.eye(9) if s.stm is None else np.asarray(s.stm, dtype=np.float64)
+            b.stm[i] = m.reshape(9, 9).T.reshape(-1)  # column-major (cosmic/spacecraft.rs:467-471)
+    return b
+
+
+def unpack_spacecraft(batch: _abi.StateBatch, template: Sequence[Spacecraft]) -> List[Spacecraft]:
+    out = []
+    rv = batch.rv()
+    for i, t in enumerate(template):
+        s = Spacecraft(**{**t.__dict__})
+        s.epoch_ns = int(batch.epoch_ns[i])
+        s.rv = rv[i].copy()
+        s.cr, s.cd, s.prop_mass_kg = float(batch.cr[i]), float(batch.cd[i]), float(batch.prop_mass_kg[i])
+        if batch.stm is not None:
+            s.stm = batch.stm[i].reshape(9, 9).T.copy()
+        out.append(s)
+    return out
+
+
+class GpuContext:
+    """RAII wrapper of ``nyx_hip_ctx`` (immutable after creation => shareable like `Arc<Propagator>`)."""
+
+    def __init__(self, compiled: CompiledConfig, device: int = 0):
+        self._lib = _abi.load_library()
+        self.compiled = compiled
+        h = C.c_void_p()
+        rc = self._lib.nyx_hip_ctx_create(C.byref(compiled.cfg), device, C.byref(h))
+        if rc != 0:
+            raise RuntimeError(f"nyx_hip_ctx_create failed (rc={rc}): {_abi.last_error()}")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.nyx_hip_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_column_waves(self, waves: int):
+        self._lib.nyx_hip_ctx_set_column_waves(self._h, int(waves))
+
+    def last_kernel_ms(self) -> float:
+        return float(self._lib.nyx_hip_last_kernel_ms(self._h))
+
+    def propagate(self, batch: _abi.StateBatch, duration_ns: int, out: Optional[_abi.StateBatch] = None):
+        out = out if out is not None else batch.copy()
+        stats = _abi.StatsBatch(batch.n)
+        cin, cout, cst = batch.as_c(), out.as_c(), stats.as_c()
+        rc = self._lib.nyx_hip_propagate_batch(self._h, C.byref(cin), int(duration_ns), C.byref(cout), C.byref(cst))
+        if rc != 0:
+            raise RuntimeError(f"nyx_hip_propagate_batch failed (rc={rc}): {_abi.last_error()}")
+        return out, stats
+
+    def propagate_until_epoch(self, batch: _abi.StateBatch, end_epoch_ns: int, out: Optional[_abi.StateBatch] = None):
+        out = out if out is not None else batch.copy()
+        stats = _abi.StatsBatch(batch.n)
+        cin, cout, cst = batch.as_c(), out.as_c(), stats.as_c()
+        rc = self._lib.nyx_hip_propagate_until_epoch(self._h, C.byref(cin), int(end_epoch_ns), C.byref(cout), C.byref(cst))
+        if rc != 0:
+            raise RuntimeError(f"nyx_hip_propagate_until_epoch failed (rc={rc}): {_abi.last_error()}")
+        return out, stats
+
+
+class PropInstance:
+    """instance.rs:62-352 for one state, executed as a batch of one on the device."""
+
+    def __init__(self, prop: "Propagator", state: Spacecraft, almanac: Almanac):
+        self.prop = prop
+        self.state = state
+        self.almanac = almanac
+        self.step_size = prop.opts.init_step  # propagator.rs:105
+        self.details = dict(step=prop.opts.init_step, error=0.0, attempts=1)
+        self._ctx = prop._context(almanac, state.frame, state.stm is not None)
+
+    def quiet(self):
+        return self
+
+    def for_duration(self, duration_ns: int) -> Spacecraft:
+        batch = pack_spacecraft([self.state], self.state.stm is not None)
+        batch.step_ns[0] = self.step_size
+        out, st = self._ctx.propagate(batch, int(duration_ns))
+        if st.status[0] != _abi.OK:
+            raise PropagationError(int(st.status[0]))
+        self.step_size = int(out.step_ns[0])
+        self.details = dict(step=int(st.last_step_ns[0]), error=float(st.last_error[0]), attempts=int(st.last_attempts[0]))
+        self.state = unpack_spacecraft(out, [self.state])[0]
+        return self.state
+
+    def until_epoch(self, end_epoch_ns: int) -> Spacecraft:
+        return self.for_duration(int(end_epoch_ns) - int(self.state.epoch_ns))
+
+    def latest_details(self):
+        return dict(self.details)
+
+
+class Propagator:
+    """propagator.rs:34-121."""
+
+    def __init__(self, dynamics: SpacecraftDynamics, method: IntegratorMethod, opts: IntegratorOptions, device: int = 0):
+        self.dynamics, self.method, self.opts, self.device = dynamics, method, opts, device
+        self._ctx_cache = {}
+
+    new = classmethod(lambda cls, dynamics, method, opts: cls(dynamics, method, opts))
+
+    @classmethod
+    def rk89(cls, dynamics, opts):
+        return cls(dynamics, IntegratorMethod.RungeKutta89, opts)
+
+    @classmethod
+    def dp78(cls, dynamics, opts):
+        return cls(dynamics, IntegratorMethod.DormandPrince78, opts)
+
+    @classmethod
+    def default(cls, dynamics):
+        return cls.rk89(dynamics, IntegratorOptions())
+
+    @classmethod
+    def default_dp78(cls, dynamics):
+        return cls.dp78(dynamics, IntegratorOptions())
+
+    def set_tolerance(self, tol: float):
+        self.opts.tolerance = tol
+        self._ctx_cache.clear()
+
+    def set_max_step(self, step: int):
+        self.opts.set_max_step(step)
+        self._ctx_cache.clear()
+
+    def set_min_step(self, step: int):
+        self.opts.set_min_step(step)
+        self._ctx_cache.clear()
+
+    def compile(self, almanac: Almanac, central: Frame, stm: bool = False) -> CompiledConfig:
+        return compile_config(self.dynamics, self.method, self.opts, almanac, central, stm=stm)
+
+    def _context(self, almanac: Almanac, central: Frame, stm: bool) -> GpuContext:
+        key = (id(almanac), central.naif_id, central.mu_km3_s2, stm)
+        if key not in self._ctx_cache:
+            self._ctx_cache[key] = GpuContext(self.compile(almanac, central, stm), self.device)
+        return self._ctx_cache[key]
+
+    def with_(self, state: Spacecraft, almanac: Almanac) -> PropInstance:
+        """``Propagator::with`` (propagator.rs:88-108)."""
+        return PropInstance(self, state, almanac)
+
+    def many_for_duration(self, spacecraft: Sequence[Spacecraft], almanac: Almanac, duration_ns: int, drop_failed: bool = True):
+        """``Propagator.many_for_duration`` (nyx-py/src/py_md.rs:275-321): like the reference, failed runs
+        are dropped (py_md.rs:312-315) unless ``drop_failed=False`` in which case a PropagationError is put in place."""
+        if len(spacecraft) == 0:
+            return []
+        stm = spacecraft[0].stm is not None
+        ctx = self._context(almanac, spacecraft[0].frame, stm)
+        batch = pack_spacecraft(spacecraft, stm)
+        out, st = ctx.propagate(batch, int(duration_ns))
+        res = unpack_spacecraft(out, spacecraft)
+        outl = []
+        for i, s in enumerate(res):
+            if st.status[i] == _abi.OK:
+                outl.append(s)
+            elif not drop_failed:
+                outl.append(PropagationError(int(st.status[i]), i))
+        return outl
+
+    def many_until_epoch(self, spacecraft: Sequence[Spacecraft], almanac: Almanac, end_epoch_ns: int, drop_failed: bool = True):
+        """py_md.rs:225-273."""
+        if len(spacecraft) == 0:
+            return []
+        stm = spacecraft[0].stm is not None
+        ctx = self._context(almanac, spacecraft[0].frame, stm)
+        batch = pack_spacecraft(spacecraft, stm)
+        out, st = ctx.propagate_until_epoch(batch, int(end_epoch_ns))
+        res = unpack_spacecraft(out, spacecraft)
+        return [s if st.status[i] == _abi.OK else PropagationError(int(st.status[i]), i)
+                for i, s in enumerate(res) if st.status[i] == _abi.OK or not drop_failed]

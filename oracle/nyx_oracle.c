@@ -1,0 +1,1123 @@
+/*
+ * ORACLE — TEST INFRASTRUCTURE ONLY (see nyx_oracle.h).  Build with
+ *   gcc -O2 -ffp-contract=off -fno-fast-math
+ * so that no FMA contraction changes the operation order of the reference.
+ *
+ * Every function cites the reference lines (under /root/reference/nyx-core/src)
+ * it restates.  Nothing here is copied: the reference is Rust over nalgebra /
+ * anise / hifitime; this is scalar C over plain arrays.
+ */
+#define _GNU_SOURCE
+#include "nyx_oracle.h"
+#include "rk_tableaux.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdatomic.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NV_MAX 90
+#define MAX_STAGES 16
+
+/* ------------------------------------------------------------------------- */
+/* hifitime 4.3 (absent crate) — restated                                     */
+/* ------------------------------------------------------------------------- */
+
+static int g_ns_rounding = 0;
+void nyx_oracle_set_ns_rounding(int32_t mode) { g_ns_rounding = mode; }
+
+/* `f64 * Unit::Second -> Duration`: total_ns = q * 1e9, then `as i64`
+ * (saturating truncation toward zero).  Call sites: instance.rs:447,464;
+ * cosmic/mod.rs:102 (Epoch + f64). */
+int64_t nyx_oracle_seconds_to_ns(double s) {
+    double total = s * 1e9;
+    if (total != total) return 0; /* NaN as i64 == 0 in Rust */
+    if (g_ns_rounding == 1) total = round(total);
+    if (total >= 9.2233720368547758e18) return INT64_MAX;
+    if (total <= -9.2233720368547758e18) return INT64_MIN;
+    return (int64_t)total;
+}
+
+/* `Duration::to_seconds()`: hifitime keeps (centuries: i16, nanoseconds: u64) with
+ * nanoseconds always positive; seconds = whole + sub*1e-9, plus centuries*SPC. */
+double nyx_oracle_ns_to_seconds(int64_t ns) {
+    const int64_t NS_PER_CENTURY = 3155760000000000000LL;
+    const double S_PER_CENTURY = 3155760000.0;
+    int64_t centuries = 0;
+    int64_t rem = ns;
+    if (ns < 0) {
+        /* euclidean split so that rem >= 0 */
+        centuries = -((-ns + NS_PER_CENTURY - 1) / NS_PER_CENTURY);
+        rem = ns - centuries * NS_PER_CENTURY;
+    } else if (ns >= NS_PER_CENTURY) {
+        centuries = ns / NS_PER_CENTURY;
+        rem = ns - centuries * NS_PER_CENTURY;
+    }
+    int64_t whole = rem / 1000000000LL;
+    int64_t sub = rem % 1000000000LL;
+    if (centuries == 0) return (double)whole + (double)sub * 1e-9;
+    return (double)centuries * S_PER_CENTURY + (double)whole + (double)sub * 1e-9;
+}
+
+/* f64::powi as LLVM expands it (binary method, LSB first): x^3 = x*(x*x), x^6 = x^2*x^4. */
+static double powi_(double x, int n) {
+    double res = 1.0;
+    int have = 0;
+    double sq = x;
+    int v = n < 0 ? -n : n;
+    while (v) {
+        if (v & 1) {
+            res = have ? res * sq : sq;
+            have = 1;
+        }
+        sq = sq * sq;
+        v >>= 1;
+    }
+    if (!have) res = 1.0;
+    return n < 0 ? 1.0 / res : res;
+}
+
+static double norm3(const double *v) { return sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); }
+
+/* ------------------------------------------------------------------------- */
+/* anise 0.10 (absent crate) — restated from published definitions             */
+/* ------------------------------------------------------------------------- */
+
+/* SPK type 2 (Chebyshev position) evaluation with the Clenshaw recurrence, as in
+ * NAIF CHBINT.  Replaces what almanac.transform() reads (orbital.rs:230-234). */
+static int cheby_eval(const nyx_hip_cheby_segment_t *seg, double et_s, double *r3) {
+    double rel = (et_s - seg->init_et_s) / seg->interval_s;
+    long idx = (long)floor(rel);
+    if (idx < 0 || idx > seg->n_records) return NYX_HIP_ERR_EPHEM_RANGE;
+    if (idx == seg->n_records) {
+        if (et_s > seg->init_et_s + seg->interval_s * (double)seg->n_records) return NYX_HIP_ERR_EPHEM_RANGE;
+        idx = seg->n_records - 1; /* exactly the end of coverage */
+    }
+    const int nc = seg->n_coeffs;
+    const double *rec = seg->records + (size_t)idx * (size_t)(2 + 3 * nc);
+    const double t = (et_s - rec[0]) / rec[1];
+    const double two_t = 2.0 * t;
+    for (int c = 0; c < 3; ++c) {
+        const double *cf = rec + 2 + c * nc;
+        double w0 = 0.0, w1 = 0.0, w2;
+        for (int j = nc - 1; j >= 1; --j) {
+            w2 = w1;
+            w1 = w0;
+            w0 = cf[j] + (two_t * w1 - w2);
+        }
+        r3[c] = cf[0] + (t * w0 - w1);
+    }
+    return NYX_HIP_OK;
+}
+
+/* Position of bodies[b] w.r.t. the integration centre = signed sum over its chain. */
+static int body_position(const nyx_hip_config_t *cfg, int b, double et_s, double *r3) {
+    const nyx_hip_body_t *body = &cfg->bodies[b];
+    r3[0] = r3[1] = r3[2] = 0.0;
+    for (int k = 0; k < body->n_chain; ++k) {
+        double p[3];
+        int st = cheby_eval(&cfg->segments[body->chain_segment[k]], et_s, p);
+        if (st) return st;
+        double sg = (double)body->chain_sign[k];
+        for (int c = 0; c < 3; ++c) r3[c] = r3[c] + sg * p[c];
+    }
+    return NYX_HIP_OK;
+}
+
+void nyx_oracle_body_position(const nyx_hip_config_t *cfg, int32_t body, int64_t epoch_ns, double *r3, int32_t *status) {
+    int st = body_position(cfg, body, nyx_oracle_ns_to_seconds(epoch_ns), r3);
+    if (status) *status = st;
+}
+
+/* IAU orientation: DCM(inertial -> body-fixed) = R3(W) R1(pi/2 - dec) R3(pi/2 + ra),
+ * angles from PCK-style polynomials (T centuries / d days past J2000 TDB).
+ * Replaces almanac.transform_to / almanac.rotate at gravity_field.rs:150-154,258-265. */
+static void rotation_dcm(const nyx_hip_rotation_t *rot, double et_s, double m[3][3]) {
+    const double DEG = M_PI / 180.0;
+    const double d = et_s / 86400.0;
+    const double T = et_s / (86400.0 * 36525.0);
+    const double ra = (rot->ra_deg[0] + rot->ra_deg[1] * T + rot->ra_deg[2] * T * T) * DEG;
+    const double dec = (rot->dec_deg[0] + rot->dec_deg[1] * T + rot->dec_deg[2] * T * T) * DEG;
+    const double w = (rot->w_deg[0] + rot->w_deg[1] * d + rot->w_deg[2] * d * d) * DEG;
+    const double a1 = M_PI_2 + ra, a2 = M_PI_2 - dec, a3 = w;
+    const double c1 = cos(a1), s1 = sin(a1);
+    const double c2 = cos(a2), s2 = sin(a2);
+    const double c3 = cos(a3), s3 = sin(a3);
+    /* R3(a3) * R1(a2) * R3(a1), multiplied out */
+    m[0][0] = c3 * c1 - s3 * c2 * s1;
+    m[0][1] = c3 * s1 + s3 * c2 * c1;
+    m[0][2] = s3 * s2;
+    m[1][0] = -s3 * c1 - c3 * c2 * s1;
+    m[1][1] = -s3 * s1 + c3 * c2 * c1;
+    m[1][2] = c3 * s2;
+    m[2][0] = s2 * s1;
+    m[2][1] = -s2 * c1;
+    m[2][2] = c2;
+}
+
+void nyx_oracle_rotation_dcm(const nyx_hip_rotation_t *rot, int64_t epoch_ns, double *dcm9) {
+    double m[3][3];
+    rotation_dcm(rot, nyx_oracle_ns_to_seconds(epoch_ns), m);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) dcm9[3 * i + j] = m[i][j];
+}
+
+/* Area of a circular segment of radius r cut at distance d from the centre. */
+static double circ_seg_area(double r, double d) { return r * r * acos(d / r) - d * sqrt(r * r - d * d); }
+
+/* anise Almanac::solar_eclipsing -> Occultation.factor(): fraction (0..1) of the
+ * solar disk hidden by `front` as seen from the spacecraft; apparent-disk overlap.
+ * r_eb = observer w.r.t. eclipsing body, r_ls = Sun w.r.t. observer. */
+static double occultation_pct(double r_back_km, double r_front_km, const double *r_eb, const double *r_ls) {
+    const double n_ls = norm3(r_ls), n_eb = norm3(r_eb);
+    const double ls_p = (r_back_km >= n_ls) ? r_back_km : asin(r_back_km / n_ls);
+    const double fo_p = (r_front_km >= n_eb) ? r_front_km : asin(r_front_km / n_eb);
+    const double dot = r_ls[0] * r_eb[0] + r_ls[1] * r_eb[1] + r_ls[2] * r_eb[2];
+    const double d_p = acos(-dot / (n_eb * n_ls));
+    double pct;
+    if (d_p - ls_p > fo_p) {
+        pct = 0.0; /* Sun fully visible */
+    } else if (fo_p > d_p + ls_p) {
+        pct = 100.0; /* umbra */
+    } else if (fabs(ls_p - fo_p) < d_p && d_p < ls_p + fo_p) {
+        /* penumbra: asymmetric lens of two overlapping disks */
+        const double d1 = (d_p * d_p - ls_p * ls_p + fo_p * fo_p) / (2.0 * d_p);
+        const double d2 = (d_p * d_p + ls_p * ls_p - fo_p * fo_p) / (2.0 * d_p);
+        const double shadow = circ_seg_area(fo_p, d1) + circ_seg_area(ls_p, d2);
+        if (shadow != shadow) {
+            pct = 100.0;
+        } else {
+            const double nominal = M_PI * (ls_p * ls_p);
+            pct = 100.0 * shadow / nominal;
+        }
+    } else {
+        pct = 100.0 * (fo_p * fo_p) / (ls_p * ls_p); /* annular */
+    }
+    return pct; /* Occultation.percentage; .factor() = percentage / 100 */
+}
+
+/* ------------------------------------------------------------------------- */
+/* Prepared (per-config) tables: GravityField::new, gravity_field.rs:52-132    */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+    int deg, ord, ld; /* ld = deg+3: leading dimension of a_nm (column-major like DMatrix) */
+    int ld2;          /* deg+2: leading dimension of b,c,vr01,vr11 */
+    double *a_diag_tmpl; /* a_nm template with diagonal set, ld*ld */
+    double *b, *c, *vr01, *vr11;
+    double *cfull, *sfull; /* (deg+1)^2 column-major copies of C,S */
+} grav_tables_t;
+
+static void grav_tables_free(grav_tables_t *t) {
+    free(t->a_diag_tmpl); free(t->b); free(t->c); free(t->vr01); free(t->vr11); free(t->cfull); free(t->sfull);
+    memset(t, 0, sizeof *t);
+}
+
+static void grav_tables_build(const nyx_hip_gravity_field_t *g, grav_tables_t *t) {
+    const int np2 = g->degree + 2;
+    t->deg = g->degree; t->ord = g->order; t->ld = np2 + 1; t->ld2 = np2;
+    t->a_diag_tmpl = calloc((size_t)t->ld * t->ld, sizeof(double));
+    t->b = calloc((size_t)np2 * np2, sizeof(double));
+    t->c = calloc((size_t)np2 * np2, sizeof(double));
+    t->vr01 = calloc((size_t)np2 * np2, sizeof(double));
+    t->vr11 = calloc((size_t)np2 * np2, sizeof(double));
+#define A_(n, m) t->a_diag_tmpl[(n) + (size_t)(m) * t->ld]
+    A_(0, 0) = 1.0;
+    for (int n = 1; n <= np2; ++n) { /* :61-66 */
+        double nf = (double)n;
+        A_(n, n) = sqrt(1.0 + 1.0 / (2.0 * nf)) * A_(n - 1, n - 1);
+    }
+#undef A_
+    for (int n = 0; n < np2; ++n) { /* :69-92 */
+        for (int m = 0; m < np2; ++m) {
+            double nf = (double)n, mf = (double)m;
+            size_t i = (size_t)n + (size_t)m * np2;
+            t->c[i] = sqrt(((2.0 * nf + 1.0) * (nf + mf - 1.0) * (nf - mf - 1.0)) / ((nf - mf) * (nf + mf) * (2.0 * nf - 3.0)));
+            t->b[i] = sqrt(((2.0 * nf + 1.0) * (2.0 * nf - 1.0)) / ((nf + mf) * (nf - mf)));
+            t->vr01[i] = sqrt((nf - mf) * (nf + mf + 1.0));
+            t->vr11[i] = sqrt(((2.0 * nf + 1.0) * (nf + mf + 2.0) * (nf + mf + 1.0)) / (2.0 * nf + 3.0));
+            if (m == 0) {
+                t->vr01[i] /= sqrt(2.0);
+                t->vr11[i] /= sqrt(2.0);
+            }
+        }
+    }
+    const int n1 = g->degree + 1;
+    t->cfull = calloc((size_t)n1 * n1, sizeof(double));
+    t->sfull = calloc((size_t)n1 * n1, sizeof(double));
+    for (int n = 0; n <= g->degree; ++n)
+        for (int m = 0; m <= n; ++m) {
+            t->cfull[n + (size_t)m * n1] = g->c_nm[(size_t)n * (n + 1) / 2 + m];
+            t->sfull[n + (size_t)m * n1] = g->s_nm[(size_t)n * (n + 1) / 2 + m];
+        }
+}
+
+typedef struct {
+    const nyx_hip_config_t *cfg;
+    grav_tables_t gt;
+    int has_grav;
+} prepared_t;
+
+static void prepared_init(prepared_t *p, const nyx_hip_config_t *cfg) {
+    memset(p, 0, sizeof *p);
+    p->cfg = cfg;
+    if (cfg->gravity) {
+        grav_tables_build(cfg->gravity, &p->gt);
+        p->has_grav = 1;
+    }
+}
+static void prepared_free(prepared_t *p) {
+    if (p->has_grav) grav_tables_free(&p->gt);
+}
+
+/* ------------------------------------------------------------------------- */
+/* GravityField::eom, gravity_field.rs:148-268                                 */
+/* ------------------------------------------------------------------------- */
+
+static void gravity_eom(const nyx_hip_gravity_field_t *g, const grav_tables_t *t, double et_s, const double *r_in,
+                        double *acc, double *a_work, double *rm_work, double *im_work) {
+    double dcm[3][3];
+    rotation_dcm(&g->rotation, et_s, dcm);
+    /* almanac.transform_to(osc, frame): same centre, rotate the position (:150-154) */
+    double rb[3];
+    for (int i = 0; i < 3; ++i) rb[i] = dcm[i][0] * r_in[0] + dcm[i][1] * r_in[1] + dcm[i][2] * r_in[2];
+
+    const double r_ = norm3(rb);
+    const double s_ = rb[0] / r_, t_ = rb[1] / r_, u_ = rb[2] / r_;
+    const int N = t->deg, M = t->ord, ld = t->ld, ld2 = t->ld2;
+    double *a = a_work;
+    memcpy(a, t->a_diag_tmpl, sizeof(double) * (size_t)ld * ld); /* `self.a_nm.clone()` :165 */
+#define A_(n, m) a[(n) + (size_t)(m) * ld]
+#define T2(tab, n, m) t->tab[(n) + (size_t)(m) * ld2]
+    A_(1, 0) = u_ * sqrt(3.0);
+    for (int n = 1; n <= N + 1; ++n) {
+        double nf = (double)n;
+        A_(n + 1, n) = sqrt(2.0 * nf + 3.0) * u_ * A_(n, n);
+    }
+    for (int m = 0; m <= M + 1; ++m)
+        for (int n = m + 2; n <= N + 1; ++n) A_(n, m) = u_ * T2(b, n, m) * A_(n - 1, m) - T2(c, n, m) * A_(n - 2, m);
+
+    const int mm = N < M ? N : M;
+    rm_work[0] = 1.0;
+    im_work[0] = 0.0;
+    for (int m = 1; m <= mm; ++m) {
+        rm_work[m] = s_ * rm_work[m - 1] - t_ * im_work[m - 1];
+        im_work[m] = s_ * im_work[m - 1] + t_ * rm_work[m - 1];
+    }
+    const double re = g->eq_radius_km, mu = g->mu_km3_s2;
+    const double rho = re / r_;
+    double rho_np1 = mu / r_ * rho;
+    double ax = 0.0, ay = 0.0, az = 0.0, aw = 0.0;
+    const double SQ2 = sqrt(2.0);
+    const int n1 = N + 1;
+    for (int n = 1; n <= N; ++n) {
+        double sx = 0.0, sy = 0.0, sz = 0.0, sw = 0.0;
+        rho_np1 *= rho;
+        const int mtop = n < M ? n : M;
+        for (int m = 0; m <= mtop; ++m) {
+            const double cv = t->cfull[n + (size_t)m * n1], sv = t->sfull[n + (size_t)m * n1];
+            const double d_ = (cv * rm_work[m] + sv * im_work[m]) * SQ2;
+            const double e_ = (m == 0) ? 0.0 : (cv * rm_work[m - 1] + sv * im_work[m - 1]) * SQ2;
+            const double f_ = (m == 0) ? 0.0 : (sv * rm_work[m - 1] - cv * im_work[m - 1]) * SQ2;
+            sx += (double)m * A_(n, m) * e_;
+            sy += (double)m * A_(n, m) * f_;
+            sz += T2(vr01, n, m) * A_(n, m + 1) * d_;
+            sw -= T2(vr11, n, m) * A_(n + 1, m + 1) * d_;
+        }
+        const double rr = rho_np1 / re;
+        ax += rr * sx; ay += rr * sy; az += rr * sz; aw += rr * sw;
+    }
+#undef A_
+#undef T2
+    const double al[3] = {ax + aw * s_, ay + aw * t_, az + aw * u_};
+    /* dcm.rot_mat (fixed -> inertial) = transpose (:258-267) */
+    for (int i = 0; i < 3; ++i) acc[i] = dcm[0][i] * al[0] + dcm[1][i] * al[1] + dcm[2][i] * al[2];
+}
+
+void nyx_oracle_gravity_accel(const nyx_hip_gravity_field_t *g, int64_t epoch_ns, const double *r3, double *a3) {
+    grav_tables_t t;
+    grav_tables_build(g, &t);
+    double *a = malloc(sizeof(double) * (size_t)t.ld * t.ld);
+    double *rm = malloc(sizeof(double) * (size_t)(t.deg + 2)), *im = malloc(sizeof(double) * (size_t)(t.deg + 2));
+    gravity_eom(g, &t, nyx_oracle_ns_to_seconds(epoch_ns), r3, a3, a, rm, im);
+    free(a); free(rm); free(im);
+    grav_tables_free(&t);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Forward-mode duals (value + 3 position partials), stand-in for hyperdual    */
+/* OHyperdual<f64, 7> whose slots 1..3 carry d/dx, d/dy, d/dz.                 */
+/* ------------------------------------------------------------------------- */
+
+typedef struct { double v, d[3]; } d3;
+static d3 d3c(double v) { d3 r = {v, {0, 0, 0}}; return r; }
+static d3 d3add(d3 a, d3 b) { d3 r = {a.v + b.v, {a.d[0] + b.d[0], a.d[1] + b.d[1], a.d[2] + b.d[2]}}; return r; }
+static d3 d3sub(d3 a, d3 b) { d3 r = {a.v - b.v, {a.d[0] - b.d[0], a.d[1] - b.d[1], a.d[2] - b.d[2]}}; return r; }
+static d3 d3mul(d3 a, d3 b) {
+    d3 r = {a.v * b.v, {a.v * b.d[0] + a.d[0] * b.v, a.v * b.d[1] + a.d[1] * b.v, a.v * b.d[2] + a.d[2] * b.v}};
+    return r;
+}
+static d3 d3scale(d3 a, double s) { d3 r = {a.v * s, {a.d[0] * s, a.d[1] * s, a.d[2] * s}}; return r; }
+static d3 d3div(d3 a, d3 b) {
+    /* hyperdual 1.5 Div: real = a/b, dual_i = (a_i*b - a*b_i) / (b*b) */
+    double dd = b.v * b.v;
+    d3 r = {a.v / b.v, {(a.d[0] * b.v - a.v * b.d[0]) / dd, (a.d[1] * b.v - a.v * b.d[1]) / dd,
+                        (a.d[2] * b.v - a.v * b.d[2]) / dd}};
+    return r;
+}
+static d3 d3divs(d3 a, double s) { d3 r = {a.v / s, {a.d[0] / s, a.d[1] / s, a.d[2] / s}}; return r; }
+static d3 d3sqrt(d3 a) {
+    double s = sqrt(a.v);
+    double h = 0.5 / s;
+    d3 r = {s, {a.d[0] * h, a.d[1] * h, a.d[2] * h}};
+    return r;
+}
+static d3 d3powi(d3 a, int n) {
+    double p = powi_(a.v, n - 1);
+    double f = (double)n * p;
+    d3 r = {p * a.v, {a.d[0] * f, a.d[1] * f, a.d[2] * f}};
+    return r;
+}
+static d3 d3norm(const d3 *v) {
+    return d3sqrt(d3add(d3add(d3mul(v[0], v[0]), d3mul(v[1], v[1])), d3mul(v[2], v[2])));
+}
+
+/* GravityField::gradient, gravity_field.rs:273-431: same recursion on duals seeded
+ * in the body-fixed frame; returns accel (inertial) and dcm * grad_local * dcm^T. */
+static void gravity_gradient(const nyx_hip_gravity_field_t *g, const grav_tables_t *t, double et_s,
+                             const double *r_in, double *acc, double grad[3][3]) {
+    double dcm[3][3];
+    rotation_dcm(&g->rotation, et_s, dcm);
+    double rb[3];
+    for (int i = 0; i < 3; ++i) rb[i] = dcm[i][0] * r_in[0] + dcm[i][1] * r_in[1] + dcm[i][2] * r_in[2];
+    d3 rad[3];
+    for (int i = 0; i < 3; ++i) { rad[i] = d3c(rb[i]); rad[i].d[i] = 1.0; }
+    const d3 r_ = d3norm(rad);
+    const d3 s_ = d3div(rad[0], r_), t_ = d3div(rad[1], r_), u_ = d3div(rad[2], r_);
+    const int N = t->deg, M = t->ord, ld = t->ld, ld2 = t->ld2;
+    d3 *a = calloc((size_t)ld * ld, sizeof(d3));
+#define A_(n, m) a[(n) + (size_t)(m) * ld]
+#define T2(tab, n, m) t->tab[(n) + (size_t)(m) * ld2]
+    for (int i = 0; i <= N + 1; ++i) A_(i, i) = d3c(t->a_diag_tmpl[i + (size_t)i * ld]);
+    A_(1, 0) = d3scale(u_, sqrt(3.0));
+    for (int n = 1; n <= N + 1; ++n) A_(n + 1, n) = d3mul(d3mul(d3c(sqrt(2.0 * (double)n + 3.0)), u_), A_(n, n));
+    for (int m = 0; m <= M + 1; ++m)
+        for (int n = m + 2; n <= N + 1; ++n)
+            A_(n, m) = d3sub(d3mul(d3mul(u_, d3c(T2(b, n, m))), A_(n - 1, m)), d3mul(d3c(T2(c, n, m)), A_(n - 2, m)));
+    const int mm = N < M ? N : M;
+    d3 *rm = calloc((size_t)mm + 2, sizeof(d3)), *im = calloc((size_t)mm + 2, sizeof(d3));
+    rm[0] = d3c(1.0); im[0] = d3c(0.0);
+    for (int m = 1; m <= mm; ++m) {
+        rm[m] = d3sub(d3mul(s_, rm[m - 1]), d3mul(t_, im[m - 1]));
+        im[m] = d3add(d3mul(s_, im[m - 1]), d3mul(t_, rm[m - 1]));
+    }
+    const d3 re = d3c(g->eq_radius_km);
+    const d3 rho = d3div(re, r_);
+    d3 rho_np1 = d3mul(d3div(d3c(g->mu_km3_s2), r_), rho);
+    d3 a0 = d3c(0), a1 = d3c(0), a2 = d3c(0), a3 = d3c(0);
+    const d3 sq2 = d3c(sqrt(2.0));
+    const int n1 = N + 1;
+    for (int n = 1; n <= N; ++n) {
+        d3 s0 = d3c(0), s1 = d3c(0), s2 = d3c(0), s3 = d3c(0);
+        rho_np1 = d3mul(rho_np1, rho);
+        const int mtop = n < M ? n : M;
+        for (int m = 0; m <= mtop; ++m) {
+            const d3 cv = d3c(t->cfull[n + (size_t)m * n1]), sv = d3c(t->sfull[n + (size_t)m * n1]);
+            const d3 dd = d3mul(d3add(d3mul(cv, rm[m]), d3mul(sv, im[m])), sq2);
+            const d3 ee = (m == 0) ? d3c(0) : d3mul(d3add(d3mul(cv, rm[m - 1]), d3mul(sv, im[m - 1])), sq2);
+            const d3 ff = (m == 0) ? d3c(0) : d3mul(d3sub(d3mul(sv, rm[m - 1]), d3mul(cv, im[m - 1])), sq2);
+            s0 = d3add(s0, d3mul(d3mul(d3c((double)m), A_(n, m)), ee));
+            s1 = d3add(s1, d3mul(d3mul(d3c((double)m), A_(n, m)), ff));
+            s2 = d3add(s2, d3mul(d3mul(d3c(T2(vr01, n, m)), A_(n, m + 1)), dd));
+            s3 = d3add(s3, d3mul(d3mul(d3c(T2(vr11, n, m)), A_(n + 1, m + 1)), dd));
+        }
+        const d3 rr = d3div(rho_np1, re);
+        a0 = d3add(a0, d3mul(rr, s0));
+        a1 = d3add(a1, d3mul(rr, s1));
+        a2 = d3add(a2, d3mul(rr, s2));
+        a3 = d3sub(a3, d3mul(rr, s3));
+    }
+#undef A_
+#undef T2
+    const d3 al[3] = {d3add(a0, d3mul(a3, s_)), d3add(a1, d3mul(a3, t_)), d3add(a2, d3mul(a3, u_))};
+    for (int i = 0; i < 3; ++i) acc[i] = dcm[0][i] * al[0].v + dcm[1][i] * al[1].v + dcm[2][i] * al[2].v;
+    /* grad = dcm^T * G_local * dcm  (with dcm = inertial->fixed) */
+    double tmp[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) tmp[i][j] = dcm[0][i] * al[0].d[j] + dcm[1][i] * al[1].d[j] + dcm[2][i] * al[2].d[j];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) grad[i][j] = tmp[i][0] * dcm[0][j] + tmp[i][1] * dcm[1][j] + tmp[i][2] * dcm[2][j];
+    free(a); free(rm); free(im);
+}
+
+/* ------------------------------------------------------------------------- */
+/* Osculating spacecraft rebuilt from the state vector                         */
+/* (Spacecraft::set, cosmic/spacecraft.rs:477-497)                             */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+    double dry, extra, srp_area, drag_area;
+} sc_const_t;
+
+typedef struct {
+    double *a_work, *rm, *im; /* gravity scratch */
+} scratch_t;
+
+static double clamp02(double x) { return x < 0.0 ? 0.0 : (x > 2.0 ? 2.0 : x); } /* f64::clamp */
+
+/* PointMasses::eom, orbital.rs:214-247 */
+static int point_masses_eom(const nyx_hip_config_t *cfg, double et_s, const double *r, double *acc) {
+    acc[0] = acc[1] = acc[2] = 0.0;
+    for (int k = 0; k < cfg->n_point_masses; ++k) {
+        const int b = cfg->point_mass_body[k];
+        const nyx_hip_body_t *body = &cfg->bodies[b];
+        if (body->n_chain == 0) continue; /* the central body itself (:219-222) */
+        double r_ij[3];
+        int st = body_position(cfg, b, et_s, r_ij);
+        if (st) return st;
+        const double r_ij3 = powi_(norm3(r_ij), 3);
+        double r_j[3] = {r[0] - r_ij[0], r[1] - r_ij[1], r[2] - r_ij[2]};
+        const double r_j3 = powi_(norm3(r_j), 3);
+        const double nmu = -body->mu_km3_s2;
+        for (int c = 0; c < 3; ++c) acc[c] += nmu * (r_j[c] / r_j3 + r_ij[c] / r_ij3);
+    }
+    return NYX_HIP_OK;
+}
+
+/* ShadowModel::compute (cosmic/eclipse.rs:69-83): max occultation over shadow bodies. */
+static int shadow_factor(const nyx_hip_config_t *cfg, double et_s, const double *r, const double *r_sun_wrt_center,
+                         double *factor) {
+    const nyx_hip_srp_t *srp = cfg->srp;
+    const double sun_radius = cfg->bodies[srp->sun_body].mean_radius_km;
+    double best_pct = 0.0;
+    for (int k = 0; k < srp->n_shadow_bodies; ++k) {
+        const int b = srp->shadow_body[k];
+        double pb[3] = {0, 0, 0};
+        if (cfg->bodies[b].n_chain > 0) {
+            int st = body_position(cfg, b, et_s, pb);
+            if (st) return st;
+        }
+        double r_eb[3] = {r[0] - pb[0], r[1] - pb[1], r[2] - pb[2]};
+        double r_ls[3] = {r_sun_wrt_center[0] - r[0], r_sun_wrt_center[1] - r[1], r_sun_wrt_center[2] - r[2]};
+        double pct = occultation_pct(sun_radius, cfg->bodies[b].mean_radius_km, r_eb, r_ls);
+        if (pct > best_pct) best_pct = pct;
+    }
+    *factor = best_pct / 100.0;
+    return NYX_HIP_OK;
+}
+
+double nyx_oracle_occultation_factor(const nyx_hip_config_t *cfg, int32_t eclipsing_body, int32_t sun_body,
+                                     int64_t epoch_ns, const double *r3, int32_t *status) {
+    double et = nyx_oracle_ns_to_seconds(epoch_ns);
+    double ps[3], pb[3] = {0, 0, 0};
+    int st = body_position(cfg, sun_body, et, ps);
+    if (!st && cfg->bodies[eclipsing_body].n_chain > 0) st = body_position(cfg, eclipsing_body, et, pb);
+    if (status) *status = st;
+    if (st) return 0.0;
+    double r_eb[3] = {r3[0] - pb[0], r3[1] - pb[1], r3[2] - pb[2]};
+    double r_ls[3] = {ps[0] - r3[0], ps[1] - r3[1], ps[2] - r3[2]};
+    return occultation_pct(cfg->bodies[sun_body].mean_radius_km, cfg->bodies[eclipsing_body].mean_radius_km, r_eb, r_ls) / 100.0;
+}
+
+#define AU_KM 149597870.700 /* cosmic/mod.rs:183 */
+
+/* SolarPressure::eom, solarpressure.rs:135-165 (force in kg km/s^2, caller divides by mass) */
+static int srp_eom(const nyx_hip_config_t *cfg, double et_s, const double *r, double cr, double area, double *force) {
+    const nyx_hip_srp_t *srp = cfg->srp;
+    double ps[3];
+    int st = body_position(cfg, srp->sun_body, et_s, ps);
+    if (st) return st;
+    double r_sun[3] = {r[0] - ps[0], r[1] - ps[1], r[2] - ps[2]}; /* s/c as seen from the Sun */
+    const double n = norm3(r_sun);
+    double unit[3] = {r_sun[0] / n, r_sun[1] / n, r_sun[2] / n};
+    double occult;
+    st = shadow_factor(cfg, et_s, r, ps, &occult);
+    if (st) return st;
+    const double k = fabs(occult - 1.0);
+    const double r_au = n / AU_KM;
+    const double c_m_s = cfg->speed_of_light_km_s * 1e3; /* cosmic/mod.rs:179 */
+    const double flux = (k * srp->phi_w_m2 / c_m_s) * powi_(1.0 / r_au, 2);
+    const double scal = 1e-3 * cr * area * flux;
+    for (int c = 0; c < 3; ++c) force[c] = scal * unit[c];
+    return NYX_HIP_OK;
+}
+
+/* SolarPressure::gradient, solarpressure.rs:167-232: position Jacobian with k frozen;
+ * row 3 = d force / d Cr. */
+static int srp_gradient(const nyx_hip_config_t *cfg, double et_s, const double *r, double cr, double area,
+                        double *force, double grad[4][3]) {
+    const nyx_hip_srp_t *srp = cfg->srp;
+    double ps[3];
+    int st = body_position(cfg, srp->sun_body, et_s, ps);
+    if (st) return st;
+    d3 rs[3];
+    for (int i = 0; i < 3; ++i) { rs[i] = d3c(r[i] - ps[i]); rs[i].d[i] = 1.0; }
+    const d3 n = d3norm(rs);
+    d3 unit[3] = {d3div(rs[0], n), d3div(rs[1], n), d3div(rs[2], n)};
+    double occult;
+    st = shadow_factor(cfg, et_s, r, ps, &occult);
+    if (st) return st;
+    const double k = fabs(occult - 1.0);
+    const d3 r_au = d3divs(n, AU_KM);
+    const d3 inv = d3div(d3c(1.0), r_au);
+    const d3 inv2 = d3powi(inv, 2);
+    const double c_m_s = cfg->speed_of_light_km_s * 1e3;
+    const d3 flux = d3mul(d3c(k * srp->phi_w_m2 / c_m_s), inv2);
+    const d3 scal = d3c(1e-3 * cr * area);
+    for (int i = 0; i < 3; ++i) {
+        d3 f = d3mul(d3mul(scal, flux), unit[i]);
+        force[i] = f.v;
+        for (int j = 0; j < 3; ++j) grad[i][j] = f.d[j];
+    }
+    double fr[3];
+    st = srp_eom(cfg, et_s, r, cr, area, fr);
+    if (st) return st;
+    for (int j = 0; j < 3; ++j) grad[3][j] = fr[j] / cr;
+    return NYX_HIP_OK;
+}
+
+/* Drag::eom, drag.rs:181-284 — including the reference's unit/frame quirks. */
+static int drag_eom(const nyx_hip_config_t *cfg, double et_s, const double *r, const double *v, double cd, double area,
+                    double *force) {
+    const nyx_hip_drag_t *dg = cfg->drag;
+    double m[3][3];
+    rotation_dcm(&dg->rotation, et_s, m);
+    /* transform_to(orbit, drag frame): r' = R r, v' = R v + dR/dt r.  dR/dt from the
+     * twist rate only would be an approximation; ANISE differentiates all three
+     * angles.  We use a symmetric finite difference-free analytic form: dR/dt = -[w]x R
+     * with w = W_dot * z_body (pole drift neglected: |ra_dot|,|dec_dot| ~ 1e-13 rad/s). */
+    const double DEG = M_PI / 180.0;
+    const double d = et_s / 86400.0;
+    const double wdot = (dg->rotation.w_deg[1] + 2.0 * dg->rotation.w_deg[2] * d) * DEG / 86400.0;
+    double rb[3], vb[3];
+    for (int i = 0; i < 3; ++i) {
+        rb[i] = m[i][0] * r[0] + m[i][1] * r[1] + m[i][2] * r[2];
+        vb[i] = m[i][0] * v[0] + m[i][1] * v[1] + m[i][2] * v[2];
+    }
+    /* v_fixed = R v - w x (R r), w = (0,0,wdot) in the fixed frame */
+    vb[0] = vb[0] + wdot * rb[1];
+    vb[1] = vb[1] - wdot * rb[0];
+    double rho;
+    const double rmag = norm3(rb);
+    if (dg->density == NYX_HIP_RHO_CONSTANT) {
+        rho = dg->rho0;
+        const double vn = norm3(vb);
+        const double s = -0.5 * 1e3 * rho * cd * area * vn;
+        for (int c = 0; c < 3; ++c) force[c] = s * vb[c];
+        return NYX_HIP_OK;
+    } else if (dg->density == NYX_HIP_RHO_EXPONENTIAL) {
+        rho = dg->rho0 * exp(-(rmag - (dg->r0 + dg->eq_radius_km)) / dg->ref_alt_m);
+    } else {
+        const double alt = rmag - dg->eq_radius_km;
+        if (alt > dg->max_alt_m / 1000.0) {
+            rho = pow(10.0, (-7e-5) * alt - 14.464);
+        } else {
+            const double sc = (alt - 526.8000) / 292.8563;
+            const double lg = 0.34047 * powi_(sc, 6) - 0.5889 * powi_(sc, 5) - 0.5269 * powi_(sc, 4) +
+                              1.0036 * powi_(sc, 3) + 0.60713 * powi_(sc, 2) - 2.3024 * sc - 12.575;
+            rho = pow(10.0, lg);
+        }
+    }
+    /* velocity_integr_frame - osc_drag_frame.velocity (drag.rs:223-230): the
+     * round-trip back to the integration frame returns the inertial velocity. */
+    double vel[3] = {v[0] - vb[0], v[1] - vb[1], v[2] - vb[2]};
+    const double vn = norm3(vel);
+    const double s = -0.5 * 1e3 * rho * cd * area * vn;
+    for (int c = 0; c < 3; ++c) force[c] = s * vel[c];
+    return NYX_HIP_OK;
+}
+
+/* ------------------------------------------------------------------------- */
+/* SpacecraftDynamics::eom / dual_eom                                          */
+/* ------------------------------------------------------------------------- */
+
+static int any_force_model(const nyx_hip_config_t *cfg) { return cfg->srp != NULL || cfg->drag != NULL; }
+
+/* OrbitalDynamics::dual_eom (orbital.rs:116-172) + SpacecraftDynamics::dual_eom (spacecraft.rs:312-363).
+ * grad is 9x9 column-major (nalgebra storage). */
+static int dual_eom(const prepared_t *p, double et_s, const double *y9, const sc_const_t *sc, double *fx, double *grad) {
+    const nyx_hip_config_t *cfg = p->cfg;
+    memset(fx, 0, 9 * sizeof(double));
+    memset(grad, 0, 81 * sizeof(double));
+#define G(i, j) grad[(i) + 9 * (j)]
+    const double *r = y9, *v = y9 + 3;
+    /* two-body via duals: radius * (-mu / rmag^3) */
+    d3 rad[3];
+    for (int i = 0; i < 3; ++i) { rad[i] = d3c(r[i]); rad[i].d[i] = 1.0; }
+    const d3 rmag = d3norm(rad);
+    const d3 fac = d3div(d3c(-cfg->central_mu_km3_s2), d3powi(rmag, 3));
+    for (int i = 0; i < 3; ++i) {
+        fx[i] = v[i];
+        G(i, i + 3) = 1.0;
+        d3 a = d3mul(rad[i], fac);
+        fx[i + 3] = a.v;
+        for (int j = 0; j < 3; ++j) G(i + 3, j) = a.d[j];
+    }
+    /* accel models: PointMasses::gradient orbital.rs:249-308 */
+    if (cfg->n_point_masses > 0) {
+        double acc[3] = {0, 0, 0}, g3[3][3] = {{0}};
+        for (int k = 0; k < cfg->n_point_masses; ++k) {
+            const int b = cfg->point_mass_body[k];
+            const nyx_hip_body_t *body = &cfg->bodies[b];
+            if (body->n_chain == 0) continue;
+            double pij[3];
+            int st = body_position(cfg, b, et_s, pij);
+            if (st) return st;
+            d3 r_ij[3] = {d3c(pij[0]), d3c(pij[1]), d3c(pij[2])};
+            const d3 r_ij3 = d3powi(d3norm(r_ij), 3);
+            d3 r_j[3];
+            for (int i = 0; i < 3; ++i) { r_j[i] = d3c(r[i] - pij[i]); r_j[i].d[i] = 1.0; }
+            const d3 r_j3 = d3powi(d3norm(r_j), 3);
+            const d3 gm = d3c(-body->mu_km3_s2);
+            for (int i = 0; i < 3; ++i) {
+                d3 t = d3mul(d3add(d3div(r_j[i], r_j3), d3div(r_ij[i], r_ij3)), gm);
+                acc[i] += t.v;
+                for (int j = 0; j < 3; ++j) g3[i][j] += t.d[j];
+            }
+        }
+        for (int i = 0; i < 3; ++i) {
+            fx[i + 3] += acc[i];
+            for (int j = 0; j < 3; ++j) G(i + 3, j) += g3[i][j];
+        }
+    }
+    if (cfg->gravity) {
+        double acc[3], g3[3][3];
+        gravity_gradient(cfg->gravity, &p->gt, et_s, r, acc, g3);
+        for (int i = 0; i < 3; ++i) {
+            fx[i + 3] += acc[i];
+            for (int j = 0; j < 3; ++j) G(i + 3, j) += g3[i][j];
+        }
+    }
+    /* force models (spacecraft.rs:339-360) */
+    const double cr = clamp02(y9[6]);
+    const double total_mass = sc->dry + y9[8] + sc->extra;
+    if (cfg->srp) {
+        double f[3], g4[4][3];
+        int st = srp_gradient(cfg, et_s, r, cr, sc->srp_area, f, g4);
+        if (st) return st;
+        for (int i = 0; i < 3; ++i) {
+            fx[i + 3] += f[i] / total_mass;
+            for (int j = 0; j < 3; ++j) G(i + 3, j) += g4[i][j] / total_mass;
+        }
+        if (cfg->srp->estimate)
+            for (int j = 0; j < 3; ++j) G(j + 3, 6) += g4[3][j] / total_mass;
+    }
+    if (cfg->drag) return NYX_HIP_ERR_UNSUPPORTED; /* PartialsUndefined, drag.rs:286-294 */
+#undef G
+    return NYX_HIP_OK;
+}
+
+/* SpacecraftDynamics::eom, spacecraft.rs:191-310 (no guidance law on this path). */
+static int sc_eom(const prepared_t *p, int64_t ctx_epoch_ns, double dt_s, const double *y, int nv, const double *ctx_stm,
+                  const sc_const_t *sc, scratch_t *w, double *dy) {
+    const nyx_hip_config_t *cfg = p->cfg;
+    /* ctx.set_with_delta_seconds: epoch + dt rounded to the ns grain (cosmic/mod.rs:94-104) */
+    const int64_t epoch_ns = ctx_epoch_ns + nyx_oracle_seconds_to_ns(dt_s);
+    const double et_s = nyx_oracle_ns_to_seconds(epoch_ns);
+    const double cr = clamp02(y[6]);
+    const double cd = y[7];
+    const double mass = sc->dry + y[8] + sc->extra;
+    if (any_force_model(cfg) && !(mass > 0.0)) return NYX_HIP_ERR_MASSLESS;
+    for (int i = 0; i < nv; ++i) dy[i] = 0.0;
+
+    if (ctx_stm) {
+        double fx[9], grad[81];
+        int st = dual_eom(p, et_s, y, sc, fx, grad);
+        if (st) return st;
+        for (int i = 0; i < 9; ++i) dy[i] = fx[i];
+        /* stm_dt = ctx.stm * grad  (spacecraft.rs:214), both column-major */
+        for (int j = 0; j < 9; ++j)
+            for (int i = 0; i < 9; ++i) {
+                double s = 0.0;
+                for (int k = 0; k < 9; ++k) s += ctx_stm[i + 9 * k] * grad[k + 9 * j];
+                dy[9 + i + 9 * j] = s;
+            }
+        return NYX_HIP_OK;
+    }
+
+    const double *r = y, *v = y + 3;
+    /* OrbitalDynamics::eom orbital.rs:80-114 */
+    const double rmag = norm3(r);
+    const double f = -cfg->central_mu_km3_s2 / powi_(rmag, 3);
+    dy[0] = v[0]; dy[1] = v[1]; dy[2] = v[2];
+    dy[3] = f * r[0]; dy[4] = f * r[1]; dy[5] = f * r[2];
+    if (cfg->n_point_masses > 0) {
+        double a[3];
+        int st = point_masses_eom(cfg, et_s, r, a);
+        if (st) return st;
+        for (int c = 0; c < 3; ++c) dy[3 + c] += a[c];
+    }
+    if (cfg->gravity) {
+        double a[3];
+        gravity_eom(cfg->gravity, &p->gt, et_s, r, a, w->a_work, w->rm, w->im);
+        for (int c = 0; c < 3; ++c) dy[3 + c] += a[c];
+    }
+    if (cfg->srp) {
+        double fo[3];
+        int st = srp_eom(cfg, et_s, r, cr, sc->srp_area, fo);
+        if (st) return st;
+        for (int c = 0; c < 3; ++c) dy[3 + c] += fo[c] / mass;
+    }
+    if (cfg->drag) {
+        double fo[3];
+        int st = drag_eom(cfg, et_s, r, v, cd, sc->drag_area, fo);
+        if (st) return st;
+        for (int c = 0; c < 3; ++c) dy[3 + c] += fo[c] / mass;
+    }
+    return NYX_HIP_OK;
+}
+
+static void scratch_init(scratch_t *w, const prepared_t *p) {
+    memset(w, 0, sizeof *w);
+    if (p->has_grav) {
+        w->a_work = malloc(sizeof(double) * (size_t)p->gt.ld * p->gt.ld);
+        w->rm = malloc(sizeof(double) * (size_t)(p->gt.deg + 2));
+        w->im = malloc(sizeof(double) * (size_t)(p->gt.deg + 2));
+    }
+}
+static void scratch_free(scratch_t *w) { free(w->a_work); free(w->rm); free(w->im); }
+
+int32_t nyx_oracle_eom(const nyx_hip_config_t *cfg, int64_t ctx_epoch_ns, double delta_t_s, const double *y,
+                       const double *ctx_stm, double dry, double extra, double srp_area, double drag_area, double *dydt) {
+    prepared_t p;
+    prepared_init(&p, cfg);
+    scratch_t w;
+    scratch_init(&w, &p);
+    sc_const_t sc = {dry, extra, srp_area, drag_area};
+    int st = sc_eom(&p, ctx_epoch_ns, delta_t_s, y, ctx_stm ? 90 : 9, ctx_stm, &sc, &w, dydt);
+    scratch_free(&w);
+    prepared_free(&p);
+    return st;
+}
+
+int32_t nyx_oracle_dual_eom(const nyx_hip_config_t *cfg, int64_t epoch_ns, const double *y9, double dry, double extra,
+                            double srp_area, double *fx9, double *grad81) {
+    prepared_t p;
+    prepared_init(&p, cfg);
+    sc_const_t sc = {dry, extra, srp_area, 0.0};
+    int st = dual_eom(&p, nyx_oracle_ns_to_seconds(epoch_ns), y9, &sc, fx9, grad81);
+    prepared_free(&p);
+    return st;
+}
+
+/* ------------------------------------------------------------------------- */
+/* ErrorControl::estimate, error_ctrl.rs:79-229                                */
+/* ------------------------------------------------------------------------- */
+
+/* nalgebra's dot for long vectors: 8 independent accumulators, folded as
+ * (0+4),(1+5),(2+6),(3+7), then the tail. */
+static double nalgebra_norm(const double *x, int n) {
+    double res = 0.0, acc[8] = {0};
+    int i = 0;
+    while (n - i >= 8) {
+        for (int l = 0; l < 8; ++l) acc[l] += x[i + l] * x[i + l];
+        i += 8;
+    }
+    res += acc[0] + acc[4];
+    res += acc[1] + acc[5];
+    res += acc[2] + acc[6];
+    res += acc[3] + acc[7];
+    for (; i < n; ++i) res += x[i] * x[i];
+    return sqrt(res);
+}
+
+static double rss_step3(const double *e, const double *cand, const double *cur) {
+    double dlt[3] = {cand[0] - cur[0], cand[1] - cur[1], cand[2] - cur[2]};
+    double mag = norm3(dlt), err = norm3(e);
+    return (mag > sqrt(0.1)) ? err / mag : err;
+}
+static double rss_state3(const double *e, const double *cand, const double *cur) {
+    double sm[3] = {cand[0] + cur[0], cand[1] + cur[1], cand[2] + cur[2]};
+    double mag = 0.5 * norm3(sm), err = norm3(e);
+    return (mag > 0.1) ? err / mag : err;
+}
+
+double nyx_oracle_error_estimate(int32_t ec, int32_t nv, const double *e, const double *cand, const double *cur) {
+    double tmp[NV_MAX];
+    switch (ec) {
+    case NYX_HIP_RSS_CARTESIAN_STATE: {
+        double a = rss_state3(e, cand, cur), b = rss_state3(e + 3, cand + 3, cur + 3);
+        return fmax(a, b);
+    }
+    case NYX_HIP_RSS_CARTESIAN_STEP: {
+        double a = rss_step3(e, cand, cur), b = rss_step3(e + 3, cand + 3, cur + 3);
+        return fmax(a, b);
+    }
+    case NYX_HIP_RSS_STATE: {
+        for (int i = 0; i < nv; ++i) tmp[i] = cand[i] + cur[i];
+        double mag = 0.5 * nalgebra_norm(tmp, nv), err = nalgebra_norm(e, nv);
+        return (mag > 0.1) ? err / mag : err;
+    }
+    case NYX_HIP_RSS_STEP: {
+        for (int i = 0; i < nv; ++i) tmp[i] = cand[i] - cur[i];
+        double mag = nalgebra_norm(tmp, nv), err = nalgebra_norm(e, nv);
+        return (mag > sqrt(0.1)) ? err / mag : err;
+    }
+    case NYX_HIP_LARGEST_ERROR: {
+        double mx = 0.0;
+        for (int i = 0; i < nv; ++i) {
+            double dl = cand[i] - cur[i];
+            double er = (dl > 0.1) ? fabs(e[i] / dl) : fabs(e[i]);
+            if (er > mx) mx = er;
+        }
+        return mx;
+    }
+    case NYX_HIP_LARGEST_STATE: {
+        double mag = 0.0, err = 0.0;
+        for (int i = 0; i < nv; ++i) {
+            mag += 0.5 * fabs(cand[i] + cur[i]);
+            err += fabs(e[i]);
+        }
+        return (mag > 0.1) ? err / mag : err;
+    }
+    case NYX_HIP_LARGEST_STEP: {
+        double mag = 0.0, err = 0.0;
+        for (int i = 0; i < nv; ++i) {
+            mag += fabs(cand[i] - cur[i]);
+            err += fabs(e[i]);
+        }
+        return (mag > 0.1) ? err / mag : err;
+    }
+    }
+    return NAN;
+}
+
+/* ------------------------------------------------------------------------- */
+/* PropInstance: propagate / single_step / derive, instance.rs:87-493          */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+    const prepared_t *p;
+    const oracle_tableau_t *tab;
+    nyx_hip_integ_opts_t opts;
+    int nv;       /* 9 or 90 */
+    int has_stm;
+    /* Spacecraft */
+    int64_t epoch_ns;
+    double y[NV_MAX];
+    sc_const_t sc;
+    /* PropInstance */
+    int64_t step_size_ns;
+    int fixed_step;
+    int64_t det_step_ns;
+    double det_error;
+    int det_attempts;
+    int64_t n_acc, n_rej, n_evals;
+    double k[MAX_STAGES][NV_MAX];
+    scratch_t w;
+} inst_t;
+
+static int64_t i64abs(int64_t x) { return x < 0 ? -x : x; }
+
+/* derive(): one adaptive RK step (instance.rs:358-493).  Returns status; on success
+ * writes the step actually taken (ns) and the new state vector. */
+static int derive(inst_t *s, int64_t *step_taken_ns, double *next) {
+    const oracle_tableau_t *tb = s->tab;
+    const int nv = s->nv, stages = tb->stages;
+    const double *y = s->y;
+    const double *ctx_stm = s->has_stm ? s->y + 9 : NULL;
+    const double min_step_s = nyx_oracle_ns_to_seconds(s->opts.min_step_ns);
+    const double max_step_s = nyx_oracle_ns_to_seconds(s->opts.max_step_ns);
+    s->det_attempts = 1;
+    double h = nyx_oracle_ns_to_seconds(s->step_size_ns);
+    double wi[NV_MAX], ys[NV_MAX], err[NV_MAX];
+    for (;;) {
+        int st = sc_eom(s->p, s->epoch_ns, 0.0, y, nv, ctx_stm, &s->sc, &s->w, s->k[0]);
+        if (st) return st;
+        int a_idx = 0;
+        for (int i = 0; i < stages - 1; ++i) {
+            double ci = 0.0;
+            for (int e = 0; e < nv; ++e) wi[e] = 0.0;
+            for (int j = 0; j <= i; ++j) {
+                const double a_ij = tb->a[a_idx++];
+                ci += a_ij;
+                for (int e = 0; e < nv; ++e) wi[e] += a_ij * s->k[j][e];
+            }
+            for (int e = 0; e < nv; ++e) ys[e] = y[e] + h * wi[e];
+            st = sc_eom(s->p, s->epoch_ns, ci * h, ys, nv, ctx_stm, &s->sc, &s->w, s->k[i + 1]);
+            if (st) return st;
+        }
+        s->n_evals += stages;
+        for (int e = 0; e < nv; ++e) { next[e] = y[e]; err[e] = 0.0; }
+        for (int i = 0; i < stages; ++i) {
+            const double b_i = tb->b[i];
+            if (!s->fixed_step) {
+                const double b_s = tb->b[i + stages];
+                const double ce = h * (b_i - b_s);
+                for (int e = 0; e < nv; ++e) err[e] += ce * s->k[i][e];
+            }
+            const double cb = h * b_i;
+            for (int e = 0; e < nv; ++e) next[e] += cb * s->k[i][e];
+        }
+        if (s->fixed_step) {
+            s->det_step_ns = s->step_size_ns;
+            *step_taken_ns = s->det_step_ns;
+            return NYX_HIP_OK;
+        }
+        s->det_error = nyx_oracle_error_estimate(s->opts.error_ctrl, nv, err, next, y);
+        if (s->det_error <= s->opts.tolerance || h <= min_step_s || s->det_attempts >= s->opts.attempts) {
+            for (int e = 0; e < nv; ++e)
+                if (next[e] != next[e]) return NYX_HIP_ERR_NAN;
+            s->det_step_ns = nyx_oracle_seconds_to_ns(h);
+            if (s->det_error < s->opts.tolerance) {
+                const double prop = 0.9 * h * pow(s->opts.tolerance / s->det_error, 1.0 / (double)tb->order);
+                h = (fabs(prop) > fabs(max_step_s)) ? max_step_s * copysign(1.0, prop) : prop;
+            }
+            s->step_size_ns = nyx_oracle_seconds_to_ns(h);
+            if (i64abs(s->step_size_ns) < s->opts.min_step_ns)
+                s->step_size_ns = (s->step_size_ns < 0) ? -s->opts.min_step_ns : s->opts.min_step_ns;
+            *step_taken_ns = s->det_step_ns;
+            return NYX_HIP_OK;
+        }
+        s->det_attempts += 1;
+        s->n_rej += 1;
+        const double prop = 0.9 * h * pow(s->opts.tolerance / s->det_error, 1.0 / (double)(tb->order - 1));
+        h = (prop < min_step_s) ? min_step_s : prop;
+    }
+}
+
+/* dynamics.finally (spacecraft.rs:158-189) without guidance: prop mass check only. */
+static int finally_(const inst_t *s) { return (s->y[8] < 0.0) ? NYX_HIP_ERR_FUEL_EXHAUSTED : NYX_HIP_OK; }
+
+static int single_step(inst_t *s) {
+    double next[NV_MAX];
+    int64_t t;
+    int st = derive(s, &t, next);
+    if (st) return st;
+    /* state.set(epoch + t, vec): Cr clamp (cosmic/spacecraft.rs:494) */
+    s->epoch_ns += t;
+    memcpy(s->y, next, sizeof(double) * (size_t)s->nv);
+    s->y[6] = clamp02(s->y[6]);
+    s->n_acc += 1;
+    return finally_(s);
+}
+
+static int propagate(inst_t *s, int64_t duration_ns) {
+    if (duration_ns == 0) return NYX_HIP_OK;
+    const int64_t stop = s->epoch_ns + duration_ns;
+    int st = finally_(s);
+    if (st) return st;
+    const int backprop = duration_ns < 0;
+    if (backprop) s->step_size_ns = -s->step_size_ns;
+    for (;;) {
+        const int64_t epoch = s->epoch_ns;
+        if ((!backprop && epoch + s->step_size_ns > stop) || (backprop && epoch + s->step_size_ns <= stop)) {
+            if (stop == epoch) return NYX_HIP_OK;
+            const int64_t prev_step = s->step_size_ns;
+            const int prev_kind = s->fixed_step;
+            s->step_size_ns = stop - epoch;
+            s->fixed_step = 1;
+            st = single_step(s);
+            if (st) return st;
+            s->step_size_ns = prev_step;
+            s->fixed_step = prev_kind;
+            if (backprop) s->step_size_ns = -s->step_size_ns;
+            return NYX_HIP_OK;
+        }
+        st = single_step(s);
+        if (st) return st;
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+/* Batch driver (rayon par_iter analogue)                                      */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+    const prepared_t *p;
+    const nyx_hip_states_t *in;
+    nyx_hip_states_t *out;
+    nyx_hip_step_stats_t *stats;
+    int64_t duration_ns;
+    atomic_long next;
+} job_t;
+
+static void run_one(const job_t *jb, inst_t *s, int64_t i) {
+    const nyx_hip_config_t *cfg = jb->p->cfg;
+    const nyx_hip_states_t *in = jb->in;
+    s->p = jb->p;
+    s->tab = &ORC_TABLEAUX[cfg->opts.method];
+    s->opts = cfg->opts;
+    s->has_stm = (cfg->flags & NYX_HIP_FLAG_STM) && in->stm;
+    s->nv = s->has_stm ? 90 : 9;
+    s->epoch_ns = in->epoch_ns[i];
+    memset(s->y, 0, sizeof s->y);
+    s->y[0] = in->x_km[i]; s->y[1] = in->y_km[i]; s->y[2] = in->z_km[i];
+    s->y[3] = in->vx_km_s[i]; s->y[4] = in->vy_km_s[i]; s->y[5] = in->vz_km_s[i];
+    s->y[6] = in->cr ? in->cr[i] : 0.0;
+    s->y[7] = in->cd ? in->cd[i] : 0.0;
+    s->y[8] = in->prop_mass_kg ? in->prop_mass_kg[i] : 0.0;
+    if (s->has_stm) memcpy(s->y + 9, in->stm + 81 * i, 81 * sizeof(double));
+    s->sc.dry = in->dry_mass_kg ? in->dry_mass_kg[i] : 0.0;
+    s->sc.extra = in->extra_mass_kg ? in->extra_mass_kg[i] : 0.0;
+    s->sc.srp_area = in->srp_area_m2 ? in->srp_area_m2[i] : 0.0;
+    s->sc.drag_area = in->drag_area_m2 ? in->drag_area_m2[i] : 0.0;
+    s->step_size_ns = (in->step_ns && in->step_ns[i] != 0) ? in->step_ns[i] : cfg->opts.init_step_ns;
+    s->fixed_step = cfg->opts.fixed_step;
+    s->det_step_ns = cfg->opts.init_step_ns;
+    s->det_error = 0.0;
+    s->det_attempts = 1;
+    s->n_acc = s->n_rej = s->n_evals = 0;
+
+    int st = propagate(s, jb->duration_ns);
+
+    nyx_hip_states_t *o = jb->out;
+    o->epoch_ns[i] = s->epoch_ns;
+    o->x_km[i] = s->y[0]; o->y_km[i] = s->y[1]; o->z_km[i] = s->y[2];
+    o->vx_km_s[i] = s->y[3]; o->vy_km_s[i] = s->y[4]; o->vz_km_s[i] = s->y[5];
+    if (o->cr) o->cr[i] = s->y[6];
+    if (o->cd) o->cd[i] = s->y[7];
+    if (o->prop_mass_kg) o->prop_mass_kg[i] = s->y[8];
+    if (o->dry_mass_kg) o->dry_mass_kg[i] = s->sc.dry;
+    if (o->extra_mass_kg) o->extra_mass_kg[i] = s->sc.extra;
+    if (o->srp_area_m2) o->srp_area_m2[i] = s->sc.srp_area;
+    if (o->drag_area_m2) o->drag_area_m2[i] = s->sc.drag_area;
+    if (o->stm && s->has_stm) memcpy(o->stm + 81 * i, s->y + 9, 81 * sizeof(double));
+    if (o->step_ns) o->step_ns[i] = s->step_size_ns;
+    nyx_hip_step_stats_t *t = jb->stats;
+    if (t) {
+        if (t->status) t->status[i] = st;
+        if (t->last_step_ns) t->last_step_ns[i] = s->det_step_ns;
+        if (t->last_error) t->last_error[i] = s->det_error;
+        if (t->last_attempts) t->last_attempts[i] = s->det_attempts;
+        if (t->n_accepted) t->n_accepted[i] = s->n_acc;
+        if (t->n_rejected) t->n_rejected[i] = s->n_rej;
+        if (t->n_evals) t->n_evals[i] = s->n_evals;
+    }
+}
+
+static void *worker(void *arg) {
+    job_t *jb = arg;
+    inst_t *s = malloc(sizeof *s);
+    scratch_init(&s->w, jb->p);
+    for (;;) {
+        long i = atomic_fetch_add(&jb->next, 1);
+        if (i >= jb->in->n) break;
+        scratch_t keep = s->w;
+        run_one(jb, s, i);
+        s->w = keep;
+    }
+    scratch_free(&s->w);
+    free(s);
+    return NULL;
+}
+
+int32_t nyx_oracle_propagate_batch(const nyx_hip_config_t *cfg, const nyx_hip_states_t *in, int64_t duration_ns,
+                                   nyx_hip_states_t *out, nyx_hip_step_stats_t *stats, int32_t n_threads) {
+    if (!cfg || !in || !out || cfg->opts.method < 0 || cfg->opts.method > 5) return NYX_HIP_RC_BAD_ARG;
+    prepared_t p;
+    prepared_init(&p, cfg);
+    job_t jb = {&p, in, out, stats, duration_ns, 0};
+    if (n_threads < 1) n_threads = 1;
+    if (n_threads > 256) n_threads = 256;
+    if (n_threads == 1 || in->n <= 1) {
+        worker(&jb);
+    } else {
+        pthread_t th[256];
+        for (int t = 0; t < n_threads; ++t) pthread_create(&th[t], NULL, worker, &jb);
+        for (int t = 0; t < n_threads; ++t) pthread_join(th[t], NULL);
+    }
+    prepared_free(&p);
+    return NYX_HIP_RC_OK;
+}

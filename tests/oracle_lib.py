@@ -1,0 +1,81 @@
+"""Loader of the CPU oracle (oracle/libnyx_oracle.so).  TEST INFRASTRUCTURE: only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg import this."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from nyx_amd import _abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+_LIB = None
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+
+
+def load():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = os.path.join(ORACLE_DIR, "libnyx_oracle.so")
+    src = os.path.join(ORACLE_DIR, "nyx_oracle.c")
+    if not os.path.exists(path) or (os.path.exists(src) and os.path.getmtime(src) > os.path.getmtime(path)):
+        build()
+    lib = C.CDLL(path)
+    lib.nyx_oracle_propagate_batch.argtypes = [C.POINTER(_abi.Config), C.POINTER(_abi.States), C.c_int64,
+                                               C.POINTER(_abi.States), C.POINTER(_abi.StepStats), C.c_int32]
+    lib.nyx_oracle_propagate_batch.restype = C.c_int32
+    lib.nyx_oracle_eom.argtypes = [C.POINTER(_abi.Config), C.c_int64, C.c_double, _abi.c_double_p, _abi.c_double_p,
+                                   C.c_double, C.c_double, C.c_double, C.c_double, _abi.c_double_p]
+    lib.nyx_oracle_eom.restype = C.c_int32
+    lib.nyx_oracle_dual_eom.argtypes = [C.POINTER(_abi.Config), C.c_int64, _abi.c_double_p, C.c_double, C.c_double,
+                                        C.c_double, _abi.c_double_p, _abi.c_double_p]
+    lib.nyx_oracle_dual_eom.restype = C.c_int32
+    lib.nyx_oracle_body_position.argtypes = [C.POINTER(_abi.Config), C.c_int32, C.c_int64, _abi.c_double_p, _abi.c_int32_p]
+    lib.nyx_oracle_rotation_dcm.argtypes = [C.POINTER(_abi.Rotation), C.c_int64, _abi.c_double_p]
+    lib.nyx_oracle_gravity_accel.argtypes = [C.POINTER(_abi.GravityField), C.c_int64, _abi.c_double_p, _abi.c_double_p]
+    lib.nyx_oracle_occultation_factor.argtypes = [C.POINTER(_abi.Config), C.c_int32, C.c_int32, C.c_int64, _abi.c_double_p, _abi.c_int32_p]
+    lib.nyx_oracle_occultation_factor.restype = C.c_double
+    lib.nyx_oracle_error_estimate.argtypes = [C.c_int32, C.c_int32, _abi.c_double_p, _abi.c_double_p, _abi.c_double_p]
+    lib.nyx_oracle_error_estimate.restype = C.c_double
+    lib.nyx_oracle_seconds_to_ns.argtypes = [C.c_double]
+    lib.nyx_oracle_seconds_to_ns.restype = C.c_int64
+    lib.nyx_oracle_ns_to_seconds.argtypes = [C.c_int64]
+    lib.nyx_oracle_ns_to_seconds.restype = C.c_double
+    lib.nyx_oracle_set_ns_rounding.argtypes = [C.c_int32]
+    _LIB = lib
+    return lib
+
+
+def propagate(compiled, batch, duration_ns, n_threads=1):
+    """Oracle twin of GpuContext.propagate."""
+    lib = load()
+    out = batch.copy()
+    stats = _abi.StatsBatch(batch.n)
+    cin, cout, cst = batch.as_c(), out.as_c(), stats.as_c()
+    rc = lib.nyx_oracle_propagate_batch(C.byref(compiled.cfg), C.byref(cin), int(duration_ns), C.byref(cout), C.byref(cst), n_threads)
+    assert rc == 0
+    return out, stats
+
+
+def eom(compiled, epoch_ns, dt_s, y, ctx_stm=None, dry=0.0, extra=0.0, srp_area=0.0, drag_area=0.0):
+    lib = load()
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    out = np.zeros_like(y)
+    stm_p = _abi.c_double_p() if ctx_stm is None else np.ascontiguousarray(ctx_stm, dtype=np.float64).ctypes.data_as(_abi.c_double_p)
+    st = lib.nyx_oracle_eom(C.byref(compiled.cfg), int(epoch_ns), float(dt_s), y.ctypes.data_as(_abi.c_double_p), stm_p,
+                            dry, extra, srp_area, drag_area, out.ctypes.data_as(_abi.c_double_p))
+    return st, out
+
+
+def dual_eom(compiled, epoch_ns, y9, dry=0.0, extra=0.0, srp_area=0.0):
+    lib = load()
+    y9 = np.ascontiguousarray(y9, dtype=np.float64)
+    fx, grad = np.zeros(9), np.zeros(81)
+    st = lib.nyx_oracle_dual_eom(C.byref(compiled.cfg), int(epoch_ns), y9.ctypes.data_as(_abi.c_double_p), dry, extra, srp_area,
+                                 fx.ctypes.data_as(_abi.c_double_p), grad.ctypes.data_as(_abi.c_double_p))
+    return st, fx, grad.reshape(9, 9).T  # column-major -> [i, j]
