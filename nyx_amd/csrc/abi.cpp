@@ -1,0 +1,540 @@
+// abi.cpp — host side of the C-ABI (include/nyx_hip.h): context creation (table building,
+// column scheduling, upload), batch staging and kernel launch.  Compiled with hipcc.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/nyx_hip.h"
+#include "butcher.h"
+#include "devcfg.h"
+
+extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg, const HarmEntry *htab,
+                                           const int32_t *colstart, const double *colscale, const double *records,
+                                           int n_waves, hipStream_t stream);
+
+// ---------------------------------------------------------------------------------------------
+// error reporting
+// ---------------------------------------------------------------------------------------------
+
+static thread_local char g_err[512] = "";
+
+void nyx_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *nyx_hip_last_error(void) { return g_err; }
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            nyx_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return NYX_HIP_RC_HIP_ERROR;                                                   \
+        }                                                                                  \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+
+struct DevArrays {  // one SoA batch resident on the device
+    int64_t cap = 0;
+    int64_t *epoch = nullptr, *step = nullptr;
+    double *f[13] = {nullptr};
+    int32_t *status = nullptr, *last_attempts = nullptr;
+    int64_t *last_step = nullptr, *n_acc = nullptr, *n_rej = nullptr, *n_evals = nullptr;
+    double *last_error = nullptr;
+};
+
+struct nyx_hip_ctx {
+    int device = 0;
+    DevCfg host_cfg;
+    DevCfg *d_cfg = nullptr;
+    HarmEntry *d_htab = nullptr;
+    int32_t *d_colstart = nullptr;
+    double *d_colscale = nullptr;
+    double *d_records = nullptr;
+    std::vector<int32_t> col_len;  // rows per column (index = c)
+    int n_waves = 1;
+    int forced_waves = 0;
+    double master_handicap = 0.0;
+    DevArrays in, out;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_ms = -1.0;
+};
+
+static void free_arrays(DevArrays &a) {
+    hipFree(a.epoch); hipFree(a.step);
+    for (auto &p : a.f) hipFree(p);
+    hipFree(a.status); hipFree(a.last_attempts); hipFree(a.last_step); hipFree(a.n_acc); hipFree(a.n_rej);
+    hipFree(a.n_evals); hipFree(a.last_error);
+    a = DevArrays();
+}
+
+static int ensure_arrays(DevArrays &a, int64_t n, bool stats) {
+    if (n <= a.cap) return NYX_HIP_RC_OK;
+    free_arrays(a);
+    int64_t cap = std::max<int64_t>(n, 1024);
+    HIP_TRY(hipMalloc(&a.epoch, cap * sizeof(int64_t)));
+    HIP_TRY(hipMalloc(&a.step, cap * sizeof(int64_t)));
+    for (auto &p : a.f) HIP_TRY(hipMalloc(&p, cap * sizeof(double)));
+    if (stats) {
+        HIP_TRY(hipMalloc(&a.status, cap * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&a.last_attempts, cap * sizeof(int32_t)));
+        HIP_TRY(hipMalloc(&a.last_step, cap * sizeof(int64_t)));
+        HIP_TRY(hipMalloc(&a.n_acc, cap * sizeof(int64_t)));
+        HIP_TRY(hipMalloc(&a.n_rej, cap * sizeof(int64_t)));
+        HIP_TRY(hipMalloc(&a.n_evals, cap * sizeof(int64_t)));
+        HIP_TRY(hipMalloc(&a.last_error, cap * sizeof(double)));
+    }
+    a.cap = cap;
+    return NYX_HIP_RC_OK;
+}
+
+extern "C" int32_t nyx_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int64_t nyx_hip_abi_sizeof(int32_t which) {
+    switch (which) {
+    case 0: return sizeof(nyx_hip_integ_opts_t);
+    case 1: return sizeof(nyx_hip_cheby_segment_t);
+    case 2: return sizeof(nyx_hip_body_t);
+    case 3: return sizeof(nyx_hip_rotation_t);
+    case 4: return sizeof(nyx_hip_gravity_field_t);
+    case 5: return sizeof(nyx_hip_srp_t);
+    case 6: return sizeof(nyx_hip_drag_t);
+    case 7: return sizeof(nyx_hip_config_t);
+    case 8: return sizeof(nyx_hip_states_t);
+    case 9: return sizeof(nyx_hip_step_stats_t);
+    default: return -1;
+    }
+}
+
+static double ns_to_seconds_host(int64_t ns) {  // Duration::to_seconds for |ns| < 1 century, ns >= 0
+    int64_t q = ns / 1000000000LL, r = ns % 1000000000LL;
+    return (double)q + (double)r * 1e-9;
+}
+
+// GravityField::new (reference dynamics/gravity_field.rs:52-132) re-expressed as the per-column
+// entry table the kernel streams (see HarmEntry in devcfg.h).
+static void build_harmonics(const nyx_hip_gravity_field_t *g, std::vector<HarmEntry> &tab, std::vector<int32_t> &colstart,
+                            std::vector<double> &colscale, std::vector<int32_t> &col_len, int &n_cols) {
+    const int N = g->degree, M = std::min(g->order, g->degree);
+    auto C = [&](int n, int m) -> double { return (n < 0 || m < 0 || n > N || m > n || m > M) ? 0.0 : g->c_nm[(size_t)n * (n + 1) / 2 + m]; };
+    auto S = [&](int n, int m) -> double { return (n < 0 || m < 0 || n > N || m > n || m > M) ? 0.0 : g->s_nm[(size_t)n * (n + 1) / 2 + m]; };
+    auto vr01 = [&](int n, int m) -> double {
+        double nf = n, mf = m;
+        double v = std::sqrt((nf - mf) * (nf + mf + 1.0));
+        return m == 0 ? v / std::sqrt(2.0) : v;
+    };
+    auto vr11 = [&](int n, int m) -> double {
+        double nf = n, mf = m;
+        double v = std::sqrt(((2.0 * nf + 1.0) * (nf + mf + 2.0) * (nf + mf + 1.0)) / (2.0 * nf + 3.0));
+        return m == 0 ? v / std::sqrt(2.0) : v;
+    };
+    auto bnm = [&](int n, int m) -> double {
+        double nf = n, mf = m;
+        return std::sqrt(((2.0 * nf + 1.0) * (2.0 * nf - 1.0)) / ((nf + mf) * (nf - mf)));
+    };
+    auto cnm = [&](int n, int m) -> double {
+        double nf = n, mf = m;
+        return std::sqrt(((2.0 * nf + 1.0) * (nf + mf - 1.0) * (nf - mf - 1.0)) / ((nf - mf) * (nf + mf) * (2.0 * nf - 3.0)));
+    };
+    // diagonal A[n][n]
+    std::vector<double> diag(N + 3);
+    diag[0] = 1.0;
+    for (int n = 1; n <= N + 2; ++n) diag[n] = std::sqrt(1.0 + 1.0 / (2.0 * (double)n)) * diag[n - 1];
+    // column c carries x/y terms of order m = c (c <= M) and z/w terms of order m = c - 1 (c - 1 <= M)
+    n_cols = std::min(N + 1, M + 1);
+    const double SQ2 = std::sqrt(2.0);
+    colstart.assign(n_cols + 2, 0);
+    colscale.assign(n_cols + 2, 0.0);
+    col_len.assign(n_cols + 2, 0);
+    tab.clear();
+    for (int c = 1; c <= n_cols; ++c) {
+        colstart[c] = (int32_t)tab.size();
+        colscale[c] = (double)c * SQ2;
+        col_len[c] = N + 2 - c;
+        for (int n = c; n <= N + 1; ++n) {
+            HarmEntry e;
+            e.bb = (n == c) ? diag[c] : bnm(n, c);
+            e.cc = (n <= c + 1) ? 0.0 : cnm(n, c);
+            e.t1 = C(n, c);
+            e.t2 = S(n, c);
+            // z: (n, m = c-1), n in 1..N
+            const bool zok = (n >= 1 && n <= N);
+            e.t3 = zok ? SQ2 * vr01(n, c - 1) * C(n, c - 1) : 0.0;
+            e.t4 = zok ? SQ2 * vr01(n, c - 1) * S(n, c - 1) : 0.0;
+            // w: (n-1, m = c-1), n-1 in 1..N
+            const bool wok = (n - 1 >= 1 && n - 1 <= N && n - 1 >= c - 1);
+            e.t5 = wok ? SQ2 * vr11(n - 1, c - 1) * C(n - 1, c - 1) : 0.0;
+            e.t6 = wok ? SQ2 * vr11(n - 1, c - 1) * S(n - 1, c - 1) : 0.0;
+            tab.push_back(e);
+        }
+    }
+}
+
+// Column schedule: wave w walks at most two contiguous ranges — long columns from the low-c end,
+// topped up with short columns from the high-c end — so that one complex power per range suffices.
+static void build_schedule(nyx_hip_ctx *ctx, int n_waves) {
+    DevCfg &dc = ctx->host_cfg;
+    const int nc = dc.n_cols;
+    for (int w = 0; w < DEV_MAX_WAVES; ++w) dc.n_ranges[w] = 0;
+    dc.n_waves = n_waves;
+    if (!dc.has_grav || nc == 0) return;
+    double total = ctx->master_handicap * (n_waves > 1 ? 1.0 : 0.0);
+    for (int c = 1; c <= nc; ++c) total += ctx->col_len[c];
+    int lo = 1, hi = nc;
+    for (int w = n_waves - 1; w >= 0; --w) {  // master (wave 0) last: it takes what is left
+        double tgt = total / n_waves;
+        if (w == 0) {
+            if (lo <= hi) { dc.range_c0[0][0] = lo; dc.range_cnt[0][0] = hi - lo + 1; dc.n_ranges[0] = 1; }
+            break;
+        }
+        double load = 0.0;
+        int a0 = lo, acnt = 0;
+        while (lo <= hi && (load + ctx->col_len[lo] <= tgt + 0.5 * ctx->col_len[lo] || acnt == 0)) {
+            load += ctx->col_len[lo];
+            ++lo; ++acnt;
+            if (load >= tgt) break;
+        }
+        int bend = hi, bcnt = 0;
+        while (lo <= hi && load + ctx->col_len[hi] <= tgt + 0.5 * ctx->col_len[hi]) {
+            load += ctx->col_len[hi];
+            --hi; ++bcnt;
+        }
+        int nr = 0;
+        if (acnt) { dc.range_c0[w][nr] = a0; dc.range_cnt[w][nr] = acnt; ++nr; }
+        if (bcnt) { dc.range_c0[w][nr] = bend - bcnt + 1; dc.range_cnt[w][nr] = bcnt; ++nr; }
+        dc.n_ranges[w] = nr;
+    }
+}
+
+static int pick_waves(const nyx_hip_ctx *ctx, int64_t n) {
+    if (!ctx->host_cfg.has_grav) return 1;
+    if (ctx->forced_waves > 0) return std::min(ctx->forced_waves, DEV_MAX_WAVES);
+    // Fill the 256 CUs: workgroups = ceil(n/64); with fewer than ~2 workgroups per CU the column
+    // split is what creates the waves that keep the SIMDs busy.
+    const int64_t wgs = (n + DEV_LANES - 1) / DEV_LANES;
+    const int deg = ctx->host_cfg.deg;
+    int want = 8;
+    if (wgs >= 2048) want = 1;
+    else if (wgs >= 1024) want = 2;
+    else if (wgs >= 512) want = 4;
+    if (deg < 8) want = std::min(want, 2);
+    else if (deg < 24) want = std::min(want, 4);
+    return want;
+}
+
+extern "C" int32_t nyx_hip_ctx_set_column_waves(nyx_hip_ctx *ctx, int32_t waves) {
+    if (!ctx || waves < 0 || waves > DEV_MAX_WAVES) return NYX_HIP_RC_BAD_ARG;
+    ctx->forced_waves = waves;
+    return NYX_HIP_RC_OK;
+}
+
+extern "C" double nyx_hip_last_kernel_ms(nyx_hip_ctx *ctx) {
+    if (!ctx || !ctx->ev1) return -1.0;
+    if (hipEventSynchronize(ctx->ev1) != hipSuccess) return -1.0;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) return -1.0;
+    ctx->last_ms = ms;
+    return ms;
+}
+
+extern "C" void nyx_hip_ctx_destroy(nyx_hip_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipFree(ctx->d_cfg); hipFree(ctx->d_htab); hipFree(ctx->d_colstart); hipFree(ctx->d_colscale); hipFree(ctx->d_records);
+    free_arrays(ctx->in);
+    free_arrays(ctx->out);
+    if (ctx->ev0) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    delete ctx;
+}
+
+extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t device, nyx_hip_ctx **out) {
+    if (!cfg || !out) { nyx_set_error("null argument"); return NYX_HIP_RC_BAD_ARG; }
+    *out = nullptr;
+    if (cfg->abi_version != NYX_HIP_ABI_VERSION) { nyx_set_error("ABI version mismatch"); return NYX_HIP_RC_BAD_ARG; }
+    const nyx_hip_integ_opts_t &o = cfg->opts;
+    if (o.method < 0 || o.method > 5 || o.error_ctrl < 0 || o.error_ctrl > 6) { nyx_set_error("bad method / error_ctrl"); return NYX_HIP_RC_BAD_ARG; }
+    if (cfg->flags & NYX_HIP_FLAG_STM) { nyx_set_error("STM propagation is not on the device path yet"); return NYX_HIP_RC_UNSUPPORTED; }
+    if (cfg->drag) { nyx_set_error("drag is not on the device path yet"); return NYX_HIP_RC_UNSUPPORTED; }
+    if (nyx_hip_device_count() <= device || device < 0) { nyx_set_error("no HIP device %d", device); return NYX_HIP_RC_NO_DEVICE; }
+    HIP_TRY(hipSetDevice(device));
+
+    nyx_hip_ctx *ctx = new nyx_hip_ctx();
+    ctx->device = device;
+    DevCfg &dc = ctx->host_cfg;
+    std::memset(&dc, 0, sizeof dc);
+    const NyxTableau &tb = NYX_TABLEAUX[o.method];
+    dc.stages = tb.stages; dc.order = tb.order;
+    dc.fixed_step = o.fixed_step; dc.error_ctrl = o.error_ctrl; dc.attempts = o.attempts; dc.flags = (int32_t)cfg->flags;
+    dc.tol = o.tolerance;
+    dc.init_step_ns = o.init_step_ns; dc.min_step_ns = o.min_step_ns; dc.max_step_ns = o.max_step_ns;
+    dc.min_step_s = ns_to_seconds_host(o.min_step_ns);
+    dc.max_step_s = ns_to_seconds_host(o.max_step_ns);
+    dc.inv_order = 1.0 / (double)tb.order;
+    dc.inv_order_m1 = 1.0 / (double)(tb.order - 1);
+    {
+        int a_idx = 0;
+        dc.c[0] = 0.0;
+        for (int i = 0; i < tb.stages - 1; ++i) {  // c_i = running sum of row i (reference instance.rs:379-387)
+            double ci = 0.0;
+            for (int j = 0; j <= i; ++j) { dc.a[a_idx] = tb.a[a_idx]; ci += tb.a[a_idx]; ++a_idx; }
+            dc.c[i + 1] = ci;
+        }
+        for (int i = 0; i < tb.stages; ++i) { dc.b[i] = tb.b[i]; dc.bdiff[i] = tb.b[i] - tb.b[i + tb.stages]; }
+    }
+    dc.mu_central = cfg->central_mu_km3_s2;
+
+    // ---- bodies -> slots (every non-central body referenced by a model)
+    std::vector<int> slot_of(cfg->n_bodies, -1);
+    auto slot_for = [&](int b) -> int {
+        if (b < 0 || b >= cfg->n_bodies) return -2;
+        if (cfg->bodies[b].n_chain == 0) return -1;  // the integration centre
+        if (slot_of[b] >= 0) return slot_of[b];
+        if (dc.n_slots >= DEV_MAX_SLOTS) return -2;
+        const nyx_hip_body_t &bd = cfg->bodies[b];
+        DevSlot &s = dc.slot[dc.n_slots];
+        s.mu = bd.mu_km3_s2; s.radius = bd.mean_radius_km; s.n_chain = bd.n_chain;
+        for (int k = 0; k < bd.n_chain; ++k) { s.seg[k] = bd.chain_segment[k]; s.sign[k] = (double)bd.chain_sign[k]; }
+        slot_of[b] = dc.n_slots++;
+        return slot_of[b];
+    };
+    for (int b = 0; b < cfg->n_bodies; ++b)
+        if (cfg->bodies[b].n_chain == 0) dc.central_radius = cfg->bodies[b].mean_radius_km;
+    for (int k = 0; k < cfg->n_point_masses; ++k) {
+        int s = slot_for(cfg->point_mass_body[k]);
+        if (s == -2) { delete ctx; nyx_set_error("too many / invalid point-mass bodies"); return NYX_HIP_RC_BAD_ARG; }
+        if (s == -1) continue;  // central body is skipped by PointMasses::eom (orbital.rs:219-222)
+        dc.pm_slot[dc.n_pm++] = s;
+    }
+    if (cfg->srp) {
+        dc.has_srp = 1;
+        dc.srp_estimate = cfg->srp->estimate;
+        dc.phi = cfg->srp->phi_w_m2;
+        dc.c_m_s = cfg->speed_of_light_km_s * 1e3;
+        int s = slot_for(cfg->srp->sun_body);
+        if (s < 0) { delete ctx; nyx_set_error("SRP light source must be a non-central body with an ephemeris"); return NYX_HIP_RC_BAD_ARG; }
+        dc.sun_slot = s;
+        dc.n_shadow = cfg->srp->n_shadow_bodies;
+        if (dc.n_shadow > DEV_MAX_SLOTS) { delete ctx; nyx_set_error("too many shadow bodies"); return NYX_HIP_RC_BAD_ARG; }
+        for (int k = 0; k < dc.n_shadow; ++k) {
+            int sb = slot_for(cfg->srp->shadow_body[k]);
+            if (sb == -2) { delete ctx; nyx_set_error("invalid shadow body"); return NYX_HIP_RC_BAD_ARG; }
+            dc.shadow_slot[k] = sb;
+        }
+    }
+    // ---- segments
+    if (cfg->n_segments > DEV_MAX_SEG) { delete ctx; nyx_set_error("too many ephemeris segments"); return NYX_HIP_RC_BAD_ARG; }
+    std::vector<double> records;
+    dc.n_seg = cfg->n_segments;
+    for (int i = 0; i < cfg->n_segments; ++i) {
+        const nyx_hip_cheby_segment_t &sg = cfg->segments[i];
+        DevSeg &d = dc.seg[i];
+        d.init_et = sg.init_et_s; d.interval = sg.interval_s; d.n_rec = sg.n_records; d.n_coef = sg.n_coeffs;
+        d.end_et = sg.init_et_s + sg.interval_s * (double)sg.n_records;
+        d.stride = 2 + 3 * sg.n_coeffs;
+        d.offset = (int32_t)records.size();
+        records.insert(records.end(), sg.records, sg.records + (size_t)sg.n_records * d.stride);
+    }
+    for (int s = 0; s < dc.n_slots; ++s)
+        for (int k = 0; k < dc.slot[s].n_chain; ++k)
+            if (dc.slot[s].seg[k] < 0 || dc.slot[s].seg[k] >= dc.n_seg) { delete ctx; nyx_set_error("bad chain segment index"); return NYX_HIP_RC_BAD_ARG; }
+
+    // ---- gravity field
+    std::vector<HarmEntry> tab;
+    std::vector<int32_t> colstart;
+    std::vector<double> colscale;
+    if (cfg->gravity) {
+        const nyx_hip_gravity_field_t *g = cfg->gravity;
+        if (g->degree < 1 || !g->c_nm || !g->s_nm) { delete ctx; nyx_set_error("bad gravity field"); return NYX_HIP_RC_BAD_ARG; }
+        dc.has_grav = 1; dc.deg = g->degree; dc.ord = std::min(g->order, g->degree);
+        dc.g_mu = g->mu_km3_s2; dc.g_re = g->eq_radius_km;
+        for (int k = 0; k < 3; ++k) { dc.g_rot.ra[k] = g->rotation.ra_deg[k]; dc.g_rot.dec[k] = g->rotation.dec_deg[k]; dc.g_rot.w[k] = g->rotation.w_deg[k]; }
+        int n_cols = 0;
+        build_harmonics(g, tab, colstart, colscale, ctx->col_len, n_cols);
+        dc.n_cols = n_cols;
+    }
+    // master's serial work per force evaluation, in units of one harmonics term (~10 f64 ops):
+    // RK bookkeeping + rotation (3 sincos) + Chebyshev chains + third-body and SRP/eclipse terms.
+    {
+        double hcap = 40.0;
+        int nseg_eval = 0;
+        for (int s = 0; s < dc.n_slots; ++s) nseg_eval += dc.slot[s].n_chain;
+        hcap += 12.0 * nseg_eval + 10.0 * dc.n_pm + (dc.has_srp ? 45.0 + 25.0 * dc.n_shadow : 0.0) + (dc.has_grav ? 35.0 : 0.0);
+        if (const char *e = std::getenv("NYX_HIP_MASTER_HANDICAP")) hcap = std::atof(e);
+        ctx->master_handicap = hcap;
+    }
+    build_schedule(ctx, 1);
+
+    // ---- upload
+    HIP_TRY(hipMalloc(&ctx->d_cfg, sizeof(DevCfg)));
+    HIP_TRY(hipMemcpy(ctx->d_cfg, &dc, sizeof(DevCfg), hipMemcpyHostToDevice));
+    if (!tab.empty()) {
+        HIP_TRY(hipMalloc(&ctx->d_htab, tab.size() * sizeof(HarmEntry)));
+        HIP_TRY(hipMemcpy(ctx->d_htab, tab.data(), tab.size() * sizeof(HarmEntry), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(&ctx->d_colstart, colstart.size() * sizeof(int32_t)));
+        HIP_TRY(hipMemcpy(ctx->d_colstart, colstart.data(), colstart.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(&ctx->d_colscale, colscale.size() * sizeof(double)));
+        HIP_TRY(hipMemcpy(ctx->d_colscale, colscale.data(), colscale.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (records.empty()) records.push_back(0.0);
+    HIP_TRY(hipMalloc(&ctx->d_records, records.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(ctx->d_records, records.data(), records.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipEventCreate(&ctx->ev0));
+    HIP_TRY(hipEventCreate(&ctx->ev1));
+    *out = ctx;
+    return NYX_HIP_RC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// propagate
+// ---------------------------------------------------------------------------------------------
+
+static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t *out, nyx_hip_step_stats_t *st,
+                  int64_t duration_ns, int64_t end_epoch_ns, int use_end, hipStream_t stream, bool time_it) {
+    const int nw = pick_waves(ctx, in->n);
+    if (nw != ctx->host_cfg.n_waves) {
+        build_schedule(ctx, nw);
+        HIP_TRY(hipMemcpyAsync(ctx->d_cfg, &ctx->host_cfg, sizeof(DevCfg), hipMemcpyHostToDevice, stream));
+    }
+    DevBatch bt;
+    std::memset(&bt, 0, sizeof bt);
+    bt.n = in->n;
+    bt.duration_ns = duration_ns; bt.end_epoch_ns = end_epoch_ns; bt.use_end_epoch = use_end;
+    bt.epoch_ns = in->epoch_ns;
+    bt.x = in->x_km; bt.y = in->y_km; bt.z = in->z_km; bt.vx = in->vx_km_s; bt.vy = in->vy_km_s; bt.vz = in->vz_km_s;
+    bt.cr = in->cr; bt.cd = in->cd; bt.mprop = in->prop_mass_kg; bt.mdry = in->dry_mass_kg; bt.mextra = in->extra_mass_kg;
+    bt.asrp = in->srp_area_m2; bt.adrag = in->drag_area_m2; bt.step_in = in->step_ns;
+    bt.o_epoch_ns = out->epoch_ns;
+    bt.o_x = out->x_km; bt.o_y = out->y_km; bt.o_z = out->z_km; bt.o_vx = out->vx_km_s; bt.o_vy = out->vy_km_s; bt.o_vz = out->vz_km_s;
+    bt.o_cr = out->cr; bt.o_cd = out->cd; bt.o_mprop = out->prop_mass_kg; bt.o_mdry = out->dry_mass_kg;
+    bt.o_mextra = out->extra_mass_kg; bt.o_asrp = out->srp_area_m2; bt.o_adrag = out->drag_area_m2; bt.o_step = out->step_ns;
+    if (st) {
+        bt.status = st->status; bt.last_step_ns = st->last_step_ns; bt.last_error = st->last_error;
+        bt.last_attempts = st->last_attempts; bt.n_acc = st->n_accepted; bt.n_rej = st->n_rejected; bt.n_evals = st->n_evals;
+    }
+    if (time_it) HIP_TRY(hipEventRecord(ctx->ev0, stream));
+    HIP_TRY(nyx_launch_propagate(bt, ctx->d_cfg, ctx->d_htab, ctx->d_colstart, ctx->d_colscale, ctx->d_records, nw, stream));
+    if (time_it) HIP_TRY(hipEventRecord(ctx->ev1, stream));
+    return NYX_HIP_RC_OK;
+}
+
+static int check_states(const nyx_hip_states_t *s, const char *what) {
+    if (!s || s->n < 0 || !s->epoch_ns || !s->x_km || !s->y_km || !s->z_km || !s->vx_km_s || !s->vy_km_s || !s->vz_km_s) {
+        nyx_set_error("%s: epoch and the six Cartesian arrays are mandatory", what);
+        return NYX_HIP_RC_BAD_ARG;
+    }
+    return NYX_HIP_RC_OK;
+}
+
+extern "C" int32_t nyx_hip_propagate_batch_device(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t duration_ns,
+                                                  nyx_hip_states_t *out, nyx_hip_step_stats_t *stats, void *hip_stream) {
+    if (!ctx) { nyx_set_error("null ctx"); return NYX_HIP_RC_BAD_ARG; }
+    if (int rc = check_states(in, "in")) return rc;
+    if (int rc = check_states(out, "out")) return rc;
+    if (in->n == 0) return NYX_HIP_RC_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = launch(ctx, in, out, stats, duration_ns, 0, 0, (hipStream_t)hip_stream, true);
+    return rc;
+}
+
+static int host_propagate(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t duration_ns, int64_t end_epoch_ns, int use_end,
+                          nyx_hip_states_t *out, nyx_hip_step_stats_t *stats) {
+    if (!ctx) { nyx_set_error("null ctx"); return NYX_HIP_RC_BAD_ARG; }
+    if (int rc = check_states(in, "in")) return rc;
+    if (int rc = check_states(out, "out")) return rc;
+    const int64_t n = in->n;
+    if (n == 0) return NYX_HIP_RC_OK;
+    if (out->n < n) { nyx_set_error("out batch smaller than in batch"); return NYX_HIP_RC_BAD_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (int rc = ensure_arrays(ctx->in, n, false)) return rc;
+    if (int rc = ensure_arrays(ctx->out, n, true)) return rc;
+    DevArrays &di = ctx->in, &dq = ctx->out;
+    const double *hin[13] = {in->x_km, in->y_km, in->z_km, in->vx_km_s, in->vy_km_s, in->vz_km_s, in->cr, in->cd,
+                             in->prop_mass_kg, in->dry_mass_kg, in->extra_mass_kg, in->srp_area_m2, in->drag_area_m2};
+    HIP_TRY(hipMemcpy(di.epoch, in->epoch_ns, n * sizeof(int64_t), hipMemcpyHostToDevice));
+    for (int k = 0; k < 13; ++k)
+        if (hin[k]) HIP_TRY(hipMemcpy(di.f[k], hin[k], n * sizeof(double), hipMemcpyHostToDevice));
+    if (in->step_ns) HIP_TRY(hipMemcpy(di.step, in->step_ns, n * sizeof(int64_t), hipMemcpyHostToDevice));
+
+    nyx_hip_states_t din;
+    std::memset(&din, 0, sizeof din);
+    din.n = n; din.epoch_ns = di.epoch;
+    double **dinf[13] = {&din.x_km, &din.y_km, &din.z_km, &din.vx_km_s, &din.vy_km_s, &din.vz_km_s, &din.cr, &din.cd,
+                         &din.prop_mass_kg, &din.dry_mass_kg, &din.extra_mass_kg, &din.srp_area_m2, &din.drag_area_m2};
+    for (int k = 0; k < 13; ++k) *dinf[k] = hin[k] ? di.f[k] : nullptr;
+    din.step_ns = in->step_ns ? di.step : nullptr;
+
+    nyx_hip_states_t dout;
+    std::memset(&dout, 0, sizeof dout);
+    dout.n = n; dout.epoch_ns = dq.epoch;
+    double **doutf[13] = {&dout.x_km, &dout.y_km, &dout.z_km, &dout.vx_km_s, &dout.vy_km_s, &dout.vz_km_s, &dout.cr, &dout.cd,
+                          &dout.prop_mass_kg, &dout.dry_mass_kg, &dout.extra_mass_kg, &dout.srp_area_m2, &dout.drag_area_m2};
+    for (int k = 0; k < 13; ++k) *doutf[k] = dq.f[k];
+    dout.step_ns = dq.step;
+    nyx_hip_step_stats_t dst = {dq.status, dq.last_step, dq.last_error, dq.last_attempts, dq.n_acc, dq.n_rej, dq.n_evals};
+
+    if (int rc = launch(ctx, &din, &dout, &dst, duration_ns, end_epoch_ns, use_end, nullptr, true)) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    {
+        float ms = 0.f;
+        ctx->last_ms = (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ? ms : -1.0;
+    }
+    double *hout[13] = {out->x_km, out->y_km, out->z_km, out->vx_km_s, out->vy_km_s, out->vz_km_s, out->cr, out->cd,
+                        out->prop_mass_kg, out->dry_mass_kg, out->extra_mass_kg, out->srp_area_m2, out->drag_area_m2};
+    HIP_TRY(hipMemcpy(out->epoch_ns, dq.epoch, n * sizeof(int64_t), hipMemcpyDeviceToHost));
+    for (int k = 0; k < 13; ++k)
+        if (hout[k]) HIP_TRY(hipMemcpy(hout[k], dq.f[k], n * sizeof(double), hipMemcpyDeviceToHost));
+    if (out->step_ns) HIP_TRY(hipMemcpy(out->step_ns, dq.step, n * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (stats) {
+        if (stats->status) HIP_TRY(hipMemcpy(stats->status, dq.status, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (stats->last_step_ns) HIP_TRY(hipMemcpy(stats->last_step_ns, dq.last_step, n * sizeof(int64_t), hipMemcpyDeviceToHost));
+        if (stats->last_error) HIP_TRY(hipMemcpy(stats->last_error, dq.last_error, n * sizeof(double), hipMemcpyDeviceToHost));
+        if (stats->last_attempts) HIP_TRY(hipMemcpy(stats->last_attempts, dq.last_attempts, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (stats->n_accepted) HIP_TRY(hipMemcpy(stats->n_accepted, dq.n_acc, n * sizeof(int64_t), hipMemcpyDeviceToHost));
+        if (stats->n_rejected) HIP_TRY(hipMemcpy(stats->n_rejected, dq.n_rej, n * sizeof(int64_t), hipMemcpyDeviceToHost));
+        if (stats->n_evals) HIP_TRY(hipMemcpy(stats->n_evals, dq.n_evals, n * sizeof(int64_t), hipMemcpyDeviceToHost));
+    }
+    return NYX_HIP_RC_OK;
+}
+
+extern "C" int32_t nyx_hip_propagate_batch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t duration_ns,
+                                           nyx_hip_states_t *out, nyx_hip_step_stats_t *stats) {
+    return host_propagate(ctx, in, duration_ns, 0, 0, out, stats);
+}
+
+extern "C" int32_t nyx_hip_propagate_until_epoch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t end_epoch_ns,
+                                                 nyx_hip_states_t *out, nyx_hip_step_stats_t *stats) {
+    return host_propagate(ctx, in, 0, end_epoch_ns, 1, out, stats);
+}
+
+// Introspection for tests / DESIGN.md: column schedule of the current context.
+extern "C" int32_t nyx_hip_debug_schedule(nyx_hip_ctx *ctx, int32_t n_waves, int32_t *loads /* [8] */) {
+    if (!ctx || n_waves < 1 || n_waves > DEV_MAX_WAVES) return NYX_HIP_RC_BAD_ARG;
+    const int keep = ctx->host_cfg.n_waves;
+    build_schedule(ctx, n_waves);
+    for (int w = 0; w < DEV_MAX_WAVES; ++w) {
+        int l = 0;
+        for (int q = 0; q < ctx->host_cfg.n_ranges[w]; ++q)
+            for (int c = ctx->host_cfg.range_c0[w][q]; c < ctx->host_cfg.range_c0[w][q] + ctx->host_cfg.range_cnt[w][q]; ++c) l += ctx->col_len[c];
+        loads[w] = l;
+    }
+    build_schedule(ctx, keep);
+    return NYX_HIP_RC_OK;
+}

@@ -1,0 +1,100 @@
+// devcfg.h — flattened, device-resident description of one propagation context.
+// Built once by nyx_hip_ctx_create (abi.cpp) from nyx_hip_config_t; read by every wave through
+// scalar loads (all fields are wave-uniform).
+#ifndef NYX_AMD_DEVCFG_H
+#define NYX_AMD_DEVCFG_H
+
+#include <stdint.h>
+
+#define DEV_MAX_STAGES 16
+#define DEV_MAX_SLOTS 4   /* non-central bodies whose position is evaluated per stage */
+#define DEV_MAX_SEG 8
+#define DEV_MAX_WAVES 8   /* waves per 64-trajectory workgroup (column split) */
+#define DEV_MAX_RANGES 6  /* contiguous column ranges per wave */
+#define DEV_LANES 64
+
+struct DevSeg {
+    double init_et, interval, end_et;
+    int32_t n_rec, n_coef, stride, offset; /* offset (in doubles) into the records array */
+};
+
+struct DevSlot { /* one evaluated body: position w.r.t. the integration centre = sum sign_k * seg_k */
+    double mu, radius;
+    int32_t n_chain;
+    int32_t seg[4];
+    double sign[4];
+};
+
+struct DevRot {
+    double ra[3], dec[3], w[3];
+};
+
+struct DevCfg {
+    /* --- integrator (IntegratorOptions + flattened tableau) --- */
+    int32_t stages, order, fixed_step, error_ctrl, attempts, flags;
+    double tol;
+    int64_t init_step_ns, min_step_ns, max_step_ns;
+    double min_step_s, max_step_s;
+    double inv_order, inv_order_m1; /* 1/order, 1/(order-1) as the reference evaluates them */
+    double a[DEV_MAX_STAGES * (DEV_MAX_STAGES - 1) / 2];
+    double b[DEV_MAX_STAGES];
+    double bdiff[DEV_MAX_STAGES]; /* b_i - b*_i */
+    double c[DEV_MAX_STAGES];     /* running row sums of A, in the reference's order */
+
+    /* --- dynamics --- */
+    double mu_central;
+    double central_radius;
+    int32_t n_slots, n_seg;
+    DevSlot slot[DEV_MAX_SLOTS];
+    DevSeg seg[DEV_MAX_SEG];
+    int32_t n_pm;
+    int32_t pm_slot[DEV_MAX_SLOTS];
+
+    int32_t has_srp, srp_estimate, sun_slot, n_shadow;
+    int32_t shadow_slot[DEV_MAX_SLOTS]; /* -1 => the central body */
+    double phi, c_m_s;
+
+    int32_t has_grav, deg, ord, n_cols; /* columns 1..n_cols (= deg+1) */
+    double g_mu, g_re;
+    DevRot g_rot;
+
+    int32_t has_drag, drag_density;
+    double drag_rho0, drag_r0, drag_ref_alt_m, drag_max_alt_m, drag_re;
+    DevRot d_rot;
+
+    /* --- column schedule: wave w walks n_ranges[w] contiguous column ranges --- */
+    int32_t n_waves;
+    int32_t n_ranges[DEV_MAX_WAVES];
+    int32_t range_c0[DEV_MAX_WAVES][DEV_MAX_RANGES];
+    int32_t range_cnt[DEV_MAX_WAVES][DEV_MAX_RANGES];
+};
+
+/* One (n', c) entry of the harmonics table, 64 B = one s_load_dwordx16:
+ *   bb, cc : recursion coefficients b[n'][c], c[n'][c] (row n' = c holds the diagonal seed in bb)
+ *   t1, t2 : C, S of (n', c)                       -> x / y sums
+ *   t3, t4 : sqrt2 * vr01[n'][c-1] * (C, S)[n'][c-1]   -> z sum
+ *   t5, t6 : sqrt2 * vr11[n'-1][c-1] * (C, S)[n'-1][c-1] -> w sum */
+struct HarmEntry {
+    double bb, cc, t1, t2, t3, t4, t5, t6;
+};
+
+struct DevBatch { /* device pointers of one launch */
+    int64_t n;
+    int64_t duration_ns;
+    int64_t end_epoch_ns;
+    int32_t use_end_epoch;
+    int32_t _pad;
+    const int64_t *epoch_ns;
+    const double *x, *y, *z, *vx, *vy, *vz, *cr, *cd, *mprop, *mdry, *mextra, *asrp, *adrag;
+    const int64_t *step_in;
+    int64_t *o_epoch_ns;
+    double *o_x, *o_y, *o_z, *o_vx, *o_vy, *o_vz, *o_cr, *o_cd, *o_mprop, *o_mdry, *o_mextra, *o_asrp, *o_adrag;
+    int64_t *o_step;
+    int32_t *status;
+    int64_t *last_step_ns;
+    double *last_error;
+    int32_t *last_attempts;
+    int64_t *n_acc, *n_rej, *n_evals;
+};
+
+#endif
