@@ -16,8 +16,8 @@
 #include "devcfg.h"
 
 extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg, const HarmEntry *htab,
-                                           const int32_t *colstart, const double *colscale, const double *records,
-                                           int n_waves, hipStream_t stream);
+                                           const ColHdr *cols, const double *records, int n_waves, int rec_lds_doubles,
+                                           hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // error reporting
@@ -61,8 +61,7 @@ struct nyx_hip_ctx {
     DevCfg host_cfg;
     DevCfg *d_cfg = nullptr;
     HarmEntry *d_htab = nullptr;
-    int32_t *d_colstart = nullptr;
-    double *d_colscale = nullptr;
+    ColHdr *d_cols = nullptr;
     double *d_records = nullptr;
     std::vector<int32_t> col_len;  // rows per column (index = c)
     int n_waves = 1;
@@ -130,8 +129,8 @@ static double ns_to_seconds_host(int64_t ns) {  // Duration::to_seconds for |ns|
 
 // GravityField::new (reference dynamics/gravity_field.rs:52-132) re-expressed as the per-column
 // entry table the kernel streams (see HarmEntry in devcfg.h).
-static void build_harmonics(const nyx_hip_gravity_field_t *g, std::vector<HarmEntry> &tab, std::vector<int32_t> &colstart,
-                            std::vector<double> &colscale, std::vector<int32_t> &col_len, int &n_cols) {
+static void build_harmonics(const nyx_hip_gravity_field_t *g, std::vector<HarmEntry> &tab, std::vector<ColHdr> &cols,
+                            std::vector<int32_t> &col_len, int &n_cols) {
     const int N = g->degree, M = std::min(g->order, g->degree);
     auto C = [&](int n, int m) -> double { return (n < 0 || m < 0 || n > N || m > n || m > M) ? 0.0 : g->c_nm[(size_t)n * (n + 1) / 2 + m]; };
     auto S = [&](int n, int m) -> double { return (n < 0 || m < 0 || n > N || m > n || m > M) ? 0.0 : g->s_nm[(size_t)n * (n + 1) / 2 + m]; };
@@ -160,18 +159,23 @@ static void build_harmonics(const nyx_hip_gravity_field_t *g, std::vector<HarmEn
     // column c carries x/y terms of order m = c (c <= M) and z/w terms of order m = c - 1 (c - 1 <= M)
     n_cols = std::min(N + 1, M + 1);
     const double SQ2 = std::sqrt(2.0);
-    colstart.assign(n_cols + 2, 0);
-    colscale.assign(n_cols + 2, 0.0);
+    ColHdr zero_hdr;
+    std::memset(&zero_hdr, 0, sizeof zero_hdr);
+    cols.assign(n_cols + 2, zero_hdr);
     col_len.assign(n_cols + 2, 0);
     tab.clear();
     for (int c = 1; c <= n_cols; ++c) {
-        colstart[c] = (int32_t)tab.size();
-        colscale[c] = (double)c * SQ2;
-        col_len[c] = N + 2 - c;
+        const int rows = N + 2 - c;
+        const int nb = (rows + 3) / 4;
+        cols[c].start = (int32_t)tab.size();
+        cols[c].nb = nb;
+        cols[c].scale = (double)c * SQ2;
+        cols[c].diag = diag[c];
+        col_len[c] = 4 * nb;
         for (int n = c; n <= N + 1; ++n) {
             HarmEntry e;
-            e.bb = (n == c) ? diag[c] : bnm(n, c);
-            e.cc = (n <= c + 1) ? 0.0 : cnm(n, c);
+            e.bb = (n == c) ? 0.0 : bnm(n, c);
+            e.cc = (n == c) ? -1.0 : ((n == c + 1) ? 0.0 : cnm(n, c));
             e.t1 = C(n, c);
             e.t2 = S(n, c);
             // z: (n, m = c-1), n in 1..N
@@ -184,35 +188,43 @@ static void build_harmonics(const nyx_hip_gravity_field_t *g, std::vector<HarmEn
             e.t6 = wok ? SQ2 * vr11(n - 1, c - 1) * S(n - 1, c - 1) : 0.0;
             tab.push_back(e);
         }
+        HarmEntry z;
+        std::memset(&z, 0, sizeof z);
+        for (int k = rows; k < 4 * nb; ++k) tab.push_back(z);  // neutral padding rows
     }
 }
 
 // Column schedule: wave w walks at most two contiguous ranges — long columns from the low-c end,
 // topped up with short columns from the high-c end — so that one complex power per range suffices.
+// The master (wave 0) carries the serial work of the force evaluation (`master_handicap`, in units
+// of one harmonics term), so it receives a reduced share of the columns, possibly none.
 static void build_schedule(nyx_hip_ctx *ctx, int n_waves) {
     DevCfg &dc = ctx->host_cfg;
     const int nc = dc.n_cols;
     for (int w = 0; w < DEV_MAX_WAVES; ++w) dc.n_ranges[w] = 0;
     dc.n_waves = n_waves;
     if (!dc.has_grav || nc == 0) return;
-    double total = ctx->master_handicap * (n_waves > 1 ? 1.0 : 0.0);
-    for (int c = 1; c <= nc; ++c) total += ctx->col_len[c];
+    double terms = 0.0;
+    for (int c = 1; c <= nc; ++c) terms += ctx->col_len[c];
+    if (n_waves == 1) {
+        dc.range_c0[0][0] = 1; dc.range_cnt[0][0] = nc; dc.n_ranges[0] = 1;
+        return;
+    }
+    double share = 1.0 - ctx->master_handicap / ((terms + ctx->master_handicap) / n_waves);  // of a worker's load
+    if (share < 0.0) share = 0.0;
+    if (const char *e = std::getenv("NYX_HIP_MASTER_SHARE")) share = std::atof(e);
+    const double tgt = terms / ((double)(n_waves - 1) + share);
     int lo = 1, hi = nc;
-    for (int w = n_waves - 1; w >= 0; --w) {  // master (wave 0) last: it takes what is left
-        double tgt = total / n_waves;
-        if (w == 0) {
-            if (lo <= hi) { dc.range_c0[0][0] = lo; dc.range_cnt[0][0] = hi - lo + 1; dc.n_ranges[0] = 1; }
-            break;
-        }
+    for (int w = n_waves - 1; w >= 1; --w) {
         double load = 0.0;
         int a0 = lo, acnt = 0;
-        while (lo <= hi && (load + ctx->col_len[lo] <= tgt + 0.5 * ctx->col_len[lo] || acnt == 0)) {
+        const bool last_worker = (w == 1) && share <= 0.0;
+        while (lo <= hi && (last_worker || acnt == 0 || load + 0.5 * ctx->col_len[lo] <= tgt)) {
             load += ctx->col_len[lo];
             ++lo; ++acnt;
-            if (load >= tgt) break;
         }
         int bend = hi, bcnt = 0;
-        while (lo <= hi && load + ctx->col_len[hi] <= tgt + 0.5 * ctx->col_len[hi]) {
+        while (lo <= hi && load + 0.5 * ctx->col_len[hi] <= tgt) {
             load += ctx->col_len[hi];
             --hi; ++bcnt;
         }
@@ -221,6 +233,7 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves) {
         if (bcnt) { dc.range_c0[w][nr] = bend - bcnt + 1; dc.range_cnt[w][nr] = bcnt; ++nr; }
         dc.n_ranges[w] = nr;
     }
+    if (lo <= hi) { dc.range_c0[0][0] = lo; dc.range_cnt[0][0] = hi - lo + 1; dc.n_ranges[0] = 1; }
 }
 
 static int pick_waves(const nyx_hip_ctx *ctx, int64_t n) {
@@ -257,7 +270,7 @@ extern "C" double nyx_hip_last_kernel_ms(nyx_hip_ctx *ctx) {
 extern "C" void nyx_hip_ctx_destroy(nyx_hip_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
-    hipFree(ctx->d_cfg); hipFree(ctx->d_htab); hipFree(ctx->d_colstart); hipFree(ctx->d_colscale); hipFree(ctx->d_records);
+    hipFree(ctx->d_cfg); hipFree(ctx->d_htab); hipFree(ctx->d_cols); hipFree(ctx->d_records);
     free_arrays(ctx->in);
     free_arrays(ctx->out);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
@@ -283,6 +296,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
     const NyxTableau &tb = NYX_TABLEAUX[o.method];
     dc.stages = tb.stages; dc.order = tb.order;
     dc.fixed_step = o.fixed_step; dc.error_ctrl = o.error_ctrl; dc.attempts = o.attempts; dc.flags = (int32_t)cfg->flags;
+    if (const char *e = std::getenv("NYX_HIP_DEBUG")) dc.flags |= (int32_t)std::strtol(e, nullptr, 0) & 0xff00;  // timing-only switches
     dc.tol = o.tolerance;
     dc.init_step_ns = o.init_step_ns; dc.min_step_ns = o.min_step_ns; dc.max_step_ns = o.max_step_ns;
     dc.min_step_s = ns_to_seconds_host(o.min_step_ns);
@@ -358,8 +372,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
 
     // ---- gravity field
     std::vector<HarmEntry> tab;
-    std::vector<int32_t> colstart;
-    std::vector<double> colscale;
+    std::vector<ColHdr> cols;
     if (cfg->gravity) {
         const nyx_hip_gravity_field_t *g = cfg->gravity;
         if (g->degree < 1 || !g->c_nm || !g->s_nm) { delete ctx; nyx_set_error("bad gravity field"); return NYX_HIP_RC_BAD_ARG; }
@@ -367,7 +380,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
         dc.g_mu = g->mu_km3_s2; dc.g_re = g->eq_radius_km;
         for (int k = 0; k < 3; ++k) { dc.g_rot.ra[k] = g->rotation.ra_deg[k]; dc.g_rot.dec[k] = g->rotation.dec_deg[k]; dc.g_rot.w[k] = g->rotation.w_deg[k]; }
         int n_cols = 0;
-        build_harmonics(g, tab, colstart, colscale, ctx->col_len, n_cols);
+        build_harmonics(g, tab, cols, ctx->col_len, n_cols);
         dc.n_cols = n_cols;
     }
     // master's serial work per force evaluation, in units of one harmonics term (~10 f64 ops):
@@ -380,6 +393,9 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
         if (const char *e = std::getenv("NYX_HIP_MASTER_HANDICAP")) hcap = std::atof(e);
         ctx->master_handicap = hcap;
     }
+    records.resize(records.size() + 16, 0.0);  // padding for the 16-wide coefficient window
+    dc.rec_doubles = (int32_t)records.size();
+    dc.rec_in_lds = (records.size() * sizeof(double) <= 24 * 1024) ? 1 : 0;
     build_schedule(ctx, 1);
 
     // ---- upload
@@ -388,12 +404,9 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
     if (!tab.empty()) {
         HIP_TRY(hipMalloc(&ctx->d_htab, tab.size() * sizeof(HarmEntry)));
         HIP_TRY(hipMemcpy(ctx->d_htab, tab.data(), tab.size() * sizeof(HarmEntry), hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc(&ctx->d_colstart, colstart.size() * sizeof(int32_t)));
-        HIP_TRY(hipMemcpy(ctx->d_colstart, colstart.data(), colstart.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        HIP_TRY(hipMalloc(&ctx->d_colscale, colscale.size() * sizeof(double)));
-        HIP_TRY(hipMemcpy(ctx->d_colscale, colscale.data(), colscale.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(&ctx->d_cols, cols.size() * sizeof(ColHdr)));
+        HIP_TRY(hipMemcpy(ctx->d_cols, cols.data(), cols.size() * sizeof(ColHdr), hipMemcpyHostToDevice));
     }
-    if (records.empty()) records.push_back(0.0);
     HIP_TRY(hipMalloc(&ctx->d_records, records.size() * sizeof(double)));
     HIP_TRY(hipMemcpy(ctx->d_records, records.data(), records.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipEventCreate(&ctx->ev0));
@@ -430,7 +443,8 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
         bt.last_attempts = st->last_attempts; bt.n_acc = st->n_accepted; bt.n_rej = st->n_rejected; bt.n_evals = st->n_evals;
     }
     if (time_it) HIP_TRY(hipEventRecord(ctx->ev0, stream));
-    HIP_TRY(nyx_launch_propagate(bt, ctx->d_cfg, ctx->d_htab, ctx->d_colstart, ctx->d_colscale, ctx->d_records, nw, stream));
+    HIP_TRY(nyx_launch_propagate(bt, ctx->d_cfg, ctx->d_htab, ctx->d_cols, ctx->d_records, nw,
+                                 ctx->host_cfg.rec_in_lds ? ctx->host_cfg.rec_doubles : 0, stream));
     if (time_it) HIP_TRY(hipEventRecord(ctx->ev1, stream));
     return NYX_HIP_RC_OK;
 }

@@ -45,6 +45,7 @@ struct DevCfg {
     double mu_central;
     double central_radius;
     int32_t n_slots, n_seg;
+    int32_t rec_in_lds, rec_doubles; /* segment records staged in LDS when they fit */
     DevSlot slot[DEV_MAX_SLOTS];
     DevSeg seg[DEV_MAX_SEG];
     int32_t n_pm;
@@ -69,8 +70,18 @@ struct DevCfg {
     int32_t range_cnt[DEV_MAX_WAVES][DEV_MAX_RANGES];
 };
 
+/* Column header (32 B = one s_load_dwordx8): rows of column c start at htab[start] and come in
+ * `nb` batches of 4 entries (zero-padded); the recursion is seeded with a2 = diag / rho, a1 = 0. */
+struct ColHdr {
+    int32_t start, nb;
+    double scale; /* c * sqrt(2) */
+    double diag;  /* A[c][c] */
+    double _pad;
+};
+
 /* One (n', c) entry of the harmonics table, 64 B = one s_load_dwordx16:
- *   bb, cc : recursion coefficients b[n'][c], c[n'][c] (row n' = c holds the diagonal seed in bb)
+ *   bb, cc : recursion coefficients b[n'][c], c[n'][c]; row n' = c has bb = 0, cc = -1 so that the
+ *            generic step  a_n = (bb rho_u) a1 - (cc rho^2) a2  yields rho * diag from the seed
  *   t1, t2 : C, S of (n', c)                       -> x / y sums
  *   t3, t4 : sqrt2 * vr01[n'][c-1] * (C, S)[n'][c-1]   -> z sum
  *   t5, t6 : sqrt2 * vr11[n'-1][c-1] * (C, S)[n'-1][c-1] -> w sum */

@@ -33,8 +33,7 @@
 #define CAS __attribute__((address_space(4)))
 typedef const CAS DevCfg *CfgPtr;
 typedef const CAS HarmEntry *HarmPtr;
-typedef const CAS int32_t *CIntPtr;
-typedef const CAS double *CDblPtr;
+typedef const CAS ColHdr *ColPtr;
 
 #define DEVFN static __device__ __forceinline__
 
@@ -119,32 +118,44 @@ DEVFN void rotation_dcm(const CAS DevRot &rot, double et_s, double *m) {
     m[8] = c2;
 }
 
-// SPK type 2 evaluation (Clenshaw); record index is per lane, metadata is uniform.
-DEVFN int cheby_eval(const CAS DevSeg &sg, const double *__restrict__ records, double et_s, double *r3) {
+// SPK type 2 evaluation (Clenshaw); record index is per lane, metadata is uniform.  `records` is the
+// LDS copy of the segment table when it fits (cfg->rec_in_lds), else the global array.  The 16-wide
+// coefficient window is loaded before the recurrence starts (the table is padded by 16 doubles), so the
+// loads are independent of the serial w0/w1/w2 chain.
+#define CHEB_MAXC 16
+template <typename P>
+DEVFN int cheby_eval(const CAS DevSeg &sg, P records, double et_s, double *r3) {
     const double rel = (et_s - sg.init_et) / sg.interval;
     int idx = (int)floor(rel);
     int st = NYX_HIP_OK;
     if (idx < 0 || idx > sg.n_rec || (idx == sg.n_rec && et_s > sg.end_et)) st = NYX_HIP_ERR_EPHEM_RANGE;
     idx = idx < 0 ? 0 : (idx >= sg.n_rec ? sg.n_rec - 1 : idx);
     const int nc = sg.n_coef;
-    const double *rec = records + sg.offset + (int64_t)idx * sg.stride;
+    P rec = records + sg.offset + idx * sg.stride;
     const double t = (et_s - rec[0]) / rec[1];
     const double two_t = 2.0 * t;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const double *cf = rec + 2 + c * nc;
+        P cf = rec + 2 + c * nc;
+        double cv[CHEB_MAXC];
+#pragma unroll
+        for (int j = 0; j < CHEB_MAXC; ++j) cv[j] = cf[j];
         double w0 = 0.0, w1 = 0.0, w2;
-        for (int j = nc - 1; j >= 1; --j) {
-            w2 = w1;
-            w1 = w0;
-            w0 = cf[j] + (two_t * w1 - w2);
+#pragma unroll
+        for (int j = CHEB_MAXC - 1; j >= 1; --j) {
+            if (j < nc) {  // uniform
+                w2 = w1;
+                w1 = w0;
+                w0 = cv[j] + (two_t * w1 - w2);
+            }
         }
-        r3[c] = cf[0] + (t * w0 - w1);
+        r3[c] = cv[0] + (t * w0 - w1);
     }
     return st;
 }
 
-DEVFN void epoch_data(CfgPtr cfg, const double *__restrict__ records, int64_t epoch_ns, EpochData &ed) {
+template <typename P>
+DEVFN void epoch_data(CfgPtr cfg, P records, int64_t epoch_ns, EpochData &ed) {
     const double et = ns_to_seconds(epoch_ns);
     ed.status = NYX_HIP_OK;
     if (cfg->has_grav) rotation_dcm(cfg->g_rot, et, ed.m);
@@ -291,8 +302,21 @@ DEVFN void cpow_uniform(double zr, double zi, int e, double &pr, double &pi) {
     }
 }
 
-DEVFN void harmonics_partial(CfgPtr cfg, HarmPtr htab, CIntPtr colstart, CDblPtr colscale, int wave, double zr,
-                             double zi, double rho_u, double rho, double &px, double &py, double &pz, double &pw) {
+#define HARM_TERM(h)                                                              \
+    {                                                                             \
+        const double an = __builtin_fma((h).bb * rho_u, a1, -(((h).cc * rho2) * a2)); \
+        s1 = __builtin_fma(an, (h).t1, s1);                                       \
+        s2 = __builtin_fma(an, (h).t2, s2);                                       \
+        s3 = __builtin_fma(an, (h).t3, s3);                                       \
+        s4 = __builtin_fma(an, (h).t4, s4);                                       \
+        s5 = __builtin_fma(an, (h).t5, s5);                                       \
+        s6 = __builtin_fma(an, (h).t6, s6);                                       \
+        a2 = a1;                                                                  \
+        a1 = an;                                                                  \
+    }
+
+DEVFN void harmonics_partial(CfgPtr cfg, HarmPtr htab, ColPtr cols, int wave, double zr, double zi, double rho_u,
+                             double rho, double inv_rho, double &px, double &py, double &pz, double &pw) {
     px = py = pz = pw = 0.0;
     const double rho2 = rho * rho;
     const int nr = cfg->n_ranges[wave];
@@ -302,26 +326,23 @@ DEVFN void harmonics_partial(CfgPtr cfg, HarmPtr htab, CIntPtr colstart, CDblPtr
         double rc, ic;
         cpow_uniform(zr, zi, c0 - 1, rc, ic);
         for (int c = c0; c < c0 + cnt; ++c) {
-            HarmPtr e = htab + colstart[c];
-            const int len = cfg->deg + 2 - c;  // rows c .. N+1
-            // row n' = c: diagonal seed
-            double a1 = rho * e[0].bb;
-            double a2 = 0.0;
-            double s1 = a1 * e[0].t1, s2 = a1 * e[0].t2, s3 = a1 * e[0].t3, s4 = a1 * e[0].t4, s5 = a1 * e[0].t5,
-                   s6 = a1 * e[0].t6;
-            for (int k = 1; k < len; ++k) {
-                const HarmEntry CAS &h = e[k];
-                const double an = __builtin_fma(h.bb * rho_u, a1, -((h.cc * rho2) * a2));
-                s1 = __builtin_fma(an, h.t1, s1);
-                s2 = __builtin_fma(an, h.t2, s2);
-                s3 = __builtin_fma(an, h.t3, s3);
-                s4 = __builtin_fma(an, h.t4, s4);
-                s5 = __builtin_fma(an, h.t5, s5);
-                s6 = __builtin_fma(an, h.t6, s6);
-                a2 = a1;
-                a1 = an;
+            const ColHdr CAS &hd = cols[c];
+            HarmPtr e = htab + hd.start;
+            const int nb = hd.nb;
+            double a1 = 0.0, a2 = hd.diag * inv_rho;
+            double s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0;
+            for (int b = 0; b < nb; ++b, e += 4) {
+                // four 64-byte entries per batch: 4 x s_load_dwordx16 in flight, then 40 f64 VALU ops
+                const HarmEntry CAS &h0 = e[0];
+                const HarmEntry CAS &h1 = e[1];
+                const HarmEntry CAS &h2 = e[2];
+                const HarmEntry CAS &h3 = e[3];
+                HARM_TERM(h0)
+                HARM_TERM(h1)
+                HARM_TERM(h2)
+                HARM_TERM(h3)
             }
-            const double sc = rho * colscale[c];  // rho * c * sqrt(2)
+            const double sc = rho * hd.scale;  // rho * c * sqrt(2)
             px = __builtin_fma(sc, __builtin_fma(rc, s1, ic * s2), px);
             py = __builtin_fma(sc, __builtin_fma(rc, s2, -(ic * s1)), py);
             pz = __builtin_fma(rho, __builtin_fma(rc, s3, ic * s4), pz);
@@ -402,24 +423,37 @@ DEVFN double error_estimate(int ec, const double *e, const double *cand, const d
 // The kernel
 // ---------------------------------------------------------------------------------------------
 
+#define NIN 5
+// timing-only debug switches (NYX_HIP_DEBUG env, never set in production): results are physically wrong
+#define DBG_SKIP_SERIAL 0x100
+#define DBG_SKIP_HARMONICS 0x200
 #define KB(stage, comp) kbuf[((stage)*6 + (comp)) * DEV_LANES + lane]
 
 extern "C" __global__ void __launch_bounds__(DEV_MAX_WAVES *DEV_LANES)
-    nyx_propagate_kernel(DevBatch bt, const DevCfg *cfg_g, const HarmEntry *htab_g, const int32_t *colstart_g,
-                         const double *colscale_g, const double *__restrict__ records) {
+    nyx_propagate_kernel(DevBatch bt, const DevCfg *cfg_g, const HarmEntry *htab_g, const ColHdr *cols_g,
+                         const double *__restrict__ records) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *kbuf = (double *)smem;                          // [16][6][64]
-    double *inb = kbuf + DEV_MAX_STAGES * 6 * DEV_LANES;    // [4][64]: zr, zi, rho_u, rho
-    double *part = inb + 4 * DEV_LANES;                     // [P-1][4][64]
+    double *inb = kbuf + DEV_MAX_STAGES * 6 * DEV_LANES;    // [5][64]: zr, zi, rho_u, rho, 1/rho
+    double *part = inb + NIN * DEV_LANES;                     // [P-1][4][64]
     volatile int *ctl = (volatile int *)(part + (DEV_MAX_WAVES - 1) * 4 * DEV_LANES);
+    double *rec_lds = (double *)(ctl + 16);  // [cfg->rec_doubles] when cfg->rec_in_lds
 
     const int lane = threadIdx.x & (DEV_LANES - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nw = (int)(blockDim.x >> 6);
     CfgPtr cfg = (CfgPtr)cfg_g;
     HarmPtr htab = (HarmPtr)htab_g;
-    CIntPtr colstart = (CIntPtr)colstart_g;
-    CDblPtr colscale = (CDblPtr)colscale_g;
+    ColPtr cols = (ColPtr)cols_g;
+
+    // ephemeris records -> LDS (all waves cooperate), so the per-lane Chebyshev windows are LDS reads
+    const bool rec_in_lds = cfg->rec_in_lds != 0;
+    if (rec_in_lds) {
+        const int nd = cfg->rec_doubles;
+        for (int q = (int)threadIdx.x; q < nd; q += (int)blockDim.x) rec_lds[q] = records[q];
+    }
+    if (lane == 0 && wave == 0) ctl[0] = 0;
+    __syncthreads();
 
     // ------------------------------------------------------------------ workers
     if (wave != 0) {
@@ -428,8 +462,10 @@ extern "C" __global__ void __launch_bounds__(DEV_MAX_WAVES *DEV_LANES)
             if (ctl[0]) break;
             const double zr = inb[0 * DEV_LANES + lane], zi = inb[1 * DEV_LANES + lane];
             const double rho_u = inb[2 * DEV_LANES + lane], rho = inb[3 * DEV_LANES + lane];
-            double px, py, pz, pw;
-            harmonics_partial(cfg, htab, colstart, colscale, wave, zr, zi, rho_u, rho, px, py, pz, pw);
+            const double inv_rho = inb[4 * DEV_LANES + lane];
+            double px = 0.0, py = 0.0, pz = 0.0, pw = 0.0;
+            if (!(cfg->flags & DBG_SKIP_HARMONICS))
+                harmonics_partial(cfg, htab, cols, wave, zr, zi, rho_u, rho, inv_rho, px, py, pz, pw);
             double *pp = part + (wave - 1) * 4 * DEV_LANES;
             pp[0 * DEV_LANES + lane] = px;
             pp[1 * DEV_LANES + lane] = py;
@@ -461,6 +497,7 @@ extern "C" __global__ void __launch_bounds__(DEV_MAX_WAVES *DEV_LANES)
     const bool has_srp = cfg->has_srp != 0;
     const bool any_force = has_srp;  // drag is not on the device path yet (ctx_create refuses it)
     const int64_t min_step_ns = cfg->min_step_ns;
+    const bool dbg_skip_serial = (cfg->flags & DBG_SKIP_SERIAL) != 0;
 
     const int64_t duration = bt.use_end_epoch ? (bt.end_epoch_ns - epoch) : bt.duration_ns;
     const int64_t stop = epoch + duration;
@@ -483,8 +520,6 @@ extern "C" __global__ void __launch_bounds__(DEV_MAX_WAVES *DEV_LANES)
     bool prev_kind = false;
     double h = 0.0;
     int attempts = 1;
-
-    if (lane == 0) ctl[0] = 0;
 
     EpochData cur, nxt;
 
@@ -551,6 +586,7 @@ extern "C" __global__ void __launch_bounds__(DEV_MAX_WAVES *DEV_LANES)
                     inb[1 * DEV_LANES + lane] = rho * t_;
                     inb[2 * DEV_LANES + lane] = rho * u_;
                     inb[3 * DEV_LANES + lane] = rho;
+                    inb[4 * DEV_LANES + lane] = r_ / cfg->g_re;
                     if (nw > 1) __syncthreads();  // B1
                 }
             }
@@ -562,21 +598,22 @@ extern "C" __global__ void __launch_bounds__(DEV_MAX_WAVES *DEV_LANES)
                 const double rmag = norm3(ys[0], ys[1], ys[2]);
                 const double f = -cfg->mu_central / cube(rmag);
                 acc[0] = f * ys[0]; acc[1] = f * ys[1]; acc[2] = f * ys[2];
-                if (cfg->n_pm > 0) {
+                if (cfg->n_pm > 0 && !dbg_skip_serial) {
                     double a3[3];
                     point_masses_accel(cfg, cur, ys, a3);
                     acc[0] += a3[0]; acc[1] += a3[1]; acc[2] += a3[2];
                 }
             }
             double fsrp[3] = {0.0, 0.0, 0.0};
-            if (i >= 0 && has_srp) srp_force(cfg, cur, ys, cr, a_srp, fsrp);
-            if (i + 1 < stages) {
+            if (i >= 0 && has_srp && !dbg_skip_serial) srp_force(cfg, cur, ys, cr, a_srp, fsrp);
+            if (i + 1 < stages && !(dbg_skip_serial && i >= 0)) {
                 const double dt = (i + 1 == 0) ? 0.0 : cfg->c[i + 1] * h;
-                epoch_data(cfg, records, epoch + seconds_to_ns(dt), nxt);
+                if (rec_in_lds) epoch_data(cfg, (const double *)rec_lds, epoch + seconds_to_ns(dt), nxt);
+                else epoch_data(cfg, records, epoch + seconds_to_ns(dt), nxt);
             }
             if (i >= 0 && has_grav) {
-                harmonics_partial(cfg, htab, colstart, colscale, 0, inb[0 * DEV_LANES + lane], inb[1 * DEV_LANES + lane],
-                                  inb[2 * DEV_LANES + lane], inb[3 * DEV_LANES + lane], px, py, pz, pw);
+                harmonics_partial(cfg, htab, cols, 0, inb[0 * DEV_LANES + lane], inb[1 * DEV_LANES + lane],
+                                  inb[2 * DEV_LANES + lane], inb[3 * DEV_LANES + lane], inb[4 * DEV_LANES + lane], px, py, pz, pw);
                 if (nw > 1) __syncthreads();  // B2
                 // ---- Phase C: fold the partials (fixed wave order), rotate back
                 for (int w = 1; w < nw; ++w) {
@@ -706,16 +743,16 @@ extern "C" __global__ void __launch_bounds__(DEV_MAX_WAVES *DEV_LANES)
     }
 }
 
-extern "C" size_t nyx_kernel_lds_bytes() {
-    return (size_t)(DEV_MAX_STAGES * 6 * DEV_LANES + 4 * DEV_LANES + (DEV_MAX_WAVES - 1) * 4 * DEV_LANES) * sizeof(double) + 64;
+extern "C" size_t nyx_kernel_lds_bytes(int rec_doubles) {
+    return (size_t)(DEV_MAX_STAGES * 6 * DEV_LANES + NIN * DEV_LANES + (DEV_MAX_WAVES - 1) * 4 * DEV_LANES + rec_doubles) * sizeof(double) + 64;
 }
 
 extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg, const HarmEntry *htab,
-                                           const int32_t *colstart, const double *colscale, const double *records,
-                                           int n_waves, hipStream_t stream) {
+                                           const ColHdr *cols, const double *records, int n_waves, int rec_lds_doubles,
+                                           hipStream_t stream) {
     const int64_t blocks = (bt.n + DEV_LANES - 1) / DEV_LANES;
     if (blocks == 0) return hipSuccess;
     hipLaunchKernelGGL(nyx_propagate_kernel, dim3((unsigned)blocks), dim3((unsigned)(n_waves * DEV_LANES)),
-                       nyx_kernel_lds_bytes(), stream, bt, cfg, htab, colstart, colscale, records);
+                       nyx_kernel_lds_bytes(rec_lds_doubles), stream, bt, cfg, htab, cols, records);
     return hipGetLastError();
 }
