@@ -66,8 +66,9 @@ struct nyx_hip_ctx {
     std::vector<int32_t> col_len;  // rows per column (index = c)
     int n_waves = 1;
     int forced_waves = 0;
-    double master_handicap = 0.0;
+    double role_handicap[3] = {0.0, 0.0, 0.0};  // integrator, almanac, perturbations (harmonics-term units)
     DevArrays in, out;
+    int64_t *d_prof = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_ms = -1.0;
 };
@@ -196,8 +197,8 @@ static void build_harmonics(const nyx_hip_gravity_field_t *g, std::vector<HarmEn
 
 // Column schedule: wave w walks at most two contiguous ranges — long columns from the low-c end,
 // topped up with short columns from the high-c end — so that one complex power per range suffices.
-// The master (wave 0) carries the serial work of the force evaluation (`master_handicap`, in units
-// of one harmonics term), so it receives a reduced share of the columns, possibly none.
+// Waves 0/1/2 also carry the integrator / almanac / perturbation duties (`role_handicap`, in units of
+// one harmonics term), so they receive a reduced share of the columns, possibly none.
 static void build_schedule(nyx_hip_ctx *ctx, int n_waves) {
     DevCfg &dc = ctx->host_cfg;
     const int nc = dc.n_cols;
@@ -206,20 +207,33 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves) {
     if (!dc.has_grav || nc == 0) return;
     double terms = 0.0;
     for (int c = 1; c <= nc; ++c) terms += ctx->col_len[c];
-    if (n_waves == 1) {
-        dc.range_c0[0][0] = 1; dc.range_cnt[0][0] = nc; dc.n_ranges[0] = 1;
-        return;
+    // role handicaps of this workgroup shape (merged roles when there are fewer than three waves)
+    double hc[DEV_MAX_WAVES] = {0};
+    if (n_waves == 1) hc[0] = ctx->role_handicap[0] + ctx->role_handicap[1] + ctx->role_handicap[2];
+    else if (n_waves == 2) { hc[0] = ctx->role_handicap[0]; hc[1] = ctx->role_handicap[1] + ctx->role_handicap[2]; }
+    else { hc[0] = ctx->role_handicap[0]; hc[1] = ctx->role_handicap[1]; hc[2] = ctx->role_handicap[2]; }
+    // water-filling: level such that sum_w max(0, level - hc[w]) = terms
+    double level = 0.0;
+    {
+        double lo = 0.0, hi = terms + hc[0] + hc[1] + hc[2];
+        for (int it = 0; it < 60; ++it) {
+            level = 0.5 * (lo + hi);
+            double s = 0.0;
+            for (int w = 0; w < n_waves; ++w) s += std::max(0.0, level - hc[w]);
+            if (s < terms) lo = level; else hi = level;
+        }
     }
-    double share = 1.0 - ctx->master_handicap / ((terms + ctx->master_handicap) / n_waves);  // of a worker's load
-    if (share < 0.0) share = 0.0;
-    if (const char *e = std::getenv("NYX_HIP_MASTER_SHARE")) share = std::atof(e);
-    const double tgt = terms / ((double)(n_waves - 1) + share);
     int lo = 1, hi = nc;
-    for (int w = n_waves - 1; w >= 1; --w) {
+    // plain column workers first (highest wave index), role waves last so they take what is left
+    for (int w = n_waves - 1; w >= 0; --w) {
+        const double tgt = std::max(0.0, level - hc[w]);
+        if (w == 0) {
+            if (lo <= hi) { dc.range_c0[0][0] = lo; dc.range_cnt[0][0] = hi - lo + 1; dc.n_ranges[0] = 1; }
+            break;
+        }
         double load = 0.0;
         int a0 = lo, acnt = 0;
-        const bool last_worker = (w == 1) && share <= 0.0;
-        while (lo <= hi && (last_worker || acnt == 0 || load + 0.5 * ctx->col_len[lo] <= tgt)) {
+        while (lo <= hi && load + 0.5 * ctx->col_len[lo] <= tgt) {
             load += ctx->col_len[lo];
             ++lo; ++acnt;
         }
@@ -233,22 +247,21 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves) {
         if (bcnt) { dc.range_c0[w][nr] = bend - bcnt + 1; dc.range_cnt[w][nr] = bcnt; ++nr; }
         dc.n_ranges[w] = nr;
     }
-    if (lo <= hi) { dc.range_c0[0][0] = lo; dc.range_cnt[0][0] = hi - lo + 1; dc.n_ranges[0] = 1; }
 }
 
 static int pick_waves(const nyx_hip_ctx *ctx, int64_t n) {
-    if (!ctx->host_cfg.has_grav) return 1;
     if (ctx->forced_waves > 0) return std::min(ctx->forced_waves, DEV_MAX_WAVES);
+    // no harmonics: integrator + almanac + perturbation waves form a 3-stage pipeline
+    if (!ctx->host_cfg.has_grav) return (ctx->host_cfg.n_slots > 0) ? 3 : 1;
     // Fill the 256 CUs: workgroups = ceil(n/64); with fewer than ~2 workgroups per CU the column
     // split is what creates the waves that keep the SIMDs busy.
     const int64_t wgs = (n + DEV_LANES - 1) / DEV_LANES;
     const int deg = ctx->host_cfg.deg;
-    int want = 8;
-    if (wgs >= 2048) want = 1;
-    else if (wgs >= 1024) want = 2;
-    else if (wgs >= 512) want = 4;
-    if (deg < 8) want = std::min(want, 2);
-    else if (deg < 24) want = std::min(want, 4);
+    int want = 16;
+    if (wgs >= 2048) want = 4;
+    else if (wgs >= 512) want = 8;
+    if (deg < 8) want = std::min(want, 4);
+    else if (deg < 24) want = std::min(want, 8);
     return want;
 }
 
@@ -265,6 +278,13 @@ extern "C" double nyx_hip_last_kernel_ms(nyx_hip_ctx *ctx) {
     if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) return -1.0;
     ctx->last_ms = ms;
     return ms;
+}
+
+// Cycle accounting of workgroup 0 of the last launch (NYX_HIP_PROFILE=1): out[16][8], see the kernel.
+extern "C" int32_t nyx_hip_debug_profile(nyx_hip_ctx *ctx, int64_t *out) {
+    if (!ctx || !ctx->d_prof) return NYX_HIP_RC_BAD_ARG;
+    if (hipMemcpy(out, ctx->d_prof, 16 * 8 * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return NYX_HIP_RC_HIP_ERROR;
+    return NYX_HIP_RC_OK;
 }
 
 extern "C" void nyx_hip_ctx_destroy(nyx_hip_ctx *ctx) {
@@ -383,15 +403,19 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
         build_harmonics(g, tab, cols, ctx->col_len, n_cols);
         dc.n_cols = n_cols;
     }
-    // master's serial work per force evaluation, in units of one harmonics term (~10 f64 ops):
-    // RK bookkeeping + rotation (3 sincos) + Chebyshev chains + third-body and SRP/eclipse terms.
+    // serial duties of the role waves per force evaluation, in units of one harmonics term (~10 f64 ops):
+    // integrator: stage combination, body-fixed transform, fold of the partials; almanac: 3 sincos + Chebyshev
+    // chains; perturbations: third-body and SRP/eclipse terms.
     {
-        double hcap = 40.0;
         int nseg_eval = 0;
         for (int s = 0; s < dc.n_slots; ++s) nseg_eval += dc.slot[s].n_chain;
-        hcap += 12.0 * nseg_eval + 10.0 * dc.n_pm + (dc.has_srp ? 45.0 + 25.0 * dc.n_shadow : 0.0) + (dc.has_grav ? 35.0 : 0.0);
-        if (const char *e = std::getenv("NYX_HIP_MASTER_HANDICAP")) hcap = std::atof(e);
-        ctx->master_handicap = hcap;
+        ctx->role_handicap[0] = 60.0;
+        ctx->role_handicap[1] = 18.0 * nseg_eval + (dc.has_grav ? 45.0 : 0.0);
+        ctx->role_handicap[2] = 14.0 * dc.n_pm + (dc.has_srp ? 40.0 + 30.0 * dc.n_shadow : 0.0);
+        if (const char *e = std::getenv("NYX_HIP_ROLE_HANDICAP")) {
+            double h0, h1, h2;
+            if (std::sscanf(e, "%lf,%lf,%lf", &h0, &h1, &h2) == 3) { ctx->role_handicap[0] = h0; ctx->role_handicap[1] = h1; ctx->role_handicap[2] = h2; }
+        }
     }
     records.resize(records.size() + 16, 0.0);  // padding for the 16-wide coefficient window
     dc.rec_doubles = (int32_t)records.size();
@@ -441,6 +465,11 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
     if (st) {
         bt.status = st->status; bt.last_step_ns = st->last_step_ns; bt.last_error = st->last_error;
         bt.last_attempts = st->last_attempts; bt.n_acc = st->n_accepted; bt.n_rej = st->n_rejected; bt.n_evals = st->n_evals;
+    }
+    if (std::getenv("NYX_HIP_PROFILE")) {
+        if (!ctx->d_prof) HIP_TRY(hipMalloc(&ctx->d_prof, 16 * 8 * sizeof(int64_t)));
+        HIP_TRY(hipMemsetAsync(ctx->d_prof, 0, 16 * 8 * sizeof(int64_t), stream));
+        bt.prof = ctx->d_prof;
     }
     if (time_it) HIP_TRY(hipEventRecord(ctx->ev0, stream));
     HIP_TRY(nyx_launch_propagate(bt, ctx->d_cfg, ctx->d_htab, ctx->d_cols, ctx->d_records, nw,

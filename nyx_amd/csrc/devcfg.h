@@ -9,7 +9,7 @@
 #define DEV_MAX_STAGES 16
 #define DEV_MAX_SLOTS 4   /* non-central bodies whose position is evaluated per stage */
 #define DEV_MAX_SEG 8
-#define DEV_MAX_WAVES 8   /* waves per 64-trajectory workgroup (column split) */
+#define DEV_MAX_WAVES 16  /* waves per 64-trajectory workgroup (column split) */
 #define DEV_MAX_RANGES 6  /* contiguous column ranges per wave */
 #define DEV_LANES 64
 
@@ -106,6 +106,7 @@ struct DevBatch { /* device pointers of one launch */
     double *last_error;
     int32_t *last_attempts;
     int64_t *n_acc, *n_rej, *n_evals;
+    int64_t *prof; /* optional [16][8] cycle counters written by workgroup 0 (NYX_HIP_PROFILE) */
 };
 
 #endif

@@ -3,25 +3,28 @@
 // One workgroup integrates 64 trajectories from t0 to tf in a single launch:
 //
 //   * lane <-> trajectory.  Every lane of every wave of the workgroup is bound to the same
-//     trajectory slot, so all shared tables (Butcher tableau, Stokes coefficients and Legendre
-//     recursion constants, column schedule) are WAVE-UNIFORM and are fetched with scalar loads
-//     (s_load_dwordx16 = one 64-byte harmonics entry) straight into SGPRs: the f64 VALU ops take
-//     them as scalar operands, no LDS/VGPR traffic for tables at all.
-//   * wave 0 ("master") owns the RK state machine of the 64 trajectories: per-lane adaptive step,
-//     accept/reject, integer-nanosecond epoch bookkeeping (reference instance.rs:87-493).  The 16
-//     stage derivatives k_i live in LDS (48 KiB per workgroup), not in registers.
+//     trajectory slot, so all shared tables (Stokes coefficients and Legendre recursion constants,
+//     column schedule) are WAVE-UNIFORM and are fetched with scalar loads (4 x s_load_dwordx16 = four
+//     64-byte harmonics entries per batch) straight into SGPRs: the f64 VALU ops take them as scalar
+//     operands, no LDS/VGPR traffic for the big table at all.
+//   * the waves of the workgroup are ROLE-SPECIALISED (all roles also carry harmonics columns):
+//       wave 0  "integrator"    RK state machine of the 64 trajectories: per-lane adaptive step,
+//                               accept/reject, integer-ns epoch bookkeeping (reference instance.rs:87-493),
+//                               stage combination, two-body term, final accumulation of k_i.
+//       wave 1  "almanac"       everything that depends only on the stage EPOCH — body-fixed DCM
+//                               (3 sincos), Sun/Moon Chebyshev chains — one stage AHEAD, into LDS.
+//       wave 2  "perturbations" position-dependent third-body and SRP/eclipse terms of the current stage.
+//       wave 3+ "columns"       spherical-harmonics column workers.
+//     Roles only meet in LDS; two workgroup barriers per force evaluation.  The split keeps every code
+//     path under 128 VGPRs so that 16 waves (4 per SIMD) fit and hide the scalar-load latency.
 //   * the spherical-harmonics double sum (reference gravity_field.rs:148-268), ~97 % of the work,
-//     is split BY COLUMN (order m) over the P waves of the workgroup.  Columns of the normalised
-//     derived-Legendre table are independent given u = z/r, so each wave runs a rolling 2-term
-//     recursion down its columns with O(1) registers instead of the reference's (N+3)^2 matrix;
-//     rho^n is folded into the recursion and (s+it)^m into a per-column complex power.  Partial
-//     accelerations meet in LDS (2 barriers per force evaluation).
-//   * everything that depends only on the stage EPOCH (body-fixed DCM: 3 sincos; Sun/Moon Chebyshev
-//     chains) is computed by the master one stage ahead, inside the window in which the other waves
-//     are busy with harmonics; the position-dependent third-body / SRP / eclipse terms run in the
-//     same window.
+//     is split BY COLUMN (order m) over the waves.  Columns of the normalised derived-Legendre table
+//     are independent given u = z/r, so each wave runs a rolling 2-term recursion down its columns
+//     with O(1) registers instead of the reference's (N+3)^2 matrix; rho^n is folded into the
+//     recursion and (s+it)^m into a per-column complex power.
+//   * the 16 stage derivatives k_i, the Butcher tableau and the ephemeris records live in LDS.
 //
-// FP64 VALU bound by design (no MFMA: there is no dense contraction; HBM traffic is ~250 B per
+// FP64 VALU bound by design (no MFMA: there is no dense contraction; HBM traffic is ~270 B per
 // trajectory per launch).  Compiled with -ffp-contract=off: the RK / two-body part reproduces the
 // reference's operation order (bit-exact golden vectors); FMAs in the harmonics are explicit.
 
@@ -88,11 +91,9 @@ DEVFN double clamp02(double x) { return x < 0.0 ? 0.0 : (x > 2.0 ? 2.0 : x); }
 // Epoch-only data of one stage: body-fixed DCM and body positions
 // ---------------------------------------------------------------------------------------------
 
-struct EpochData {
-    double m[9];                  // DCM inertial -> body-fixed, row-major
-    double bp[DEV_MAX_SLOTS][3];  // slot positions w.r.t. the integration centre
-    int32_t status;
-};
+// LDS slot of one stage's epoch data, per lane: m[9] (DCM inertial -> body-fixed, row-major) then
+// bp[DEV_MAX_SLOTS][3] (slot positions w.r.t. the integration centre).  Field-major: slot[f * 64 + lane].
+#define ED_FIELDS (9 + 3 * DEV_MAX_SLOTS)
 
 DEVFN void rotation_dcm(const CAS DevRot &rot, double et_s, double *m) {
     const double DEG = 3.14159265358979323846 / 180.0;
@@ -155,46 +156,54 @@ DEVFN int cheby_eval(const CAS DevSeg &sg, P records, double et_s, double *r3) {
 }
 
 template <typename P>
-DEVFN void epoch_data(CfgPtr cfg, P records, int64_t epoch_ns, EpochData &ed) {
+DEVFN int epoch_data(CfgPtr cfg, P records, int64_t epoch_ns, double *slot, int lane) {
     const double et = ns_to_seconds(epoch_ns);
-    ed.status = NYX_HIP_OK;
-    if (cfg->has_grav) rotation_dcm(cfg->g_rot, et, ed.m);
+    int status = NYX_HIP_OK;
+    if (cfg->has_grav) {
+        double m[9];
+        rotation_dcm(cfg->g_rot, et, m);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) slot[q * DEV_LANES + lane] = m[q];
+    }
     const int ns = cfg->n_slots;
 #pragma unroll
     for (int s = 0; s < DEV_MAX_SLOTS; ++s) {
-        ed.bp[s][0] = ed.bp[s][1] = ed.bp[s][2] = 0.0;
         if (s < ns) {
+            double b0 = 0.0, b1 = 0.0, b2 = 0.0;
             const int nch = cfg->slot[s].n_chain;
             for (int k = 0; k < nch; ++k) {
                 double p[3];
                 const int sgi = cfg->slot[s].seg[k];
                 int st = cheby_eval(cfg->seg[sgi], records, et, p);
-                if (st) ed.status = st;
+                if (st) status = st;
                 const double sg = cfg->slot[s].sign[k];
-                ed.bp[s][0] = ed.bp[s][0] + sg * p[0];
-                ed.bp[s][1] = ed.bp[s][1] + sg * p[1];
-                ed.bp[s][2] = ed.bp[s][2] + sg * p[2];
+                b0 = b0 + sg * p[0];
+                b1 = b1 + sg * p[1];
+                b2 = b2 + sg * p[2];
             }
+            slot[(9 + 3 * s + 0) * DEV_LANES + lane] = b0;
+            slot[(9 + 3 * s + 1) * DEV_LANES + lane] = b1;
+            slot[(9 + 3 * s + 2) * DEV_LANES + lane] = b2;
         }
     }
+    return status;
 }
+
+#define ED_BP(slot, s, c) (slot)[(9 + 3 * (s) + (c)) * DEV_LANES + lane]
 
 // ---------------------------------------------------------------------------------------------
 // Position-dependent non-harmonic terms (master, inside the harmonics window)
 // ---------------------------------------------------------------------------------------------
 
 // PointMasses::eom, reference dynamics/orbital.rs:214-247
-DEVFN void point_masses_accel(CfgPtr cfg, const EpochData &ed, const double *r, double *acc) {
+DEVFN void point_masses_accel(CfgPtr cfg, const double *ed, int lane, const double *r, double *acc) {
     acc[0] = acc[1] = acc[2] = 0.0;
     const int npm = cfg->n_pm;
 #pragma unroll
     for (int k = 0; k < DEV_MAX_SLOTS; ++k) {
         if (k < npm) {
             const int s = cfg->pm_slot[k];
-            double pij[3];
-#pragma unroll
-            for (int q = 0; q < DEV_MAX_SLOTS; ++q)
-                if (q == s) { pij[0] = ed.bp[q][0]; pij[1] = ed.bp[q][1]; pij[2] = ed.bp[q][2]; }
+            const double pij[3] = {ED_BP(ed, s, 0), ED_BP(ed, s, 1), ED_BP(ed, s, 2)};
             const double r_ij3 = cube(norm3(pij[0], pij[1], pij[2]));
             const double rj0 = r[0] - pij[0], rj1 = r[1] - pij[1], rj2 = r[2] - pij[2];
             const double r_j3 = cube(norm3(rj0, rj1, rj2));
@@ -237,12 +246,9 @@ DEVFN double occultation_pct(double r_back, double r_front, const double *r_eb, 
 }
 
 // SolarPressure::eom (reference dynamics/solarpressure.rs:135-165) + ShadowModel::compute (cosmic/eclipse.rs:69-83)
-DEVFN void srp_force(CfgPtr cfg, const EpochData &ed, const double *r, double cr, double area, double *force) {
+DEVFN void srp_force(CfgPtr cfg, const double *ed, int lane, const double *r, double cr, double area, double *force) {
     const int ss = cfg->sun_slot;
-    double ps[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-    for (int q = 0; q < DEV_MAX_SLOTS; ++q)
-        if (q == ss) { ps[0] = ed.bp[q][0]; ps[1] = ed.bp[q][1]; ps[2] = ed.bp[q][2]; }
+    const double ps[3] = {ED_BP(ed, ss, 0), ED_BP(ed, ss, 1), ED_BP(ed, ss, 2)};
     const double rs0 = r[0] - ps[0], rs1 = r[1] - ps[1], rs2 = r[2] - ps[2];
     const double n = norm3(rs0, rs1, rs2);
     const double u0 = rs0 / n, u1 = rs1 / n, u2 = rs2 / n;
@@ -255,10 +261,8 @@ DEVFN void srp_force(CfgPtr cfg, const EpochData &ed, const double *r, double cr
             const int sb = cfg->shadow_slot[k];
             double pb[3] = {0.0, 0.0, 0.0};
             double rad = cfg->central_radius;
-            if (sb >= 0) {
-#pragma unroll
-                for (int q = 0; q < DEV_MAX_SLOTS; ++q)
-                    if (q == sb) { pb[0] = ed.bp[q][0]; pb[1] = ed.bp[q][1]; pb[2] = ed.bp[q][2]; }
+            if (sb >= 0) {  // uniform
+                pb[0] = ED_BP(ed, sb, 0); pb[1] = ED_BP(ed, sb, 1); pb[2] = ED_BP(ed, sb, 2);
                 rad = cfg->slot[sb].radius;
             }
             const double r_eb[3] = {r[0] - pb[0], r[1] - pb[1], r[2] - pb[2]};
@@ -315,9 +319,27 @@ DEVFN void cpow_uniform(double zr, double zi, int e, double &pr, double &pi) {
         a1 = an;                                                                  \
     }
 
-DEVFN void harmonics_partial(CfgPtr cfg, HarmPtr htab, ColPtr cols, int wave, double zr, double zi, double rho_u,
-                             double rho, double inv_rho, double &px, double &py, double &pz, double &pw) {
-    px = py = pz = pw = 0.0;
+DEVFN uint64_t uniform_u64(uint64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+struct Partial4 {
+    double x, y, z, w;
+};
+
+// Not inlined on purpose: the batch loop wants 64 SGPRs for its four in-flight table entries, which it only
+// gets when it is register-allocated on its own, away from the role code that calls it.  Arguments arrive in
+// VGPRs under the device-function ABI, so the wave-uniform ones are re-scalarised with v_readfirstlane.
+static __device__ __attribute__((noinline)) Partial4 harmonics_partial(uint64_t cfg_u, uint64_t htab_u, uint64_t cols_u, int wave_v,
+                                                                     double zr, double zi, double rho_u, double rho,
+                                                                     double inv_rho) {
+    CfgPtr cfg = (CfgPtr)uniform_u64(cfg_u);
+    HarmPtr htab = (HarmPtr)uniform_u64(htab_u);
+    ColPtr cols = (ColPtr)uniform_u64(cols_u);
+    const int wave = __builtin_amdgcn_readfirstlane(wave_v);
+    double px = 0.0, py = 0.0, pz = 0.0, pw = 0.0;
     const double rho2 = rho * rho;
     const int nr = cfg->n_ranges[wave];
     for (int q = 0; q < nr; ++q) {
@@ -352,6 +374,8 @@ DEVFN void harmonics_partial(CfgPtr cfg, HarmPtr htab, ColPtr cols, int wave, do
             rc = t;
         }
     }
+    Partial4 r = {px, py, pz, pw};
+    return r;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -429,308 +453,374 @@ DEVFN double error_estimate(int ec, const double *e, const double *cand, const d
 #define DBG_SKIP_HARMONICS 0x200
 #define KB(stage, comp) kbuf[((stage)*6 + (comp)) * DEV_LANES + lane]
 
-extern "C" __global__ void __launch_bounds__(DEV_MAX_WAVES *DEV_LANES)
-    nyx_propagate_kernel(DevBatch bt, const DevCfg *cfg_g, const HarmEntry *htab_g, const ColHdr *cols_g,
-                         const double *__restrict__ records) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *kbuf = (double *)smem;                          // [16][6][64]
-    double *inb = kbuf + DEV_MAX_STAGES * 6 * DEV_LANES;    // [5][64]: zr, zi, rho_u, rho, 1/rho
-    double *part = inb + NIN * DEV_LANES;                     // [P-1][4][64]
-    volatile int *ctl = (volatile int *)(part + (DEV_MAX_WAVES - 1) * 4 * DEV_LANES);
-    double *rec_lds = (double *)(ctl + 16);  // [cfg->rec_doubles] when cfg->rec_in_lds
+// LDS carve (doubles unless noted), see nyx_kernel_lds_bytes()
+struct LdsMap {
+    double *kbuf;   // [16][6][64]    stage derivatives k_i
+    double *tabl;   // [16*16 + 3*16] Butcher tableau: rows of A (padded to 16), b, b - b*, c
+    double *ys;     // [6][64]        stage state published by the integrator
+    double *inb;    // [NIN][64]      zr, zi, rho_u, rho, 1/rho
+    double *ed;     // [2][ED_FIELDS][64]  epoch data, double-buffered by stage parity
+    double *pert;   // [6][64]        point-mass accel (3) and SRP force / mass (3)
+    double *step;   // [2][64]        epoch (as i64 bits) and h of the current attempt
+    double *part;   // [P][4][64]     harmonics partials (wave 0's slot unused)
+    int *edst;      // [2][64]        almanac status per buffer
+    int *pertst;    // [64]
+    int *ctl;       // [16]
+    double *rec;    // [rec_doubles]
+};
 
-    const int lane = threadIdx.x & (DEV_LANES - 1);
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int nw = (int)(blockDim.x >> 6);
-    CfgPtr cfg = (CfgPtr)cfg_g;
-    HarmPtr htab = (HarmPtr)htab_g;
-    ColPtr cols = (ColPtr)cols_g;
+DEVFN LdsMap carve_lds(char *smem, int n_waves) {
+    LdsMap m;
+    double *p = (double *)smem;
+    m.kbuf = p; p += DEV_MAX_STAGES * 6 * DEV_LANES;
+    m.tabl = p; p += DEV_MAX_STAGES * DEV_MAX_STAGES + 3 * DEV_MAX_STAGES;
+    m.ys = p; p += 6 * DEV_LANES;
+    m.inb = p; p += NIN * DEV_LANES;
+    m.ed = p; p += 2 * ED_FIELDS * DEV_LANES;
+    m.pert = p; p += 6 * DEV_LANES;
+    m.step = p; p += 2 * DEV_LANES;
+    m.part = p; p += n_waves * 4 * DEV_LANES;
+    m.edst = (int *)p; p += DEV_LANES;       // 2*64 ints
+    m.pertst = (int *)p; p += DEV_LANES / 2; // 64 ints
+    m.ctl = (int *)p; p += 8;
+    m.rec = p;
+    return m;
+}
 
-    // ephemeris records -> LDS (all waves cooperate), so the per-lane Chebyshev windows are LDS reads
+extern "C" size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles) {
+    size_t d = (size_t)DEV_MAX_STAGES * 6 * DEV_LANES + DEV_MAX_STAGES * DEV_MAX_STAGES + 3 * DEV_MAX_STAGES + 6 * DEV_LANES +
+               NIN * DEV_LANES + 2 * ED_FIELDS * DEV_LANES + 6 * DEV_LANES + 2 * DEV_LANES + (size_t)n_waves * 4 * DEV_LANES +
+               DEV_LANES + DEV_LANES / 2 + 8 + (size_t)rec_doubles;
+    return d * sizeof(double) + 64;
+}
+
+#define PROF_T0() const int64_t pt0_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0
+#define PROF_ADD(slot) if (prof_on) prof_acc[slot] += (int64_t)__builtin_readcyclecounter() - pt0_
+#define A_ROW(i, j) tabl[(i)*DEV_MAX_STAGES + (j)]
+#define B_COEF(i) tabl[DEV_MAX_STAGES * DEV_MAX_STAGES + (i)]
+#define BD_COEF(i) tabl[DEV_MAX_STAGES * DEV_MAX_STAGES + DEV_MAX_STAGES + (i)]
+#define C_COEF(i) tabl[DEV_MAX_STAGES * DEV_MAX_STAGES + 2 * DEV_MAX_STAGES + (i)]
+
+// One role (or a merged set of roles) of the workgroup.  Every instantiation executes the SAME sequence of
+// workgroup barriers; only the work between them differs, so that each role keeps just its own state live.
+template <bool INTEG, bool ALMANAC, bool PERT>
+DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPtr htab, ColPtr cols,
+                     const double *__restrict__ records, const LdsMap &L, const int lane, const int wave, const int nw) {
+    double *const kbuf = L.kbuf;
+    double *const tabl = L.tabl;
+    const int stages = cfg->stages;
+    const bool has_grav = cfg->has_grav != 0;
+    const bool has_srp = cfg->has_srp != 0;
+    const bool has_pm = cfg->n_pm > 0;
+    const bool need_almanac = has_grav || cfg->n_slots > 0;
     const bool rec_in_lds = cfg->rec_in_lds != 0;
-    if (rec_in_lds) {
-        const int nd = cfg->rec_doubles;
-        for (int q = (int)threadIdx.x; q < nd; q += (int)blockDim.x) rec_lds[q] = records[q];
-    }
-    if (lane == 0 && wave == 0) ctl[0] = 0;
-    __syncthreads();
+    const bool dbg_skip_serial = (cfg->flags & DBG_SKIP_SERIAL) != 0;
+    const bool dbg_skip_harm = (cfg->flags & DBG_SKIP_HARMONICS) != 0;
+    // optional cycle accounting (workgroup 0 only): [0] phase A, [1] window duty (almanac / pert), [2] harmonics,
+    // [3] phase C, [4] step control, [5] total, [6] barrier waits, [7] realtime (100 MHz)
+    const bool prof_on = bt.prof != nullptr && blockIdx.x == 0;
+    int64_t prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int64_t prof_start = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;
+    const int64_t prof_rt0 = prof_on ? (int64_t)__builtin_amdgcn_s_memrealtime() : 0;
 
-    // ------------------------------------------------------------------ workers
-    if (wave != 0) {
-        for (;;) {
-            __syncthreads();  // B1: inputs published (or exit requested)
-            if (ctl[0]) break;
-            const double zr = inb[0 * DEV_LANES + lane], zi = inb[1 * DEV_LANES + lane];
-            const double rho_u = inb[2 * DEV_LANES + lane], rho = inb[3 * DEV_LANES + lane];
-            const double inv_rho = inb[4 * DEV_LANES + lane];
-            double px = 0.0, py = 0.0, pz = 0.0, pw = 0.0;
-            if (!(cfg->flags & DBG_SKIP_HARMONICS))
-                harmonics_partial(cfg, htab, cols, wave, zr, zi, rho_u, rho, inv_rho, px, py, pz, pw);
-            double *pp = part + (wave - 1) * 4 * DEV_LANES;
-            pp[0 * DEV_LANES + lane] = px;
-            pp[1 * DEV_LANES + lane] = py;
-            pp[2 * DEV_LANES + lane] = pz;
-            pp[3 * DEV_LANES + lane] = pw;
-            __syncthreads();  // B2: partials published
-        }
-        return;
-    }
-
-    // ------------------------------------------------------------------ master
+    // ---- per-lane trajectory binding (every wave maps lane -> the same trajectory)
     const int64_t gid = (int64_t)blockIdx.x * DEV_LANES + lane;
     const bool valid = gid < bt.n;
     const int64_t idx = valid ? gid : bt.n - 1;
 
-    int64_t epoch = bt.epoch_ns[idx];
-    double y[9];
-    y[0] = bt.x[idx]; y[1] = bt.y[idx]; y[2] = bt.z[idx];
-    y[3] = bt.vx[idx]; y[4] = bt.vy[idx]; y[5] = bt.vz[idx];
-    y[6] = bt.cr ? bt.cr[idx] : 0.0;
-    y[7] = bt.cd ? bt.cd[idx] : 0.0;
-    y[8] = bt.mprop ? bt.mprop[idx] : 0.0;
-    const double m_dry = bt.mdry ? bt.mdry[idx] : 0.0;
-    const double m_extra = bt.mextra ? bt.mextra[idx] : 0.0;
-    const double a_srp = bt.asrp ? bt.asrp[idx] : 0.0;
+    // integrator state (only meaningful in wave 0; kept in registers there)
+    int64_t epoch = 0, stop = 0, step_size = 0, prev_step = 0, det_step = 0, n_acc = 0, n_rej = 0, n_evals = 0;
+    double y[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    double h = 0.0, det_error = 0.0;
+    int det_attempts = 1, attempts = 1, status = NYX_HIP_OK;
+    bool done = true, fresh = true, is_final = false, fixed = false, prev_kind = false, backprop = false;
+    // perturbation-wave constants
+    double p_cr = 0.0, p_area = 0.0, p_mass = 1.0;
+    bool massless = false;
 
-    const int stages = cfg->stages;
-    const bool has_grav = cfg->has_grav != 0;
-    const bool has_srp = cfg->has_srp != 0;
-    const bool any_force = has_srp;  // drag is not on the device path yet (ctx_create refuses it)
-    const int64_t min_step_ns = cfg->min_step_ns;
-    const bool dbg_skip_serial = (cfg->flags & DBG_SKIP_SERIAL) != 0;
+    if (INTEG) {
+        epoch = bt.epoch_ns[idx];
+        y[0] = bt.x[idx]; y[1] = bt.y[idx]; y[2] = bt.z[idx];
+        y[3] = bt.vx[idx]; y[4] = bt.vy[idx]; y[5] = bt.vz[idx];
+        y[6] = bt.cr ? bt.cr[idx] : 0.0;
+        y[7] = bt.cd ? bt.cd[idx] : 0.0;
+        y[8] = bt.mprop ? bt.mprop[idx] : 0.0;
+        const int64_t duration = bt.use_end_epoch ? (bt.end_epoch_ns - epoch) : bt.duration_ns;
+        stop = epoch + duration;
+        backprop = duration < 0;
+        step_size = (bt.step_in && bt.step_in[idx] != 0) ? bt.step_in[idx] : cfg->init_step_ns;
+        fixed = cfg->fixed_step != 0;
+        det_step = cfg->init_step_ns;
+        done = !valid || duration == 0;
+        if (!done && y[8] < 0.0) { status = NYX_HIP_ERR_FUEL_EXHAUSTED; done = true; }  // dynamics.finally
+        if (backprop) step_size = -step_size;
+        const double mass = (bt.mdry ? bt.mdry[idx] : 0.0) + y[8] + (bt.mextra ? bt.mextra[idx] : 0.0);
+        if (has_srp && !(mass > 0.0)) massless = true;  // MasslessSpacecraft (spacecraft.rs:201-203)
+    }
+    if (PERT) {
+        // constant along the trajectory: no guidance law on this path => d(Cr, mass)/dt = 0
+        p_cr = clamp02(bt.cr ? bt.cr[idx] : 0.0);
+        p_area = bt.asrp ? bt.asrp[idx] : 0.0;
+        p_mass = (bt.mdry ? bt.mdry[idx] : 0.0) + (bt.mprop ? bt.mprop[idx] : 0.0) + (bt.mextra ? bt.mextra[idx] : 0.0);
+    }
+    __syncthreads();
 
-    const int64_t duration = bt.use_end_epoch ? (bt.end_epoch_ns - epoch) : bt.duration_ns;
-    const int64_t stop = epoch + duration;
-    const bool backprop = duration < 0;
-
-    int64_t step_size = (bt.step_in && bt.step_in[idx] != 0) ? bt.step_in[idx] : cfg->init_step_ns;
-    bool fixed = cfg->fixed_step != 0;
-    int64_t det_step = cfg->init_step_ns;
-    double det_error = 0.0;
-    int det_attempts = 1;
-    int64_t n_acc = 0, n_rej = 0, n_evals = 0;
-    int status = NYX_HIP_OK;
-
-    bool done = !valid || duration == 0;
-    if (!done && y[8] < 0.0) { status = NYX_HIP_ERR_FUEL_EXHAUSTED; done = true; }  // dynamics.finally
-    if (backprop) step_size = -step_size;
-
-    bool fresh = true, is_final = false;
-    int64_t prev_step = 0;
-    bool prev_kind = false;
-    double h = 0.0;
-    int attempts = 1;
-
-    EpochData cur, nxt;
-
-    while (__any(!done)) {
-        // ---- start of a step (per lane): final-step test on integer epochs (instance.rs:149-186)
-        if (!done && fresh) {
-            if ((!backprop && epoch + step_size > stop) || (backprop && epoch + step_size <= stop)) {
-                if (stop == epoch) {
-                    done = true;
-                } else {
-                    prev_step = step_size;
-                    prev_kind = fixed;
-                    step_size = stop - epoch;
-                    fixed = true;
-                    is_final = true;
+    for (;;) {  // one iteration = one RK attempt for every live lane (derive(), instance.rs:368-414)
+        if (INTEG) {
+            // start of a step: final-step test on integer epochs (instance.rs:149-186)
+            if (!done && fresh) {
+                if ((!backprop && epoch + step_size > stop) || (backprop && epoch + step_size <= stop)) {
+                    if (stop == epoch) {
+                        done = true;
+                    } else {
+                        prev_step = step_size;
+                        prev_kind = fixed;
+                        step_size = stop - epoch;
+                        fixed = true;
+                        is_final = true;
+                    }
                 }
+                attempts = 1;
+                h = ns_to_seconds(step_size);
+                fresh = false;
             }
-            attempts = 1;
-            h = ns_to_seconds(step_size);
-            fresh = false;
+            if (!done && massless) { status = NYX_HIP_ERR_MASSLESS; done = true; }
+            L.step[lane] = __longlong_as_double(epoch);
+            L.step[DEV_LANES + lane] = h;
+            if (!__any(!done)) {
+                if (lane == 0) L.ctl[0] = 1;
+            }
         }
-        if (!__any(!done)) break;
+        __syncthreads();  // B0: attempt published (or exit requested)
+        if (((volatile int *)L.ctl)[0]) break;
 
-        // ---- one RK attempt for every live lane (derive(), instance.rs:368-414)
-        const double cr = clamp02(y[6]);
-        const double mass = m_dry + y[8] + m_extra;
+        // prologue: epoch data of stage 0
+        if (ALMANAC && need_almanac) {
+            const int64_t ep = __double_as_longlong(L.step[lane]);
+            int st = rec_in_lds ? epoch_data(cfg, (const double *)L.rec, ep, L.ed, lane) : epoch_data(cfg, records, ep, L.ed, lane);
+            L.edst[lane] = st;
+        }
+        __syncthreads();  // Bp
+
         int st_att = NYX_HIP_OK;
-        if (any_force && !(mass > 0.0)) st_att = NYX_HIP_ERR_MASSLESS;
-
-        int a_idx = 0;
-        for (int i = -1; i < stages; ++i) {
-            double ys[6];
-            double px = 0.0, py = 0.0, pz = 0.0, pw = 0.0;
+        for (int i = 0; i < stages; ++i) {
+            double *const edc = L.ed + (i & 1) * ED_FIELDS * DEV_LANES;
             double s_ = 0.0, t_ = 0.0, u_ = 0.0, kfac = 0.0;
-            if (i >= 0) {
+            double ys[6];
+            PROF_T0();
+            if (INTEG) {
                 // ---- Phase A: stage state  y + h * sum_j a_ij k_j   (instance.rs:376-394)
                 if (i == 0) {
 #pragma unroll
                     for (int e = 0; e < 6; ++e) ys[e] = y[e];
                 } else {
                     double wi[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-                    for (int j = 0; j < i; ++j) {
-                        const double a_ij = cfg->a[a_idx + j];
-                        if (a_ij != 0.0) {
+#pragma unroll
+                    for (int j = 0; j < DEV_MAX_STAGES - 1; ++j) {
+                        if (j < i) {  // uniform; zero coefficients add an exact 0
+                            const double a_ij = A_ROW(i, j);
 #pragma unroll
                             for (int e = 0; e < 6; ++e) wi[e] += a_ij * KB(j, e);
                         }
                     }
-                    a_idx += i;
 #pragma unroll
                     for (int e = 0; e < 6; ++e) ys[e] = y[e] + h * wi[e];
                 }
-                if (cur.status) st_att = cur.status;
+#pragma unroll
+                for (int e = 0; e < 6; ++e) L.ys[e * DEV_LANES + lane] = ys[e];
+                if (need_almanac && L.edst[(i & 1) * DEV_LANES + lane]) st_att = L.edst[(i & 1) * DEV_LANES + lane];
                 if (has_grav) {
                     // body-fixed position and the scaled inputs of the column recursion
-                    const double rb0 = cur.m[0] * ys[0] + cur.m[1] * ys[1] + cur.m[2] * ys[2];
-                    const double rb1 = cur.m[3] * ys[0] + cur.m[4] * ys[1] + cur.m[5] * ys[2];
-                    const double rb2 = cur.m[6] * ys[0] + cur.m[7] * ys[1] + cur.m[8] * ys[2];
+                    const double rb0 = edc[0 * DEV_LANES + lane] * ys[0] + edc[1 * DEV_LANES + lane] * ys[1] + edc[2 * DEV_LANES + lane] * ys[2];
+                    const double rb1 = edc[3 * DEV_LANES + lane] * ys[0] + edc[4 * DEV_LANES + lane] * ys[1] + edc[5 * DEV_LANES + lane] * ys[2];
+                    const double rb2 = edc[6 * DEV_LANES + lane] * ys[0] + edc[7 * DEV_LANES + lane] * ys[1] + edc[8 * DEV_LANES + lane] * ys[2];
                     const double r_ = norm3(rb0, rb1, rb2);
                     s_ = rb0 / r_; t_ = rb1 / r_; u_ = rb2 / r_;
                     const double rho = cfg->g_re / r_;
                     kfac = cfg->g_mu / r_ / cfg->g_re;  // (mu / r) / R_eq
-                    inb[0 * DEV_LANES + lane] = rho * s_;
-                    inb[1 * DEV_LANES + lane] = rho * t_;
-                    inb[2 * DEV_LANES + lane] = rho * u_;
-                    inb[3 * DEV_LANES + lane] = rho;
-                    inb[4 * DEV_LANES + lane] = r_ / cfg->g_re;
-                    if (nw > 1) __syncthreads();  // B1
+                    L.inb[0 * DEV_LANES + lane] = rho * s_;
+                    L.inb[1 * DEV_LANES + lane] = rho * t_;
+                    L.inb[2 * DEV_LANES + lane] = rho * u_;
+                    L.inb[3 * DEV_LANES + lane] = rho;
+                    L.inb[4 * DEV_LANES + lane] = r_ / cfg->g_re;
                 }
             }
+            PROF_ADD(0);
+            {
+                PROF_T0();
+                __syncthreads();  // B1: stage state and harmonics inputs published
+                PROF_ADD(6);
+            }
+            const int64_t ptw_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;
 
-            // ---- window: position-dependent non-harmonic terms for stage i, epoch data for stage i+1,
-            //      and this wave's own share of the harmonics columns
-            double acc[3] = {0.0, 0.0, 0.0};
-            if (i >= 0) {
+            // ---- window --------------------------------------------------------------------------
+            if (ALMANAC && need_almanac && i + 1 < stages) {
+                // epoch-only data of the NEXT stage
+                const int64_t ep = __double_as_longlong(L.step[lane]) + seconds_to_ns(C_COEF(i + 1) * L.step[DEV_LANES + lane]);
+                double *edn = L.ed + ((i + 1) & 1) * ED_FIELDS * DEV_LANES;
+                int st = NYX_HIP_OK;
+                if (!dbg_skip_serial || i == 0)  // (timing switch: reuse the data of stages 0/1)
+                    st = rec_in_lds ? epoch_data(cfg, (const double *)L.rec, ep, edn, lane) : epoch_data(cfg, records, ep, edn, lane);
+                L.edst[((i + 1) & 1) * DEV_LANES + lane] = st;
+            }
+            if (PERT && (has_pm || has_srp)) {
+                // position-dependent third-body and SRP terms of THIS stage
+                double r[3] = {L.ys[0 * DEV_LANES + lane], L.ys[1 * DEV_LANES + lane], L.ys[2 * DEV_LANES + lane]};
+                double a3[3] = {0.0, 0.0, 0.0}, f3[3] = {0.0, 0.0, 0.0};
+                if (has_pm && !dbg_skip_serial) point_masses_accel(cfg, edc, lane, r, a3);
+                if (has_srp && !dbg_skip_serial) {
+                    srp_force(cfg, edc, lane, r, p_cr, p_area, f3);
+                    f3[0] = f3[0] / p_mass; f3[1] = f3[1] / p_mass; f3[2] = f3[2] / p_mass;
+                }
+#pragma unroll
+                for (int e = 0; e < 3; ++e) { L.pert[e * DEV_LANES + lane] = a3[e]; L.pert[(3 + e) * DEV_LANES + lane] = f3[e]; }
+            }
+            if (prof_on) prof_acc[1] += (int64_t)__builtin_readcyclecounter() - ptw_;
+            const int64_t pth_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;
+            double px = 0.0, py = 0.0, pz = 0.0, pw = 0.0;
+            if (has_grav && dbg_skip_harm && !INTEG) {
+                double *pp = L.part + wave * 4 * DEV_LANES;
+                pp[0 * DEV_LANES + lane] = 0.0; pp[1 * DEV_LANES + lane] = 0.0;
+                pp[2 * DEV_LANES + lane] = 0.0; pp[3 * DEV_LANES + lane] = 0.0;
+            }
+            if (has_grav && !dbg_skip_harm) {
+                const Partial4 pr = harmonics_partial((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, L.inb[0 * DEV_LANES + lane],
+                                                      L.inb[1 * DEV_LANES + lane], L.inb[2 * DEV_LANES + lane],
+                                                      L.inb[3 * DEV_LANES + lane], L.inb[4 * DEV_LANES + lane]);
+                px = pr.x; py = pr.y; pz = pr.z; pw = pr.w;
+                if (!INTEG) {
+                    double *pp = L.part + wave * 4 * DEV_LANES;
+                    pp[0 * DEV_LANES + lane] = px; pp[1 * DEV_LANES + lane] = py;
+                    pp[2 * DEV_LANES + lane] = pz; pp[3 * DEV_LANES + lane] = pw;
+                }
+            }
+            if (prof_on) prof_acc[2] += (int64_t)__builtin_readcyclecounter() - pth_;
+            {
+                PROF_T0();
+                __syncthreads();  // B2: partials / perturbations / next epoch data published
+                PROF_ADD(6);
+            }
+            const int64_t ptc_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;
+
+            if (INTEG) {
+                // ---- Phase C: assemble the derivative in the reference's order (orbital.rs:80-114, spacecraft.rs:227-243)
                 const double rmag = norm3(ys[0], ys[1], ys[2]);
                 const double f = -cfg->mu_central / cube(rmag);
-                acc[0] = f * ys[0]; acc[1] = f * ys[1]; acc[2] = f * ys[2];
-                if (cfg->n_pm > 0 && !dbg_skip_serial) {
-                    double a3[3];
-                    point_masses_accel(cfg, cur, ys, a3);
-                    acc[0] += a3[0]; acc[1] += a3[1]; acc[2] += a3[2];
+                double acc[3] = {f * ys[0], f * ys[1], f * ys[2]};
+                if (has_pm) {
+                    acc[0] += L.pert[0 * DEV_LANES + lane]; acc[1] += L.pert[1 * DEV_LANES + lane]; acc[2] += L.pert[2 * DEV_LANES + lane];
                 }
-            }
-            double fsrp[3] = {0.0, 0.0, 0.0};
-            if (i >= 0 && has_srp && !dbg_skip_serial) srp_force(cfg, cur, ys, cr, a_srp, fsrp);
-            if (i + 1 < stages && !(dbg_skip_serial && i >= 0)) {
-                const double dt = (i + 1 == 0) ? 0.0 : cfg->c[i + 1] * h;
-                if (rec_in_lds) epoch_data(cfg, (const double *)rec_lds, epoch + seconds_to_ns(dt), nxt);
-                else epoch_data(cfg, records, epoch + seconds_to_ns(dt), nxt);
-            }
-            if (i >= 0 && has_grav) {
-                harmonics_partial(cfg, htab, cols, 0, inb[0 * DEV_LANES + lane], inb[1 * DEV_LANES + lane],
-                                  inb[2 * DEV_LANES + lane], inb[3 * DEV_LANES + lane], inb[4 * DEV_LANES + lane], px, py, pz, pw);
-                if (nw > 1) __syncthreads();  // B2
-                // ---- Phase C: fold the partials (fixed wave order), rotate back
-                for (int w = 1; w < nw; ++w) {
-                    const double *pp = part + (w - 1) * 4 * DEV_LANES;
-                    px += pp[0 * DEV_LANES + lane];
-                    py += pp[1 * DEV_LANES + lane];
-                    pz += pp[2 * DEV_LANES + lane];
-                    pw += pp[3 * DEV_LANES + lane];
+                if (has_grav) {
+                    for (int w = 1; w < nw; ++w) {  // fixed wave order
+                        const double *pp = L.part + w * 4 * DEV_LANES;
+                        px += pp[0 * DEV_LANES + lane]; py += pp[1 * DEV_LANES + lane];
+                        pz += pp[2 * DEV_LANES + lane]; pw += pp[3 * DEV_LANES + lane];
+                    }
+                    px *= kfac; py *= kfac; pz *= kfac; pw *= kfac;
+                    const double al0 = px + pw * s_, al1 = py + pw * t_, al2 = pz + pw * u_;
+                    acc[0] += edc[0 * DEV_LANES + lane] * al0 + edc[3 * DEV_LANES + lane] * al1 + edc[6 * DEV_LANES + lane] * al2;
+                    acc[1] += edc[1 * DEV_LANES + lane] * al0 + edc[4 * DEV_LANES + lane] * al1 + edc[7 * DEV_LANES + lane] * al2;
+                    acc[2] += edc[2 * DEV_LANES + lane] * al0 + edc[5 * DEV_LANES + lane] * al1 + edc[8 * DEV_LANES + lane] * al2;
                 }
-                px *= kfac; py *= kfac; pz *= kfac; pw *= kfac;
-                const double al0 = px + pw * s_, al1 = py + pw * t_, al2 = pz + pw * u_;
-                acc[0] += cur.m[0] * al0 + cur.m[3] * al1 + cur.m[6] * al2;
-                acc[1] += cur.m[1] * al0 + cur.m[4] * al1 + cur.m[7] * al2;
-                acc[2] += cur.m[2] * al0 + cur.m[5] * al1 + cur.m[8] * al2;
-            }
-            if (i >= 0) {
                 if (has_srp) {
-                    acc[0] += fsrp[0] / mass; acc[1] += fsrp[1] / mass; acc[2] += fsrp[2] / mass;
+                    acc[0] += L.pert[3 * DEV_LANES + lane]; acc[1] += L.pert[4 * DEV_LANES + lane]; acc[2] += L.pert[5 * DEV_LANES + lane];
                 }
                 KB(i, 0) = ys[3]; KB(i, 1) = ys[4]; KB(i, 2) = ys[5];
                 KB(i, 3) = acc[0]; KB(i, 4) = acc[1]; KB(i, 5) = acc[2];
             }
-            cur = nxt;
-        }
-        if (!done) n_evals += stages;
-
-        // ---- next state and error estimate (instance.rs:401-414).  d(Cr, Cd, prop mass)/dt = 0.
-        double next[9], err[9];
-#pragma unroll
-        for (int e = 0; e < 9; ++e) { next[e] = y[e]; err[e] = 0.0; }
-        for (int i = 0; i < stages; ++i) {
-            const double b_i = cfg->b[i];
-            const double bd = cfg->bdiff[i];
-            if (bd != 0.0 && !fixed) {
-                const double ce = h * bd;
-#pragma unroll
-                for (int e = 0; e < 6; ++e) err[e] += ce * KB(i, e);
-            }
-            if (b_i != 0.0) {
-                const double cb = h * b_i;
-#pragma unroll
-                for (int e = 0; e < 6; ++e) next[e] += cb * KB(i, e);
-            }
+            if (prof_on) prof_acc[3] += (int64_t)__builtin_readcyclecounter() - ptc_;
         }
 
-        if (!done) {
-            bool accept = false;
-            if (st_att != NYX_HIP_OK) {
-                status = st_att;
-                done = true;
-            } else if (fixed) {
-                det_step = step_size;
-                accept = true;
-            } else {
-                det_error = error_estimate(cfg->error_ctrl, err, next, y);
-                if (det_error <= cfg->tol || h <= cfg->min_step_s || attempts >= cfg->attempts) {
-                    bool nan = false;
+        const int64_t pts_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;
+        if (INTEG) {
+            if (!done) n_evals += stages;
+            // ---- next state and error estimate (instance.rs:401-414).  d(Cr, Cd, prop mass)/dt = 0.
+            double next[9], err[9];
 #pragma unroll
-                    for (int e = 0; e < 9; ++e) nan = nan || (next[e] != next[e]);
-                    if (nan) {
-                        status = NYX_HIP_ERR_NAN;
-                        done = true;
-                    } else {
-                        det_step = seconds_to_ns(h);
-                        if (det_error < cfg->tol) {
-                            const double prop = 0.9 * h * pow(cfg->tol / det_error, cfg->inv_order);
-                            h = (fabs(prop) > fabs(cfg->max_step_s)) ? cfg->max_step_s * copysign(1.0, prop) : prop;
-                        }
-                        step_size = seconds_to_ns(h);
-                        const int64_t ab = step_size < 0 ? -step_size : step_size;
-                        if (ab < min_step_ns) step_size = (step_size < 0) ? -min_step_ns : min_step_ns;
-                        accept = true;
-                    }
-                } else {
-                    attempts += 1;
-                    n_rej += 1;
-                    const double prop = 0.9 * h * pow(cfg->tol / det_error, cfg->inv_order_m1);
-                    h = (prop < cfg->min_step_s) ? cfg->min_step_s : prop;
+            for (int e = 0; e < 9; ++e) { next[e] = y[e]; err[e] = 0.0; }
+            for (int i = 0; i < stages; ++i) {
+                const double ce = h * BD_COEF(i);
+                const double cb = h * B_COEF(i);
+#pragma unroll
+                for (int e = 0; e < 6; ++e) {
+                    const double kv = KB(i, e);
+                    err[e] += ce * kv;
+                    next[e] += cb * kv;
                 }
             }
-            if (accept) {
-                // single_step(): state.set(epoch + t, vec) with the Cr clamp, then finally()
-                epoch += det_step;
-#pragma unroll
-                for (int e = 0; e < 9; ++e) y[e] = next[e];
-                y[6] = clamp02(y[6]);
-                n_acc += 1;
-                det_attempts = attempts;
-                if (y[8] < 0.0) { status = NYX_HIP_ERR_FUEL_EXHAUSTED; done = true; }
-                if (is_final) {
-                    step_size = prev_step;
-                    fixed = prev_kind;
-                    if (backprop) step_size = -step_size;
-                    is_final = false;
+            if (!done) {
+                bool accept = false;
+                if (st_att != NYX_HIP_OK) {
+                    status = st_att;
                     done = true;
+                } else if (fixed) {
+                    det_step = step_size;
+                    accept = true;
+                } else {
+                    det_error = error_estimate(cfg->error_ctrl, err, next, y);
+                    if (det_error <= cfg->tol || h <= cfg->min_step_s || attempts >= cfg->attempts) {
+                        bool nan = false;
+#pragma unroll
+                        for (int e = 0; e < 9; ++e) nan = nan || (next[e] != next[e]);
+                        if (nan) {
+                            status = NYX_HIP_ERR_NAN;
+                            done = true;
+                        } else {
+                            det_step = seconds_to_ns(h);
+                            if (det_error < cfg->tol) {
+                                const double prop = 0.9 * h * pow(cfg->tol / det_error, cfg->inv_order);
+                                h = (fabs(prop) > fabs(cfg->max_step_s)) ? cfg->max_step_s * copysign(1.0, prop) : prop;
+                            }
+                            step_size = seconds_to_ns(h);
+                            const int64_t ab = step_size < 0 ? -step_size : step_size;
+                            if (ab < cfg->min_step_ns) step_size = (step_size < 0) ? -cfg->min_step_ns : cfg->min_step_ns;
+                            accept = true;
+                        }
+                    } else {
+                        attempts += 1;
+                        n_rej += 1;
+                        const double prop = 0.9 * h * pow(cfg->tol / det_error, cfg->inv_order_m1);
+                        h = (prop < cfg->min_step_s) ? cfg->min_step_s : prop;
+                    }
                 }
-                fresh = true;
+                if (accept) {
+                    // single_step(): state.set(epoch + t, vec) with the Cr clamp, then finally()
+                    epoch += det_step;
+#pragma unroll
+                    for (int e = 0; e < 9; ++e) y[e] = next[e];
+                    y[6] = clamp02(y[6]);
+                    n_acc += 1;
+                    det_attempts = attempts;
+                    if (y[8] < 0.0) { status = NYX_HIP_ERR_FUEL_EXHAUSTED; done = true; }
+                    if (is_final) {
+                        step_size = prev_step;
+                        fixed = prev_kind;
+                        if (backprop) step_size = -step_size;
+                        is_final = false;
+                        done = true;
+                    }
+                    fresh = true;
+                }
             }
         }
+        if (prof_on) prof_acc[4] += (int64_t)__builtin_readcyclecounter() - pts_;
+    }
+    if (prof_on && lane == 0) {
+        prof_acc[5] = (int64_t)__builtin_readcyclecounter() - prof_start;
+        prof_acc[7] = (int64_t)__builtin_amdgcn_s_memrealtime() - prof_rt0;
+        for (int q = 0; q < 8; ++q) bt.prof[wave * 8 + q] = prof_acc[q];
     }
 
-    // release the workers
-    if (nw > 1) {
-        if (lane == 0) ctl[0] = 1;
-        __syncthreads();
-    }
-
-    if (valid) {
+    if (INTEG && valid) {
         bt.o_epoch_ns[gid] = epoch;
         bt.o_x[gid] = y[0]; bt.o_y[gid] = y[1]; bt.o_z[gid] = y[2];
         bt.o_vx[gid] = y[3]; bt.o_vy[gid] = y[4]; bt.o_vz[gid] = y[5];
         if (bt.o_cr) bt.o_cr[gid] = y[6];
         if (bt.o_cd) bt.o_cd[gid] = y[7];
         if (bt.o_mprop) bt.o_mprop[gid] = y[8];
-        if (bt.o_mdry) bt.o_mdry[gid] = m_dry;
-        if (bt.o_mextra) bt.o_mextra[gid] = m_extra;
-        if (bt.o_asrp) bt.o_asrp[gid] = a_srp;
+        if (bt.o_mdry) bt.o_mdry[gid] = bt.mdry ? bt.mdry[idx] : 0.0;
+        if (bt.o_mextra) bt.o_mextra[gid] = bt.mextra ? bt.mextra[idx] : 0.0;
+        if (bt.o_asrp) bt.o_asrp[gid] = bt.asrp ? bt.asrp[idx] : 0.0;
         if (bt.o_adrag) bt.o_adrag[gid] = bt.adrag ? bt.adrag[idx] : 0.0;
         if (bt.o_step) bt.o_step[gid] = step_size;
         if (bt.status) bt.status[gid] = status;
@@ -743,8 +833,54 @@ extern "C" __global__ void __launch_bounds__(DEV_MAX_WAVES *DEV_LANES)
     }
 }
 
-extern "C" size_t nyx_kernel_lds_bytes(int rec_doubles) {
-    return (size_t)(DEV_MAX_STAGES * 6 * DEV_LANES + NIN * DEV_LANES + (DEV_MAX_WAVES - 1) * 4 * DEV_LANES + rec_doubles) * sizeof(double) + 64;
+extern "C" __global__ void __launch_bounds__(DEV_MAX_WAVES *DEV_LANES)
+    nyx_propagate_kernel(DevBatch bt, const DevCfg *cfg_g, const HarmEntry *htab_g, const ColHdr *cols_g,
+                         const double *__restrict__ records) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & (DEV_LANES - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int nw = (int)(blockDim.x >> 6);
+    const LdsMap L = carve_lds(smem, nw);
+    double *const kbuf = L.kbuf;
+    double *const tabl = L.tabl;
+    CfgPtr cfg = (CfgPtr)cfg_g;
+    HarmPtr htab = (HarmPtr)htab_g;
+    ColPtr cols = (ColPtr)cols_g;
+
+    const int stages = cfg->stages;
+    const bool rec_in_lds = cfg->rec_in_lds != 0;
+
+    // ---- one-time staging: ephemeris records and the Butcher tableau -> LDS (all waves cooperate)
+    if (rec_in_lds) {
+        const int nd = cfg->rec_doubles;
+        for (int q = (int)threadIdx.x; q < nd; q += (int)blockDim.x) L.rec[q] = records[q];
+    }
+    for (int q = (int)threadIdx.x; q < DEV_MAX_STAGES * DEV_MAX_STAGES + 3 * DEV_MAX_STAGES; q += (int)blockDim.x) {
+        double v;
+        if (q < DEV_MAX_STAGES * DEV_MAX_STAGES) {
+            const int i = q / DEV_MAX_STAGES, j = q % DEV_MAX_STAGES;
+            v = (j < i && i < stages) ? cfg_g->a[i * (i - 1) / 2 + j] : 0.0;
+        } else {
+            const int r = q - DEV_MAX_STAGES * DEV_MAX_STAGES;
+            const int which = r / DEV_MAX_STAGES, i = r % DEV_MAX_STAGES;
+            v = (i < stages) ? (which == 0 ? cfg_g->b[i] : (which == 1 ? cfg_g->bdiff[i] : cfg_g->c[i])) : 0.0;
+        }
+        tabl[q] = v;
+    }
+    if (threadIdx.x == 0) L.ctl[0] = 0;
+
+    // ---- role dispatch (wave-uniform): merged roles when the workgroup has fewer than three waves
+    if (nw == 1) {
+        role_loop<true, true, true>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
+    } else if (nw == 2) {
+        if (wave == 0) role_loop<true, false, false>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
+        else role_loop<false, true, true>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
+    } else {
+        if (wave == 0) role_loop<true, false, false>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
+        else if (wave == 1) role_loop<false, true, false>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
+        else if (wave == 2) role_loop<false, false, true>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
+        else role_loop<false, false, false>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
+    }
 }
 
 extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg, const HarmEntry *htab,
@@ -752,7 +888,12 @@ extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg
                                            hipStream_t stream) {
     const int64_t blocks = (bt.n + DEV_LANES - 1) / DEV_LANES;
     if (blocks == 0) return hipSuccess;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
     hipLaunchKernelGGL(nyx_propagate_kernel, dim3((unsigned)blocks), dim3((unsigned)(n_waves * DEV_LANES)),
-                       nyx_kernel_lds_bytes(rec_lds_doubles), stream, bt, cfg, htab, cols, records);
+                       nyx_kernel_lds_bytes(n_waves, rec_lds_doubles), stream, bt, cfg, htab, cols, records);
     return hipGetLastError();
 }

@@ -33,6 +33,17 @@ ms = ctx.last_kernel_ms()
 ev = int(st.n_evals.sum())
 print(f"n={n} hours={hours} deg={degree} waves={waves or 'auto'}: kernel {ms:.1f} ms (wall {wall*1e3:.1f}), evals {ev} -> {ev/ms*1e3:.3e} evals/s, "
       f"{n/ms*1e3*(24/hours):.1f} traj-days/s equiv, acc {st.n_accepted.sum()} rej {st.n_rejected.sum()} status!=0: {(st.status!=0).sum()}")
+if os.environ.get("NYX_HIP_PROFILE"):
+    import ctypes as C
+    buf = (C.c_int64 * 128)()
+    ctx._lib.nyx_hip_debug_profile.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    if ctx._lib.nyx_hip_debug_profile(ctx._h, buf) == 0:
+        p = np.array(buf[:]).reshape(16, 8)
+        ne = int(st.n_evals[:64].max())
+        print("  wg0 cycles per eval (phaseA, duty, harmonics, phaseC, stepctl | total, barrier-wait) clock %.0f MHz" % (p[0, 5] / max(p[0, 7], 1) * 100.0))
+        for w in range(16):
+            if p[w, 5]:
+                print(f"   wave {w:2d}: " + " ".join(f"{p[w, q] / ne:9.0f}" for q in (0, 1, 2, 3, 4)) + f" | {p[w, 5] / ne:9.0f} {p[w, 6] / ne:9.0f}")
 if check:
     import oracle_lib
     sub = batch.slice(0, check)
