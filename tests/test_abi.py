@@ -1,0 +1,103 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/nyx_hip.h declares,
+and its struct layouts match the ctypes mirror.  No compute calls (no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import nyx_amd as nx
+from nyx_amd import _abi
+from scenarios import leo_full_setup
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _abi.load_library()
+    header = open(os.path.join(ROOT, "include", "nyx_hip.h")).read()
+    declared = set(re.findall(r"^(?:int32_t|void|double|const char \*)\s*(nyx_hip_[a-z_0-9]+)\(", header, flags=re.M))
+    assert len(declared) == 12
+    assert declared >= set(_abi.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in nyx_hip.h but not exported"
+
+
+def test_struct_layouts_match_the_header():
+    lib = _abi.load_library()
+    mirror = [_abi.IntegOpts, _abi.ChebySegment, _abi.Body, _abi.Rotation, _abi.GravityField, _abi.Srp, _abi.Drag,
+              _abi.Config, _abi.States, _abi.StepStats]
+    for which, cls in enumerate(mirror):
+        assert lib.nyx_hip_abi_sizeof(which) == C.sizeof(cls), cls.__name__
+
+
+def test_no_device_is_reported_not_papered_over():
+    """On a box without a GPU the product path must fail loudly (no CPU fallback)."""
+    lib = _abi.load_library()
+    if lib.nyx_hip_device_count() > 0:
+        pytest.skip("a GPU is visible")
+    prop, almanac, central = leo_full_setup(degree=4)
+    with pytest.raises(RuntimeError, match="nyx_hip_ctx_create failed"):
+        nx.GpuContext(prop.compile(almanac, central))
+
+
+def test_config_flattening():
+    prop, almanac, central = leo_full_setup(degree=21, order=10)
+    cc = prop.compile(almanac, central)
+    cfg = cc.cfg
+    assert cfg.abi_version == _abi.ABI_VERSION and cfg.opts.method == _abi.RK89 and cfg.opts.error_ctrl == _abi.RSS_CARTESIAN_STEP
+    assert cfg.opts.init_step_ns == 60 * nx.NS_PER_S and cfg.opts.min_step_ns == 1_000_000 and cfg.opts.max_step_ns == 2700 * nx.NS_PER_S
+    ids = [cfg.bodies[i].naif_id for i in range(cfg.n_bodies)]
+    assert ids[0] == nx.EARTH and set(ids) == {nx.EARTH, nx.SUN, nx.MOON}
+    assert cfg.bodies[0].n_chain == 0 and cfg.n_point_masses == 2
+    g = cfg.gravity.contents
+    assert (g.degree, g.order) == (21, 10)
+    # coefficients above the requested order are never stored by the loaders
+    assert g.c_nm[21 * 22 // 2 + 11] == 0.0 and g.c_nm[21 * 22 // 2 + 10] != 0.0
+    assert g.c_nm[3] == pytest.approx(-4.84165374886470e-04)  # JGM3 C20 (data/01_planetary/JGM3.cof.gz)
+    srp = cfg.srp.contents
+    assert srp.phi_w_m2 == 1367.0 and srp.estimate == 1 and cfg.bodies[srp.sun_body].naif_id == nx.SUN
+    assert srp.n_shadow_bodies == 1 and cfg.bodies[srp.shadow_body[0]].naif_id == nx.EARTH
+
+
+def test_integrator_options_mirror_the_reference():
+    # reference: propagators/options.rs ut_integr_opts::test_options (:216-248)
+    o = nx.IntegratorOptions.with_fixed_step_s(1e-1)
+    assert o.min_step == nx.seconds(1e-1) == o.max_step and o.tolerance == 0.0 and o.fixed_step
+    o = nx.IntegratorOptions.with_adaptive_step_s(1e-2, 10.0, 1e-12, nx.ErrorControl.RSSStep)
+    assert o.min_step == nx.seconds(1e-2) and o.max_step == nx.seconds(10.0) and not o.fixed_step and o.init_step == o.max_step
+    o = nx.IntegratorOptions()
+    assert (o.init_step, o.min_step, o.max_step, o.tolerance, o.attempts, o.fixed_step) == (60 * 10**9, 10**6, 2700 * 10**9, 1e-12, 50, False)
+    o = nx.IntegratorOptions.with_max_step(nx.seconds(1.0))
+    assert o.init_step == nx.seconds(1.0) == o.max_step and o.min_step == 10**6
+    # rk_methods/mod.rs ut_propagator::from_str_ok
+    for m in nx.IntegratorMethod:
+        assert nx.IntegratorMethod.from_str(m.name.upper()) == m
+    with pytest.raises(ValueError):
+        nx.IntegratorMethod.from_str("blah")
+    # Duration conversions (hifitime): truncation toward zero, to_seconds = whole + sub * 1e-9
+    assert nx.seconds(0.1) == 100_000_000 and nx.seconds(29.9999999999) == 29_999_999_999
+    assert nx.to_seconds(1_500_000_000) == 1.5 and nx.to_seconds(-30 * 10**9) == -30.0
+
+
+def _build_cxx_check(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "host_mirror_check")
+    subprocess.run(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cxx", "host_mirror_check.cpp"),
+                    "-L" + os.path.join(ROOT, "nyx_amd"), "-lnyx_hip", "-Wl,-rpath," + os.path.join(ROOT, "nyx_amd"), "-o", exe], check=True)
+    return exe
+
+
+def test_cxx_host_mirror_compiles_and_links(tmp_path):
+    import subprocess
+    _abi.load_library()
+    r = subprocess.run([_build_cxx_check(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_cxx_host_mirror_golden_on_gpu(tmp_path):
+    import subprocess
+    r = subprocess.run([_build_cxx_check(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0 and "max |delta|" in r.stdout, r.stdout + r.stderr
