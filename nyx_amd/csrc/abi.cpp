@@ -162,7 +162,7 @@ static void build_harmonics(const nyx_hip_gravity_field_t *g, std::vector<HarmEn
     const double SQ2 = std::sqrt(2.0);
     ColHdr zero_hdr;
     std::memset(&zero_hdr, 0, sizeof zero_hdr);
-    cols.assign(n_cols + 2, zero_hdr);
+    cols.assign(n_cols + 3, zero_hdr);  // spare tail entries: the kernel prefetches header c + 1
     col_len.assign(n_cols + 2, 0);
     tab.clear();
     for (int c = 1; c <= n_cols; ++c) {
@@ -212,10 +212,12 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves) {
     if (n_waves == 1) hc[0] = ctx->role_handicap[0] + ctx->role_handicap[1] + ctx->role_handicap[2];
     else if (n_waves == 2) { hc[0] = ctx->role_handicap[0]; hc[1] = ctx->role_handicap[1] + ctx->role_handicap[2]; }
     else { hc[0] = ctx->role_handicap[0]; hc[1] = ctx->role_handicap[1]; hc[2] = ctx->role_handicap[2]; }
+    // with enough column workers the integrator keeps its window free: its serial phases A / C gate every other wave
+    if (n_waves >= 8 && !std::getenv("NYX_HIP_ROLE_HANDICAP")) hc[0] = 1e9;
     // water-filling: level such that sum_w max(0, level - hc[w]) = terms
     double level = 0.0;
     {
-        double lo = 0.0, hi = terms + hc[0] + hc[1] + hc[2];
+        double lo = 0.0, hi = terms + std::min(hc[0], 1e6) + hc[1] + hc[2];
         for (int it = 0; it < 60; ++it) {
             level = 0.5 * (lo + hi);
             double s = 0.0;
@@ -397,7 +399,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
         const nyx_hip_gravity_field_t *g = cfg->gravity;
         if (g->degree < 1 || !g->c_nm || !g->s_nm) { delete ctx; nyx_set_error("bad gravity field"); return NYX_HIP_RC_BAD_ARG; }
         dc.has_grav = 1; dc.deg = g->degree; dc.ord = std::min(g->order, g->degree);
-        dc.g_mu = g->mu_km3_s2; dc.g_re = g->eq_radius_km;
+        dc.g_mu = g->mu_km3_s2; dc.g_re = g->eq_radius_km; dc.g_inv_re = 1.0 / g->eq_radius_km;
         for (int k = 0; k < 3; ++k) { dc.g_rot.ra[k] = g->rotation.ra_deg[k]; dc.g_rot.dec[k] = g->rotation.dec_deg[k]; dc.g_rot.w[k] = g->rotation.w_deg[k]; }
         int n_cols = 0;
         build_harmonics(g, tab, cols, ctx->col_len, n_cols);
@@ -409,9 +411,9 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
     {
         int nseg_eval = 0;
         for (int s = 0; s < dc.n_slots; ++s) nseg_eval += dc.slot[s].n_chain;
-        ctx->role_handicap[0] = 60.0;
-        ctx->role_handicap[1] = 18.0 * nseg_eval + (dc.has_grav ? 45.0 : 0.0);
-        ctx->role_handicap[2] = 14.0 * dc.n_pm + (dc.has_srp ? 40.0 + 30.0 * dc.n_shadow : 0.0);
+        ctx->role_handicap[0] = 15.0;
+        ctx->role_handicap[1] = 12.0 * nseg_eval + (dc.has_grav ? 18.0 : 0.0);
+        ctx->role_handicap[2] = 6.0 * dc.n_pm + (dc.has_srp ? 6.0 + 6.0 * dc.n_shadow : 0.0);
         if (const char *e = std::getenv("NYX_HIP_ROLE_HANDICAP")) {
             double h0, h1, h2;
             if (std::sscanf(e, "%lf,%lf,%lf", &h0, &h1, &h2) == 3) { ctx->role_handicap[0] = h0; ctx->role_handicap[1] = h1; ctx->role_handicap[2] = h2; }

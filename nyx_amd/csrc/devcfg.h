@@ -56,7 +56,7 @@ struct DevCfg {
     double phi, c_m_s;
 
     int32_t has_grav, deg, ord, n_cols; /* columns 1..n_cols (= deg+1) */
-    double g_mu, g_re;
+    double g_mu, g_re, g_inv_re;
     DevRot g_rot;
 
     int32_t has_drag, drag_density;

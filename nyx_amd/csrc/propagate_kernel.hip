@@ -325,6 +325,13 @@ DEVFN uint64_t uniform_u64(uint64_t v) {
     return ((uint64_t)hi << 32) | lo;
 }
 
+DEVFN ColHdr load_hdr(ColPtr cols, int c) {
+    const ColHdr CAS &r = cols[c];
+    ColHdr h;
+    h.start = r.start; h.nb = r.nb; h.scale = r.scale; h.diag = r.diag; h._pad = 0.0;
+    return h;
+}
+
 struct Partial4 {
     double x, y, z, w;
 };
@@ -347,8 +354,9 @@ static __device__ __attribute__((noinline)) Partial4 harmonics_partial(uint64_t 
         const int cnt = cfg->range_cnt[wave][q];
         double rc, ic;
         cpow_uniform(zr, zi, c0 - 1, rc, ic);
+        ColHdr hd = load_hdr(cols, c0);  // the next column's header is fetched under this column's batches
         for (int c = c0; c < c0 + cnt; ++c) {
-            const ColHdr CAS &hd = cols[c];
+            const ColHdr hn = load_hdr(cols, c + 1);  // (the header array has a spare tail entry)
             HarmPtr e = htab + hd.start;
             const int nb = hd.nb;
             double a1 = 0.0, a2 = hd.diag * inv_rho;
@@ -372,6 +380,7 @@ static __device__ __attribute__((noinline)) Partial4 harmonics_partial(uint64_t 
             const double t = rc * zr - ic * zi;
             ic = rc * zi + ic * zr;
             rc = t;
+            hd = hn;
         }
     }
     Partial4 r = {px, py, pz, pw};
@@ -453,6 +462,43 @@ DEVFN double error_estimate(int ec, const double *e, const double *cand, const d
 #define DBG_SKIP_HARMONICS 0x200
 #define KB(stage, comp) kbuf[((stage)*6 + (comp)) * DEV_LANES + lane]
 
+// Integrator state that is only touched between attempts lives in LDS (per lane, field-major), not in
+// registers: the stage loop then keeps ~30 VGPRs of integrator state live instead of ~90 (no scratch spills).
+#define CS_FIELDS 21
+struct ColdState {
+    int64_t epoch, stop, step_size, prev_step, det_step, n_acc, n_rej, n_evals;
+    double y[9];
+    double h, det_error;
+    int det_attempts, attempts, status;
+    bool done, fresh, is_final, fixed, prev_kind, backprop, massless;
+};
+#define CS_I64(f) __double_as_longlong(cs[(f)*DEV_LANES + lane])
+DEVFN void cold_load(const double *cs, int lane, ColdState &c) {
+    c.epoch = CS_I64(0); c.stop = CS_I64(1); c.step_size = CS_I64(2); c.prev_step = CS_I64(3);
+    c.det_step = CS_I64(4); c.n_acc = CS_I64(5); c.n_rej = CS_I64(6); c.n_evals = CS_I64(7);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) c.y[e] = cs[(8 + e) * DEV_LANES + lane];
+    c.h = cs[17 * DEV_LANES + lane];
+    c.det_error = cs[18 * DEV_LANES + lane];
+    const int64_t a = CS_I64(19), b = CS_I64(20);
+    c.det_attempts = (int)(a & 0xffff); c.attempts = (int)((a >> 16) & 0xffff); c.status = (int)((a >> 32) & 0xffff);
+    c.done = b & 1; c.fresh = b & 2; c.is_final = b & 4; c.fixed = b & 8; c.prev_kind = b & 16; c.backprop = b & 32; c.massless = b & 64;
+}
+#define CS_SET_I64(f, v) cs[(f)*DEV_LANES + lane] = __longlong_as_double(v)
+DEVFN void cold_store(double *cs, int lane, const ColdState &c) {
+    CS_SET_I64(0, c.epoch); CS_SET_I64(1, c.stop); CS_SET_I64(2, c.step_size); CS_SET_I64(3, c.prev_step);
+    CS_SET_I64(4, c.det_step); CS_SET_I64(5, c.n_acc); CS_SET_I64(6, c.n_rej); CS_SET_I64(7, c.n_evals);
+#pragma unroll
+    for (int e = 0; e < 9; ++e) cs[(8 + e) * DEV_LANES + lane] = c.y[e];
+    cs[17 * DEV_LANES + lane] = c.h;
+    cs[18 * DEV_LANES + lane] = c.det_error;
+    const int64_t a = (int64_t)(c.det_attempts & 0xffff) | ((int64_t)(c.attempts & 0xffff) << 16) | ((int64_t)(c.status & 0xffff) << 32);
+    const int64_t b = (c.done ? 1 : 0) | (c.fresh ? 2 : 0) | (c.is_final ? 4 : 0) | (c.fixed ? 8 : 0) | (c.prev_kind ? 16 : 0) |
+                      (c.backprop ? 32 : 0) | (c.massless ? 64 : 0);
+    CS_SET_I64(19, a); CS_SET_I64(20, b);
+}
+#define CS_Y(e) L.cs[(8 + (e)) * DEV_LANES + lane]
+
 // LDS carve (doubles unless noted), see nyx_kernel_lds_bytes()
 struct LdsMap {
     double *kbuf;   // [16][6][64]    stage derivatives k_i
@@ -462,6 +508,7 @@ struct LdsMap {
     double *ed;     // [2][ED_FIELDS][64]  epoch data, double-buffered by stage parity
     double *pert;   // [6][64]        point-mass accel (3) and SRP force / mass (3)
     double *step;   // [2][64]        epoch (as i64 bits) and h of the current attempt
+    double *cs;     // [CS_FIELDS][64] integrator cold state
     double *part;   // [P][4][64]     harmonics partials (wave 0's slot unused)
     int *edst;      // [2][64]        almanac status per buffer
     int *pertst;    // [64]
@@ -479,7 +526,8 @@ DEVFN LdsMap carve_lds(char *smem, int n_waves) {
     m.ed = p; p += 2 * ED_FIELDS * DEV_LANES;
     m.pert = p; p += 6 * DEV_LANES;
     m.step = p; p += 2 * DEV_LANES;
-    m.part = p; p += n_waves * 4 * DEV_LANES;
+    m.cs = p; p += CS_FIELDS * DEV_LANES;
+    m.part = p; p += DEV_MAX_WAVES * 4 * DEV_LANES;
     m.edst = (int *)p; p += DEV_LANES;       // 2*64 ints
     m.pertst = (int *)p; p += DEV_LANES / 2; // 64 ints
     m.ctl = (int *)p; p += 8;
@@ -489,7 +537,7 @@ DEVFN LdsMap carve_lds(char *smem, int n_waves) {
 
 extern "C" size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles) {
     size_t d = (size_t)DEV_MAX_STAGES * 6 * DEV_LANES + DEV_MAX_STAGES * DEV_MAX_STAGES + 3 * DEV_MAX_STAGES + 6 * DEV_LANES +
-               NIN * DEV_LANES + 2 * ED_FIELDS * DEV_LANES + 6 * DEV_LANES + 2 * DEV_LANES + (size_t)n_waves * 4 * DEV_LANES +
+               NIN * DEV_LANES + 2 * ED_FIELDS * DEV_LANES + 6 * DEV_LANES + 2 * DEV_LANES + CS_FIELDS * DEV_LANES + (size_t)DEV_MAX_WAVES * 4 * DEV_LANES +
                DEV_LANES + DEV_LANES / 2 + 8 + (size_t)rec_doubles;
     return d * sizeof(double) + 64;
 }
@@ -528,34 +576,32 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     const bool valid = gid < bt.n;
     const int64_t idx = valid ? gid : bt.n - 1;
 
-    // integrator state (only meaningful in wave 0; kept in registers there)
-    int64_t epoch = 0, stop = 0, step_size = 0, prev_step = 0, det_step = 0, n_acc = 0, n_rej = 0, n_evals = 0;
-    double y[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    double h = 0.0, det_error = 0.0;
-    int det_attempts = 1, attempts = 1, status = NYX_HIP_OK;
-    bool done = true, fresh = true, is_final = false, fixed = false, prev_kind = false, backprop = false;
     // perturbation-wave constants
     double p_cr = 0.0, p_area = 0.0, p_mass = 1.0;
-    bool massless = false;
 
     if (INTEG) {
-        epoch = bt.epoch_ns[idx];
-        y[0] = bt.x[idx]; y[1] = bt.y[idx]; y[2] = bt.z[idx];
-        y[3] = bt.vx[idx]; y[4] = bt.vy[idx]; y[5] = bt.vz[idx];
-        y[6] = bt.cr ? bt.cr[idx] : 0.0;
-        y[7] = bt.cd ? bt.cd[idx] : 0.0;
-        y[8] = bt.mprop ? bt.mprop[idx] : 0.0;
-        const int64_t duration = bt.use_end_epoch ? (bt.end_epoch_ns - epoch) : bt.duration_ns;
-        stop = epoch + duration;
-        backprop = duration < 0;
-        step_size = (bt.step_in && bt.step_in[idx] != 0) ? bt.step_in[idx] : cfg->init_step_ns;
-        fixed = cfg->fixed_step != 0;
-        det_step = cfg->init_step_ns;
-        done = !valid || duration == 0;
-        if (!done && y[8] < 0.0) { status = NYX_HIP_ERR_FUEL_EXHAUSTED; done = true; }  // dynamics.finally
-        if (backprop) step_size = -step_size;
-        const double mass = (bt.mdry ? bt.mdry[idx] : 0.0) + y[8] + (bt.mextra ? bt.mextra[idx] : 0.0);
-        if (has_srp && !(mass > 0.0)) massless = true;  // MasslessSpacecraft (spacecraft.rs:201-203)
+        ColdState c;
+        c.epoch = bt.epoch_ns[idx];
+        c.y[0] = bt.x[idx]; c.y[1] = bt.y[idx]; c.y[2] = bt.z[idx];
+        c.y[3] = bt.vx[idx]; c.y[4] = bt.vy[idx]; c.y[5] = bt.vz[idx];
+        c.y[6] = bt.cr ? bt.cr[idx] : 0.0;
+        c.y[7] = bt.cd ? bt.cd[idx] : 0.0;
+        c.y[8] = bt.mprop ? bt.mprop[idx] : 0.0;
+        const int64_t duration = bt.use_end_epoch ? (bt.end_epoch_ns - c.epoch) : bt.duration_ns;
+        c.stop = c.epoch + duration;
+        c.backprop = duration < 0;
+        c.step_size = (bt.step_in && bt.step_in[idx] != 0) ? bt.step_in[idx] : cfg->init_step_ns;
+        c.prev_step = 0; c.prev_kind = false;
+        c.fixed = cfg->fixed_step != 0;
+        c.det_step = cfg->init_step_ns; c.det_error = 0.0; c.det_attempts = 1; c.attempts = 1;
+        c.n_acc = c.n_rej = c.n_evals = 0;
+        c.h = 0.0; c.status = NYX_HIP_OK; c.fresh = true; c.is_final = false;
+        c.done = !valid || duration == 0;
+        if (!c.done && c.y[8] < 0.0) { c.status = NYX_HIP_ERR_FUEL_EXHAUSTED; c.done = true; }  // dynamics.finally
+        if (c.backprop) c.step_size = -c.step_size;
+        const double mass = (bt.mdry ? bt.mdry[idx] : 0.0) + c.y[8] + (bt.mextra ? bt.mextra[idx] : 0.0);
+        c.massless = has_srp && !(mass > 0.0);  // MasslessSpacecraft (spacecraft.rs:201-203)
+        cold_store(L.cs, lane, c);
     }
     if (PERT) {
         // constant along the trajectory: no guidance law on this path => d(Cr, mass)/dt = 0
@@ -566,28 +612,33 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     __syncthreads();
 
     for (;;) {  // one iteration = one RK attempt for every live lane (derive(), instance.rs:368-414)
+        double h = 0.0;
         if (INTEG) {
             // start of a step: final-step test on integer epochs (instance.rs:149-186)
-            if (!done && fresh) {
-                if ((!backprop && epoch + step_size > stop) || (backprop && epoch + step_size <= stop)) {
-                    if (stop == epoch) {
-                        done = true;
+            ColdState c;
+            cold_load(L.cs, lane, c);
+            if (!c.done && c.fresh) {
+                if ((!c.backprop && c.epoch + c.step_size > c.stop) || (c.backprop && c.epoch + c.step_size <= c.stop)) {
+                    if (c.stop == c.epoch) {
+                        c.done = true;
                     } else {
-                        prev_step = step_size;
-                        prev_kind = fixed;
-                        step_size = stop - epoch;
-                        fixed = true;
-                        is_final = true;
+                        c.prev_step = c.step_size;
+                        c.prev_kind = c.fixed;
+                        c.step_size = c.stop - c.epoch;
+                        c.fixed = true;
+                        c.is_final = true;
                     }
                 }
-                attempts = 1;
-                h = ns_to_seconds(step_size);
-                fresh = false;
+                c.attempts = 1;
+                c.h = ns_to_seconds(c.step_size);
+                c.fresh = false;
             }
-            if (!done && massless) { status = NYX_HIP_ERR_MASSLESS; done = true; }
-            L.step[lane] = __longlong_as_double(epoch);
+            if (!c.done && c.massless) { c.status = NYX_HIP_ERR_MASSLESS; c.done = true; }
+            cold_store(L.cs, lane, c);
+            h = c.h;
+            L.step[lane] = __longlong_as_double(c.epoch);
             L.step[DEV_LANES + lane] = h;
-            if (!__any(!done)) {
+            if (!__any(!c.done)) {
                 if (lane == 0) L.ctl[0] = 1;
             }
         }
@@ -603,6 +654,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
         __syncthreads();  // Bp
 
         int st_att = NYX_HIP_OK;
+        double wpre[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
         for (int i = 0; i < stages; ++i) {
             double *const edc = L.ed + (i & 1) * ED_FIELDS * DEV_LANES;
             double s_ = 0.0, t_ = 0.0, u_ = 0.0, kfac = 0.0;
@@ -612,19 +664,16 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 // ---- Phase A: stage state  y + h * sum_j a_ij k_j   (instance.rs:376-394)
                 if (i == 0) {
 #pragma unroll
-                    for (int e = 0; e < 6; ++e) ys[e] = y[e];
+                    for (int e = 0; e < 6; ++e) ys[e] = CS_Y(e);
                 } else {
-                    double wi[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+                    // wpre = sum_{j < i-1} a_ij k_j was accumulated in the previous window (same j order as the
+                    // reference, zero coefficients add an exact 0); only the newest k enters on the critical path
+                    const double a_last = A_ROW(i, i - 1);
 #pragma unroll
-                    for (int j = 0; j < DEV_MAX_STAGES - 1; ++j) {
-                        if (j < i) {  // uniform; zero coefficients add an exact 0
-                            const double a_ij = A_ROW(i, j);
-#pragma unroll
-                            for (int e = 0; e < 6; ++e) wi[e] += a_ij * KB(j, e);
-                        }
+                    for (int e = 0; e < 6; ++e) {
+                        const double wi = wpre[e] + a_last * KB(i - 1, e);
+                        ys[e] = CS_Y(e) + h * wi;
                     }
-#pragma unroll
-                    for (int e = 0; e < 6; ++e) ys[e] = y[e] + h * wi[e];
                 }
 #pragma unroll
                 for (int e = 0; e < 6; ++e) L.ys[e * DEV_LANES + lane] = ys[e];
@@ -634,15 +683,17 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     const double rb0 = edc[0 * DEV_LANES + lane] * ys[0] + edc[1 * DEV_LANES + lane] * ys[1] + edc[2 * DEV_LANES + lane] * ys[2];
                     const double rb1 = edc[3 * DEV_LANES + lane] * ys[0] + edc[4 * DEV_LANES + lane] * ys[1] + edc[5 * DEV_LANES + lane] * ys[2];
                     const double rb2 = edc[6 * DEV_LANES + lane] * ys[0] + edc[7 * DEV_LANES + lane] * ys[1] + edc[8 * DEV_LANES + lane] * ys[2];
+                    // one sqrt and one divide on the critical path; the rest are multiplies
                     const double r_ = norm3(rb0, rb1, rb2);
-                    s_ = rb0 / r_; t_ = rb1 / r_; u_ = rb2 / r_;
-                    const double rho = cfg->g_re / r_;
-                    kfac = cfg->g_mu / r_ / cfg->g_re;  // (mu / r) / R_eq
+                    const double inv_r = 1.0 / r_;
+                    s_ = rb0 * inv_r; t_ = rb1 * inv_r; u_ = rb2 * inv_r;
+                    const double rho = cfg->g_re * inv_r;
+                    kfac = (cfg->g_mu * inv_r) * cfg->g_inv_re;  // (mu / r) / R_eq
                     L.inb[0 * DEV_LANES + lane] = rho * s_;
                     L.inb[1 * DEV_LANES + lane] = rho * t_;
                     L.inb[2 * DEV_LANES + lane] = rho * u_;
                     L.inb[3 * DEV_LANES + lane] = rho;
-                    L.inb[4 * DEV_LANES + lane] = r_ / cfg->g_re;
+                    L.inb[4 * DEV_LANES + lane] = r_ * cfg->g_inv_re;
                 }
             }
             PROF_ADD(0);
@@ -675,6 +726,25 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
 #pragma unroll
                 for (int e = 0; e < 3; ++e) { L.pert[e * DEV_LANES + lane] = a3[e]; L.pert[(3 + e) * DEV_LANES + lane] = f3[e]; }
             }
+            double acc[3] = {0.0, 0.0, 0.0};
+            if (INTEG) {
+                // two-body term of this stage (orbital.rs:86-92) and sum_{j<i} a_{i+1,j} k_j of the next one
+                const double rmag = norm3(ys[0], ys[1], ys[2]);
+                const double f = -cfg->mu_central / cube(rmag);
+                acc[0] = f * ys[0]; acc[1] = f * ys[1]; acc[2] = f * ys[2];
+#pragma unroll
+                for (int e = 0; e < 6; ++e) wpre[e] = 0.0;
+                if (i + 1 < stages) {
+#pragma unroll
+                    for (int j = 0; j < DEV_MAX_STAGES - 2; ++j) {
+                        if (j < i) {  // uniform
+                            const double a_nj = A_ROW(i + 1, j);
+#pragma unroll
+                            for (int e = 0; e < 6; ++e) wpre[e] += a_nj * KB(j, e);
+                        }
+                    }
+                }
+            }
             if (prof_on) prof_acc[1] += (int64_t)__builtin_readcyclecounter() - ptw_;
             const int64_t pth_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;
             double px = 0.0, py = 0.0, pz = 0.0, pw = 0.0;
@@ -704,14 +774,14 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
 
             if (INTEG) {
                 // ---- Phase C: assemble the derivative in the reference's order (orbital.rs:80-114, spacecraft.rs:227-243)
-                const double rmag = norm3(ys[0], ys[1], ys[2]);
-                const double f = -cfg->mu_central / cube(rmag);
-                double acc[3] = {f * ys[0], f * ys[1], f * ys[2]};
                 if (has_pm) {
                     acc[0] += L.pert[0 * DEV_LANES + lane]; acc[1] += L.pert[1 * DEV_LANES + lane]; acc[2] += L.pert[2 * DEV_LANES + lane];
                 }
                 if (has_grav) {
-                    for (int w = 1; w < nw; ++w) {  // fixed wave order
+                    // fixed wave order; all 15 slots are read unconditionally (slots of absent waves hold an exact
+                    // 0.0) so that the LDS reads carry no control dependence and pipeline
+#pragma unroll
+                    for (int w = 1; w < DEV_MAX_WAVES; ++w) {
                         const double *pp = L.part + w * 4 * DEV_LANES;
                         px += pp[0 * DEV_LANES + lane]; py += pp[1 * DEV_LANES + lane];
                         pz += pp[2 * DEV_LANES + lane]; pw += pp[3 * DEV_LANES + lane];
@@ -733,7 +803,10 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
 
         const int64_t pts_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;
         if (INTEG) {
-            if (!done) n_evals += stages;
+            ColdState c;
+            cold_load(L.cs, lane, c);
+            double *const y = c.y;
+            if (!c.done) c.n_evals += stages;
             // ---- next state and error estimate (instance.rs:401-414).  d(Cr, Cd, prop mass)/dt = 0.
             double next[9], err[9];
 #pragma unroll
@@ -748,60 +821,62 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     next[e] += cb * kv;
                 }
             }
-            if (!done) {
+            if (!c.done) {
                 bool accept = false;
                 if (st_att != NYX_HIP_OK) {
-                    status = st_att;
-                    done = true;
-                } else if (fixed) {
-                    det_step = step_size;
+                    c.status = st_att;
+                    c.done = true;
+                } else if (c.fixed) {
+                    c.det_step = c.step_size;
                     accept = true;
                 } else {
-                    det_error = error_estimate(cfg->error_ctrl, err, next, y);
-                    if (det_error <= cfg->tol || h <= cfg->min_step_s || attempts >= cfg->attempts) {
+                    c.det_error = error_estimate(cfg->error_ctrl, err, next, y);
+                    if (c.det_error <= cfg->tol || h <= cfg->min_step_s || c.attempts >= cfg->attempts) {
                         bool nan = false;
 #pragma unroll
                         for (int e = 0; e < 9; ++e) nan = nan || (next[e] != next[e]);
                         if (nan) {
-                            status = NYX_HIP_ERR_NAN;
-                            done = true;
+                            c.status = NYX_HIP_ERR_NAN;
+                            c.done = true;
                         } else {
-                            det_step = seconds_to_ns(h);
-                            if (det_error < cfg->tol) {
-                                const double prop = 0.9 * h * pow(cfg->tol / det_error, cfg->inv_order);
+                            c.det_step = seconds_to_ns(h);
+                            if (c.det_error < cfg->tol) {
+                                const double prop = 0.9 * h * pow(cfg->tol / c.det_error, cfg->inv_order);
                                 h = (fabs(prop) > fabs(cfg->max_step_s)) ? cfg->max_step_s * copysign(1.0, prop) : prop;
                             }
-                            step_size = seconds_to_ns(h);
-                            const int64_t ab = step_size < 0 ? -step_size : step_size;
-                            if (ab < cfg->min_step_ns) step_size = (step_size < 0) ? -cfg->min_step_ns : cfg->min_step_ns;
+                            c.step_size = seconds_to_ns(h);
+                            const int64_t ab = c.step_size < 0 ? -c.step_size : c.step_size;
+                            if (ab < cfg->min_step_ns) c.step_size = (c.step_size < 0) ? -cfg->min_step_ns : cfg->min_step_ns;
                             accept = true;
                         }
                     } else {
-                        attempts += 1;
-                        n_rej += 1;
-                        const double prop = 0.9 * h * pow(cfg->tol / det_error, cfg->inv_order_m1);
+                        c.attempts += 1;
+                        c.n_rej += 1;
+                        const double prop = 0.9 * h * pow(cfg->tol / c.det_error, cfg->inv_order_m1);
                         h = (prop < cfg->min_step_s) ? cfg->min_step_s : prop;
                     }
                 }
                 if (accept) {
-                    // single_step(): state.set(epoch + t, vec) with the Cr clamp, then finally()
-                    epoch += det_step;
+                    // single_step(): state.set(c.epoch + t, vec) with the Cr clamp, then finally()
+                    c.epoch += c.det_step;
 #pragma unroll
                     for (int e = 0; e < 9; ++e) y[e] = next[e];
                     y[6] = clamp02(y[6]);
-                    n_acc += 1;
-                    det_attempts = attempts;
-                    if (y[8] < 0.0) { status = NYX_HIP_ERR_FUEL_EXHAUSTED; done = true; }
-                    if (is_final) {
-                        step_size = prev_step;
-                        fixed = prev_kind;
-                        if (backprop) step_size = -step_size;
-                        is_final = false;
-                        done = true;
+                    c.n_acc += 1;
+                    c.det_attempts = c.attempts;
+                    if (y[8] < 0.0) { c.status = NYX_HIP_ERR_FUEL_EXHAUSTED; c.done = true; }
+                    if (c.is_final) {
+                        c.step_size = c.prev_step;
+                        c.fixed = c.prev_kind;
+                        if (c.backprop) c.step_size = -c.step_size;
+                        c.is_final = false;
+                        c.done = true;
                     }
-                    fresh = true;
+                    c.fresh = true;
                 }
             }
+            c.h = h;
+            cold_store(L.cs, lane, c);
         }
         if (prof_on) prof_acc[4] += (int64_t)__builtin_readcyclecounter() - pts_;
     }
@@ -812,24 +887,26 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     }
 
     if (INTEG && valid) {
-        bt.o_epoch_ns[gid] = epoch;
-        bt.o_x[gid] = y[0]; bt.o_y[gid] = y[1]; bt.o_z[gid] = y[2];
-        bt.o_vx[gid] = y[3]; bt.o_vy[gid] = y[4]; bt.o_vz[gid] = y[5];
-        if (bt.o_cr) bt.o_cr[gid] = y[6];
-        if (bt.o_cd) bt.o_cd[gid] = y[7];
-        if (bt.o_mprop) bt.o_mprop[gid] = y[8];
+        ColdState c;
+        cold_load(L.cs, lane, c);
+        bt.o_epoch_ns[gid] = c.epoch;
+        bt.o_x[gid] = c.y[0]; bt.o_y[gid] = c.y[1]; bt.o_z[gid] = c.y[2];
+        bt.o_vx[gid] = c.y[3]; bt.o_vy[gid] = c.y[4]; bt.o_vz[gid] = c.y[5];
+        if (bt.o_cr) bt.o_cr[gid] = c.y[6];
+        if (bt.o_cd) bt.o_cd[gid] = c.y[7];
+        if (bt.o_mprop) bt.o_mprop[gid] = c.y[8];
         if (bt.o_mdry) bt.o_mdry[gid] = bt.mdry ? bt.mdry[idx] : 0.0;
         if (bt.o_mextra) bt.o_mextra[gid] = bt.mextra ? bt.mextra[idx] : 0.0;
         if (bt.o_asrp) bt.o_asrp[gid] = bt.asrp ? bt.asrp[idx] : 0.0;
         if (bt.o_adrag) bt.o_adrag[gid] = bt.adrag ? bt.adrag[idx] : 0.0;
-        if (bt.o_step) bt.o_step[gid] = step_size;
-        if (bt.status) bt.status[gid] = status;
-        if (bt.last_step_ns) bt.last_step_ns[gid] = det_step;
-        if (bt.last_error) bt.last_error[gid] = det_error;
-        if (bt.last_attempts) bt.last_attempts[gid] = det_attempts;
-        if (bt.n_acc) bt.n_acc[gid] = n_acc;
-        if (bt.n_rej) bt.n_rej[gid] = n_rej;
-        if (bt.n_evals) bt.n_evals[gid] = n_evals;
+        if (bt.o_step) bt.o_step[gid] = c.step_size;
+        if (bt.status) bt.status[gid] = c.status;
+        if (bt.last_step_ns) bt.last_step_ns[gid] = c.det_step;
+        if (bt.last_error) bt.last_error[gid] = c.det_error;
+        if (bt.last_attempts) bt.last_attempts[gid] = c.det_attempts;
+        if (bt.n_acc) bt.n_acc[gid] = c.n_acc;
+        if (bt.n_rej) bt.n_rej[gid] = c.n_rej;
+        if (bt.n_evals) bt.n_evals[gid] = c.n_evals;
     }
 }
 
@@ -868,6 +945,7 @@ extern "C" __global__ void __launch_bounds__(DEV_MAX_WAVES *DEV_LANES)
         tabl[q] = v;
     }
     if (threadIdx.x == 0) L.ctl[0] = 0;
+    for (int q = (int)threadIdx.x; q < DEV_MAX_WAVES * 4 * DEV_LANES; q += (int)blockDim.x) L.part[q] = 0.0;
 
     // ---- role dispatch (wave-uniform): merged roles when the workgroup has fewer than three waves
     if (nw == 1) {
