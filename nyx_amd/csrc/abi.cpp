@@ -15,6 +15,7 @@
 #include "butcher.h"
 #include "devcfg.h"
 
+extern "C" size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles, int stm);
 extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg, const HarmEntry *htab,
                                            const ColHdr *cols, const double *records, int n_waves, int rec_lds_doubles,
                                            hipStream_t stream);
@@ -51,6 +52,8 @@ struct DevArrays {  // one SoA batch resident on the device
     int64_t cap = 0;
     int64_t *epoch = nullptr, *step = nullptr;
     double *f[13] = {nullptr};
+    double *stm = nullptr;  // [cap][81], allocated on first STM use
+    int64_t stm_cap = 0;
     int32_t *status = nullptr, *last_attempts = nullptr;
     int64_t *last_step = nullptr, *n_acc = nullptr, *n_rej = nullptr, *n_evals = nullptr;
     double *last_error = nullptr;
@@ -74,7 +77,7 @@ struct nyx_hip_ctx {
 };
 
 static void free_arrays(DevArrays &a) {
-    hipFree(a.epoch); hipFree(a.step);
+    hipFree(a.epoch); hipFree(a.step); hipFree(a.stm);
     for (auto &p : a.f) hipFree(p);
     hipFree(a.status); hipFree(a.last_attempts); hipFree(a.last_step); hipFree(a.n_acc); hipFree(a.n_rej);
     hipFree(a.n_evals); hipFree(a.last_error);
@@ -252,6 +255,11 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves) {
 }
 
 static int pick_waves(const nyx_hip_ctx *ctx, int64_t n) {
+    const bool stm = (ctx->host_cfg.flags & NYX_HIP_FLAG_STM) != 0;
+    if (stm) {  // dual-number variant: 256 VGPRs per wave, at most DEV_MAX_WAVES_STM waves
+        if (ctx->forced_waves > 0) return std::min(ctx->forced_waves, DEV_MAX_WAVES_STM);
+        return ctx->host_cfg.has_grav ? DEV_MAX_WAVES_STM : 3;
+    }
     if (ctx->forced_waves > 0) return std::min(ctx->forced_waves, DEV_MAX_WAVES);
     // no harmonics: integrator + almanac + perturbation waves form a 3-stage pipeline
     if (!ctx->host_cfg.has_grav) return (ctx->host_cfg.n_slots > 0) ? 3 : 1;
@@ -306,7 +314,11 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
     if (cfg->abi_version != NYX_HIP_ABI_VERSION) { nyx_set_error("ABI version mismatch"); return NYX_HIP_RC_BAD_ARG; }
     const nyx_hip_integ_opts_t &o = cfg->opts;
     if (o.method < 0 || o.method > 5 || o.error_ctrl < 0 || o.error_ctrl > 6) { nyx_set_error("bad method / error_ctrl"); return NYX_HIP_RC_BAD_ARG; }
-    if (cfg->flags & NYX_HIP_FLAG_STM) { nyx_set_error("STM propagation is not on the device path yet"); return NYX_HIP_RC_UNSUPPORTED; }
+    if ((cfg->flags & NYX_HIP_FLAG_STM) && o.error_ctrl != NYX_HIP_RSS_CARTESIAN_STEP && o.error_ctrl != NYX_HIP_RSS_CARTESIAN_STATE) {
+        nyx_set_error("STM propagation on the device supports the RSSCartesianStep / RSSCartesianState error controls only");
+        return NYX_HIP_RC_UNSUPPORTED;
+    }
+    if (cfg->flags & NYX_HIP_FLAG_STM_TEXTBOOK) { nyx_set_error("textbook STM form (A Phi) is not implemented"); return NYX_HIP_RC_UNSUPPORTED; }
     if (cfg->drag) { nyx_set_error("drag is not on the device path yet"); return NYX_HIP_RC_UNSUPPORTED; }
     if (nyx_hip_device_count() <= device || device < 0) { nyx_set_error("no HIP device %d", device); return NYX_HIP_RC_NO_DEVICE; }
     HIP_TRY(hipSetDevice(device));
@@ -422,6 +434,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
     records.resize(records.size() + 16, 0.0);  // padding for the 16-wide coefficient window
     dc.rec_doubles = (int32_t)records.size();
     dc.rec_in_lds = (records.size() * sizeof(double) <= 24 * 1024) ? 1 : 0;
+    if ((cfg->flags & NYX_HIP_FLAG_STM) && nyx_kernel_lds_bytes(DEV_MAX_WAVES_STM, dc.rec_doubles, 1) > 160 * 1024) dc.rec_in_lds = 0;
     build_schedule(ctx, 1);
 
     // ---- upload
@@ -460,6 +473,10 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
     bt.x = in->x_km; bt.y = in->y_km; bt.z = in->z_km; bt.vx = in->vx_km_s; bt.vy = in->vy_km_s; bt.vz = in->vz_km_s;
     bt.cr = in->cr; bt.cd = in->cd; bt.mprop = in->prop_mass_kg; bt.mdry = in->dry_mass_kg; bt.mextra = in->extra_mass_kg;
     bt.asrp = in->srp_area_m2; bt.adrag = in->drag_area_m2; bt.step_in = in->step_ns;
+    if (ctx->host_cfg.flags & NYX_HIP_FLAG_STM) {
+        if (!in->stm || !out->stm) { nyx_set_error("STM context: in->stm and out->stm are mandatory"); return NYX_HIP_RC_BAD_ARG; }
+        bt.stm = in->stm; bt.o_stm = out->stm;
+    }
     bt.o_epoch_ns = out->epoch_ns;
     bt.o_x = out->x_km; bt.o_y = out->y_km; bt.o_z = out->z_km; bt.o_vx = out->vx_km_s; bt.o_vy = out->vy_km_s; bt.o_vz = out->vz_km_s;
     bt.o_cr = out->cr; bt.o_cd = out->cd; bt.o_mprop = out->prop_mass_kg; bt.o_mdry = out->dry_mass_kg;
@@ -517,6 +534,19 @@ static int host_propagate(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t 
     for (int k = 0; k < 13; ++k)
         if (hin[k]) HIP_TRY(hipMemcpy(di.f[k], hin[k], n * sizeof(double), hipMemcpyHostToDevice));
     if (in->step_ns) HIP_TRY(hipMemcpy(di.step, in->step_ns, n * sizeof(int64_t), hipMemcpyHostToDevice));
+    const bool stm = (ctx->host_cfg.flags & NYX_HIP_FLAG_STM) != 0;
+    if (stm) {
+        if (!in->stm || !out->stm) { nyx_set_error("STM context: in->stm and out->stm are mandatory"); return NYX_HIP_RC_BAD_ARG; }
+        for (DevArrays *d : {&di, &dq}) {
+            if (d->stm_cap < n) {
+                hipFree(d->stm);
+                d->stm = nullptr;
+                HIP_TRY(hipMalloc(&d->stm, (size_t)std::max<int64_t>(n, 1024) * 81 * sizeof(double)));
+                d->stm_cap = std::max<int64_t>(n, 1024);
+            }
+        }
+        HIP_TRY(hipMemcpy(di.stm, in->stm, (size_t)n * 81 * sizeof(double), hipMemcpyHostToDevice));
+    }
 
     nyx_hip_states_t din;
     std::memset(&din, 0, sizeof din);
@@ -525,6 +555,7 @@ static int host_propagate(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t 
                          &din.prop_mass_kg, &din.dry_mass_kg, &din.extra_mass_kg, &din.srp_area_m2, &din.drag_area_m2};
     for (int k = 0; k < 13; ++k) *dinf[k] = hin[k] ? di.f[k] : nullptr;
     din.step_ns = in->step_ns ? di.step : nullptr;
+    din.stm = stm ? di.stm : nullptr;
 
     nyx_hip_states_t dout;
     std::memset(&dout, 0, sizeof dout);
@@ -533,6 +564,7 @@ static int host_propagate(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t 
                           &dout.prop_mass_kg, &dout.dry_mass_kg, &dout.extra_mass_kg, &dout.srp_area_m2, &dout.drag_area_m2};
     for (int k = 0; k < 13; ++k) *doutf[k] = dq.f[k];
     dout.step_ns = dq.step;
+    dout.stm = stm ? dq.stm : nullptr;
     nyx_hip_step_stats_t dst = {dq.status, dq.last_step, dq.last_error, dq.last_attempts, dq.n_acc, dq.n_rej, dq.n_evals};
 
     if (int rc = launch(ctx, &din, &dout, &dst, duration_ns, end_epoch_ns, use_end, nullptr, true)) return rc;
@@ -547,6 +579,7 @@ static int host_propagate(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t 
     for (int k = 0; k < 13; ++k)
         if (hout[k]) HIP_TRY(hipMemcpy(hout[k], dq.f[k], n * sizeof(double), hipMemcpyDeviceToHost));
     if (out->step_ns) HIP_TRY(hipMemcpy(out->step_ns, dq.step, n * sizeof(int64_t), hipMemcpyDeviceToHost));
+    if (stm) HIP_TRY(hipMemcpy(out->stm, dq.stm, (size_t)n * 81 * sizeof(double), hipMemcpyDeviceToHost));
     if (stats) {
         if (stats->status) HIP_TRY(hipMemcpy(stats->status, dq.status, n * sizeof(int32_t), hipMemcpyDeviceToHost));
         if (stats->last_step_ns) HIP_TRY(hipMemcpy(stats->last_step_ns, dq.last_step, n * sizeof(int64_t), hipMemcpyDeviceToHost));

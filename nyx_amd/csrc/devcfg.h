@@ -10,6 +10,7 @@
 #define DEV_MAX_SLOTS 4   /* non-central bodies whose position is evaluated per stage */
 #define DEV_MAX_SEG 8
 #define DEV_MAX_WAVES 16  /* waves per 64-trajectory workgroup (column split) */
+#define DEV_MAX_WAVES_STM 4 /* STM variant: dual numbers need 256 VGPRs per wave and 16 partial slots per wave */
 #define DEV_MAX_RANGES 6  /* contiguous column ranges per wave */
 #define DEV_LANES 64
 
@@ -98,6 +99,8 @@ struct DevBatch { /* device pointers of one launch */
     const int64_t *epoch_ns;
     const double *x, *y, *z, *vx, *vy, *vz, *cr, *cd, *mprop, *mdry, *mextra, *asrp, *adrag;
     const int64_t *step_in;
+    const double *stm; /* [n][81] column-major per trajectory, or NULL */
+    double *o_stm;
     int64_t *o_epoch_ns;
     double *o_x, *o_y, *o_z, *o_vx, *o_vy, *o_vz, *o_cr, *o_cd, *o_mprop, *o_mdry, *o_mextra, *o_asrp, *o_adrag;
     int64_t *o_step;

@@ -246,7 +246,7 @@ DEVFN double occultation_pct(double r_back, double r_front, const double *r_eb, 
 }
 
 // SolarPressure::eom (reference dynamics/solarpressure.rs:135-165) + ShadowModel::compute (cosmic/eclipse.rs:69-83)
-DEVFN void srp_force(CfgPtr cfg, const double *ed, int lane, const double *r, double cr, double area, double *force) {
+DEVFN double srp_force(CfgPtr cfg, const double *ed, int lane, const double *r, double cr, double area, double *force) {
     const int ss = cfg->sun_slot;
     const double ps[3] = {ED_BP(ed, ss, 0), ED_BP(ed, ss, 1), ED_BP(ed, ss, 2)};
     const double rs0 = r[0] - ps[0], rs1 = r[1] - ps[1], rs2 = r[2] - ps[2];
@@ -280,6 +280,7 @@ DEVFN void srp_force(CfgPtr cfg, const double *ed, int lane, const double *r, do
     force[0] = scal * u0;
     force[1] = scal * u1;
     force[2] = scal * u2;
+    return k;  // illumination factor |occultation - 1|, frozen in the partials (solarpressure.rs:194-203)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -289,34 +290,84 @@ DEVFN void srp_force(CfgPtr cfg, const double *ed, int lane, const double *r, do
 // (At_n' = rho^(n'-c+1) A[n'][c]); per-column complex power (Rc, Ic) = (rho (s + i t))^(c-1).
 // ---------------------------------------------------------------------------------------------
 
-DEVFN void cpow_uniform(double zr, double zi, int e, double &pr, double &pi) {
-    pr = 1.0;
-    pi = 0.0;
-    double br = zr, bi = zi;
+// Forward-mode dual number: value + partials w.r.t. the three position components (stand-in for the
+// reference's OHyperdual<f64, 7> whose slots 1..3 carry d/dx, d/dy, d/dz; gravity_field.rs:273-431).
+struct D3 {
+    double v, x, y, z;
+};
+DEVFN D3 d3c(double v) { D3 r = {v, 0.0, 0.0, 0.0}; return r; }
+DEVFN D3 operator+(D3 a, D3 b) { D3 r = {a.v + b.v, a.x + b.x, a.y + b.y, a.z + b.z}; return r; }
+DEVFN D3 operator-(D3 a, D3 b) { D3 r = {a.v - b.v, a.x - b.x, a.y - b.y, a.z - b.z}; return r; }
+DEVFN D3 operator-(D3 a) { D3 r = {-a.v, -a.x, -a.y, -a.z}; return r; }
+DEVFN D3 operator*(D3 a, D3 b) {
+    D3 r = {a.v * b.v, __builtin_fma(a.v, b.x, a.x * b.v), __builtin_fma(a.v, b.y, a.y * b.v), __builtin_fma(a.v, b.z, a.z * b.v)};
+    return r;
+}
+DEVFN D3 operator*(D3 a, double s) { D3 r = {a.v * s, a.x * s, a.y * s, a.z * s}; return r; }
+DEVFN D3 operator*(double s, D3 a) { return a * s; }
+DEVFN D3 d3div(D3 a, D3 b) {  // hyperdual Div: real = a/b, dual_i = (a_i b - a b_i) / b^2
+    const double dd = b.v * b.v;
+    D3 r = {a.v / b.v, (a.x * b.v - a.v * b.x) / dd, (a.y * b.v - a.v * b.y) / dd, (a.z * b.v - a.v * b.z) / dd};
+    return r;
+}
+DEVFN D3 d3sqrt(D3 a) {
+    const double s = sqrt(a.v);
+    const double hh = 0.5 / s;
+    D3 r = {s, a.x * hh, a.y * hh, a.z * hh};
+    return r;
+}
+DEVFN D3 d3norm(D3 a, D3 b, D3 c) { return d3sqrt(a * a + b * b + c * c); }
+DEVFN D3 d3cube(D3 a) {  // powi(3): real = (a*a)*a, dual = 3 a^2 da
+    const double p = a.v * a.v;
+    const double f = 3.0 * p;
+    D3 r = {p * a.v, a.x * f, a.y * f, a.z * f};
+    return r;
+}
+
+// scalar-generic helpers so that the column recursion is written once for double and D3
+DEVFN double sfma(double a, double s, double c) { return __builtin_fma(a, s, c); }              // a * s + c, s uniform
+DEVFN D3 sfma(D3 a, double s, D3 c) {
+    D3 r = {__builtin_fma(a.v, s, c.v), __builtin_fma(a.x, s, c.x), __builtin_fma(a.y, s, c.y), __builtin_fma(a.z, s, c.z)};
+    return r;
+}
+DEVFN double gmul(double a, double b) { return a * b; }
+DEVFN D3 gmul(D3 a, D3 b) { return a * b; }
+DEVFN double gfma(double a, double b, double c) { return __builtin_fma(a, b, c); }               // a * b + c
+DEVFN D3 gfma(D3 a, D3 b, D3 c) { return a * b + c; }
+DEVFN double gzero(double) { return 0.0; }
+DEVFN D3 gzero(D3) { return d3c(0.0); }
+DEVFN double gone(double) { return 1.0; }
+DEVFN D3 gone(D3) { return d3c(1.0); }
+
+template <typename T>
+DEVFN void cpow_uniform(T zr, T zi, int e, T &pr, T &pi) {
+    pr = gone(zr);
+    pi = gzero(zr);
+    T br = zr, bi = zi;
     while (e) {  // e is wave-uniform
         if (e & 1) {
-            const double t = pr * br - pi * bi;
-            pi = pr * bi + pi * br;
+            const T t = gmul(pr, br) - gmul(pi, bi);
+            pi = gmul(pr, bi) + gmul(pi, br);
             pr = t;
         }
-        const double t = br * br - bi * bi;
-        bi = 2.0 * (br * bi);
+        const T t = gmul(br, br) - gmul(bi, bi);
+        bi = (gmul(br, bi)) * 2.0;
         br = t;
         e >>= 1;
     }
 }
 
-#define HARM_TERM(h)                                                              \
-    {                                                                             \
-        const double an = __builtin_fma((h).bb * rho_u, a1, -(((h).cc * rho2) * a2)); \
-        s1 = __builtin_fma(an, (h).t1, s1);                                       \
-        s2 = __builtin_fma(an, (h).t2, s2);                                       \
-        s3 = __builtin_fma(an, (h).t3, s3);                                       \
-        s4 = __builtin_fma(an, (h).t4, s4);                                       \
-        s5 = __builtin_fma(an, (h).t5, s5);                                       \
-        s6 = __builtin_fma(an, (h).t6, s6);                                       \
-        a2 = a1;                                                                  \
-        a1 = an;                                                                  \
+#define HARM_TERM(h)                                                                       \
+    {                                                                                      \
+        const T an = gfma(rho_u * (h).bb, a1, -(gmul(rho2 * (h).cc, a2)));                 \
+        s1 = sfma(an, (h).t1, s1);                                                         \
+        s2 = sfma(an, (h).t2, s2);                                                         \
+        s3 = sfma(an, (h).t3, s3);                                                         \
+        s4 = sfma(an, (h).t4, s4);                                                         \
+        s5 = sfma(an, (h).t5, s5);                                                         \
+        s6 = sfma(an, (h).t6, s6);                                                         \
+        a2 = a1;                                                                           \
+        a1 = an;                                                                           \
     }
 
 DEVFN uint64_t uniform_u64(uint64_t v) {
@@ -332,37 +383,35 @@ DEVFN ColHdr load_hdr(ColPtr cols, int c) {
     return h;
 }
 
-struct Partial4 {
-    double x, y, z, w;
+template <typename T>
+struct Partial4T {
+    T x, y, z, w;
 };
+typedef Partial4T<double> Partial4;
 
 // Not inlined on purpose: the batch loop wants 64 SGPRs for its four in-flight table entries, which it only
 // gets when it is register-allocated on its own, away from the role code that calls it.  Arguments arrive in
 // VGPRs under the device-function ABI, so the wave-uniform ones are re-scalarised with v_readfirstlane.
-static __device__ __attribute__((noinline)) Partial4 harmonics_partial(uint64_t cfg_u, uint64_t htab_u, uint64_t cols_u, int wave_v,
-                                                                     double zr, double zi, double rho_u, double rho,
-                                                                     double inv_rho) {
-    CfgPtr cfg = (CfgPtr)uniform_u64(cfg_u);
-    HarmPtr htab = (HarmPtr)uniform_u64(htab_u);
-    ColPtr cols = (ColPtr)uniform_u64(cols_u);
-    const int wave = __builtin_amdgcn_readfirstlane(wave_v);
-    double px = 0.0, py = 0.0, pz = 0.0, pw = 0.0;
-    const double rho2 = rho * rho;
+// T = double: accelerations only; T = D3: accelerations and their body-fixed position partials (STM path).
+template <typename T>
+DEVFN Partial4T<T> harmonics_core(CfgPtr cfg, HarmPtr htab, ColPtr cols, const int wave, T zr, T zi, T rho_u, T rho, T inv_rho) {
+    T px = gzero(zr), py = gzero(zr), pz = gzero(zr), pw = gzero(zr);
+    const T rho2 = gmul(rho, rho);
     const int nr = cfg->n_ranges[wave];
     for (int q = 0; q < nr; ++q) {
         const int c0 = cfg->range_c0[wave][q];
         const int cnt = cfg->range_cnt[wave][q];
-        double rc, ic;
+        T rc, ic;
         cpow_uniform(zr, zi, c0 - 1, rc, ic);
         ColHdr hd = load_hdr(cols, c0);  // the next column's header is fetched under this column's batches
         for (int c = c0; c < c0 + cnt; ++c) {
             const ColHdr hn = load_hdr(cols, c + 1);  // (the header array has a spare tail entry)
             HarmPtr e = htab + hd.start;
             const int nb = hd.nb;
-            double a1 = 0.0, a2 = hd.diag * inv_rho;
-            double s1 = 0.0, s2 = 0.0, s3 = 0.0, s4 = 0.0, s5 = 0.0, s6 = 0.0;
+            T a1 = gzero(zr), a2 = inv_rho * hd.diag;
+            T s1 = gzero(zr), s2 = gzero(zr), s3 = gzero(zr), s4 = gzero(zr), s5 = gzero(zr), s6 = gzero(zr);
             for (int b = 0; b < nb; ++b, e += 4) {
-                // four 64-byte entries per batch: 4 x s_load_dwordx16 in flight, then 40 f64 VALU ops
+                // four 64-byte entries per batch: 4 x s_load_dwordx16 in flight, then 40 f64 VALU ops (x4.5 with duals)
                 const HarmEntry CAS &h0 = e[0];
                 const HarmEntry CAS &h1 = e[1];
                 const HarmEntry CAS &h2 = e[2];
@@ -372,19 +421,50 @@ static __device__ __attribute__((noinline)) Partial4 harmonics_partial(uint64_t 
                 HARM_TERM(h2)
                 HARM_TERM(h3)
             }
-            const double sc = rho * hd.scale;  // rho * c * sqrt(2)
-            px = __builtin_fma(sc, __builtin_fma(rc, s1, ic * s2), px);
-            py = __builtin_fma(sc, __builtin_fma(rc, s2, -(ic * s1)), py);
-            pz = __builtin_fma(rho, __builtin_fma(rc, s3, ic * s4), pz);
-            pw = pw - __builtin_fma(rc, s5, ic * s6);
-            const double t = rc * zr - ic * zi;
-            ic = rc * zi + ic * zr;
+            const T sc = rho * hd.scale;  // rho * c * sqrt(2)
+            px = gfma(sc, gfma(rc, s1, gmul(ic, s2)), px);
+            py = gfma(sc, gfma(rc, s2, -(gmul(ic, s1))), py);
+            pz = gfma(rho, gfma(rc, s3, gmul(ic, s4)), pz);
+            pw = pw - gfma(rc, s5, gmul(ic, s6));
+            const T t = gmul(rc, zr) - gmul(ic, zi);
+            ic = gmul(rc, zi) + gmul(ic, zr);
             rc = t;
             hd = hn;
         }
     }
-    Partial4 r = {px, py, pz, pw};
+    Partial4T<T> r = {px, py, pz, pw};
     return r;
+}
+
+static __device__ __attribute__((noinline)) Partial4 harmonics_partial(uint64_t cfg_u, uint64_t htab_u, uint64_t cols_u, int wave_v,
+                                                                     double zr, double zi, double rho_u, double rho, double inv_rho) {
+    CfgPtr cfg = (CfgPtr)uniform_u64(cfg_u);
+    HarmPtr htab = (HarmPtr)uniform_u64(htab_u);
+    ColPtr cols = (ColPtr)uniform_u64(cols_u);
+    const int wave = __builtin_amdgcn_readfirstlane(wave_v);
+    return harmonics_core<double>(cfg, htab, cols, wave, zr, zi, rho_u, rho, inv_rho);
+}
+
+// Dual variant: inputs and outputs go through LDS (20 + 16 doubles per lane) instead of the register ABI.
+static __device__ __attribute__((noinline)) void harmonics_partial_dual(uint64_t cfg_u, uint64_t htab_u, uint64_t cols_u, int wave_v,
+                                                                      const double *inbD, double *outD, int lane) {
+    CfgPtr cfg = (CfgPtr)uniform_u64(cfg_u);
+    HarmPtr htab = (HarmPtr)uniform_u64(htab_u);
+    ColPtr cols = (ColPtr)uniform_u64(cols_u);
+    const int wave = __builtin_amdgcn_readfirstlane(wave_v);
+    D3 in[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        in[q].v = inbD[(4 * q + 0) * DEV_LANES + lane]; in[q].x = inbD[(4 * q + 1) * DEV_LANES + lane];
+        in[q].y = inbD[(4 * q + 2) * DEV_LANES + lane]; in[q].z = inbD[(4 * q + 3) * DEV_LANES + lane];
+    }
+    const Partial4T<D3> pd = harmonics_core<D3>(cfg, htab, cols, wave, in[0], in[1], in[2], in[3], in[4]);
+    const D3 o4[4] = {pd.x, pd.y, pd.z, pd.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        outD[(4 * q + 0) * DEV_LANES + lane] = o4[q].v; outD[(4 * q + 1) * DEV_LANES + lane] = o4[q].x;
+        outD[(4 * q + 2) * DEV_LANES + lane] = o4[q].y; outD[(4 * q + 3) * DEV_LANES + lane] = o4[q].z;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -453,6 +533,91 @@ DEVFN double error_estimate(int ec, const double *e, const double *cand, const d
 }
 
 // ---------------------------------------------------------------------------------------------
+// STM variant: position partials of the perturbations (perturbation wave) and the per-step update
+// ---------------------------------------------------------------------------------------------
+
+// PointMasses::gradient (orbital.rs:249-308) and SolarPressure::gradient (solarpressure.rs:167-232, k frozen).
+// out[27][64]: a_pm(3), G_pm(9 row-major), f_srp/m(3), G_srp/m(9), c = (F/Cr)/m (3, zero unless `estimate`).
+DEVFN void pert_gradients(CfgPtr cfg, const double *ed, int lane, const double *r, double cr, double area, double mass,
+                          bool has_pm, bool has_srp, double *out) {
+    double o[27];
+#pragma unroll
+    for (int q = 0; q < 27; ++q) o[q] = 0.0;
+    if (has_pm) {
+        const int npm = cfg->n_pm;
+#pragma unroll
+        for (int k = 0; k < DEV_MAX_SLOTS; ++k) {
+            if (k < npm) {
+                const int s = cfg->pm_slot[k];
+                const D3 rij[3] = {d3c(ED_BP(ed, s, 0)), d3c(ED_BP(ed, s, 1)), d3c(ED_BP(ed, s, 2))};
+                const D3 rij3 = d3cube(d3norm(rij[0], rij[1], rij[2]));
+                const D3 rj[3] = {{r[0] - rij[0].v, 1.0, 0.0, 0.0}, {r[1] - rij[1].v, 0.0, 1.0, 0.0}, {r[2] - rij[2].v, 0.0, 0.0, 1.0}};
+                const D3 rj3 = d3cube(d3norm(rj[0], rj[1], rj[2]));
+                const D3 gm = d3c(-cfg->slot[s].mu);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const D3 t = (d3div(rj[i], rj3) + d3div(rij[i], rij3)) * gm;
+                    o[i] += t.v;
+                    o[3 + 3 * i + 0] += t.x; o[3 + 3 * i + 1] += t.y; o[3 + 3 * i + 2] += t.z;
+                }
+            }
+        }
+    }
+    if (has_srp) {
+        const int ss = cfg->sun_slot;
+        const double ps[3] = {ED_BP(ed, ss, 0), ED_BP(ed, ss, 1), ED_BP(ed, ss, 2)};
+        const D3 rs[3] = {{r[0] - ps[0], 1.0, 0.0, 0.0}, {r[1] - ps[1], 0.0, 1.0, 0.0}, {r[2] - ps[2], 0.0, 0.0, 1.0}};
+        const D3 n = d3norm(rs[0], rs[1], rs[2]);
+        // illumination factor exactly as the real path computes it (frozen in the partials)
+        double f3[3];
+        const double kfro = srp_force(cfg, ed, lane, r, cr, area, f3);  // real path: force and the frozen illumination factor
+        const D3 r_au = n * (1.0 / 149597870.700);
+        const D3 inv = d3div(d3c(1.0), r_au);
+        const D3 flux = (inv * inv) * (kfro * cfg->phi / cfg->c_m_s);
+        const double scal = 1e-3 * cr * area;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const D3 f = (flux * scal) * d3div(rs[i], n);
+            o[12 + i] = f3[i] / mass;  // real part from the real path (spacecraft.rs:349)
+            o[15 + 3 * i + 0] = f.x / mass; o[15 + 3 * i + 1] = f.y / mass; o[15 + 3 * i + 2] = f.z / mass;
+            if (cfg->srp_estimate) o[24 + i] = (f3[i] / cr) / mass;  // solarpressure.rs:225-229, spacecraft.rs:355-359
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 27; ++q) out[q * DEV_LANES + lane] = o[q];
+}
+
+// Phi_next = Phi + h * Phi * A_sum with A_sum = [[0, (sum b) I, 0], [Gs, 0, cs], [0, 0, 0]]  — the reference integrates
+// Phi_dot = Phi_ctx * A with the STEP-START Phi (dynamics/spacecraft.rs:214), so the RK sum factorises exactly.
+// phi: this trajectory's 81 entries, column-major (cosmic/spacecraft.rs:467-471).
+DEVFN bool stm_update(double *phi, double h, const double *sacc, int lane, double sumb) {
+    double gs[12];
+#pragma unroll
+    for (int q = 0; q < 12; ++q) gs[q] = sacc[q * DEV_LANES + lane];
+    bool nan = false;
+    for (int r = 0; r < 9; ++r) {
+        double row[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) row[c] = phi[r + 9 * c];
+        double nw[9];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            nw[j] = row[j] + h * (row[3] * gs[0 * 3 + j] + row[4] * gs[1 * 3 + j] + row[5] * gs[2 * 3 + j]);
+            nw[3 + j] = row[3 + j] + h * (sumb * row[j]);
+        }
+        nw[6] = row[6] + h * (row[3] * gs[9] + row[4] * gs[10] + row[5] * gs[11]);
+        nw[7] = row[7];
+        nw[8] = row[8];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            nan = nan || (nw[c] != nw[c]);
+            phi[r + 9 * c] = nw[c];
+        }
+    }
+    return nan;
+}
+
+// ---------------------------------------------------------------------------------------------
 // The kernel
 // ---------------------------------------------------------------------------------------------
 
@@ -514,31 +679,47 @@ struct LdsMap {
     int *pertst;    // [64]
     int *ctl;       // [16]
     double *rec;    // [rec_doubles]
+    // STM variant only
+    double *inbD;   // [20][64]       5 dual inputs (zr, zi, rho_u, rho, 1/rho)
+    double *pertD;  // [27][64]       a_pm(3) G_pm(9) f_srp/m(3) G_srp/m(9) c_srp(3)
+    double *sacc;   // [12][64]       sum_i b_i * (G_i (9, row-major), c_i (3)) of the current attempt
+    double *partD;  // [P][16][64]    dual harmonics partials
 };
 
-DEVFN LdsMap carve_lds(char *smem, int n_waves) {
+DEVFN LdsMap carve_lds(char *smem, int n_waves, bool stm) {
     LdsMap m;
     double *p = (double *)smem;
     m.kbuf = p; p += DEV_MAX_STAGES * 6 * DEV_LANES;
     m.tabl = p; p += DEV_MAX_STAGES * DEV_MAX_STAGES + 3 * DEV_MAX_STAGES;
     m.ys = p; p += 6 * DEV_LANES;
-    m.inb = p; p += NIN * DEV_LANES;
     m.ed = p; p += 2 * ED_FIELDS * DEV_LANES;
-    m.pert = p; p += 6 * DEV_LANES;
     m.step = p; p += 2 * DEV_LANES;
     m.cs = p; p += CS_FIELDS * DEV_LANES;
-    m.part = p; p += DEV_MAX_WAVES * 4 * DEV_LANES;
+    m.part = p; p += DEV_MAX_WAVES * 4 * DEV_LANES;  // = DEV_MAX_WAVES_STM * 16 * DEV_LANES: reused for the dual partials
     m.edst = (int *)p; p += DEV_LANES;       // 2*64 ints
     m.pertst = (int *)p; p += DEV_LANES / 2; // 64 ints
     m.ctl = (int *)p; p += 8;
+    m.inbD = m.pertD = m.sacc = m.partD = nullptr;
+    if (stm) {
+        // the plain inb / pert slots alias the head of their dual counterparts (written first, overwritten after)
+        m.inbD = p; m.inb = p; p += 20 * DEV_LANES;
+        m.pertD = p; m.pert = p; p += 27 * DEV_LANES;
+        m.sacc = p; p += 12 * DEV_LANES;
+        m.partD = m.part;
+    } else {
+        m.inb = p; p += NIN * DEV_LANES;
+        m.pert = p; p += 6 * DEV_LANES;
+    }
     m.rec = p;
     return m;
 }
 
-extern "C" size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles) {
+extern "C" size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles, int stm) {
     size_t d = (size_t)DEV_MAX_STAGES * 6 * DEV_LANES + DEV_MAX_STAGES * DEV_MAX_STAGES + 3 * DEV_MAX_STAGES + 6 * DEV_LANES +
-               NIN * DEV_LANES + 2 * ED_FIELDS * DEV_LANES + 6 * DEV_LANES + 2 * DEV_LANES + CS_FIELDS * DEV_LANES + (size_t)DEV_MAX_WAVES * 4 * DEV_LANES +
-               DEV_LANES + DEV_LANES / 2 + 8 + (size_t)rec_doubles;
+               2 * ED_FIELDS * DEV_LANES + 2 * DEV_LANES + CS_FIELDS * DEV_LANES + (size_t)DEV_MAX_WAVES * 4 * DEV_LANES + DEV_LANES +
+               DEV_LANES / 2 + 8 + (size_t)rec_doubles;
+    d += stm ? (size_t)(20 + 27 + 12) * DEV_LANES : (size_t)(NIN + 6) * DEV_LANES;
+    (void)n_waves;
     return d * sizeof(double) + 64;
 }
 
@@ -551,7 +732,7 @@ extern "C" size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles) {
 
 // One role (or a merged set of roles) of the workgroup.  Every instantiation executes the SAME sequence of
 // workgroup barriers; only the work between them differs, so that each role keeps just its own state live.
-template <bool INTEG, bool ALMANAC, bool PERT>
+template <bool INTEG, bool ALMANAC, bool PERT, bool STM>
 DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPtr htab, ColPtr cols,
                      const double *__restrict__ records, const LdsMap &L, const int lane, const int wave, const int nw) {
     double *const kbuf = L.kbuf;
@@ -602,6 +783,9 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
         const double mass = (bt.mdry ? bt.mdry[idx] : 0.0) + c.y[8] + (bt.mextra ? bt.mextra[idx] : 0.0);
         c.massless = has_srp && !(mass > 0.0);  // MasslessSpacecraft (spacecraft.rs:201-203)
         cold_store(L.cs, lane, c);
+        if (STM && valid && bt.o_stm != bt.stm) {
+            for (int q = 0; q < 81; ++q) bt.o_stm[gid * 81 + q] = bt.stm[gid * 81 + q];
+        }
     }
     if (PERT) {
         // constant along the trajectory: no guidance law on this path => d(Cr, mass)/dt = 0
@@ -636,6 +820,10 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             if (!c.done && c.massless) { c.status = NYX_HIP_ERR_MASSLESS; c.done = true; }
             cold_store(L.cs, lane, c);
             h = c.h;
+            if (STM) {
+#pragma unroll
+                for (int q = 0; q < 12; ++q) L.sacc[q * DEV_LANES + lane] = 0.0;
+            }
             L.step[lane] = __longlong_as_double(c.epoch);
             L.step[DEV_LANES + lane] = h;
             if (!__any(!c.done)) {
@@ -694,6 +882,22 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     L.inb[2 * DEV_LANES + lane] = rho * u_;
                     L.inb[3 * DEV_LANES + lane] = rho;
                     L.inb[4 * DEV_LANES + lane] = r_ * cfg->g_inv_re;
+                    if (STM) {
+                        // the same quantities as duals seeded in the BODY-FIXED frame (gravity_field.rs:285-291)
+                        const D3 x0 = {rb0, 1.0, 0.0, 0.0}, x1 = {rb1, 0.0, 1.0, 0.0}, x2 = {rb2, 0.0, 0.0, 1.0};
+                        const D3 rD = d3norm(x0, x1, x2);
+                        const D3 sD = d3div(x0, rD), tD = d3div(x1, rD), uD = d3div(x2, rD);
+                        const D3 rhoD = d3div(d3c(cfg->g_re), rD);
+                        const D3 kD = d3div(d3div(d3c(cfg->g_mu), rD), d3c(cfg->g_re));
+                        const D3 invD = rD * cfg->g_inv_re;
+                        (void)kD;
+                        const D3 pub[5] = {rhoD * sD, rhoD * tD, rhoD * uD, rhoD, invD};
+#pragma unroll
+                        for (int q = 0; q < 5; ++q) {
+                            L.inbD[(4 * q + 0) * DEV_LANES + lane] = pub[q].v; L.inbD[(4 * q + 1) * DEV_LANES + lane] = pub[q].x;
+                            L.inbD[(4 * q + 2) * DEV_LANES + lane] = pub[q].y; L.inbD[(4 * q + 3) * DEV_LANES + lane] = pub[q].z;
+                        }
+                    }
                 }
             }
             PROF_ADD(0);
@@ -725,6 +929,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 }
 #pragma unroll
                 for (int e = 0; e < 3; ++e) { L.pert[e * DEV_LANES + lane] = a3[e]; L.pert[(3 + e) * DEV_LANES + lane] = f3[e]; }
+                if (STM) pert_gradients(cfg, edc, lane, r, p_cr, p_area, p_mass, has_pm, has_srp, L.pertD);
             }
             double acc[3] = {0.0, 0.0, 0.0};
             if (INTEG) {
@@ -753,7 +958,9 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 pp[0 * DEV_LANES + lane] = 0.0; pp[1 * DEV_LANES + lane] = 0.0;
                 pp[2 * DEV_LANES + lane] = 0.0; pp[3 * DEV_LANES + lane] = 0.0;
             }
-            if (has_grav && !dbg_skip_harm) {
+            if (STM && has_grav)
+                harmonics_partial_dual((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, L.inbD, L.partD + wave * 16 * DEV_LANES, lane);
+            if (!STM && has_grav && !dbg_skip_harm) {
                 const Partial4 pr = harmonics_partial((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, L.inb[0 * DEV_LANES + lane],
                                                       L.inb[1 * DEV_LANES + lane], L.inb[2 * DEV_LANES + lane],
                                                       L.inb[3 * DEV_LANES + lane], L.inb[4 * DEV_LANES + lane]);
@@ -774,10 +981,10 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
 
             if (INTEG) {
                 // ---- Phase C: assemble the derivative in the reference's order (orbital.rs:80-114, spacecraft.rs:227-243)
-                if (has_pm) {
+                if (!STM && has_pm) {
                     acc[0] += L.pert[0 * DEV_LANES + lane]; acc[1] += L.pert[1 * DEV_LANES + lane]; acc[2] += L.pert[2 * DEV_LANES + lane];
                 }
-                if (has_grav) {
+                if (!STM && has_grav) {
                     // fixed wave order; all 15 slots are read unconditionally (slots of absent waves hold an exact
                     // 0.0) so that the LDS reads carry no control dependence and pipeline
 #pragma unroll
@@ -792,8 +999,74 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     acc[1] += edc[1 * DEV_LANES + lane] * al0 + edc[4 * DEV_LANES + lane] * al1 + edc[7 * DEV_LANES + lane] * al2;
                     acc[2] += edc[2 * DEV_LANES + lane] * al0 + edc[5 * DEV_LANES + lane] * al1 + edc[8 * DEV_LANES + lane] * al2;
                 }
-                if (has_srp) {
+                if (!STM && has_srp) {
                     acc[0] += L.pert[3 * DEV_LANES + lane]; acc[1] += L.pert[4 * DEV_LANES + lane]; acc[2] += L.pert[5 * DEV_LANES + lane];
+                }
+                if (STM) {
+                    // dual path (dual_eom, spacecraft.rs:312-363): f(x) and A = df/dx; the derivative written to k_i is
+                    // the dual path's real part, as in the reference's STM branch (spacecraft.rs:208-224)
+                    double G[9], cv[3] = {0.0, 0.0, 0.0};
+                    const D3 rad[3] = {{ys[0], 1.0, 0.0, 0.0}, {ys[1], 0.0, 1.0, 0.0}, {ys[2], 0.0, 0.0, 1.0}};
+                    const D3 fac = d3div(d3c(-cfg->mu_central), d3cube(d3norm(rad[0], rad[1], rad[2])));
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const D3 a = rad[q] * fac;
+                        acc[q] = a.v; G[3 * q + 0] = a.x; G[3 * q + 1] = a.y; G[3 * q + 2] = a.z;
+                    }
+                    if (has_pm) {
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) acc[q] += L.pertD[q * DEV_LANES + lane];
+#pragma unroll
+                        for (int q = 0; q < 9; ++q) G[q] += L.pertD[(3 + q) * DEV_LANES + lane];
+                    }
+                    if (has_grav) {
+                        D3 pD[4] = {d3c(0.0), d3c(0.0), d3c(0.0), d3c(0.0)};
+                        for (int w = 0; w < nw; ++w) {  // fixed wave order
+                            const double *pp = L.partD + w * 16 * DEV_LANES;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                pD[q].v += pp[(4 * q + 0) * DEV_LANES + lane]; pD[q].x += pp[(4 * q + 1) * DEV_LANES + lane];
+                                pD[q].y += pp[(4 * q + 2) * DEV_LANES + lane]; pD[q].z += pp[(4 * q + 3) * DEV_LANES + lane];
+                            }
+                        }
+                        double m[9];
+#pragma unroll
+                        for (int q = 0; q < 9; ++q) m[q] = edc[q * DEV_LANES + lane];
+                        // s, t, u, (mu / r) / R_eq as duals of the body-fixed position (recomputed: cheaper than 16 LDS slots)
+                        const D3 x0 = {m[0] * ys[0] + m[1] * ys[1] + m[2] * ys[2], 1.0, 0.0, 0.0};
+                        const D3 x1 = {m[3] * ys[0] + m[4] * ys[1] + m[5] * ys[2], 0.0, 1.0, 0.0};
+                        const D3 x2 = {m[6] * ys[0] + m[7] * ys[1] + m[8] * ys[2], 0.0, 0.0, 1.0};
+                        const D3 rD = d3norm(x0, x1, x2);
+                        const D3 aux[4] = {d3div(x0, rD), d3div(x1, rD), d3div(x2, rD), d3div(d3div(d3c(cfg->g_mu), rD), d3c(cfg->g_re))};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) pD[q] = pD[q] * aux[3];
+                        const D3 al[3] = {pD[0] + pD[3] * aux[0], pD[1] + pD[3] * aux[1], pD[2] + pD[3] * aux[2]};
+                        // a = R^T a_bf ; G_h = R^T G_bf R   (gravity_field.rs:403-430)
+                        double tmp[9];
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) {
+                            acc[a] += m[0 + a] * al[0].v + m[3 + a] * al[1].v + m[6 + a] * al[2].v;
+                            tmp[3 * a + 0] = m[0 + a] * al[0].x + m[3 + a] * al[1].x + m[6 + a] * al[2].x;
+                            tmp[3 * a + 1] = m[0 + a] * al[0].y + m[3 + a] * al[1].y + m[6 + a] * al[2].y;
+                            tmp[3 * a + 2] = m[0 + a] * al[0].z + m[3 + a] * al[1].z + m[6 + a] * al[2].z;
+                        }
+#pragma unroll
+                        for (int a = 0; a < 3; ++a)
+#pragma unroll
+                            for (int b = 0; b < 3; ++b)
+                                G[3 * a + b] += tmp[3 * a + 0] * m[0 + b] + tmp[3 * a + 1] * m[3 + b] + tmp[3 * a + 2] * m[6 + b];
+                    }
+                    if (has_srp) {
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) { acc[q] += L.pertD[(12 + q) * DEV_LANES + lane]; cv[q] = L.pertD[(24 + q) * DEV_LANES + lane]; }
+#pragma unroll
+                        for (int q = 0; q < 9; ++q) G[q] += L.pertD[(15 + q) * DEV_LANES + lane];
+                    }
+                    const double b_i = B_COEF(i);
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) L.sacc[q * DEV_LANES + lane] += b_i * G[q];
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) L.sacc[(9 + q) * DEV_LANES + lane] += b_i * cv[q];
                 }
                 KB(i, 0) = ys[3]; KB(i, 1) = ys[4]; KB(i, 2) = ys[5];
                 KB(i, 3) = acc[0]; KB(i, 4) = acc[1]; KB(i, 5) = acc[2];
@@ -821,6 +1094,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     next[e] += cb * kv;
                 }
             }
+            const double h_used = h;
             if (!c.done) {
                 bool accept = false;
                 if (st_att != NYX_HIP_OK) {
@@ -864,6 +1138,11 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     y[6] = clamp02(y[6]);
                     c.n_acc += 1;
                     c.det_attempts = c.attempts;
+                    if (STM && valid) {
+                        double sumb = 0.0;
+                        for (int q = 0; q < stages; ++q) sumb += B_COEF(q);
+                        if (stm_update(bt.o_stm + gid * 81, h_used, L.sacc, lane, sumb)) { c.status = NYX_HIP_ERR_NAN; c.done = true; }
+                    }
                     if (y[8] < 0.0) { c.status = NYX_HIP_ERR_FUEL_EXHAUSTED; c.done = true; }
                     if (c.is_final) {
                         c.step_size = c.prev_step;
@@ -910,14 +1189,13 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     }
 }
 
-extern "C" __global__ void __launch_bounds__(DEV_MAX_WAVES *DEV_LANES)
-    nyx_propagate_kernel(DevBatch bt, const DevCfg *cfg_g, const HarmEntry *htab_g, const ColHdr *cols_g,
-                         const double *__restrict__ records) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+template <bool STM>
+DEVFN void propagate_body(const DevBatch &bt, const DevCfg *cfg_g, const HarmEntry *htab_g, const ColHdr *cols_g,
+                          const double *__restrict__ records, char *smem) {
     const int lane = threadIdx.x & (DEV_LANES - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nw = (int)(blockDim.x >> 6);
-    const LdsMap L = carve_lds(smem, nw);
+    const LdsMap L = carve_lds(smem, nw, STM);
     double *const kbuf = L.kbuf;
     double *const tabl = L.tabl;
     CfgPtr cfg = (CfgPtr)cfg_g;
@@ -949,16 +1227,32 @@ extern "C" __global__ void __launch_bounds__(DEV_MAX_WAVES *DEV_LANES)
 
     // ---- role dispatch (wave-uniform): merged roles when the workgroup has fewer than three waves
     if (nw == 1) {
-        role_loop<true, true, true>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
+        role_loop<true, true, true, STM>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
     } else if (nw == 2) {
-        if (wave == 0) role_loop<true, false, false>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
-        else role_loop<false, true, true>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
+        if (wave == 0) role_loop<true, false, false, STM>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
+        else role_loop<false, true, true, STM>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
     } else {
-        if (wave == 0) role_loop<true, false, false>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
-        else if (wave == 1) role_loop<false, true, false>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
-        else if (wave == 2) role_loop<false, false, true>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
-        else role_loop<false, false, false>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
+        if (wave == 0) role_loop<true, false, false, STM>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
+        else if (wave == 1) role_loop<false, true, false, STM>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
+        else if (wave == 2) role_loop<false, false, true, STM>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
+        else role_loop<false, false, false, STM>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
     }
+}
+
+extern "C" __global__ void __launch_bounds__(DEV_MAX_WAVES *DEV_LANES)
+    nyx_propagate_kernel(DevBatch bt, const DevCfg *cfg_g, const HarmEntry *htab_g, const ColHdr *cols_g,
+                         const double *__restrict__ records) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    propagate_body<false>(bt, cfg_g, htab_g, cols_g, records, smem);
+}
+
+// STM variant (Spacecraft.stm = Some): 9x9 state-transition matrix alongside the state.  Dual-number harmonics need
+// ~4x the registers, hence at most DEV_MAX_WAVES_STM waves per workgroup (256 VGPRs each).
+extern "C" __global__ void __launch_bounds__(DEV_MAX_WAVES_STM *DEV_LANES)
+    nyx_propagate_kernel_stm(DevBatch bt, const DevCfg *cfg_g, const HarmEntry *htab_g, const ColHdr *cols_g,
+                             const double *__restrict__ records) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    propagate_body<true>(bt, cfg_g, htab_g, cols_g, records, smem);
 }
 
 extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg, const HarmEntry *htab,
@@ -969,9 +1263,16 @@ extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_stm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(nyx_propagate_kernel, dim3((unsigned)blocks), dim3((unsigned)(n_waves * DEV_LANES)),
-                       nyx_kernel_lds_bytes(n_waves, rec_lds_doubles), stream, bt, cfg, htab, cols, records);
+    const bool stm = bt.o_stm != nullptr;
+    const size_t lds = nyx_kernel_lds_bytes(n_waves, rec_lds_doubles, stm ? 1 : 0);
+    if (stm)
+        hipLaunchKernelGGL(nyx_propagate_kernel_stm, dim3((unsigned)blocks), dim3((unsigned)(n_waves * DEV_LANES)), lds, stream, bt, cfg,
+                           htab, cols, records);
+    else
+        hipLaunchKernelGGL(nyx_propagate_kernel, dim3((unsigned)blocks), dim3((unsigned)(n_waves * DEV_LANES)), lds, stream, bt, cfg,
+                           htab, cols, records);
     return hipGetLastError();
 }
