@@ -107,3 +107,78 @@ def dispersed_leo_batch(n, seed=0, nominal=None):
 def pos_vel_errors(a, b):
     d = a.rv() - b.rv()
     return np.linalg.norm(d[:, :3], axis=1), np.linalg.norm(d[:, 3:], axis=1)
+
+
+# ---------------------------------------------------------------------------------------------
+# BASELINE config 3 (JWST-like, point masses + SRP with Earth and Moon shadows) and
+# config 5 (low lunar orbit, 150x150 synthetic field + Earth/Sun point masses)
+# ---------------------------------------------------------------------------------------------
+
+def jwst_setup(opts=None, method=nx.IntegratorMethod.RungeKutta89, jupiter=True):
+    """examples/02_jwst_covar_monte_carlo/main.rs:99-146: Sun, Moon (, Jupiter barycentre) point masses + SRP with
+    Earth and Moon shadows."""
+    almanac = almanac_earth()
+    central = earth_frame(ephem.MU_EARTH)
+    bodies = [nx.MOON, nx.SUN] + ([nx.JUPITER_BARYCENTER] if jupiter else [])
+    dyn = nx.SpacecraftDynamics(nx.OrbitalDynamics([nx.PointMasses(bodies)]), [nx.SolarPressure([nx.EARTH, nx.MOON])])
+    return nx.Propagator(dyn, method, opts or nx.IntegratorOptions()), almanac, central
+
+
+def jwst_batch(n, seed=0):
+    """README.md:52 state; m = 6200 kg, A = 21.197 x 14.162 m^2, Cr 1.56 (main.rs:63-70); RIC sigmas (0.5, 0.3, 1.5) km,
+    (1e-4, 6e-4, 3e-3) km/s (main.rs:77-86) rotated to inertial."""
+    r0 = np.array([119901.07, -1389299.67, -1041369.15])
+    v0 = np.array([0.045956, -0.013168, 0.034535])
+    rh = r0 / np.linalg.norm(r0)
+    ch = np.cross(r0, v0)
+    ch /= np.linalg.norm(ch)
+    ih = np.cross(ch, rh)
+    dcm = np.stack([rh, ih, ch], axis=1)  # RIC -> inertial
+    rng = np.random.default_rng(seed)
+    dr = rng.standard_normal((n, 3)) * np.array([0.5, 0.3, 1.5])
+    dv = rng.standard_normal((n, 3)) * np.array([1e-4, 6e-4, 3e-3])
+    b = _abi.StateBatch(n)
+    b.set_rv(np.concatenate([r0[None, :] + dr @ dcm.T, v0[None, :] + dv @ dcm.T], axis=1))
+    b.epoch_ns[:] = EPOCH0_NS
+    b.cr[:] = 1.56
+    b.dry_mass_kg[:] = 6200.0
+    b.srp_area_m2[:] = 21.197 * 14.162
+    return b
+
+
+def kaula_field(degree, seed=0, frame=None):
+    """Synthetic fully-normalised lunar-like field (the GRGM/JGGRX file is a missing blob): Kaula's rule
+    sigma_n = 2.5e-4 / n^2, seeded; C20, C22 set to the lunar values."""
+    rng = np.random.default_rng(seed)
+    n_tot = (degree + 1) * (degree + 2) // 2
+    c, s = np.zeros(n_tot), np.zeros(n_tot)
+    for n in range(2, degree + 1):
+        sig = 2.5e-4 / n ** 2
+        for m in range(n + 1):
+            c[n * (n + 1) // 2 + m] = sig * rng.standard_normal()
+            s[n * (n + 1) // 2 + m] = 0.0 if m == 0 else sig * rng.standard_normal()
+    c[3], c[5] = -9.088e-5, 3.467e-5
+    return nx.GravityFieldData(degree, degree, c, s, frame)
+
+
+def lunar_setup(degree=150, opts=None, method=nx.IntegratorMethod.DormandPrince78):
+    key = ("moon", 40.0)
+    if key not in _ALMANAC_CACHE:
+        _ALMANAC_CACHE[key] = ephem.build_moon_centered_almanac(nx.to_seconds(EPOCH0_NS), 40.0)
+    almanac = _ALMANAC_CACHE[key]
+    central = nx.Frame(nx.MOON, ephem.MU_MOON, ephem.R_MOON, None)
+    iau_moon = nx.Frame(nx.MOON, ephem.MU_MOON, ephem.R_MOON, nx.IAU_MOON_ROTATION_POLY)
+    accel = [nx.PointMasses([nx.EARTH, nx.SUN]), kaula_field(degree, seed=1, frame=iau_moon)]
+    dyn = nx.SpacecraftDynamics(nx.OrbitalDynamics(accel), [])
+    return nx.Propagator(dyn, method, opts or nx.IntegratorOptions()), almanac, central
+
+
+def lunar_batch(n, seed=0):
+    """~50 km altitude polar LLO (LRO-like, examples/04_lro_od/main.rs:121-145), sigma 100 m / 0.1 m/s."""
+    nominal = keplerian_to_cartesian(ephem.R_MOON + 50.0, 0.002, 89.5, 30.0, 0.0, 40.0, ephem.MU_MOON)
+    rng = np.random.default_rng(seed)
+    b = _abi.StateBatch(n)
+    b.set_rv(nominal[None, :] + rng.standard_normal((n, 6)) * np.array([0.1, 0.1, 0.1, 1e-4, 1e-4, 1e-4]))
+    b.epoch_ns[:] = EPOCH0_NS
+    b.dry_mass_kg[:] = 1000.0
+    return b

@@ -245,3 +245,81 @@ def test_stm_od_segments_with_reset():
     dr, dv = pos_vel_errors(g, o)
     assert dr.max() < 1e-3 and dv.max() < 1e-6
     ctx.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# The other BASELINE configurations, at sizes the oracle finishes in seconds + size-independent properties
+# ---------------------------------------------------------------------------------------------
+
+def test_config3_jwst_shape_vs_oracle_and_roundtrip():
+    """Config 3 shape: halo-like state, Sun/Moon/Jupiter point masses + SRP (Earth and Moon shadows), RK89, 6.5 days
+    (the example's own duration, main.rs:109)."""
+    from scenarios import jwst_batch, jwst_setup
+    prop, almanac, central = jwst_setup()
+    compiled = prop.compile(almanac, central)
+    b = jwst_batch(40, seed=2)
+    dur = int(6.5 * 86400) * nx.NS_PER_S
+    ctx = nx.GpuContext(compiled)
+    out, st = ctx.propagate(b, dur)
+    ref, rst = oracle_lib.propagate(compiled, b, dur, n_threads=NCPU)
+    assert (st.status == 0).all() and (rst.status == 0).all()
+    dr, dv = pos_vel_errors(out, ref)
+    print(f"config3: steps/run {st.n_accepted.mean():.0f} (reference example: 213), dr {dr.max()*1e3:.3e} m, dv {dv.max()*1e6:.3e} mm/s, kernel {ctx.last_kernel_ms():.1f} ms")
+    assert dr.max() < 1e-3 and dv.max() < 1e-6
+    assert 100 < st.n_accepted.mean() < 400
+    # property at the full 30-day / 5 000-state size: forward then backward returns to the start
+    big = jwst_batch(5000, seed=3)
+    fwd, s1 = ctx.propagate(big, 30 * DAY_NS)
+    back, s2 = ctx.propagate(fwd, -30 * DAY_NS)
+    assert (s1.status == 0).all() and (s2.status == 0).all() and (back.epoch_ns == big.epoch_ns).all()
+    d = back.rv() - big.rv()
+    assert np.linalg.norm(d[:, :3], axis=1).max() < 1e-2 and np.linalg.norm(d[:, 3:], axis=1).max() < 1e-7
+    ctx.close()
+
+
+@pytest.mark.parametrize("method", ["DormandPrince78", "RungeKutta89"])
+def test_config5_lunar_150x150_vs_oracle(method):
+    """Config 5 shape: low lunar orbit, 150x150 field (synthetic Kaula coefficients) in the IAU Moon frame + Earth and Sun
+    point masses; table = 755 KB streamed from L2."""
+    from scenarios import lunar_batch, lunar_setup
+    prop, almanac, central = lunar_setup(150, method=nx.IntegratorMethod[method])
+    compiled = prop.compile(almanac, central)
+    b = lunar_batch(64 + 5, seed=4)
+    dur = 2 * 3600 * nx.NS_PER_S
+    ctx = nx.GpuContext(compiled)
+    out, st = ctx.propagate(b, dur)
+    ref, rst = oracle_lib.propagate(compiled, b, dur, n_threads=NCPU)
+    assert (st.status == 0).all() and (rst.status == 0).all()
+    dr, dv = pos_vel_errors(out, ref)
+    print(f"config5 {method}: evals {st.n_evals.sum()}, dr {dr.max()*1e3:.3e} m, dv {dv.max()*1e6:.3e} mm/s, kernel {ctx.last_kernel_ms():.1f} ms")
+    assert dr.max() < 1e-3 and dv.max() < 1e-6
+    ctx.close()
+
+
+def test_full_size_properties_config2():
+    """BASELINE size (10 000 x 70x70, 3 h slice): index stability under re-batching, determinism, and the two-body
+    energy drift bound when the perturbations are switched off."""
+    prop, almanac, central = leo_full_setup(degree=70)
+    ctx = nx.GpuContext(prop.compile(almanac, central))
+    b = dispersed_leo_batch(10_000, seed=0)
+    dur = 1800 * nx.NS_PER_S
+    out, st = ctx.propagate(b, dur)
+    assert (st.status == 0).all() and (out.epoch_ns == b.epoch_ns + dur).all()
+    again, _ = ctx.propagate(b, dur)
+    np.testing.assert_array_equal(out.rv(), again.rv())  # deterministic: fixed fold order, no atomics
+    # a shard run alone reproduces its slice exactly (contiguous index shards, SURVEY 8e)
+    lo, hi = nx.shard_bounds(10_000, 3, 8)
+    part, _ = ctx.propagate(b.slice(lo, hi), dur)
+    np.testing.assert_array_equal(part.rv(), out.rv()[lo:hi])
+    ctx.close()
+    # two-body only, full day, full ensemble: specific orbital energy conserved to ~1e-12 relative
+    from scenarios import GOLDEN as G, two_body_setup
+    from nyx_amd import ephem
+    p2, a2, c2 = two_body_setup(nx.IntegratorMethod.RungeKutta89, nx.IntegratorOptions(), ephem.MU_EARTH)
+    ctx2 = nx.GpuContext(p2.compile(a2, c2))
+    o2, s2 = ctx2.propagate(b, DAY_NS)
+    def energy(x):
+        rv = x.rv()
+        return 0.5 * np.sum(rv[:, 3:] ** 2, axis=1) - ephem.MU_EARTH / np.linalg.norm(rv[:, :3], axis=1)
+    assert np.max(np.abs(energy(o2) / energy(b) - 1.0)) < 1e-11
+    ctx2.close()
