@@ -532,6 +532,25 @@ DEVFN double error_estimate(int ec, const double *e, const double *cand, const d
     }
 }
 
+// Fold of the 15 workers' partial accelerations (fixed wave order => deterministic).  Kept out of line on purpose:
+// inside the integrator role (at its 128-VGPR cap) the scheduler serialised the 60 LDS reads at one LDS latency each
+// (5 k cycles on the critical path of every force evaluation); on its own the function batches them.
+typedef const __attribute__((address_space(3))) double *LdsCPtr;
+static __device__ __attribute__((noinline)) Partial4 fold_partials(LdsCPtr part, int lane, double px, double py, double pz, double pw) {
+    double v[4][DEV_MAX_WAVES - 1];
+#pragma unroll
+    for (int w = 1; w < DEV_MAX_WAVES; ++w) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q][w - 1] = part[(w * 4 + q) * DEV_LANES + lane];
+    }
+#pragma unroll
+    for (int w = 1; w < DEV_MAX_WAVES; ++w) {
+        px += v[0][w - 1]; py += v[1][w - 1]; pz += v[2][w - 1]; pw += v[3][w - 1];
+    }
+    Partial4 r = {px, py, pz, pw};
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // STM variant: position partials of the perturbations (perturbation wave) and the per-step update
 // ---------------------------------------------------------------------------------------------
@@ -987,11 +1006,9 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 if (!STM && has_grav) {
                     // fixed wave order; all 15 slots are read unconditionally (slots of absent waves hold an exact
                     // 0.0) so that the LDS reads carry no control dependence and pipeline
-#pragma unroll
-                    for (int w = 1; w < DEV_MAX_WAVES; ++w) {
-                        const double *pp = L.part + w * 4 * DEV_LANES;
-                        px += pp[0 * DEV_LANES + lane]; py += pp[1 * DEV_LANES + lane];
-                        pz += pp[2 * DEV_LANES + lane]; pw += pp[3 * DEV_LANES + lane];
+                    {
+                        const Partial4 f4 = fold_partials((LdsCPtr)L.part, lane, px, py, pz, pw);
+                        px = f4.x; py = f4.y; pz = f4.z; pw = f4.w;
                     }
                     px *= kfac; py *= kfac; pz *= kfac; pw *= kfac;
                     const double al0 = px + pw * s_, al1 = py + pw * t_, al2 = pz + pw * u_;
