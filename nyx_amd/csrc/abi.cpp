@@ -262,7 +262,7 @@ static int pick_waves(const nyx_hip_ctx *ctx, int64_t n) {
     }
     if (ctx->forced_waves > 0) return std::min(ctx->forced_waves, DEV_MAX_WAVES);
     // no harmonics: integrator + almanac + perturbation waves form a 3-stage pipeline
-    if (!ctx->host_cfg.has_grav) return (ctx->host_cfg.n_slots > 0) ? 3 : 1;
+    if (!ctx->host_cfg.has_grav) return (ctx->host_cfg.n_slots > 0 || ctx->host_cfg.has_drag) ? 3 : 1;
     // Fill the 256 CUs: workgroups = ceil(n/64); with fewer than ~2 workgroups per CU the column
     // split is what creates the waves that keep the SIMDs busy.
     const int64_t wgs = (n + DEV_LANES - 1) / DEV_LANES;
@@ -319,7 +319,14 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
         return NYX_HIP_RC_UNSUPPORTED;
     }
     if (cfg->flags & NYX_HIP_FLAG_STM_TEXTBOOK) { nyx_set_error("textbook STM form (A Phi) is not implemented"); return NYX_HIP_RC_UNSUPPORTED; }
-    if (cfg->drag) { nyx_set_error("drag is not on the device path yet"); return NYX_HIP_RC_UNSUPPORTED; }
+    if (cfg->drag && (cfg->flags & NYX_HIP_FLAG_STM)) {  // PartialsUndefined in the reference too (drag.rs:286-294)
+        nyx_set_error("drag has no partials: STM propagation with drag is undefined");
+        return NYX_HIP_RC_UNSUPPORTED;
+    }
+    if (cfg->drag && cfg->gravity && std::memcmp(&cfg->drag->rotation, &cfg->gravity->rotation, sizeof(nyx_hip_rotation_t)) != 0) {
+        nyx_set_error("device path: the drag frame must be the gravity-field frame when both are present");
+        return NYX_HIP_RC_UNSUPPORTED;
+    }
     if (nyx_hip_device_count() <= device || device < 0) { nyx_set_error("no HIP device %d", device); return NYX_HIP_RC_NO_DEVICE; }
     HIP_TRY(hipSetDevice(device));
 
@@ -417,6 +424,14 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
         build_harmonics(g, tab, cols, ctx->col_len, n_cols);
         dc.n_cols = n_cols;
     }
+    if (cfg->drag) {
+        const nyx_hip_drag_t *dg = cfg->drag;
+        if (dg->density < 0 || dg->density > 2) { delete ctx; nyx_set_error("bad drag density model"); return NYX_HIP_RC_BAD_ARG; }
+        dc.has_drag = 1; dc.drag_density = dg->density;
+        dc.drag_rho0 = dg->rho0; dc.drag_r0 = dg->r0; dc.drag_ref_alt_m = dg->ref_alt_m; dc.drag_max_alt_m = dg->max_alt_m;
+        dc.drag_re = dg->eq_radius_km;
+        for (int k = 0; k < 3; ++k) { dc.d_rot.ra[k] = dg->rotation.ra_deg[k]; dc.d_rot.dec[k] = dg->rotation.dec_deg[k]; dc.d_rot.w[k] = dg->rotation.w_deg[k]; }
+    }
     // serial duties of the role waves per force evaluation, in units of one harmonics term (~10 f64 ops):
     // integrator: stage combination, body-fixed transform, fold of the partials; almanac: 3 sincos + Chebyshev
     // chains; perturbations: third-body and SRP/eclipse terms.
@@ -425,7 +440,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
         for (int s = 0; s < dc.n_slots; ++s) nseg_eval += dc.slot[s].n_chain;
         ctx->role_handicap[0] = 15.0;
         ctx->role_handicap[1] = 12.0 * nseg_eval + (dc.has_grav ? 18.0 : 0.0);
-        ctx->role_handicap[2] = 6.0 * dc.n_pm + (dc.has_srp ? 6.0 + 6.0 * dc.n_shadow : 0.0);
+        ctx->role_handicap[2] = 6.0 * dc.n_pm + (dc.has_srp ? 6.0 + 6.0 * dc.n_shadow : 0.0) + (dc.has_drag ? 10.0 : 0.0);
         if (const char *e = std::getenv("NYX_HIP_ROLE_HANDICAP")) {
             double h0, h1, h2;
             if (std::sscanf(e, "%lf,%lf,%lf", &h0, &h1, &h2) == 3) { ctx->role_handicap[0] = h0; ctx->role_handicap[1] = h1; ctx->role_handicap[2] = h2; }

@@ -159,9 +159,10 @@ template <typename P>
 DEVFN int epoch_data(CfgPtr cfg, P records, int64_t epoch_ns, double *slot, int lane) {
     const double et = ns_to_seconds(epoch_ns);
     int status = NYX_HIP_OK;
-    if (cfg->has_grav) {
+    if (cfg->has_grav || cfg->has_drag) {  // (ctx_create requires the drag frame == the gravity frame when both exist)
         double m[9];
-        rotation_dcm(cfg->g_rot, et, m);
+        if (cfg->has_grav) rotation_dcm(cfg->g_rot, et, m);
+        else rotation_dcm(cfg->d_rot, et, m);
 #pragma unroll
         for (int q = 0; q < 9; ++q) slot[q * DEV_LANES + lane] = m[q];
     }
@@ -281,6 +282,64 @@ DEVFN double srp_force(CfgPtr cfg, const double *ed, int lane, const double *r, 
     force[1] = scal * u1;
     force[2] = scal * u2;
     return k;  // illumination factor |occultation - 1|, frozen in the partials (solarpressure.rs:194-203)
+}
+
+// f64::powi as LLVM expands it (binary method, LSB first)
+DEVFN double powi_dev(double x, int n) {
+    double res = 1.0, sq = x;
+    bool have = false;
+    while (n) {
+        if (n & 1) { res = have ? res * sq : sq; have = true; }
+        sq = sq * sq;
+        n >>= 1;
+    }
+    return res;
+}
+
+// Drag::eom (reference dynamics/drag.rs:181-284) with its unit / frame quirks, as restated in the oracle (drag_eom):
+// velocity in the drag frame = R v - w x (R r) with w = W_dot z_body; Exponential mixes metres and km; the relative
+// velocity is (inertial velocity) - (drag-frame velocity components).  `m` = DCM inertial -> drag frame of this stage.
+DEVFN void drag_force(CfgPtr cfg, const double *ed, int lane, double et_s, const double *r, const double *v, double cd, double area,
+                      double *force) {
+    double m[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) m[q] = ed[q * DEV_LANES + lane];
+    const double DEG = 3.14159265358979323846 / 180.0;
+    const double d = et_s / 86400.0;
+    const double wdot = (cfg->d_rot.w[1] + 2.0 * cfg->d_rot.w[2] * d) * DEG / 86400.0;
+    double rb[3], vb[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        rb[i] = m[3 * i + 0] * r[0] + m[3 * i + 1] * r[1] + m[3 * i + 2] * r[2];
+        vb[i] = m[3 * i + 0] * v[0] + m[3 * i + 1] * v[1] + m[3 * i + 2] * v[2];
+    }
+    vb[0] = vb[0] + wdot * rb[1];
+    vb[1] = vb[1] - wdot * rb[0];
+    const double rmag = norm3(rb[0], rb[1], rb[2]);
+    double rho;
+    if (cfg->drag_density == NYX_HIP_RHO_CONSTANT) {
+        rho = cfg->drag_rho0;
+        const double vn = norm3(vb[0], vb[1], vb[2]);
+        const double s = -0.5 * 1e3 * rho * cd * area * vn;
+        force[0] = s * vb[0]; force[1] = s * vb[1]; force[2] = s * vb[2];
+        return;
+    } else if (cfg->drag_density == NYX_HIP_RHO_EXPONENTIAL) {
+        rho = cfg->drag_rho0 * exp(-(rmag - (cfg->drag_r0 + cfg->drag_re)) / cfg->drag_ref_alt_m);
+    } else {
+        const double alt = rmag - cfg->drag_re;
+        if (alt > cfg->drag_max_alt_m / 1000.0) {
+            rho = pow(10.0, (-7e-5) * alt - 14.464);
+        } else {
+            const double sc = (alt - 526.8000) / 292.8563;
+            const double lg = 0.34047 * powi_dev(sc, 6) - 0.5889 * powi_dev(sc, 5) - 0.5269 * powi_dev(sc, 4) + 1.0036 * powi_dev(sc, 3) +
+                              0.60713 * powi_dev(sc, 2) - 2.3024 * sc - 12.575;
+            rho = pow(10.0, lg);
+        }
+    }
+    const double vel[3] = {v[0] - vb[0], v[1] - vb[1], v[2] - vb[2]};
+    const double vn = norm3(vel[0], vel[1], vel[2]);
+    const double s = -0.5 * 1e3 * rho * cd * area * vn;
+    force[0] = s * vel[0]; force[1] = s * vel[1]; force[2] = s * vel[2];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -690,7 +749,7 @@ struct LdsMap {
     double *ys;     // [6][64]        stage state published by the integrator
     double *inb;    // [NIN][64]      zr, zi, rho_u, rho, 1/rho
     double *ed;     // [2][ED_FIELDS][64]  epoch data, double-buffered by stage parity
-    double *pert;   // [6][64]        point-mass accel (3) and SRP force / mass (3)
+    double *pert;   // [9][64]        point-mass accel (3), SRP force / mass (3), drag force / mass (3)
     double *step;   // [2][64]        epoch (as i64 bits) and h of the current attempt
     double *cs;     // [CS_FIELDS][64] integrator cold state
     double *part;   // [P][4][64]     harmonics partials (wave 0's slot unused)
@@ -727,7 +786,7 @@ DEVFN LdsMap carve_lds(char *smem, int n_waves, bool stm) {
         m.partD = m.part;
     } else {
         m.inb = p; p += NIN * DEV_LANES;
-        m.pert = p; p += 6 * DEV_LANES;
+        m.pert = p; p += 9 * DEV_LANES;
     }
     m.rec = p;
     return m;
@@ -737,7 +796,7 @@ extern "C" size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles, int stm) {
     size_t d = (size_t)DEV_MAX_STAGES * 6 * DEV_LANES + DEV_MAX_STAGES * DEV_MAX_STAGES + 3 * DEV_MAX_STAGES + 6 * DEV_LANES +
                2 * ED_FIELDS * DEV_LANES + 2 * DEV_LANES + CS_FIELDS * DEV_LANES + (size_t)DEV_MAX_WAVES * 4 * DEV_LANES + DEV_LANES +
                DEV_LANES / 2 + 8 + (size_t)rec_doubles;
-    d += stm ? (size_t)(20 + 27 + 12) * DEV_LANES : (size_t)(NIN + 6) * DEV_LANES;
+    d += stm ? (size_t)(20 + 27 + 12) * DEV_LANES : (size_t)(NIN + 9) * DEV_LANES;
     (void)n_waves;
     return d * sizeof(double) + 64;
 }
@@ -760,7 +819,8 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     const bool has_grav = cfg->has_grav != 0;
     const bool has_srp = cfg->has_srp != 0;
     const bool has_pm = cfg->n_pm > 0;
-    const bool need_almanac = has_grav || cfg->n_slots > 0;
+    const bool has_drag = cfg->has_drag != 0;
+    const bool need_almanac = has_grav || has_drag || cfg->n_slots > 0;
     const bool rec_in_lds = cfg->rec_in_lds != 0;
     const bool dbg_skip_serial = (cfg->flags & DBG_SKIP_SERIAL) != 0;
     const bool dbg_skip_harm = (cfg->flags & DBG_SKIP_HARMONICS) != 0;
@@ -777,7 +837,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     const int64_t idx = valid ? gid : bt.n - 1;
 
     // perturbation-wave constants
-    double p_cr = 0.0, p_area = 0.0, p_mass = 1.0;
+    double p_cr = 0.0, p_area = 0.0, p_mass = 1.0, p_cd = 0.0, p_darea = 0.0;
 
     if (INTEG) {
         ColdState c;
@@ -800,7 +860,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
         if (!c.done && c.y[8] < 0.0) { c.status = NYX_HIP_ERR_FUEL_EXHAUSTED; c.done = true; }  // dynamics.finally
         if (c.backprop) c.step_size = -c.step_size;
         const double mass = (bt.mdry ? bt.mdry[idx] : 0.0) + c.y[8] + (bt.mextra ? bt.mextra[idx] : 0.0);
-        c.massless = has_srp && !(mass > 0.0);  // MasslessSpacecraft (spacecraft.rs:201-203)
+        c.massless = (has_srp || has_drag) && !(mass > 0.0);  // MasslessSpacecraft (spacecraft.rs:201-203)
         cold_store(L.cs, lane, c);
         if (STM && valid && bt.o_stm != bt.stm) {
             for (int q = 0; q < 81; ++q) bt.o_stm[gid * 81 + q] = bt.stm[gid * 81 + q];
@@ -810,6 +870,8 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
         // constant along the trajectory: no guidance law on this path => d(Cr, mass)/dt = 0
         p_cr = clamp02(bt.cr ? bt.cr[idx] : 0.0);
         p_area = bt.asrp ? bt.asrp[idx] : 0.0;
+        p_cd = bt.cd ? bt.cd[idx] : 0.0;
+        p_darea = bt.adrag ? bt.adrag[idx] : 0.0;
         p_mass = (bt.mdry ? bt.mdry[idx] : 0.0) + (bt.mprop ? bt.mprop[idx] : 0.0) + (bt.mextra ? bt.mextra[idx] : 0.0);
     }
     __syncthreads();
@@ -937,7 +999,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     st = rec_in_lds ? epoch_data(cfg, (const double *)L.rec, ep, edn, lane) : epoch_data(cfg, records, ep, edn, lane);
                 L.edst[((i + 1) & 1) * DEV_LANES + lane] = st;
             }
-            if (PERT && (has_pm || has_srp)) {
+            if (PERT && (has_pm || has_srp || has_drag)) {
                 // position-dependent third-body and SRP terms of THIS stage
                 double r[3] = {L.ys[0 * DEV_LANES + lane], L.ys[1 * DEV_LANES + lane], L.ys[2 * DEV_LANES + lane]};
                 double a3[3] = {0.0, 0.0, 0.0}, f3[3] = {0.0, 0.0, 0.0};
@@ -948,6 +1010,14 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 }
 #pragma unroll
                 for (int e = 0; e < 3; ++e) { L.pert[e * DEV_LANES + lane] = a3[e]; L.pert[(3 + e) * DEV_LANES + lane] = f3[e]; }
+                if (has_drag) {
+                    const double vv[3] = {L.ys[3 * DEV_LANES + lane], L.ys[4 * DEV_LANES + lane], L.ys[5 * DEV_LANES + lane]};
+                    const int64_t ep = __double_as_longlong(L.step[lane]) + seconds_to_ns(C_COEF(i) * L.step[DEV_LANES + lane]);
+                    double d3f[3];
+                    drag_force(cfg, edc, lane, ns_to_seconds(ep), r, vv, p_cd, p_darea, d3f);
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) L.pert[(6 + e) * DEV_LANES + lane] = d3f[e] / p_mass;
+                }
                 if (STM) pert_gradients(cfg, edc, lane, r, p_cr, p_area, p_mass, has_pm, has_srp, L.pertD);
             }
             double acc[3] = {0.0, 0.0, 0.0};
@@ -1018,6 +1088,9 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 }
                 if (!STM && has_srp) {
                     acc[0] += L.pert[3 * DEV_LANES + lane]; acc[1] += L.pert[4 * DEV_LANES + lane]; acc[2] += L.pert[5 * DEV_LANES + lane];
+                }
+                if (!STM && has_drag) {
+                    acc[0] += L.pert[6 * DEV_LANES + lane]; acc[1] += L.pert[7 * DEV_LANES + lane]; acc[2] += L.pert[8 * DEV_LANES + lane];
                 }
                 if (STM) {
                     // dual path (dual_eom, spacecraft.rs:312-363): f(x) and A = df/dx; the derivative written to k_i is

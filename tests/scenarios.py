@@ -56,7 +56,7 @@ def iau_earth_frame(mu=ephem.MU_EARTH):
 
 
 def leo_full_setup(degree=70, order=None, point_masses=(nx.SUN, nx.MOON), srp=True, method=nx.IntegratorMethod.RungeKutta89,
-                   opts=None):
+                   opts=None, drag=None):
     """(Propagator, Almanac, central Frame) for the north-star force model."""
     order = degree if order is None else order
     almanac = almanac_earth()
@@ -67,6 +67,12 @@ def leo_full_setup(degree=70, order=None, point_masses=(nx.SUN, nx.MOON), srp=Tr
     if degree and degree > 0:
         accel.append(nx.GravityFieldData.from_packed_file(JGM3_PATH, iau_earth_frame(), degree, order))
     forces = [nx.SolarPressure.default_flux(nx.EARTH)] if srp else []
+    if drag == "exp":
+        forces.append(nx.Drag.earth_exp(iau_earth_frame()))          # drag.rs:128-143
+    elif drag == "stdatm":
+        forces.append(nx.Drag.std_atm1976(iau_earth_frame()))        # drag.rs:145-160
+    elif drag == "const":
+        forces.append(nx.Drag(("constant", 1e-12), iau_earth_frame()))
     dyn = nx.SpacecraftDynamics(nx.OrbitalDynamics(accel), forces)
     return nx.Propagator(dyn, method, opts or nx.IntegratorOptions()), almanac, central
 

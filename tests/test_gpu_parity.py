@@ -323,3 +323,30 @@ def test_full_size_properties_config2():
         return 0.5 * np.sum(rv[:, 3:] ** 2, axis=1) - ephem.MU_EARTH / np.linalg.norm(rv[:, :3], axis=1)
     assert np.max(np.abs(energy(o2) / energy(b) - 1.0)) < 1e-11
     ctx2.close()
+
+
+@pytest.mark.parametrize("model,degree", [("exp", 4), ("stdatm", 0), ("const", 4)])
+def test_drag_vs_oracle(model, degree):
+    """Drag::eom with its unit / frame quirks (drag.rs:181-284): the reference only smoke-tests drag
+    (tests/mission_design/force_models.rs:257-385); here the device path is held to the oracle."""
+    prop, almanac, central = leo_full_setup(degree=degree, drag=model)
+    compiled = prop.compile(almanac, central)
+    b = dispersed_leo_batch(20, seed=6)
+    b.drag_area_m2[:] = 2.0
+    b.cd[:] = 2.2
+    ctx = nx.GpuContext(compiled)
+    dur = 2 * 3600 * nx.NS_PER_S
+    out, st = ctx.propagate(b, dur)
+    ref, rst = oracle_lib.propagate(compiled, b, dur, n_threads=NCPU)
+    assert (st.status == 0).all() and (rst.status == 0).all()
+    dr, dv = pos_vel_errors(out, ref)
+    # and drag does something: compare with the same run without drag
+    p0, a0, c0 = leo_full_setup(degree=degree)
+    nod, _ = oracle_lib.propagate(p0.compile(a0, c0), b, dur, n_threads=NCPU)
+    effect = np.linalg.norm((ref.rv() - nod.rv())[:, :3], axis=1).max()
+    print(f"drag {model}: dr {dr.max()*1e3:.3e} m dv {dv.max()*1e6:.3e} mm/s; drag effect {effect*1e3:.3e} m")
+    assert dr.max() < 1e-3 and dv.max() < 1e-6 and effect > 1e-6
+    # drag + STM has no partials (drag.rs:286-294): refused, like the reference's PartialsUndefined
+    with pytest.raises(RuntimeError, match="no partials"):
+        nx.GpuContext(prop.compile(almanac, central, stm=True))
+    ctx.close()
