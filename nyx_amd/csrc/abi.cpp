@@ -207,6 +207,7 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves) {
     const int nc = dc.n_cols;
     for (int w = 0; w < DEV_MAX_WAVES; ++w) dc.n_ranges[w] = 0;
     dc.n_waves = n_waves;
+    dc.merge_roles = (std::getenv("NYX_HIP_MERGE_ROLES") && n_waves >= 8) ? 1 : 0;
     if (!dc.has_grav || nc == 0) return;
     double terms = 0.0;
     for (int c = 1; c <= nc; ++c) terms += ctx->col_len[c];
@@ -214,24 +215,32 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves) {
     double hc[DEV_MAX_WAVES] = {0};
     if (n_waves == 1) hc[0] = ctx->role_handicap[0] + ctx->role_handicap[1] + ctx->role_handicap[2];
     else if (n_waves == 2) { hc[0] = ctx->role_handicap[0]; hc[1] = ctx->role_handicap[1] + ctx->role_handicap[2]; }
+    else if (dc.merge_roles) { hc[0] = ctx->role_handicap[0]; hc[1] = ctx->role_handicap[1] + ctx->role_handicap[2]; }
     else { hc[0] = ctx->role_handicap[0]; hc[1] = ctx->role_handicap[1]; hc[2] = ctx->role_handicap[2]; }
     // with enough column workers the integrator keeps its window free: its serial phases A / C gate every other wave
     if (n_waves >= 8 && !std::getenv("NYX_HIP_ROLE_HANDICAP")) hc[0] = 1e9;
-    // water-filling: level such that sum_w max(0, level - hc[w]) = terms
+    // Age weights: the four waves that share a SIMD (w, w+4, w+8, w+12) are arbitrated oldest-first, so with equal shares
+    // the oldest finishes early and the youngest runs the tail alone, with nothing to hide its scalar-load latency.
+    // Larger shares for the older waves make the four finish together.
+    double aw[4] = {1.0, 1.0, 1.0, 1.0};
+    if (n_waves == 16) { aw[0] = 1.30; aw[1] = 1.10; aw[2] = 0.90; aw[3] = 0.70; }
+    if (const char *e = std::getenv("NYX_HIP_AGE_WEIGHTS")) std::sscanf(e, "%lf,%lf,%lf,%lf", &aw[0], &aw[1], &aw[2], &aw[3]);
+    auto wgt = [&](int w) { return n_waves == 16 ? aw[w / 4] : 1.0; };
+    // water-filling: level such that sum_w max(0, level * weight_w - hc[w]) = terms
     double level = 0.0;
     {
-        double lo = 0.0, hi = terms + std::min(hc[0], 1e6) + hc[1] + hc[2];
-        for (int it = 0; it < 60; ++it) {
+        double lo = 0.0, hi = 4.0 * (terms + std::min(hc[0], 1e6) + hc[1] + hc[2]);
+        for (int it = 0; it < 80; ++it) {
             level = 0.5 * (lo + hi);
             double s = 0.0;
-            for (int w = 0; w < n_waves; ++w) s += std::max(0.0, level - hc[w]);
+            for (int w = 0; w < n_waves; ++w) s += std::max(0.0, level * wgt(w) - hc[w]);
             if (s < terms) lo = level; else hi = level;
         }
     }
     int lo = 1, hi = nc;
     // plain column workers first (highest wave index), role waves last so they take what is left
     for (int w = n_waves - 1; w >= 0; --w) {
-        const double tgt = std::max(0.0, level - hc[w]);
+        const double tgt = std::max(0.0, level * wgt(w) - hc[w]);
         if (w == 0) {
             if (lo <= hi) { dc.range_c0[0][0] = lo; dc.range_cnt[0][0] = hi - lo + 1; dc.n_ranges[0] = 1; }
             break;

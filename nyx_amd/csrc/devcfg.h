@@ -66,6 +66,7 @@ struct DevCfg {
 
     /* --- column schedule: wave w walks n_ranges[w] contiguous column ranges --- */
     int32_t n_waves;
+    int32_t merge_roles; /* almanac and perturbation duties share wave 1 */
     int32_t n_ranges[DEV_MAX_WAVES];
     int32_t range_c0[DEV_MAX_WAVES][DEV_MAX_RANGES];
     int32_t range_cnt[DEV_MAX_WAVES][DEV_MAX_RANGES];

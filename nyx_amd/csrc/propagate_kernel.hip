@@ -1321,6 +1321,11 @@ DEVFN void propagate_body(const DevBatch &bt, const DevCfg *cfg_g, const HarmEnt
     } else if (nw == 2) {
         if (wave == 0) role_loop<true, false, false, STM>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
         else role_loop<false, true, true, STM>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
+    } else if (cfg->merge_roles) {
+        // almanac + perturbations share wave 1 (their duties fit in one harmonics window), one more column worker
+        if (wave == 0) role_loop<true, false, false, STM>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
+        else if (wave == 1) role_loop<false, true, true, STM>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
+        else role_loop<false, false, false, STM>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
     } else {
         if (wave == 0) role_loop<true, false, false, STM>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
         else if (wave == 1) role_loop<false, true, false, STM>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
