@@ -224,6 +224,17 @@ typedef struct nyx_hip_step_stats {
     int64_t *n_evals;       /* eom calls = stages * attempts */
 } nyx_hip_step_stats_t;
 
+/* Dense output: every state the reference publishes on its channel (instance.rs:188-193, 254-259) preceded by the start
+ * state — the content of `Traj` before `finalize()` sorts it (md/trajectory/traj.rs:75-80, instance.rs:297-326).
+ * Step-major arrays: entry k of trajectory i is at [k * n + i]; k = 0 is the start state.  `len[i]` counts the states
+ * PRODUCED; states beyond `capacity` are not stored. */
+typedef struct nyx_hip_traj {
+    int64_t capacity;
+    int64_t *epoch_ns;
+    double *x_km, *y_km, *z_km, *vx_km_s, *vy_km_s, *vz_km_s;
+    int32_t *len;
+} nyx_hip_traj_t;
+
 typedef struct nyx_hip_ctx nyx_hip_ctx;
 
 /* Number of visible HIP devices (0 if none / no runtime). */
@@ -247,6 +258,15 @@ int32_t nyx_hip_propagate_batch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, in
  * resident in HBM. */
 int32_t nyx_hip_propagate_batch_device(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t duration_ns,
                                        nyx_hip_states_t *out, nyx_hip_step_stats_t *stats, void *hip_stream);
+
+/* `for_duration_with_traj` (instance.rs:297-326) for the batch: as nyx_hip_propagate_batch, plus the accepted states.
+ * Host arrays; `traj` arrays must hold capacity * n elements. */
+int32_t nyx_hip_propagate_batch_with_traj(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t duration_ns,
+                                          nyx_hip_states_t *out, nyx_hip_step_stats_t *stats, nyx_hip_traj_t *traj);
+/* Device-pointer flavour (every pointer in in/out/stats/traj is a device pointer), asynchronous on `hip_stream`. */
+int32_t nyx_hip_propagate_batch_with_traj_device(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t duration_ns,
+                                                 nyx_hip_states_t *out, nyx_hip_step_stats_t *stats, nyx_hip_traj_t *traj,
+                                                 void *hip_stream);
 
 /* Per-trajectory epochs variant of until_epoch (instance.rs:279-282): duration_i = end_epoch_ns - epoch_i. */
 int32_t nyx_hip_propagate_until_epoch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t end_epoch_ns,

@@ -159,6 +159,40 @@ class StepStats(C.Structure):
     ]
 
 
+class Traj(C.Structure):
+    _fields_ = [
+        ("capacity", C.c_int64),
+        ("epoch_ns", c_int64_p),
+        ("x_km", c_double_p), ("y_km", c_double_p), ("z_km", c_double_p),
+        ("vx_km_s", c_double_p), ("vy_km_s", c_double_p), ("vz_km_s", c_double_p),
+        ("len", c_int32_p),
+    ]
+
+
+class TrajBatch:
+    """Dense output of a batch: entry k of trajectory i at [k, i]; k = 0 is the start state (step-major, as the ABI)."""
+
+    def __init__(self, n: int, capacity: int):
+        self.n, self.capacity = n, capacity
+        self.epoch_ns = np.zeros((capacity, n), dtype=np.int64)
+        self.state = np.zeros((6, capacity, n), dtype=np.float64)
+        self.len = np.zeros(n, dtype=np.int32)
+
+    def as_c(self) -> "Traj":
+        t = Traj()
+        t.capacity = self.capacity
+        t.epoch_ns = self.epoch_ns.ctypes.data_as(c_int64_p)
+        for k, f in enumerate(["x_km", "y_km", "z_km", "vx_km_s", "vy_km_s", "vz_km_s"]):
+            setattr(t, f, self.state[k].ctypes.data_as(c_double_p))
+        t.len = self.len.ctypes.data_as(c_int32_p)
+        return t
+
+    def trajectory(self, i: int):
+        """(epochs, states[len, 6]) of run i in propagation order; `finalize()` of the reference = sort by epoch."""
+        m = min(int(self.len[i]), self.capacity)
+        return self.epoch_ns[:m, i].copy(), self.state[:, :m, i].T.copy()
+
+
 F64_FIELDS = ["x_km", "y_km", "z_km", "vx_km_s", "vy_km_s", "vz_km_s", "cr", "cd", "prop_mass_kg",
               "dry_mass_kg", "extra_mass_kg", "srp_area_m2", "drag_area_m2"]
 
@@ -267,6 +301,7 @@ EXPORTS = [
     "nyx_hip_device_count", "nyx_hip_ctx_create", "nyx_hip_ctx_destroy", "nyx_hip_propagate_batch",
     "nyx_hip_propagate_batch_device", "nyx_hip_propagate_until_epoch", "nyx_hip_ctx_set_column_waves",
     "nyx_hip_last_kernel_ms", "nyx_hip_last_error", "nyx_hip_load_cof", "nyx_hip_load_shadr", "nyx_hip_free",
+    "nyx_hip_propagate_batch_with_traj", "nyx_hip_propagate_batch_with_traj_device",
 ]
 
 
@@ -292,6 +327,11 @@ def load_library():
     lib.nyx_hip_propagate_batch_device.argtypes = [C.c_void_p, C.POINTER(States), C.c_int64, C.POINTER(States),
                                                    C.POINTER(StepStats), C.c_void_p]
     lib.nyx_hip_propagate_batch_device.restype = C.c_int32
+    lib.nyx_hip_propagate_batch_with_traj.argtypes = [C.c_void_p, C.POINTER(States), C.c_int64, C.POINTER(States), C.POINTER(StepStats), C.POINTER(Traj)]
+    lib.nyx_hip_propagate_batch_with_traj.restype = C.c_int32
+    lib.nyx_hip_propagate_batch_with_traj_device.argtypes = [C.c_void_p, C.POINTER(States), C.c_int64, C.POINTER(States), C.POINTER(StepStats),
+                                                             C.POINTER(Traj), C.c_void_p]
+    lib.nyx_hip_propagate_batch_with_traj_device.restype = C.c_int32
     lib.nyx_hip_propagate_until_epoch.argtypes = [C.c_void_p, C.POINTER(States), C.c_int64, C.POINTER(States), C.POINTER(StepStats)]
     lib.nyx_hip_propagate_until_epoch.restype = C.c_int32
     lib.nyx_hip_ctx_set_column_waves.argtypes = [C.c_void_p, C.c_int32]

@@ -122,6 +122,7 @@ extern "C" int64_t nyx_hip_abi_sizeof(int32_t which) {
     case 7: return sizeof(nyx_hip_config_t);
     case 8: return sizeof(nyx_hip_states_t);
     case 9: return sizeof(nyx_hip_step_stats_t);
+    case 10: return sizeof(nyx_hip_traj_t);
     default: return -1;
     }
 }
@@ -483,7 +484,8 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
 // ---------------------------------------------------------------------------------------------
 
 static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t *out, nyx_hip_step_stats_t *st,
-                  int64_t duration_ns, int64_t end_epoch_ns, int use_end, hipStream_t stream, bool time_it) {
+                  int64_t duration_ns, int64_t end_epoch_ns, int use_end, hipStream_t stream, bool time_it,
+                  const nyx_hip_traj_t *traj = nullptr) {
     const int nw = pick_waves(ctx, in->n);
     if (nw != ctx->host_cfg.n_waves) {
         build_schedule(ctx, nw);
@@ -505,6 +507,15 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
     bt.o_x = out->x_km; bt.o_y = out->y_km; bt.o_z = out->z_km; bt.o_vx = out->vx_km_s; bt.o_vy = out->vy_km_s; bt.o_vz = out->vz_km_s;
     bt.o_cr = out->cr; bt.o_cd = out->cd; bt.o_mprop = out->prop_mass_kg; bt.o_mdry = out->dry_mass_kg;
     bt.o_mextra = out->extra_mass_kg; bt.o_asrp = out->srp_area_m2; bt.o_adrag = out->drag_area_m2; bt.o_step = out->step_ns;
+    if (traj && traj->capacity > 0) {
+        if (!traj->epoch_ns || !traj->x_km || !traj->y_km || !traj->z_km || !traj->vx_km_s || !traj->vy_km_s || !traj->vz_km_s || !traj->len) {
+            nyx_set_error("traj: every array is mandatory");
+            return NYX_HIP_RC_BAD_ARG;
+        }
+        bt.traj_cap = traj->capacity; bt.t_epoch = traj->epoch_ns; bt.t_len = traj->len;
+        bt.t_state[0] = traj->x_km; bt.t_state[1] = traj->y_km; bt.t_state[2] = traj->z_km;
+        bt.t_state[3] = traj->vx_km_s; bt.t_state[4] = traj->vy_km_s; bt.t_state[5] = traj->vz_km_s;
+    }
     if (st) {
         bt.status = st->status; bt.last_step_ns = st->last_step_ns; bt.last_error = st->last_error;
         bt.last_attempts = st->last_attempts; bt.n_acc = st->n_accepted; bt.n_rej = st->n_rejected; bt.n_evals = st->n_evals;
@@ -540,8 +551,19 @@ extern "C" int32_t nyx_hip_propagate_batch_device(nyx_hip_ctx *ctx, const nyx_hi
     return rc;
 }
 
+extern "C" int32_t nyx_hip_propagate_batch_with_traj_device(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t duration_ns,
+                                                            nyx_hip_states_t *out, nyx_hip_step_stats_t *stats, nyx_hip_traj_t *traj,
+                                                            void *hip_stream) {
+    if (!ctx || !traj) { nyx_set_error("null ctx / traj"); return NYX_HIP_RC_BAD_ARG; }
+    if (int rc = check_states(in, "in")) return rc;
+    if (int rc = check_states(out, "out")) return rc;
+    if (in->n == 0) return NYX_HIP_RC_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    return launch(ctx, in, out, stats, duration_ns, 0, 0, (hipStream_t)hip_stream, true, traj);
+}
+
 static int host_propagate(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t duration_ns, int64_t end_epoch_ns, int use_end,
-                          nyx_hip_states_t *out, nyx_hip_step_stats_t *stats) {
+                          nyx_hip_states_t *out, nyx_hip_step_stats_t *stats, nyx_hip_traj_t *traj = nullptr) {
     if (!ctx) { nyx_set_error("null ctx"); return NYX_HIP_RC_BAD_ARG; }
     if (int rc = check_states(in, "in")) return rc;
     if (int rc = check_states(out, "out")) return rc;
@@ -591,8 +613,33 @@ static int host_propagate(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t 
     dout.stm = stm ? dq.stm : nullptr;
     nyx_hip_step_stats_t dst = {dq.status, dq.last_step, dq.last_error, dq.last_attempts, dq.n_acc, dq.n_rej, dq.n_evals};
 
-    if (int rc = launch(ctx, &din, &dout, &dst, duration_ns, end_epoch_ns, use_end, nullptr, true)) return rc;
+    nyx_hip_traj_t dtraj;
+    std::memset(&dtraj, 0, sizeof dtraj);
+    void *traj_block = nullptr;
+    if (traj && traj->capacity > 0) {
+        const size_t slots = (size_t)traj->capacity * (size_t)n;
+        HIP_TRY(hipMalloc(&traj_block, slots * 7 * sizeof(double) + (size_t)n * sizeof(int32_t)));
+        dtraj.capacity = traj->capacity;
+        dtraj.epoch_ns = (int64_t *)traj_block;
+        double *base = (double *)traj_block + slots;
+        dtraj.x_km = base; dtraj.y_km = base + slots; dtraj.z_km = base + 2 * slots;
+        dtraj.vx_km_s = base + 3 * slots; dtraj.vy_km_s = base + 4 * slots; dtraj.vz_km_s = base + 5 * slots;
+        dtraj.len = (int32_t *)(base + 6 * slots);
+    }
+    if (int rc = launch(ctx, &din, &dout, &dst, duration_ns, end_epoch_ns, use_end, nullptr, true, traj_block ? &dtraj : nullptr)) {
+        if (traj_block) (void)hipFree(traj_block);
+        return rc;
+    }
     HIP_TRY(hipDeviceSynchronize());
+    if (traj_block) {
+        const size_t slots = (size_t)traj->capacity * (size_t)n;
+        HIP_TRY(hipMemcpy(traj->len, dtraj.len, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(traj->epoch_ns, dtraj.epoch_ns, slots * sizeof(int64_t), hipMemcpyDeviceToHost));
+        double *hdst[6] = {traj->x_km, traj->y_km, traj->z_km, traj->vx_km_s, traj->vy_km_s, traj->vz_km_s};
+        double *dsrc[6] = {dtraj.x_km, dtraj.y_km, dtraj.z_km, dtraj.vx_km_s, dtraj.vy_km_s, dtraj.vz_km_s};
+        for (int k = 0; k < 6; ++k) HIP_TRY(hipMemcpy(hdst[k], dsrc[k], slots * sizeof(double), hipMemcpyDeviceToHost));
+        HIP_TRY(hipFree(traj_block));
+    }
     {
         float ms = 0.f;
         ctx->last_ms = (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ? ms : -1.0;
@@ -619,6 +666,12 @@ static int host_propagate(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t 
 extern "C" int32_t nyx_hip_propagate_batch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t duration_ns,
                                            nyx_hip_states_t *out, nyx_hip_step_stats_t *stats) {
     return host_propagate(ctx, in, duration_ns, 0, 0, out, stats);
+}
+
+extern "C" int32_t nyx_hip_propagate_batch_with_traj(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t duration_ns,
+                                                     nyx_hip_states_t *out, nyx_hip_step_stats_t *stats, nyx_hip_traj_t *traj) {
+    if (!traj || traj->capacity < 1) { nyx_set_error("traj with capacity >= 1 required"); return NYX_HIP_RC_BAD_ARG; }
+    return host_propagate(ctx, in, duration_ns, 0, 0, out, stats, traj);
 }
 
 extern "C" int32_t nyx_hip_propagate_until_epoch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t end_epoch_ns,

@@ -110,6 +110,10 @@ struct DevBatch { /* device pointers of one launch */
     double *last_error;
     int32_t *last_attempts;
     int64_t *n_acc, *n_rej, *n_evals;
+    int64_t traj_cap;  /* 0 => no dense output */
+    int64_t *t_epoch;  /* [cap][n] */
+    double *t_state[6];
+    int32_t *t_len;
     int64_t *prof; /* optional [16][8] cycle counters written by workgroup 0 (NYX_HIP_PROFILE) */
 };
 

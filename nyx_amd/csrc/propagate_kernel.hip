@@ -862,6 +862,12 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
         const double mass = (bt.mdry ? bt.mdry[idx] : 0.0) + c.y[8] + (bt.mextra ? bt.mextra[idx] : 0.0);
         c.massless = (has_srp || has_drag) && !(mass > 0.0);  // MasslessSpacecraft (spacecraft.rs:201-203)
         cold_store(L.cs, lane, c);
+        if (bt.traj_cap > 0 && valid) {  // dense output: the start state is entry 0 (instance.rs:319-321)
+            bt.t_epoch[gid] = c.epoch;
+#pragma unroll
+            for (int e = 0; e < 6; ++e) bt.t_state[e][gid] = c.y[e];
+            bt.t_len[gid] = (duration == 0 || c.done) ? 1 : 1;
+        }
         if (STM && valid && bt.o_stm != bt.stm) {
             for (int q = 0; q < 81; ++q) bt.o_stm[gid * 81 + q] = bt.stm[gid * 81 + q];
         }
@@ -1228,6 +1234,15 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     y[6] = clamp02(y[6]);
                     c.n_acc += 1;
                     c.det_attempts = c.attempts;
+                    if (bt.traj_cap > 0 && valid) {  // chan.send(self.state) after every accepted step, final one included
+                        if (c.n_acc < bt.traj_cap) {
+                            const int64_t at = c.n_acc * bt.n + gid;
+                            bt.t_epoch[at] = c.epoch;
+#pragma unroll
+                            for (int e = 0; e < 6; ++e) bt.t_state[e][at] = y[e];
+                        }
+                        bt.t_len[gid] = (int32_t)(c.n_acc + 1);
+                    }
                     if (STM && valid) {
                         double sumb = 0.0;
                         for (int q = 0; q < stages; ++q) sumb += B_COEF(q);

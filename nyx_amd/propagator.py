@@ -580,6 +580,17 @@ class GpuContext:
             raise RuntimeError(f"nyx_hip_propagate_batch failed (rc={rc}): {_abi.last_error()}")
         return out, stats
 
+    def propagate_with_traj(self, batch: _abi.StateBatch, duration_ns: int, capacity: int):
+        """Batch form of `for_duration_with_traj` (instance.rs:297-326): final states, stats and the accepted states."""
+        out = batch.copy()
+        stats = _abi.StatsBatch(batch.n)
+        traj = _abi.TrajBatch(batch.n, int(capacity))
+        cin, cout, cst, ctr = batch.as_c(), out.as_c(), stats.as_c(), traj.as_c()
+        rc = self._lib.nyx_hip_propagate_batch_with_traj(self._h, C.byref(cin), int(duration_ns), C.byref(cout), C.byref(cst), C.byref(ctr))
+        if rc != 0:
+            raise RuntimeError(f"nyx_hip_propagate_batch_with_traj failed (rc={rc}): {_abi.last_error()}")
+        return out, stats, traj
+
     def propagate_until_epoch(self, batch: _abi.StateBatch, end_epoch_ns: int, out: Optional[_abi.StateBatch] = None):
         out = out if out is not None else batch.copy()
         stats = _abi.StatsBatch(batch.n)
@@ -617,6 +628,20 @@ class PropInstance:
 
     def until_epoch(self, end_epoch_ns: int) -> Spacecraft:
         return self.for_duration(int(end_epoch_ns) - int(self.state.epoch_ns))
+
+    def for_duration_with_traj(self, duration_ns: int, capacity: int = 1 << 16):
+        """instance.rs:297-326: (end state, Traj) — the trajectory is (epochs, states) sorted by epoch (`finalize`)."""
+        batch = pack_spacecraft([self.state], False)
+        batch.step_ns[0] = self.step_size
+        out, st, traj = self._ctx.propagate_with_traj(batch, int(duration_ns), capacity)
+        if st.status[0] != _abi.OK:
+            raise PropagationError(int(st.status[0]))
+        self.step_size = int(out.step_ns[0])
+        self.state = unpack_spacecraft(out, [self.state])[0]
+        ep, xs = traj.trajectory(0)
+        order = np.argsort(ep, kind="stable")
+        keep = np.concatenate([[True], np.diff(ep[order]) != 0])  # dedup_by epoch (traj.rs:76-77)
+        return self.state, (ep[order][keep], xs[order][keep])
 
     def latest_details(self):
         return dict(self.details)

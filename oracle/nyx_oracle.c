@@ -906,7 +906,23 @@ typedef struct {
     int64_t n_acc, n_rej, n_evals;
     double k[MAX_STAGES][NV_MAX];
     scratch_t w;
+    /* dense output (for_duration_with_traj, instance.rs:297-326) */
+    const nyx_hip_traj_t *traj;
+    int64_t traj_n, traj_i;
 } inst_t;
+
+static void traj_push(inst_t *s) {
+    const nyx_hip_traj_t *t = s->traj;
+    if (!t) return;
+    const int64_t k = s->n_acc; /* 0 = start state */
+    if (k < t->capacity) {
+        const int64_t at = k * s->traj_n + s->traj_i;
+        t->epoch_ns[at] = s->epoch_ns;
+        t->x_km[at] = s->y[0]; t->y_km[at] = s->y[1]; t->z_km[at] = s->y[2];
+        t->vx_km_s[at] = s->y[3]; t->vy_km_s[at] = s->y[4]; t->vz_km_s[at] = s->y[5];
+    }
+    t->len[s->traj_i] = (int32_t)(k + 1);
+}
 
 static int64_t i64abs(int64_t x) { return x < 0 ? -x : x; }
 
@@ -990,6 +1006,7 @@ static int single_step(inst_t *s) {
     memcpy(s->y, next, sizeof(double) * (size_t)s->nv);
     s->y[6] = clamp02(s->y[6]);
     s->n_acc += 1;
+    traj_push(s); /* chan.send(self.state) (instance.rs:188-193, 254-259) */
     return finally_(s);
 }
 
@@ -1031,6 +1048,7 @@ typedef struct {
     nyx_hip_step_stats_t *stats;
     int64_t duration_ns;
     atomic_long next;
+    const nyx_hip_traj_t *traj;
 } job_t;
 
 static void run_one(const job_t *jb, inst_t *s, int64_t i) {
@@ -1059,6 +1077,8 @@ static void run_one(const job_t *jb, inst_t *s, int64_t i) {
     s->det_error = 0.0;
     s->det_attempts = 1;
     s->n_acc = s->n_rej = s->n_evals = 0;
+    s->traj = jb->traj; s->traj_n = in->n; s->traj_i = i;
+    traj_push(s);
 
     int st = propagate(s, jb->duration_ns);
 
@@ -1105,10 +1125,16 @@ static void *worker(void *arg) {
 
 int32_t nyx_oracle_propagate_batch(const nyx_hip_config_t *cfg, const nyx_hip_states_t *in, int64_t duration_ns,
                                    nyx_hip_states_t *out, nyx_hip_step_stats_t *stats, int32_t n_threads) {
+    return nyx_oracle_propagate_batch_traj(cfg, in, duration_ns, out, stats, NULL, n_threads);
+}
+
+int32_t nyx_oracle_propagate_batch_traj(const nyx_hip_config_t *cfg, const nyx_hip_states_t *in, int64_t duration_ns,
+                                        nyx_hip_states_t *out, nyx_hip_step_stats_t *stats, const nyx_hip_traj_t *traj,
+                                        int32_t n_threads) {
     if (!cfg || !in || !out || cfg->opts.method < 0 || cfg->opts.method > 5) return NYX_HIP_RC_BAD_ARG;
     prepared_t p;
     prepared_init(&p, cfg);
-    job_t jb = {&p, in, out, stats, duration_ns, 0};
+    job_t jb = {&p, in, out, stats, duration_ns, 0, traj};
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 256) n_threads = 256;
     if (n_threads == 1 || in->n <= 1) {

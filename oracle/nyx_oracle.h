@@ -31,6 +31,11 @@ extern "C" {
 int32_t nyx_oracle_propagate_batch(const nyx_hip_config_t *cfg, const nyx_hip_states_t *in, int64_t duration_ns,
                                    nyx_hip_states_t *out, nyx_hip_step_stats_t *stats, int32_t n_threads);
 
+/* Same, also recording the accepted states (for_duration_with_traj, instance.rs:297-326); traj may be NULL. */
+int32_t nyx_oracle_propagate_batch_traj(const nyx_hip_config_t *cfg, const nyx_hip_states_t *in, int64_t duration_ns,
+                                        nyx_hip_states_t *out, nyx_hip_step_stats_t *stats, const nyx_hip_traj_t *traj,
+                                        int32_t n_threads);
+
 /* One call of SpacecraftDynamics::eom (dynamics/spacecraft.rs:191-310) for a single
  * state: y is the 9- (no STM) or 90-vector, dydt likewise.  ctx_stm is the
  * step-start STM (column-major 81) or NULL.  Returns a nyx_hip_status. */

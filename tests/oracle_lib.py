@@ -29,6 +29,9 @@ def load():
     lib.nyx_oracle_propagate_batch.argtypes = [C.POINTER(_abi.Config), C.POINTER(_abi.States), C.c_int64,
                                                C.POINTER(_abi.States), C.POINTER(_abi.StepStats), C.c_int32]
     lib.nyx_oracle_propagate_batch.restype = C.c_int32
+    lib.nyx_oracle_propagate_batch_traj.argtypes = [C.POINTER(_abi.Config), C.POINTER(_abi.States), C.c_int64, C.POINTER(_abi.States),
+                                                    C.POINTER(_abi.StepStats), C.POINTER(_abi.Traj), C.c_int32]
+    lib.nyx_oracle_propagate_batch_traj.restype = C.c_int32
     lib.nyx_oracle_eom.argtypes = [C.POINTER(_abi.Config), C.c_int64, C.c_double, _abi.c_double_p, _abi.c_double_p,
                                    C.c_double, C.c_double, C.c_double, C.c_double, _abi.c_double_p]
     lib.nyx_oracle_eom.restype = C.c_int32
@@ -60,6 +63,17 @@ def propagate(compiled, batch, duration_ns, n_threads=1):
     rc = lib.nyx_oracle_propagate_batch(C.byref(compiled.cfg), C.byref(cin), int(duration_ns), C.byref(cout), C.byref(cst), n_threads)
     assert rc == 0
     return out, stats
+
+
+def propagate_with_traj(compiled, batch, duration_ns, capacity, n_threads=1):
+    lib = load()
+    out = batch.copy()
+    stats = _abi.StatsBatch(batch.n)
+    traj = _abi.TrajBatch(batch.n, capacity)
+    cin, cout, cst, ctr = batch.as_c(), out.as_c(), stats.as_c(), traj.as_c()
+    rc = lib.nyx_oracle_propagate_batch_traj(C.byref(compiled.cfg), C.byref(cin), int(duration_ns), C.byref(cout), C.byref(cst), C.byref(ctr), n_threads)
+    assert rc == 0
+    return out, stats, traj
 
 
 def eom(compiled, epoch_ns, dt_s, y, ctx_stm=None, dry=0.0, extra=0.0, srp_area=0.0, drag_area=0.0):

@@ -18,7 +18,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     lib = _abi.load_library()
     header = open(os.path.join(ROOT, "include", "nyx_hip.h")).read()
     declared = set(re.findall(r"^(?:int32_t|void|double|const char \*)\s*(nyx_hip_[a-z_0-9]+)\(", header, flags=re.M))
-    assert len(declared) == 12
+    assert len(declared) == 14
     assert declared >= set(_abi.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in nyx_hip.h but not exported"
@@ -27,7 +27,7 @@ def test_library_loads_and_exports_every_declared_symbol():
 def test_struct_layouts_match_the_header():
     lib = _abi.load_library()
     mirror = [_abi.IntegOpts, _abi.ChebySegment, _abi.Body, _abi.Rotation, _abi.GravityField, _abi.Srp, _abi.Drag,
-              _abi.Config, _abi.States, _abi.StepStats]
+              _abi.Config, _abi.States, _abi.StepStats, _abi.Traj]
     for which, cls in enumerate(mirror):
         assert lib.nyx_hip_abi_sizeof(which) == C.sizeof(cls), cls.__name__
 

@@ -64,3 +64,35 @@ def test_monte_carlo_run_until_epoch_on_gpu():
     # resume_run_until_epoch(skip) reproduces the tail (montecarlo.rs:208-224)
     tail = mc.resume_run_until_epoch(prop, almanac, 6, end, 4)
     np.testing.assert_array_equal(tail.final_rv(), rslts.final_rv()[6:])
+
+
+def test_dense_output_matches_the_oracle_trajectory():
+    """for_duration_with_traj (instance.rs:297-326): start state + every accepted state (the final fixed step included)."""
+    prop, almanac, central = leo_full_setup(degree=8)
+    compiled = prop.compile(almanac, central)
+    b = dispersed_leo_batch(70, seed=12)
+    ctx = nx.GpuContext(compiled)
+    dur = 2 * 3600 * nx.NS_PER_S
+    out, st, traj = ctx.propagate_with_traj(b, dur, capacity=400)
+    ref, rst, rtraj = oracle_lib.propagate_with_traj(compiled, b, dur, 400, n_threads=4)
+    assert (st.status == 0).all()
+    assert (traj.len == st.n_accepted + 1).all() and (rtraj.len == rst.n_accepted + 1).all()
+    for i in (0, 17, 69):
+        ep, xs = traj.trajectory(i)
+        assert ep[0] == b.epoch_ns[i] and ep[-1] == b.epoch_ns[i] + dur and np.all(np.diff(ep) > 0)
+        np.testing.assert_array_equal(xs[0], b.rv()[i])
+        np.testing.assert_array_equal(xs[-1], out.rv()[i])
+        rep_, rxs = rtraj.trajectory(i)
+        if len(ep) == len(rep_) and (ep == rep_).all():  # same step sequence: states agree to the parity bar along the way
+            assert np.abs(xs - rxs)[:, :3].max() < 1e-6 and np.abs(xs - rxs)[:, 3:].max() < 1e-9
+    # capacity overflow: the count keeps going, the stored prefix is intact
+    out2, st2, small = ctx.propagate_with_traj(b, dur, capacity=10)
+    assert (small.len == traj.len).all()
+    np.testing.assert_array_equal(small.epoch_ns[:10], traj.epoch_ns[:10])
+    # single-trajectory front end, back-propagation comes back sorted by epoch like Traj::finalize
+    sc = nx.Spacecraft(int(b.epoch_ns[0]), b.rv()[0], central, dry_mass_kg=100.0, srp_area_m2=1.0, cr=1.8)
+    inst = prop.with_(sc, almanac)
+    end, (eps, states) = inst.for_duration_with_traj(-1800 * nx.NS_PER_S)
+    assert eps[0] == sc.epoch_ns - 1800 * nx.NS_PER_S and eps[-1] == sc.epoch_ns and np.all(np.diff(eps) > 0)
+    np.testing.assert_array_equal(states[0], end.rv)
+    ctx.close()
