@@ -48,15 +48,18 @@ extern "C" const char *nyx_hip_last_error(void) { return g_err; }
 // context
 // ---------------------------------------------------------------------------------------------
 
-struct DevArrays {  // one SoA batch resident on the device
+struct DevArrays {  // one SoA batch resident on the device: ONE device block, ONE pinned host mirror => one copy each way
     int64_t cap = 0;
+    char *dblock = nullptr, *hblock = nullptr;
+    size_t bytes = 0;
     int64_t *epoch = nullptr, *step = nullptr;
     double *f[13] = {nullptr};
     double *stm = nullptr;  // [cap][81], allocated on first STM use
     int64_t stm_cap = 0;
-    int32_t *status = nullptr, *last_attempts = nullptr;
     int64_t *last_step = nullptr, *n_acc = nullptr, *n_rej = nullptr, *n_evals = nullptr;
     double *last_error = nullptr;
+    int32_t *status = nullptr, *last_attempts = nullptr;
+    template <typename T> T *host(T *dev) const { return (T *)(hblock + ((char *)dev - dblock)); }
 };
 
 struct nyx_hip_ctx {
@@ -77,28 +80,33 @@ struct nyx_hip_ctx {
 };
 
 static void free_arrays(DevArrays &a) {
-    hipFree(a.epoch); hipFree(a.step); hipFree(a.stm);
-    for (auto &p : a.f) hipFree(p);
-    hipFree(a.status); hipFree(a.last_attempts); hipFree(a.last_step); hipFree(a.n_acc); hipFree(a.n_rej);
-    hipFree(a.n_evals); hipFree(a.last_error);
+    (void)hipFree(a.dblock);
+    (void)hipHostFree(a.hblock);
+    (void)hipFree(a.stm);
     a = DevArrays();
 }
 
 static int ensure_arrays(DevArrays &a, int64_t n, bool stats) {
     if (n <= a.cap) return NYX_HIP_RC_OK;
     free_arrays(a);
-    int64_t cap = std::max<int64_t>(n, 1024);
-    HIP_TRY(hipMalloc(&a.epoch, cap * sizeof(int64_t)));
-    HIP_TRY(hipMalloc(&a.step, cap * sizeof(int64_t)));
-    for (auto &p : a.f) HIP_TRY(hipMalloc(&p, cap * sizeof(double)));
+    const int64_t cap = (std::max<int64_t>(n, 1024) + 63) / 64 * 64;
+    const size_t slot = (size_t)cap * 8;
+    const size_t n64 = 15 + (stats ? 5 : 0);  // epoch, step, 13 f64 (+ last_step, n_acc, n_rej, n_evals, last_error)
+    a.bytes = n64 * slot + (stats ? 2 * (size_t)cap * 4 : 0);
+    HIP_TRY(hipMalloc((void **)&a.dblock, a.bytes));
+    HIP_TRY(hipHostMalloc((void **)&a.hblock, a.bytes, hipHostMallocDefault));
+    char *p = a.dblock;
+    a.epoch = (int64_t *)p; p += slot;
+    a.step = (int64_t *)p; p += slot;
+    for (auto &q : a.f) { q = (double *)p; p += slot; }
     if (stats) {
-        HIP_TRY(hipMalloc(&a.status, cap * sizeof(int32_t)));
-        HIP_TRY(hipMalloc(&a.last_attempts, cap * sizeof(int32_t)));
-        HIP_TRY(hipMalloc(&a.last_step, cap * sizeof(int64_t)));
-        HIP_TRY(hipMalloc(&a.n_acc, cap * sizeof(int64_t)));
-        HIP_TRY(hipMalloc(&a.n_rej, cap * sizeof(int64_t)));
-        HIP_TRY(hipMalloc(&a.n_evals, cap * sizeof(int64_t)));
-        HIP_TRY(hipMalloc(&a.last_error, cap * sizeof(double)));
+        a.last_step = (int64_t *)p; p += slot;
+        a.n_acc = (int64_t *)p; p += slot;
+        a.n_rej = (int64_t *)p; p += slot;
+        a.n_evals = (int64_t *)p; p += slot;
+        a.last_error = (double *)p; p += slot;
+        a.status = (int32_t *)p; p += (size_t)cap * 4;
+        a.last_attempts = (int32_t *)p; p += (size_t)cap * 4;
     }
     a.cap = cap;
     return NYX_HIP_RC_OK;
@@ -576,10 +584,12 @@ static int host_propagate(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t 
     DevArrays &di = ctx->in, &dq = ctx->out;
     const double *hin[13] = {in->x_km, in->y_km, in->z_km, in->vx_km_s, in->vy_km_s, in->vz_km_s, in->cr, in->cd,
                              in->prop_mass_kg, in->dry_mass_kg, in->extra_mass_kg, in->srp_area_m2, in->drag_area_m2};
-    HIP_TRY(hipMemcpy(di.epoch, in->epoch_ns, n * sizeof(int64_t), hipMemcpyHostToDevice));
+    // pack into the pinned mirror, one H2D for the whole batch
+    std::memcpy(di.host(di.epoch), in->epoch_ns, n * sizeof(int64_t));
     for (int k = 0; k < 13; ++k)
-        if (hin[k]) HIP_TRY(hipMemcpy(di.f[k], hin[k], n * sizeof(double), hipMemcpyHostToDevice));
-    if (in->step_ns) HIP_TRY(hipMemcpy(di.step, in->step_ns, n * sizeof(int64_t), hipMemcpyHostToDevice));
+        if (hin[k]) std::memcpy(di.host(di.f[k]), hin[k], n * sizeof(double));
+    if (in->step_ns) std::memcpy(di.host(di.step), in->step_ns, n * sizeof(int64_t));
+    HIP_TRY(hipMemcpy(di.dblock, di.hblock, (size_t)((char *)(di.f[12] + di.cap) - di.dblock), hipMemcpyHostToDevice));
     const bool stm = (ctx->host_cfg.flags & NYX_HIP_FLAG_STM) != 0;
     if (stm) {
         if (!in->stm || !out->stm) { nyx_set_error("STM context: in->stm and out->stm are mandatory"); return NYX_HIP_RC_BAD_ARG; }
@@ -644,21 +654,23 @@ static int host_propagate(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t 
         float ms = 0.f;
         ctx->last_ms = (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ? ms : -1.0;
     }
+    // one D2H for states + stats, then unpack from the pinned mirror
+    HIP_TRY(hipMemcpy(dq.hblock, dq.dblock, dq.bytes, hipMemcpyDeviceToHost));
     double *hout[13] = {out->x_km, out->y_km, out->z_km, out->vx_km_s, out->vy_km_s, out->vz_km_s, out->cr, out->cd,
                         out->prop_mass_kg, out->dry_mass_kg, out->extra_mass_kg, out->srp_area_m2, out->drag_area_m2};
-    HIP_TRY(hipMemcpy(out->epoch_ns, dq.epoch, n * sizeof(int64_t), hipMemcpyDeviceToHost));
+    std::memcpy(out->epoch_ns, dq.host(dq.epoch), n * sizeof(int64_t));
     for (int k = 0; k < 13; ++k)
-        if (hout[k]) HIP_TRY(hipMemcpy(hout[k], dq.f[k], n * sizeof(double), hipMemcpyDeviceToHost));
-    if (out->step_ns) HIP_TRY(hipMemcpy(out->step_ns, dq.step, n * sizeof(int64_t), hipMemcpyDeviceToHost));
+        if (hout[k]) std::memcpy(hout[k], dq.host(dq.f[k]), n * sizeof(double));
+    if (out->step_ns) std::memcpy(out->step_ns, dq.host(dq.step), n * sizeof(int64_t));
     if (stm) HIP_TRY(hipMemcpy(out->stm, dq.stm, (size_t)n * 81 * sizeof(double), hipMemcpyDeviceToHost));
     if (stats) {
-        if (stats->status) HIP_TRY(hipMemcpy(stats->status, dq.status, n * sizeof(int32_t), hipMemcpyDeviceToHost));
-        if (stats->last_step_ns) HIP_TRY(hipMemcpy(stats->last_step_ns, dq.last_step, n * sizeof(int64_t), hipMemcpyDeviceToHost));
-        if (stats->last_error) HIP_TRY(hipMemcpy(stats->last_error, dq.last_error, n * sizeof(double), hipMemcpyDeviceToHost));
-        if (stats->last_attempts) HIP_TRY(hipMemcpy(stats->last_attempts, dq.last_attempts, n * sizeof(int32_t), hipMemcpyDeviceToHost));
-        if (stats->n_accepted) HIP_TRY(hipMemcpy(stats->n_accepted, dq.n_acc, n * sizeof(int64_t), hipMemcpyDeviceToHost));
-        if (stats->n_rejected) HIP_TRY(hipMemcpy(stats->n_rejected, dq.n_rej, n * sizeof(int64_t), hipMemcpyDeviceToHost));
-        if (stats->n_evals) HIP_TRY(hipMemcpy(stats->n_evals, dq.n_evals, n * sizeof(int64_t), hipMemcpyDeviceToHost));
+        if (stats->status) std::memcpy(stats->status, dq.host(dq.status), n * sizeof(int32_t));
+        if (stats->last_step_ns) std::memcpy(stats->last_step_ns, dq.host(dq.last_step), n * sizeof(int64_t));
+        if (stats->last_error) std::memcpy(stats->last_error, dq.host(dq.last_error), n * sizeof(double));
+        if (stats->last_attempts) std::memcpy(stats->last_attempts, dq.host(dq.last_attempts), n * sizeof(int32_t));
+        if (stats->n_accepted) std::memcpy(stats->n_accepted, dq.host(dq.n_acc), n * sizeof(int64_t));
+        if (stats->n_rejected) std::memcpy(stats->n_rejected, dq.host(dq.n_rej), n * sizeof(int64_t));
+        if (stats->n_evals) std::memcpy(stats->n_evals, dq.host(dq.n_evals), n * sizeof(int64_t));
     }
     return NYX_HIP_RC_OK;
 }
