@@ -350,3 +350,44 @@ def test_drag_vs_oracle(model, degree):
     with pytest.raises(RuntimeError, match="no partials"):
         nx.GpuContext(prop.compile(almanac, central, stm=True))
     ctx.close()
+
+
+@pytest.mark.parametrize("case", ["max_attempts", "min_step_floor", "max_step_clip", "largest_error", "rss_state"])
+def test_step_controller_corner_cases(case):
+    """The accept / retry rules of derive() (instance.rs:428-489): forced accept at `attempts`, the min-step floor on
+    retries, the max-step clip with its sign, and the 90-vector error controls — GPU against the oracle."""
+    o = nx.IntegratorOptions()
+    if case == "max_attempts":
+        o.tolerance, o.attempts, o.min_step = 3e-16, 2, nx.seconds(1.0)  # rarely satisfied: steps are accepted at the 2nd attempt
+    elif case == "min_step_floor":
+        o.tolerance, o.min_step = 1e-16, nx.seconds(5.0)  # retries hit the floor and are accepted there
+    elif case == "max_step_clip":
+        o.max_step, o.init_step = nx.seconds(20.0), nx.seconds(20.0)
+    elif case == "largest_error":
+        o.error_ctrl = nx.ErrorControl.LargestError
+    elif case == "rss_state":
+        o.error_ctrl = nx.ErrorControl.RSSState
+    prop, almanac, central = leo_full_setup(degree=4, opts=o)
+    compiled = prop.compile(almanac, central)
+    b = dispersed_leo_batch(6, seed=31)
+    ctx = nx.GpuContext(compiled)
+    span = 600 if case == "max_attempts" else 1800
+    for dur in (span * nx.NS_PER_S, -span * nx.NS_PER_S):
+        out, st = ctx.propagate(b, dur)
+        ref, rst = oracle_lib.propagate(compiled, b, dur, n_threads=NCPU)
+        assert (st.status == 0).all() and (rst.status == 0).all() and (out.epoch_ns == ref.epoch_ns).all()
+        dr, dv = pos_vel_errors(out, ref)
+        assert dr.max() < 1e-3 and dv.max() < 1e-6, (case, dr.max(), dv.max())
+        if case == "max_attempts":
+            # (the last step is the exact-length fixed step: 1 attempt; all others were forced at the 3rd)
+            # one retry at most per step (attempts = 2); near round-off the estimate is noisy, so only the bound is asserted
+            assert (st.n_rejected <= st.n_accepted).all()
+            if dur > 0:
+                assert (st.n_rejected > 0).all() and (rst.n_rejected > 0).all()
+            else:  # reference quirk (instance.rs:428-431): a negative h always satisfies `h <= min_step`, so back-propagation never retries
+                assert (st.n_rejected == 0).all() and (rst.n_rejected == 0).all()
+        if case == "min_step_floor":
+            assert (st.n_rejected > 0).all() and (st.n_accepted == rst.n_accepted).all()
+        if case == "max_step_clip":
+            assert (np.abs(out.step_ns) <= nx.seconds(20.0)).all() and (np.sign(out.step_ns) == 1).all()
+    ctx.close()
