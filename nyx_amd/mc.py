@@ -131,7 +131,8 @@ class MonteCarlo:
             ctx = prop._context(almanac, self.random_state.template.frame, False)
             out, st = ctx.propagate_until_epoch(batch, int(end_epoch_ns))
         payload = np.concatenate([out.rv(), out.cr[:, None], out.cd[:, None], out.prop_mass_kg[:, None],
-                                  out.epoch_ns[:, None].astype(np.float64), st.status[:, None].astype(np.float64)], axis=1)
+                                  np.ascontiguousarray(out.epoch_ns, dtype=np.int64).view(np.float64)[:, None],  # bit pattern: ns past J2000 exceed 2^53
+                                  st.status[:, None].astype(np.float64)], axis=1)
         if dist is not None and world > 1:
             payload = all_gather_rows(dist, payload, [shard_bounds(len(states), r, world) for r in range(world)])
         runs = []
@@ -140,7 +141,7 @@ class MonteCarlo:
             status = int(row[10])
             if status == _abi.OK:
                 r = Spacecraft(**{**s.__dict__})
-                r.rv, r.cr, r.cd, r.prop_mass_kg, r.epoch_ns = row[:6].copy(), float(row[6]), float(row[7]), float(row[8]), int(row[9])
+                r.rv, r.cr, r.cd, r.prop_mass_kg, r.epoch_ns = row[:6].copy(), float(row[6]), float(row[7]), float(row[8]), int(row[9:10].view(np.int64)[0])
                 runs.append(Run(index, s, r))
             else:
                 runs.append(Run(index, s, PropagationError(status, index)))

@@ -64,6 +64,8 @@ def test_two_rank_gloo_monte_carlo(tmp_path):
     prop, almanac, mc = _build()
     single = mc.run_until_epoch(prop, almanac, EPOCH0_NS + 600 * nx.NS_PER_S, 11)
     np.testing.assert_array_equal(r0[:, 1:], single.final_rv())  # sharding does not change any trajectory
+    # integer-ns epochs survive the gather exactly (they exceed 2^53, so they travel as bit patterns)
+    assert all(r.result.epoch_ns == EPOCH0_NS + 600 * nx.NS_PER_S for r in single.runs)
     # resume(skip) reproduces the tail of the stream (montecarlo.rs:208-224)
     tail = mc.resume_run_until_epoch(prop, almanac, 5, EPOCH0_NS + 600 * nx.NS_PER_S, 6)
     assert [r.index for r in tail.runs] == list(range(5, 11))
