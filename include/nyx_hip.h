@@ -268,6 +268,35 @@ int32_t nyx_hip_propagate_batch_with_traj_device(nyx_hip_ctx *ctx, const nyx_hip
                                                  nyx_hip_states_t *out, nyx_hip_step_stats_t *stats, nyx_hip_traj_t *traj,
                                                  void *hip_stream);
 
+/* ---- `Traj` evaluation: md/trajectory/traj.rs:82-162, interpolatable.rs:52-108 ----
+ * The stored states are read as the `finalize()`d trajectory (sorted by epoch; a back-propagated batch is simply read
+ * in reverse).  One sample = `Traj::at(epoch)`: an epoch that is stored exactly returns the stored state (traj.rs:92-95);
+ * otherwise a window of up to 13 stored states around the insertion index (traj.rs:104-115: 6 to the left, 13 in
+ * total, and only the LAST 12 states when the window touches the end) feeds one Hermite interpolation per axis with
+ * abscissas in seconds (anise `hermite_eval`, i.e. SPICE HRMINT).  Spacecraft fields other than the orbit are constant
+ * on this path (no thruster), so only position and velocity are produced. */
+enum nyx_hip_interp_status {
+    NYX_HIP_INTERP_OK = 0,
+    NYX_HIP_INTERP_NO_DATA = 1, /* TrajError::NoInterpolationData: empty trajectory or epoch outside [first, last] */
+    NYX_HIP_INTERP_MATH = 2     /* InterpolationError::InterpMath (two abscissas closer than f64::EPSILON seconds) */
+};
+
+/* `Traj::at` for every trajectory at `m` shared epochs (host arrays).  Sample q of trajectory i lands at [q * n + i] of
+ * `out` (out->capacity >= m; out->epoch_ns receives the query epoch; out->len[i] = number of samples with status OK) and
+ * of `status` (enum nyx_hip_interp_status, m * n entries; failed samples are NaN). */
+int32_t nyx_hip_traj_at(nyx_hip_ctx *ctx, const nyx_hip_traj_t *traj, int64_t n, const int64_t *query_epoch_ns, int64_t m,
+                        nyx_hip_traj_t *out, int32_t *status);
+/* `Traj::every(step)` (traj.rs:148-162 + TrajIterator, traj_it.rs:33-62): per trajectory, the samples at
+ * first + k*step <= last (hifitime TimeSeries::inclusive), k = 0, 1, ...  Sample k of trajectory i lands at [k * n + i];
+ * out->len[i] = samples PRODUCED (those beyond out->capacity are not stored); the iteration of a trajectory ends at the
+ * first failing sample, as the iterator does.  step_ns must be > 0. */
+int32_t nyx_hip_traj_every(nyx_hip_ctx *ctx, const nyx_hip_traj_t *traj, int64_t n, int64_t step_ns, nyx_hip_traj_t *out);
+/* Device-pointer flavours (every pointer is a device pointer), asynchronous on `hip_stream`. */
+int32_t nyx_hip_traj_at_device(nyx_hip_ctx *ctx, const nyx_hip_traj_t *traj, int64_t n, const int64_t *query_epoch_ns,
+                               int64_t m, nyx_hip_traj_t *out, int32_t *status, void *hip_stream);
+int32_t nyx_hip_traj_every_device(nyx_hip_ctx *ctx, const nyx_hip_traj_t *traj, int64_t n, int64_t step_ns,
+                                  nyx_hip_traj_t *out, void *hip_stream);
+
 /* Per-trajectory epochs variant of until_epoch (instance.rs:279-282): duration_i = end_epoch_ns - epoch_i. */
 int32_t nyx_hip_propagate_until_epoch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t end_epoch_ns,
                                       nyx_hip_states_t *out, nyx_hip_step_stats_t *stats);

@@ -22,6 +22,8 @@ RSS_CARTESIAN_STATE, RSS_CARTESIAN_STEP, RSS_STATE, RSS_STEP, LARGEST_ERROR, LAR
 # enum nyx_hip_status
 OK, ERR_NAN, ERR_MASSLESS, ERR_FUEL_EXHAUSTED, ERR_EPHEM_RANGE, ERR_UNSUPPORTED = range(6)
 STATUS_NAMES = ["Ok", "PropMathError(NaN)", "MasslessSpacecraft", "FuelExhausted", "EphemerisOutOfRange", "Unsupported"]
+# enum nyx_hip_interp_status
+INTERP_OK, INTERP_NO_DATA, INTERP_MATH = range(3)
 # flags
 FLAG_STM = 0x1
 FLAG_STM_TEXTBOOK = 0x2
@@ -302,6 +304,7 @@ EXPORTS = [
     "nyx_hip_propagate_batch_device", "nyx_hip_propagate_until_epoch", "nyx_hip_ctx_set_column_waves",
     "nyx_hip_last_kernel_ms", "nyx_hip_last_error", "nyx_hip_load_cof", "nyx_hip_load_shadr", "nyx_hip_free",
     "nyx_hip_propagate_batch_with_traj", "nyx_hip_propagate_batch_with_traj_device",
+    "nyx_hip_traj_at", "nyx_hip_traj_every", "nyx_hip_traj_at_device", "nyx_hip_traj_every_device",
 ]
 
 
@@ -332,6 +335,14 @@ def load_library():
     lib.nyx_hip_propagate_batch_with_traj_device.argtypes = [C.c_void_p, C.POINTER(States), C.c_int64, C.POINTER(States), C.POINTER(StepStats),
                                                              C.POINTER(Traj), C.c_void_p]
     lib.nyx_hip_propagate_batch_with_traj_device.restype = C.c_int32
+    lib.nyx_hip_traj_at.argtypes = [C.c_void_p, C.POINTER(Traj), C.c_int64, c_int64_p, C.c_int64, C.POINTER(Traj), c_int32_p]
+    lib.nyx_hip_traj_at.restype = C.c_int32
+    lib.nyx_hip_traj_every.argtypes = [C.c_void_p, C.POINTER(Traj), C.c_int64, C.c_int64, C.POINTER(Traj)]
+    lib.nyx_hip_traj_every.restype = C.c_int32
+    lib.nyx_hip_traj_at_device.argtypes = [C.c_void_p, C.POINTER(Traj), C.c_int64, C.c_void_p, C.c_int64, C.POINTER(Traj), C.c_void_p, C.c_void_p]
+    lib.nyx_hip_traj_at_device.restype = C.c_int32
+    lib.nyx_hip_traj_every_device.argtypes = [C.c_void_p, C.POINTER(Traj), C.c_int64, C.c_int64, C.POINTER(Traj), C.c_void_p]
+    lib.nyx_hip_traj_every_device.restype = C.c_int32
     lib.nyx_hip_propagate_until_epoch.argtypes = [C.c_void_p, C.POINTER(States), C.c_int64, C.POINTER(States), C.POINTER(StepStats)]
     lib.nyx_hip_propagate_until_epoch.restype = C.c_int32
     lib.nyx_hip_ctx_set_column_waves.argtypes = [C.c_void_p, C.c_int32]

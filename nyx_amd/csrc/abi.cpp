@@ -14,8 +14,10 @@
 #include "../../include/nyx_hip.h"
 #include "butcher.h"
 #include "devcfg.h"
+#include "traj_args.h"
 
 extern "C" size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles, int stm);
+extern "C" hipError_t nyx_launch_traj_eval(const TrajEvalArgs *args, hipStream_t stream);
 extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg, const HarmEntry *htab,
                                            const ColHdr *cols, const double *records, int n_waves, int rec_lds_doubles,
                                            hipStream_t stream);
@@ -689,6 +691,144 @@ extern "C" int32_t nyx_hip_propagate_batch_with_traj(nyx_hip_ctx *ctx, const nyx
 extern "C" int32_t nyx_hip_propagate_until_epoch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t end_epoch_ns,
                                                  nyx_hip_states_t *out, nyx_hip_step_stats_t *stats) {
     return host_propagate(ctx, in, 0, end_epoch_ns, 1, out, stats);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Traj evaluation (md/trajectory/traj.rs:82-162): traj_kernel.hip
+// ---------------------------------------------------------------------------------------------
+static int check_traj(const nyx_hip_traj_t *t, const char *what, bool need_epochs) {
+    if (!t || t->capacity < 0 || !t->len || !t->x_km || !t->y_km || !t->z_km || !t->vx_km_s || !t->vy_km_s || !t->vz_km_s ||
+        (need_epochs && !t->epoch_ns)) {
+        nyx_set_error("%s: null array or negative capacity", what);
+        return NYX_HIP_RC_BAD_ARG;
+    }
+    return NYX_HIP_RC_OK;
+}
+
+static int traj_eval_device(nyx_hip_ctx *ctx, const nyx_hip_traj_t *traj, int64_t n, const int64_t *query, int64_t m,
+                            int64_t step_ns, nyx_hip_traj_t *out, int32_t *status, int mode, hipStream_t stream) {
+    if (!ctx) { nyx_set_error("null ctx"); return NYX_HIP_RC_BAD_ARG; }
+    if (int rc = check_traj(traj, "traj", true)) return rc;
+    if (int rc = check_traj(out, "out", true)) return rc;
+    if (n < 0) { nyx_set_error("negative n"); return NYX_HIP_RC_BAD_ARG; }
+    if (mode == TRAJ_MODE_AT) {
+        if (m < 0 || (m > 0 && (!query || !status))) { nyx_set_error("traj_at: query/status arrays required"); return NYX_HIP_RC_BAD_ARG; }
+        if (out->capacity < m) { nyx_set_error("traj_at: out->capacity < m"); return NYX_HIP_RC_BAD_ARG; }
+    } else if (step_ns <= 0) {
+        nyx_set_error("traj_every: step_ns must be > 0 (TimeSeries with a positive step)");
+        return NYX_HIP_RC_BAD_ARG;
+    }
+    if (n == 0) return NYX_HIP_RC_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    TrajEvalArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.src = *traj; a.dst = *out; a.n = n; a.query = query; a.m = m; a.step_ns = step_ns; a.status = status; a.mode = mode;
+    HIP_TRY(hipEventRecord(ctx->ev0, stream));
+    HIP_TRY(nyx_launch_traj_eval(&a, stream));
+    HIP_TRY(hipEventRecord(ctx->ev1, stream));
+    return NYX_HIP_RC_OK;
+}
+
+extern "C" int32_t nyx_hip_traj_at_device(nyx_hip_ctx *ctx, const nyx_hip_traj_t *traj, int64_t n, const int64_t *query_epoch_ns,
+                                          int64_t m, nyx_hip_traj_t *out, int32_t *status, void *hip_stream) {
+    return traj_eval_device(ctx, traj, n, query_epoch_ns, m, 0, out, status, TRAJ_MODE_AT, (hipStream_t)hip_stream);
+}
+
+extern "C" int32_t nyx_hip_traj_every_device(nyx_hip_ctx *ctx, const nyx_hip_traj_t *traj, int64_t n, int64_t step_ns,
+                                             nyx_hip_traj_t *out, void *hip_stream) {
+    return traj_eval_device(ctx, traj, n, nullptr, 0, step_ns, out, nullptr, TRAJ_MODE_EVERY, (hipStream_t)hip_stream);
+}
+
+// A nyx_hip_traj_t whose arrays are one device allocation (RAII).
+struct DevTraj {
+    nyx_hip_traj_t t;
+    void *block = nullptr;
+    size_t slots = 0;
+    int64_t n = 0;
+    ~DevTraj() { if (block) (void)hipFree(block); }
+    int alloc(int64_t capacity, int64_t n_) {
+        n = n_;
+        slots = (size_t)capacity * (size_t)n;
+        std::memset(&t, 0, sizeof t);
+        if (hipMalloc(&block, std::max<size_t>(slots, 1) * 7 * sizeof(double) + (size_t)n * sizeof(int32_t)) != hipSuccess) {
+            block = nullptr;
+            nyx_set_error("hipMalloc of the trajectory staging block failed");
+            return NYX_HIP_RC_HIP_ERROR;
+        }
+        t.capacity = capacity;
+        t.epoch_ns = (int64_t *)block;
+        double *base = (double *)block + std::max<size_t>(slots, 1);
+        t.x_km = base; t.y_km = base + slots; t.z_km = base + 2 * slots;
+        t.vx_km_s = base + 3 * slots; t.vy_km_s = base + 4 * slots; t.vz_km_s = base + 5 * slots;
+        t.len = (int32_t *)(base + 6 * std::max<size_t>(slots, 1));
+        return NYX_HIP_RC_OK;
+    }
+    int upload(const nyx_hip_traj_t *h) {
+        HIP_TRY(hipMemcpy(t.len, h->len, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+        if (!slots) return NYX_HIP_RC_OK;
+        HIP_TRY(hipMemcpy(t.epoch_ns, h->epoch_ns, slots * sizeof(int64_t), hipMemcpyHostToDevice));
+        const double *hsrc[6] = {h->x_km, h->y_km, h->z_km, h->vx_km_s, h->vy_km_s, h->vz_km_s};
+        double *ddst[6] = {t.x_km, t.y_km, t.z_km, t.vx_km_s, t.vy_km_s, t.vz_km_s};
+        for (int k = 0; k < 6; ++k) HIP_TRY(hipMemcpy(ddst[k], hsrc[k], slots * sizeof(double), hipMemcpyHostToDevice));
+        return NYX_HIP_RC_OK;
+    }
+    int download(nyx_hip_traj_t *h) const {
+        HIP_TRY(hipMemcpy(h->len, t.len, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        if (!slots) return NYX_HIP_RC_OK;
+        HIP_TRY(hipMemcpy(h->epoch_ns, t.epoch_ns, slots * sizeof(int64_t), hipMemcpyDeviceToHost));
+        double *hdst[6] = {h->x_km, h->y_km, h->z_km, h->vx_km_s, h->vy_km_s, h->vz_km_s};
+        const double *dsrc[6] = {t.x_km, t.y_km, t.z_km, t.vx_km_s, t.vy_km_s, t.vz_km_s};
+        for (int k = 0; k < 6; ++k) HIP_TRY(hipMemcpy(hdst[k], dsrc[k], slots * sizeof(double), hipMemcpyDeviceToHost));
+        return NYX_HIP_RC_OK;
+    }
+};
+
+static int traj_eval_host(nyx_hip_ctx *ctx, const nyx_hip_traj_t *traj, int64_t n, const int64_t *query, int64_t m,
+                          int64_t step_ns, nyx_hip_traj_t *out, int32_t *status, int mode) {
+    if (!ctx) { nyx_set_error("null ctx"); return NYX_HIP_RC_BAD_ARG; }
+    if (int rc = check_traj(traj, "traj", true)) return rc;
+    if (int rc = check_traj(out, "out", true)) return rc;
+    if (n <= 0) return n == 0 ? NYX_HIP_RC_OK : NYX_HIP_RC_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevTraj src, dst;
+    if (int rc = src.alloc(traj->capacity, n)) return rc;
+    if (int rc = dst.alloc(out->capacity, n)) return rc;
+    if (int rc = src.upload(traj)) return rc;
+    int64_t *d_query = nullptr;
+    int32_t *d_status = nullptr;
+    int rc = NYX_HIP_RC_OK;
+    if (mode == TRAJ_MODE_AT && m > 0) {
+        if (!query || !status) { nyx_set_error("traj_at: query/status arrays required"); return NYX_HIP_RC_BAD_ARG; }
+        if (hipMalloc(&d_query, (size_t)m * sizeof(int64_t)) != hipSuccess ||
+            hipMalloc(&d_status, (size_t)m * (size_t)n * sizeof(int32_t)) != hipSuccess ||
+            hipMemcpy(d_query, query, (size_t)m * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess) {
+            nyx_set_error("traj_at: staging of the query epochs failed");
+            rc = NYX_HIP_RC_HIP_ERROR;
+        }
+    }
+    if (!rc) rc = traj_eval_device(ctx, &src.t, n, d_query, m, step_ns, &dst.t, d_status, mode, nullptr);
+    if (!rc && hipDeviceSynchronize() != hipSuccess) { nyx_set_error("trajectory evaluation kernel failed"); rc = NYX_HIP_RC_HIP_ERROR; }
+    if (!rc) {
+        float ms = 0.f;
+        ctx->last_ms = (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ? ms : -1.0;
+        rc = dst.download(out);
+    }
+    if (!rc && d_status && hipMemcpy(status, d_status, (size_t)m * (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) {
+        nyx_set_error("traj_at: D2H of the statuses failed");
+        rc = NYX_HIP_RC_HIP_ERROR;
+    }
+    (void)hipFree(d_query);
+    (void)hipFree(d_status);
+    return rc;
+}
+
+extern "C" int32_t nyx_hip_traj_at(nyx_hip_ctx *ctx, const nyx_hip_traj_t *traj, int64_t n, const int64_t *query_epoch_ns, int64_t m,
+                                   nyx_hip_traj_t *out, int32_t *status) {
+    return traj_eval_host(ctx, traj, n, query_epoch_ns, m, 0, out, status, TRAJ_MODE_AT);
+}
+
+extern "C" int32_t nyx_hip_traj_every(nyx_hip_ctx *ctx, const nyx_hip_traj_t *traj, int64_t n, int64_t step_ns, nyx_hip_traj_t *out) {
+    return traj_eval_host(ctx, traj, n, nullptr, 0, step_ns, out, nullptr, TRAJ_MODE_EVERY);
 }
 
 // Introspection for tests / DESIGN.md: column schedule of the current context.

@@ -591,6 +591,29 @@ class GpuContext:
             raise RuntimeError(f"nyx_hip_propagate_batch_with_traj failed (rc={rc}): {_abi.last_error()}")
         return out, stats, traj
 
+    def traj_at(self, traj: _abi.TrajBatch, epochs_ns):
+        """`Traj::at(epoch)` (traj.rs:82-127) of every trajectory of the batch at the shared epochs:
+        (states[m, n, 6], status[m, n]) with status = nyx_hip_interp_status; failed samples are NaN."""
+        q = np.ascontiguousarray(epochs_ns, dtype=np.int64)
+        m = len(q)
+        out = _abi.TrajBatch(traj.n, max(m, 1))
+        status = np.zeros((max(m, 1), traj.n), dtype=np.int32)
+        cin, cout = traj.as_c(), out.as_c()
+        rc = self._lib.nyx_hip_traj_at(self._h, C.byref(cin), traj.n, q.ctypes.data_as(_abi.c_int64_p), m, C.byref(cout),
+                                       status.ctypes.data_as(_abi.c_int32_p))
+        if rc != 0:
+            raise RuntimeError(f"nyx_hip_traj_at failed (rc={rc}): {_abi.last_error()}")
+        return np.ascontiguousarray(out.state[:, :m, :].transpose(1, 2, 0)), status[:m]
+
+    def traj_every(self, traj: _abi.TrajBatch, step_ns: int, capacity: int) -> _abi.TrajBatch:
+        """`Traj::every(step)` (traj.rs:148-162) of every trajectory: a TrajBatch of the resampled states."""
+        out = _abi.TrajBatch(traj.n, int(capacity))
+        cin, cout = traj.as_c(), out.as_c()
+        rc = self._lib.nyx_hip_traj_every(self._h, C.byref(cin), traj.n, int(step_ns), C.byref(cout))
+        if rc != 0:
+            raise RuntimeError(f"nyx_hip_traj_every failed (rc={rc}): {_abi.last_error()}")
+        return out
+
     def propagate_until_epoch(self, batch: _abi.StateBatch, end_epoch_ns: int, out: Optional[_abi.StateBatch] = None):
         out = out if out is not None else batch.copy()
         stats = _abi.StatsBatch(batch.n)
@@ -638,13 +661,64 @@ class PropInstance:
             raise PropagationError(int(st.status[0]))
         self.step_size = int(out.step_ns[0])
         self.state = unpack_spacecraft(out, [self.state])[0]
-        ep, xs = traj.trajectory(0)
-        order = np.argsort(ep, kind="stable")
-        keep = np.concatenate([[True], np.diff(ep[order]) != 0])  # dedup_by epoch (traj.rs:76-77)
-        return self.state, (ep[order][keep], xs[order][keep])
+        return self.state, Traj(self._ctx, traj, 0)
 
     def latest_details(self):
         return dict(self.details)
+
+
+class TrajError(Exception):
+    """TrajError::NoInterpolationData / InterpolationError (md/trajectory/mod.rs)."""
+
+    def __init__(self, status: int, epoch_ns: int):
+        super().__init__(f"{['Ok', 'NoInterpolationData', 'InterpMath'][status]} at epoch {epoch_ns} ns")
+        self.status, self.epoch_ns = status, epoch_ns
+
+
+class Traj:
+    """One run's `Traj<Spacecraft>` (md/trajectory/traj.rs:40-162): the stored states sorted by epoch, evaluated on
+    the device.  Unpacks as `(epochs_ns, states[len, 6])` for callers that only want the stored samples."""
+
+    def __init__(self, ctx: "GpuContext", batch: _abi.TrajBatch, index: int = 0):
+        self._ctx, self._batch, self._i = ctx, batch, index
+        ep, xs = batch.trajectory(index)
+        order = np.argsort(ep, kind="stable")                       # finalize(): sort_by_key(epoch) ...
+        keep = np.concatenate([[True], np.diff(ep[order]) != 0]) if len(ep) else np.zeros(0, dtype=bool)
+        self.epochs_ns, self.states = ep[order][keep], xs[order][keep]  # ... after dedup_by epoch (traj.rs:76-79)
+
+    def __iter__(self):
+        return iter((self.epochs_ns, self.states))
+
+    def __len__(self):
+        return len(self.epochs_ns)
+
+    def first(self):
+        return self.states[0]
+
+    def last(self):
+        return self.states[-1]
+
+    def _single(self) -> _abi.TrajBatch:
+        one = _abi.TrajBatch(1, max(len(self.epochs_ns), 1))
+        one.len[0] = len(self.epochs_ns)
+        one.epoch_ns[: len(self), 0] = self.epochs_ns
+        one.state[:, : len(self), 0] = self.states.T
+        return one
+
+    def at(self, epoch_ns: int) -> np.ndarray:
+        """traj.rs:82-127: the state [x, y, z, vx, vy, vz] at `epoch_ns`; raises TrajError outside the trajectory."""
+        states, status = self._ctx.traj_at(self._single(), [int(epoch_ns)])
+        if status[0, 0] != _abi.INTERP_OK:
+            raise TrajError(int(status[0, 0]), int(epoch_ns))
+        return states[0, 0]
+
+    def every(self, step_ns: int):
+        """traj.rs:148-150: (epochs, states) every `step_ns` from the first to the last epoch, inclusive."""
+        if len(self) == 0:
+            return np.zeros(0, dtype=np.int64), np.zeros((0, 6))
+        count = int((self.epochs_ns[-1] - self.epochs_ns[0]) // int(step_ns)) + 1
+        out = self._ctx.traj_every(self._single(), int(step_ns), count)
+        return out.trajectory(0)
 
 
 class Propagator:

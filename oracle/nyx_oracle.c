@@ -11,6 +11,7 @@
 #include "nyx_oracle.h"
 #include "rk_tableaux.h"
 
+#include <float.h>
 #include <math.h>
 #include <pthread.h>
 #include <stdatomic.h>
@@ -1121,6 +1122,137 @@ static void *worker(void *arg) {
     scratch_free(&s->w);
     free(s);
     return NULL;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Traj evaluation (md/trajectory/traj.rs:82-162, interpolatable.rs:52-108).
+ *
+ * `hermite_eval` lives in the third-party crate anise (Cargo.toml:34, anise = "0.10.2",
+ * anise/src/math/interpolation/hermite.rs), which is NOT vendored under /root/reference.  It is a
+ * port of NAIF SPICE's HRMINT; what follows restates HRMINT's published algorithm (divided-difference
+ * table with every abscissa doubled; NAIF toolkit, hrmint.f "Particulars") in the operation order
+ * of the SPICE routine.  Pinned on HRMINT's documented example (a degree-7 polynomial through four
+ * points: f(2) = 141, f'(2) = 456) and on the reference's own test properties
+ * (tests/propagation/trajectory.rs:103-135, 358-420); the exact rounding of anise's port is
+ * "parity unpinned".
+ * --------------------------------------------------------------------------------------------- */
+#define INTERPOLATION_SAMPLES 13 /* interpolatable.rs:22 */
+
+int32_t nyx_oracle_hermite_eval(const double *xs, const double *ys, const double *ydots, int32_t n, double x_eval,
+                                double *f, double *df) {
+    double work[4 * INTERPOLATION_SAMPLES];
+    if (n < 1 || n > INTERPOLATION_SAMPLES) return NYX_HIP_INTERP_MATH;
+    /* first column of the table: function values and derivatives interleaved */
+    for (int i = 0; i < n; ++i) {
+        work[2 * i] = ys[i];
+        work[2 * i + 1] = ydots[i];
+    }
+    /* second column: first-degree interpolants (Fortran indices, as the routine is written) */
+    for (int i = 1; i <= n - 1; ++i) {
+        const double c1 = xs[i] - x_eval;
+        const double c2 = x_eval - xs[i - 1];
+        const double denom = xs[i] - xs[i - 1];
+        if (fabs(denom) < DBL_EPSILON) return NYX_HIP_INTERP_MATH;
+        const int prev = 2 * i - 1, cur = prev + 1, next = cur + 1;
+        work[prev + 2 * n - 1] = work[cur - 1];
+        work[cur + 2 * n - 1] = (work[next - 1] - work[prev - 1]) / denom;
+        const double temp = work[cur - 1] * (x_eval - xs[i - 1]) + work[prev - 1];
+        work[cur - 1] = (c1 * work[prev - 1] + c2 * work[next - 1]) / denom;
+        work[prev - 1] = temp;
+    }
+    work[4 * n - 2] = work[2 * n - 1];
+    work[2 * n - 2] = work[2 * n - 1] * (x_eval - xs[n - 1]) + work[2 * n - 2];
+    /* columns 3 .. 2n */
+    for (int j = 2; j <= 2 * n - 1; ++j) {
+        for (int i = 1; i <= 2 * n - j; ++i) {
+            const int xi = (i + 1) / 2;
+            const int xij = (i + j + 1) / 2;
+            const double c1 = xs[xij - 1] - x_eval;
+            const double c2 = x_eval - xs[xi - 1];
+            const double denom = xs[xij - 1] - xs[xi - 1];
+            if (fabs(denom) < DBL_EPSILON) return NYX_HIP_INTERP_MATH;
+            work[i + 2 * n - 1] = (c1 * work[i + 2 * n - 1] + c2 * work[i + 2 * n] + (work[i] - work[i - 1])) / denom;
+            work[i - 1] = (c1 * work[i - 1] + c2 * work[i]) / denom;
+        }
+    }
+    *f = work[0];
+    *df = work[2 * n];
+    return NYX_HIP_INTERP_OK;
+}
+
+/* stored states of trajectory i read as the finalize()d (epoch-sorted) sequence */
+typedef struct { const nyx_hip_traj_t *t; int64_t n, i, len; int desc; } traj_view_t;
+
+static traj_view_t traj_view(const nyx_hip_traj_t *t, int64_t n, int64_t i) {
+    traj_view_t v = {t, n, i, t->len[i] < t->capacity ? t->len[i] : t->capacity, 0};
+    if (v.len > 1) v.desc = t->epoch_ns[(v.len - 1) * n + i] < t->epoch_ns[i];
+    return v;
+}
+static int64_t view_at(const traj_view_t *v, int64_t k) { return (v->desc ? v->len - 1 - k : k) * v->n + v->i; }
+
+/* Traj::at (traj.rs:82-127) + Spacecraft::interpolate (interpolatable.rs:52-108) */
+int32_t nyx_oracle_traj_at(const nyx_hip_traj_t *traj, int64_t n, int64_t i, int64_t epoch_ns, double *state6) {
+    const traj_view_t v = traj_view(traj, n, i);
+    const double *comp[6] = {traj->x_km, traj->y_km, traj->z_km, traj->vx_km_s, traj->vy_km_s, traj->vz_km_s};
+    for (int c = 0; c < 6; ++c) state6[c] = NAN;
+    if (v.len == 0 || traj->epoch_ns[view_at(&v, 0)] > epoch_ns || traj->epoch_ns[view_at(&v, v.len - 1)] < epoch_ns)
+        return NYX_HIP_INTERP_NO_DATA;
+    /* binary search: first index whose epoch is > query, or the exact hit */
+    int64_t lo = 0, hi = v.len;
+    while (lo < hi) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        const int64_t e = traj->epoch_ns[view_at(&v, mid)];
+        if (e == epoch_ns) {
+            for (int c = 0; c < 6; ++c) state6[c] = comp[c][view_at(&v, mid)];
+            return NYX_HIP_INTERP_OK;
+        }
+        if (e < epoch_ns) lo = mid + 1; else hi = mid;
+    }
+    const int64_t idx = lo;
+    if (idx == 0 || idx >= v.len) return NYX_HIP_INTERP_NO_DATA;
+    const int64_t num_left = INTERPOLATION_SAMPLES / 2;
+    int64_t first_idx = idx > num_left ? idx - num_left : 0;
+    const int64_t last_idx = v.len < first_idx + INTERPOLATION_SAMPLES ? v.len : first_idx + INTERPOLATION_SAMPLES;
+    if (last_idx == v.len) first_idx = last_idx > 2 * num_left ? last_idx - 2 * num_left : 0; /* 12, sic (traj.rs:112-114) */
+    const int32_t ns = (int32_t)(last_idx - first_idx);
+    double xs[INTERPOLATION_SAMPLES], ys[INTERPOLATION_SAMPLES], yd[INTERPOLATION_SAMPLES];
+    for (int k = 0; k < ns; ++k) xs[k] = nyx_oracle_ns_to_seconds(traj->epoch_ns[view_at(&v, first_idx + k)]);
+    const double x_eval = nyx_oracle_ns_to_seconds(epoch_ns);
+    for (int c = 0; c < 3; ++c) {
+        for (int k = 0; k < ns; ++k) {
+            ys[k] = comp[c][view_at(&v, first_idx + k)];
+            yd[k] = comp[c + 3][view_at(&v, first_idx + k)];
+        }
+        const int32_t st = nyx_oracle_hermite_eval(xs, ys, yd, ns, x_eval, &state6[c], &state6[c + 3]);
+        if (st != NYX_HIP_INTERP_OK) {
+            for (int q = 0; q < 6; ++q) state6[q] = NAN;
+            return st;
+        }
+    }
+    return NYX_HIP_INTERP_OK;
+}
+
+/* Traj::every (traj.rs:148-162) through TrajIterator (traj_it.rs:33-62); TimeSeries::inclusive yields first + k*step
+ * while k*step <= last - first. */
+int32_t nyx_oracle_traj_every(const nyx_hip_traj_t *traj, int64_t n, int64_t step_ns, nyx_hip_traj_t *out) {
+    if (!traj || !out || step_ns <= 0) return NYX_HIP_RC_BAD_ARG;
+    double *oc[6] = {out->x_km, out->y_km, out->z_km, out->vx_km_s, out->vy_km_s, out->vz_km_s};
+    for (int64_t i = 0; i < n; ++i) {
+        const traj_view_t v = traj_view(traj, n, i);
+        out->len[i] = 0;
+        if (v.len == 0) continue;
+        const int64_t first = traj->epoch_ns[view_at(&v, 0)], last = traj->epoch_ns[view_at(&v, v.len - 1)];
+        for (int64_t k = 0; k * step_ns <= last - first; ++k) {
+            double s6[6];
+            if (nyx_oracle_traj_at(traj, n, i, first + k * step_ns, s6) != NYX_HIP_INTERP_OK) break;
+            if (k < out->capacity) {
+                out->epoch_ns[k * n + i] = first + k * step_ns;
+                for (int c = 0; c < 6; ++c) oc[c][k * n + i] = s6[c];
+            }
+            out->len[i] = (int32_t)(k + 1);
+        }
+    }
+    return NYX_HIP_RC_OK;
 }
 
 int32_t nyx_oracle_propagate_batch(const nyx_hip_config_t *cfg, const nyx_hip_states_t *in, int64_t duration_ns,

@@ -55,6 +55,12 @@ double nyx_oracle_occultation_factor(const nyx_hip_config_t *cfg, int32_t eclips
                                      int64_t epoch_ns, const double *r3, int32_t *status);
 double nyx_oracle_error_estimate(int32_t error_ctrl, int32_t nv, const double *err, const double *cand, const double *cur);
 
+/* Traj evaluation (md/trajectory/traj.rs:82-162, interpolatable.rs:52-108); statuses are nyx_hip_interp_status. */
+int32_t nyx_oracle_hermite_eval(const double *xs, const double *ys, const double *ydots, int32_t n, double x_eval,
+                                double *f, double *df);
+int32_t nyx_oracle_traj_at(const nyx_hip_traj_t *traj, int64_t n, int64_t i, int64_t epoch_ns, double *state6);
+int32_t nyx_oracle_traj_every(const nyx_hip_traj_t *traj, int64_t n, int64_t step_ns, nyx_hip_traj_t *out);
+
 /* hifitime conversions as restated (see nyx_oracle.c). */
 int64_t nyx_oracle_seconds_to_ns(double s);
 double nyx_oracle_ns_to_seconds(int64_t ns);

@@ -50,6 +50,13 @@ def load():
     lib.nyx_oracle_ns_to_seconds.argtypes = [C.c_int64]
     lib.nyx_oracle_ns_to_seconds.restype = C.c_double
     lib.nyx_oracle_set_ns_rounding.argtypes = [C.c_int32]
+    lib.nyx_oracle_hermite_eval.argtypes = [_abi.c_double_p, _abi.c_double_p, _abi.c_double_p, C.c_int32, C.c_double,
+                                            _abi.c_double_p, _abi.c_double_p]
+    lib.nyx_oracle_hermite_eval.restype = C.c_int32
+    lib.nyx_oracle_traj_at.argtypes = [C.POINTER(_abi.Traj), C.c_int64, C.c_int64, C.c_int64, _abi.c_double_p]
+    lib.nyx_oracle_traj_at.restype = C.c_int32
+    lib.nyx_oracle_traj_every.argtypes = [C.POINTER(_abi.Traj), C.c_int64, C.c_int64, C.POINTER(_abi.Traj)]
+    lib.nyx_oracle_traj_every.restype = C.c_int32
     _LIB = lib
     return lib
 
@@ -93,3 +100,36 @@ def dual_eom(compiled, epoch_ns, y9, dry=0.0, extra=0.0, srp_area=0.0):
     st = lib.nyx_oracle_dual_eom(C.byref(compiled.cfg), int(epoch_ns), y9.ctypes.data_as(_abi.c_double_p), dry, extra, srp_area,
                                  fx.ctypes.data_as(_abi.c_double_p), grad.ctypes.data_as(_abi.c_double_p))
     return st, fx, grad.reshape(9, 9).T  # column-major -> [i, j]
+
+
+def hermite_eval(xs, ys, ydots, x_eval):
+    lib = load()
+    xs, ys, ydots = (np.ascontiguousarray(a, dtype=np.float64) for a in (xs, ys, ydots))
+    f, df = C.c_double(), C.c_double()
+    st = lib.nyx_oracle_hermite_eval(xs.ctypes.data_as(_abi.c_double_p), ys.ctypes.data_as(_abi.c_double_p),
+                                     ydots.ctypes.data_as(_abi.c_double_p), len(xs), float(x_eval), C.byref(f), C.byref(df))
+    return st, f.value, df.value
+
+
+def traj_at(traj, epochs_ns):
+    """Oracle twin of GpuContext.traj_at: (states[m, n, 6], status[m, n])."""
+    lib = load()
+    ctr = traj.as_c()
+    m = len(epochs_ns)
+    out = np.full((m, traj.n, 6), np.nan)
+    status = np.zeros((m, traj.n), dtype=np.int32)
+    s6 = np.zeros(6)
+    for q, e in enumerate(epochs_ns):
+        for i in range(traj.n):
+            status[q, i] = lib.nyx_oracle_traj_at(C.byref(ctr), traj.n, i, int(e), s6.ctypes.data_as(_abi.c_double_p))
+            out[q, i] = s6
+    return out, status
+
+
+def traj_every(traj, step_ns, capacity):
+    lib = load()
+    out = _abi.TrajBatch(traj.n, capacity)
+    cin, cout = traj.as_c(), out.as_c()
+    rc = lib.nyx_oracle_traj_every(C.byref(cin), traj.n, int(step_ns), C.byref(cout))
+    assert rc == 0
+    return out
