@@ -6,15 +6,14 @@
 //
 // Mapping: lane <-> trajectory, as in the propagation kernel, so that the step-major dense output
 // ([k * n + i]) is read and the sample-major result ([q * n + i]) is written fully coalesced.  A workgroup is ONE
-// wave that owns 64 trajectories x a chunk of consecutive samples (grid.y walks the chunks).  HRMINT's table is
-// indexed by loop counters, so it lives in LDS, field-major ([slot * 64 + lane]: conflict-free ds_read_b64):
-// 13 abscissas + 52 table entries = 33 KB per wave, 4 waves per CU.  The x, y and z tables are built one after
-// the other in the same LDS slots.
+// wave that owns 64 trajectories x a chunk of consecutive samples (grid.y walks the chunks).  HRMINT's
+// divided-difference table (2 x 26 entries per axis) is held in registers: rows unrolled, columns rolled (see
+// hrmint_axis); x, y and z are built one after the other by the same code.  No LDS, <= 256 VGPRs, 2 waves per SIMD.
 //
-// Bound: FP64 VALU.  One sample costs 3 axes x (n(2n-1) table updates) x 2 IEEE divisions ~ 1 800 divisions
-// (n = 13), against 7 x 13 x 8 B = 728 B of (cached, overlapping) reads and 56 B written: ~50 FLOP/B, far
-// to the right of the HBM ridge.  The divisions are the reference's (each table entry is divided by its own
-// abscissa difference); they are kept so that the device result equals the CPU restatement bit for bit.
+// Bound: FP64 VALU.  One sample costs 3 axes x n(2n-1) table updates x 2 IEEE divisions ~ 1 800 divisions
+// (n = 13) plus ~12 kFLOP of multiply/add, against 7 x 13 x 8 B = 728 B of (cached, overlapping) reads and 56 B
+// written: far to the right of the HBM ridge.  The divisions are the reference's (each table entry is divided by its
+// own abscissa difference); they are kept so that the device result equals the CPU restatement bit for bit.
 // Compiled with -ffp-contract=off for the same reason.
 
 #include <hip/hip_runtime.h>
@@ -29,7 +28,6 @@ namespace {
 
 constexpr int LANES = 64;
 constexpr int SAMPLES = 13;                 // INTERPOLATION_SAMPLES, interpolatable.rs:22
-constexpr int LDS_SLOTS = SAMPLES + 4 * SAMPLES;  // xs + HRMINT work array (2 columns of 2n)
 
 // The stored states of one trajectory read as the finalize()d (epoch-sorted) sequence (traj.rs:75-80).
 struct View {
@@ -50,99 +48,152 @@ DEVFN View make_view(const nyx_hip_traj_t &t, int64_t n, int64_t i) {
     return v;
 }
 
-// HRMINT on the LDS-resident table of this lane.  xs = lds[0..13), work = lds[13..65); returns false on
-// |denominator| < f64::EPSILON (InterpMath, DivisionByZero).  Fortran (1-based) indices, as the routine is published.
-DEVFN bool hrmint(double *lds, int lane, int ns, double x_eval, double &f, double &df) {
-#define XS(k) lds[(k) * LANES + lane]
-#define WK(k) lds[(SAMPLES + (k)) * LANES + lane]
+// HRMINT for one axis, table in REGISTERS.  The published routine indexes its work array with loop counters; here the
+// row loops are unrolled (static register indices) and only the column loop is rolled, so F (function column),
+// D (derivative column) and the abscissas never leave the VGPRs.  The updates of one column are independent of each
+// other (each reads only entries the column has not overwritten yet) and are issued WITHOUT per-entry branches, so
+// the compiler interleaves their division sequences: that instruction-level parallelism is what hides the FP64
+// latency at one or two waves per SIMD.  Entry (i, j) exists for i <= 2n - j; the columns are walked in four groups
+// of six with static extents 24/18/12/6, the few entries computed beyond the triangle are never read by a valid
+// one (their values, possibly inf/NaN, are dead).  The upper abscissa of entry (i, j), xs[(i+j+1)/2 - 1], moves one
+// entry to the left per column: XB is shifted, not indexed.  Lanes with fewer than 13 states (short trajectories,
+// the 12-state end windows, ns = 0 for lanes without a window) run the same code under selects.
+// Returns false on |denominator| < f64::EPSILON (InterpMath, DivisionByZero) in a VALID entry.
+template <int EXTENT>
+DEVFN void hrmint_columns(int j0, int n2, double x_eval, const double (&XS)[SAMPLES], double (&F)[2 * SAMPLES],
+                          double (&D)[2 * SAMPLES], double (&XB)[2 * SAMPLES], bool &bad, double &f, double &df) {
     const double EPS = 2.220446049250313e-16;
-    bool ok = true;
-    const int n2 = 2 * ns;
-    for (int i = 1; i <= ns - 1; ++i) {
-        const double xa = XS(i - 1), xb = XS(i);
-        const double c1 = xb - x_eval;
-        const double c2 = x_eval - xa;
-        const double denom = xb - xa;
-        ok = ok && !(fabs(denom) < EPS);
-        const int prev = 2 * i - 1, cur = prev + 1, next = cur + 1;
-        const double wp = WK(prev - 1), wc = WK(cur - 1), wn = WK(next - 1);
-        WK(prev + n2 - 1) = wc;
-        WK(cur + n2 - 1) = (wn - wp) / denom;
-        const double temp = wc * (x_eval - xa) + wp;
-        WK(cur - 1) = (c1 * wp + c2 * wn) / denom;
-        WK(prev - 1) = temp;
-    }
-    {
-        const double wl = WK(n2 - 1);
-        WK(2 * n2 - 2) = wl;
-        WK(n2 - 2) = wl * (x_eval - XS(ns - 1)) + WK(n2 - 2);
-    }
-    for (int j = 2; j <= n2 - 1; ++j) {
-        double w_lo = WK(0);  // work[i-1] of the first entry; afterwards carried from the previous iteration's work[i]
-        for (int i = 1; i <= n2 - j; ++i) {
-            const int xi = (i + 1) >> 1;
-            const int xij = (i + j + 1) >> 1;
-            const double xa = XS(xi - 1), xb = XS(xij - 1);
+#pragma unroll 1
+    for (int j = j0; j < j0 + 6; ++j) {
+#pragma unroll
+        for (int i = 1; i <= EXTENT; ++i) {
+            const double xa = XS[(i + 1) / 2 - 1], xb = XB[i];
             const double c1 = xb - x_eval;
             const double c2 = x_eval - xa;
             const double denom = xb - xa;
-            ok = ok && !(fabs(denom) < EPS);
-            const double w_hi = WK(i);
-            WK(i + n2 - 1) = (c1 * WK(i + n2 - 1) + c2 * WK(i + n2) + (w_hi - w_lo)) / denom;
-            WK(i - 1) = (c1 * w_lo + c2 * w_hi) / denom;
-            w_lo = w_hi;  // the next entry reads the not-yet-overwritten work[i]
+            bad = bad || (i <= n2 - j && fabs(denom) < EPS);
+            D[i - 1] = (c1 * D[i - 1] + c2 * D[i] + (F[i] - F[i - 1])) / denom;
+            F[i - 1] = (c1 * F[i - 1] + c2 * F[i]) / denom;
         }
+        // a lane whose table ends with this column keeps its result; later columns only touch dead entries
+        f = j == n2 - 1 ? F[0] : f;
+        df = j == n2 - 1 ? D[0] : df;
+#pragma unroll
+        for (int i = 1; i <= EXTENT; ++i) XB[i] = XB[i + 1];
     }
-    f = WK(0);
-    df = WK(n2);
-    return ok;
-#undef XS
-#undef WK
 }
 
-// `Traj::at` for the trajectory of this lane.  All lanes of the wave call it together (it contains no barrier, but
-// keeping the lanes converged keeps the LDS table accesses conflict-free).
-DEVFN int traj_at(const nyx_hip_traj_t &src, const View &v, int64_t epoch_ns, double *lds, int lane, double s6[6]) {
-    const double *comp[6] = {src.x_km, src.y_km, src.z_km, src.vx_km_s, src.vy_km_s, src.vz_km_s};
+DEVFN bool hrmint_axis(const double (&XS)[SAMPLES], int ns, double x_eval, const double *py, const double *pv, const View &v,
+                       int64_t first_idx, double &f, double &df) {
+    const double EPS = 2.220446049250313e-16;
+    double F[2 * SAMPLES], D[2 * SAMPLES], XB[2 * SAMPLES];
+    bool bad = false;
+    const int n2 = 2 * ns;
+    // first column: values and derivatives interleaved (rows beyond ns repeat the last state: dead entries)
+#pragma unroll
+    for (int k = 0; k < SAMPLES; ++k) { F[2 * k] = 0.0; F[2 * k + 1] = 0.0; }
+    if (ns > 0) {
+#pragma unroll
+        for (int k = 0; k < SAMPLES; ++k) {
+            const int64_t at = v.at(first_idx + (k < ns ? k : ns - 1));
+            F[2 * k] = py[at];
+            F[2 * k + 1] = pv[at];
+        }
+    }
+    // second column: first-degree interpolants
+#pragma unroll
+    for (int i = 1; i <= SAMPLES - 1; ++i) {
+        const bool valid = i <= ns - 1;
+        const double xa = XS[i - 1], xb = XS[i];
+        const double c1 = xb - x_eval;
+        const double c2 = x_eval - xa;
+        const double denom = xb - xa;
+        bad = bad || (valid && fabs(denom) < EPS);
+        const double wp = F[2 * i - 2], wc = F[2 * i - 1], wn = F[2 * i];
+        D[2 * i - 2] = wc;
+        D[2 * i - 1] = (wn - wp) / denom;
+        const double temp = wc * (x_eval - xa) + wp;
+        F[2 * i - 1] = valid ? (c1 * wp + c2 * wn) / denom : wc;
+        F[2 * i - 2] = valid ? temp : wp;
+    }
+    D[2 * SAMPLES - 2] = 0.0; D[2 * SAMPLES - 1] = 0.0;
+#pragma unroll
+    for (int k = 0; k < SAMPLES; ++k) {
+        const bool last = k == ns - 1;
+        D[2 * k] = last ? F[2 * k + 1] : D[2 * k];
+        F[2 * k] = last ? F[2 * k + 1] * (x_eval - XS[k]) + F[2 * k] : F[2 * k];
+    }
+    // columns 3 .. 2n
+    XB[0] = 0.0; XB[2 * SAMPLES - 1] = 0.0;
+#pragma unroll
+    for (int i = 1; i <= 2 * SAMPLES - 2; ++i) XB[i] = XS[(i + 3) / 2 - 1];
+    f = F[0];   // n = 1: the table is complete already
+    df = D[0];
+    hrmint_columns<24>(2, n2, x_eval, XS, F, D, XB, bad, f, df);
+    hrmint_columns<18>(8, n2, x_eval, XS, F, D, XB, bad, f, df);
+    hrmint_columns<12>(14, n2, x_eval, XS, F, D, XB, bad, f, df);
+    hrmint_columns<6>(20, n2, x_eval, XS, F, D, XB, bad, f, df);
+    return !bad;
+}
+
+// `Traj::at` for the trajectory of this lane.
+DEVFN int traj_at(const nyx_hip_traj_t &src, const View &v, int64_t epoch_ns, double s6[6]) {
     const double qnan = __builtin_nan("");
     for (int c = 0; c < 6; ++c) s6[c] = qnan;
-    if (v.len == 0) return NYX_HIP_INTERP_NO_DATA;
-    if (v.epoch[v.at(0)] > epoch_ns || v.epoch[v.at(v.len - 1)] < epoch_ns) return NYX_HIP_INTERP_NO_DATA;
-    // binary search (traj.rs:88-91): exact hit, or the insertion index
-    int64_t lo = 0, hi = v.len, hit = -1;
-    while (lo < hi) {
-        const int64_t mid = lo + ((hi - lo) >> 1);
-        const int64_t e = v.epoch[v.at(mid)];
-        if (e == epoch_ns) { hit = mid; break; }
-        if (e < epoch_ns) lo = mid + 1; else hi = mid;
+    int st = NYX_HIP_INTERP_OK;
+    int64_t hit = -1, first_idx = 0;
+    int ns = 0;
+    if (v.len == 0 || v.epoch[v.at(0)] > epoch_ns || v.epoch[v.at(v.len - 1)] < epoch_ns) {
+        st = NYX_HIP_INTERP_NO_DATA;
+    } else {
+        // binary search (traj.rs:88-91): exact hit, or the insertion index
+        int64_t lo = 0, hi = v.len;
+        while (lo < hi) {
+            const int64_t mid = lo + ((hi - lo) >> 1);
+            const int64_t e = v.epoch[v.at(mid)];
+            if (e == epoch_ns) { hit = mid; break; }
+            if (e < epoch_ns) lo = mid + 1; else hi = mid;
+        }
+        if (hit < 0) {
+            const int64_t idx = lo;
+            if (idx == 0 || idx >= v.len) {
+                st = NYX_HIP_INTERP_NO_DATA;
+            } else {
+                const int64_t num_left = SAMPLES / 2;
+                first_idx = idx > num_left ? idx - num_left : 0;
+                const int64_t last_idx = v.len < first_idx + SAMPLES ? v.len : first_idx + SAMPLES;
+                if (last_idx == v.len) first_idx = last_idx > 2 * num_left ? last_idx - 2 * num_left : 0;  // 12 states, sic
+                ns = (int)(last_idx - first_idx);
+            }
+        }
     }
     if (hit >= 0) {
         const int64_t at = v.at(hit);
-        for (int c = 0; c < 6; ++c) s6[c] = comp[c][at];
-        return NYX_HIP_INTERP_OK;
+        s6[0] = src.x_km[at]; s6[1] = src.y_km[at]; s6[2] = src.z_km[at];
+        s6[3] = src.vx_km_s[at]; s6[4] = src.vy_km_s[at]; s6[5] = src.vz_km_s[at];
     }
-    const int64_t idx = lo;
-    if (idx == 0 || idx >= v.len) return NYX_HIP_INTERP_NO_DATA;
-    const int64_t num_left = SAMPLES / 2;
-    int64_t first_idx = idx > num_left ? idx - num_left : 0;
-    const int64_t last_idx = v.len < first_idx + SAMPLES ? v.len : first_idx + SAMPLES;
-    if (last_idx == v.len) first_idx = last_idx > 2 * num_left ? last_idx - 2 * num_left : 0;  // 12 states, sic
-    const int ns = (int)(last_idx - first_idx);
-    for (int k = 0; k < ns; ++k) lds[k * LANES + lane] = ns_to_seconds(v.epoch[v.at(first_idx + k)]);
-    const double x_eval = ns_to_seconds(epoch_ns);
-    bool ok = true;
-    double f[3], df[3];
-    for (int c = 0; c < 3; ++c) {
-        for (int k = 0; k < ns; ++k) {
-            const int64_t at = v.at(first_idx + k);
-            lds[(SAMPLES + 2 * k) * LANES + lane] = comp[c][at];
-            lds[(SAMPLES + 2 * k + 1) * LANES + lane] = comp[c + 3][at];
+    // the interpolation proper: lanes without a window carry ns = 0 and fall through every predicate
+    if (__any(ns > 0)) {
+        double XS[SAMPLES];
+#pragma unroll
+        for (int k = 0; k < SAMPLES; ++k) XS[k] = k < ns ? ns_to_seconds(v.epoch[v.at(first_idx + k)]) : 0.0;
+        const double x_eval = ns_to_seconds(epoch_ns);
+        bool ok = true;
+        double fx = qnan, fy = qnan, fz = qnan, dx = qnan, dy = qnan, dz = qnan;
+#pragma unroll 1
+        for (int c = 0; c < 3; ++c) {
+            const double *py = c == 0 ? src.x_km : (c == 1 ? src.y_km : src.z_km);
+            const double *pv = c == 0 ? src.vx_km_s : (c == 1 ? src.vy_km_s : src.vz_km_s);
+            double f, df;
+            ok = hrmint_axis(XS, ns, x_eval, py, pv, v, first_idx, f, df) && ok;
+            if (c == 0) { fx = f; dx = df; } else if (c == 1) { fy = f; dy = df; } else { fz = f; dz = df; }
         }
-        ok = hrmint(lds, lane, ns, x_eval, f[c], df[c]) && ok;
+        if (ns > 0) {
+            if (ok) { s6[0] = fx; s6[1] = fy; s6[2] = fz; s6[3] = dx; s6[4] = dy; s6[5] = dz; }
+            else st = NYX_HIP_INTERP_MATH;
+        }
     }
-    if (!ok) return NYX_HIP_INTERP_MATH;
-    for (int c = 0; c < 3; ++c) { s6[c] = f[c]; s6[c + 3] = df[c]; }
-    return NYX_HIP_INTERP_OK;
+    return st;
 }
 
 DEVFN void store_sample(const nyx_hip_traj_t &dst, int64_t at, int64_t epoch_ns, const double s6[6]) {
@@ -171,7 +222,6 @@ __global__ __launch_bounds__(256) void nyx_traj_init_kernel(TrajEvalArgs a) {
 }
 
 __global__ __launch_bounds__(LANES) void nyx_traj_eval_kernel(TrajEvalArgs a) {
-    __shared__ double lds[LDS_SLOTS * LANES];
     const int lane = threadIdx.x;
     const int64_t i = (int64_t)blockIdx.x * LANES + lane;
     const bool live = i < a.n;
@@ -196,7 +246,7 @@ __global__ __launch_bounds__(LANES) void nyx_traj_eval_kernel(TrajEvalArgs a) {
         const bool mine = live && q < q_end;
         const int64_t epoch = a.mode == TRAJ_MODE_EVERY ? first + q * a.step_ns : a.query[q < a.m ? q : a.m - 1];
         double s6[6];
-        const int st = traj_at(a.src, v, epoch, lds, lane, s6);
+        const int st = traj_at(a.src, v, epoch, s6);
         if (!mine) continue;
         const int64_t at = q * a.n + i;
         if (a.mode == TRAJ_MODE_EVERY) {
