@@ -301,6 +301,54 @@ int32_t nyx_hip_traj_every_device(nyx_hip_ctx *ctx, const nyx_hip_traj_t *traj, 
 int32_t nyx_hip_propagate_until_epoch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t end_epoch_ns,
                                       nyx_hip_states_t *out, nyx_hip_step_stats_t *stats);
 
+/* ---- covariance mapping: KalmanODProcess::predict_until (od/process/mod.rs:440-486) for the batch ----
+ * Per trajectory, repeated until epoch >= end_epoch_ns (at least once):
+ *   nominal = prop_instance.for_duration(max_step)            with the STM, step size carried over (mod.rs:466)
+ *   KalmanFilter::time_update(nominal)  (od/kalman/filtering.rs:59-99):
+ *       covar_bar = stm * covar * stm^T  [+ Gamma * Q * Gamma^T of the LAST applicable process noise, od/snc.rs:210-283]
+ *       state_bar = stm * state_deviation (DeviationTracking) or 0
+ *   prop_instance.state.reset_stm()                           (mod.rs:479)
+ * The context must have been created with NYX_HIP_FLAG_STM.  The propagation starts from an identity STM
+ * (`nominal_state().with_stm()`, mod.rs:452); in->stm is not read. */
+#define NYX_HIP_MAX_PROCESS_NOISE 4
+typedef struct nyx_hip_process_noise { /* ProcessNoise<U3> (od/snc.rs:40-59), inertial and constant */
+    double diag[3];          /* ProcessNoise::diag (from_diagonal / from_velocity_km_s, snc.rs:108-135, 288-309) */
+    int64_t disable_time_ns; /* no noise when the time update spans more than this (snc.rs:178-186, 248-250) */
+    int64_t start_time_ns;   /* start_time, read when has_start_time != 0 (snc.rs:168-175) */
+    int32_t has_start_time;
+    int32_t _pad;
+} nyx_hip_process_noise_t;
+
+typedef struct nyx_hip_predict {
+    int64_t max_step_ns;         /* KalmanODProcess::max_step, > 0 */
+    int64_t end_epoch_ns;
+    int32_t deviation_tracking;  /* KalmanVariant::DeviationTracking (filtering.rs:84-88) */
+    int32_t n_process_noise;     /* KalmanFilter::process_noise, in order; scanned from the last (filtering.rs:64) */
+    nyx_hip_process_noise_t process_noise[NYX_HIP_MAX_PROCESS_NOISE];
+} nyx_hip_predict_t;
+
+typedef struct nyx_hip_estimates { /* the KfEstimate fields that evolve (od/estimate/kfestimate.rs), trajectory-major */
+    double *covar;     /* n*81, column-major 9x9 per trajectory: in = initial covar, out = covar_bar of the last update */
+    double *state_dev; /* n*9 state_deviation in/out, or NULL (zeros in, not written) */
+} nyx_hip_estimates_t;
+
+/* ODSolution.estimates after the initial one (mod.rs:473-475): update u of trajectory i at [(u*n + i) * width]; every
+ * array except n_updates may be NULL; updates beyond `capacity` are counted, not stored. */
+typedef struct nyx_hip_predict_history {
+    int64_t capacity;
+    int64_t *epoch_ns; /* width 1  */
+    double *state;     /* width 9 : x, y, z, vx, vy, vz, Cr, Cd, prop mass */
+    double *stm;       /* width 81: column-major */
+    double *covar;     /* width 81: covar_bar */
+    double *state_dev; /* width 9  */
+    int32_t *n_updates; /* [n] time updates performed */
+} nyx_hip_predict_history_t;
+
+/* Host arrays.  `out` receives the last nominal states (STM reset to identity, like the reference's instance), `stats`
+ * the first failing status per trajectory (0 = Ok) with counters summed over the segments; `hist` may be NULL. */
+int32_t nyx_hip_predict_until(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, const nyx_hip_predict_t *cfg, nyx_hip_estimates_t *est,
+                              nyx_hip_states_t *out, nyx_hip_step_stats_t *stats, nyx_hip_predict_history_t *hist);
+
 /* Tuning knob: number of waves that split the spherical-harmonics columns of one
  * 64-trajectory workgroup (0 = pick automatically from n). */
 int32_t nyx_hip_ctx_set_column_waves(nyx_hip_ctx *ctx, int32_t waves);

@@ -171,6 +171,28 @@ class Traj(C.Structure):
     ]
 
 
+MAX_PROCESS_NOISE = 4
+
+
+class ProcessNoiseC(C.Structure):
+    _fields_ = [("diag", C.c_double * 3), ("disable_time_ns", C.c_int64), ("start_time_ns", C.c_int64),
+                ("has_start_time", C.c_int32), ("_pad", C.c_int32)]
+
+
+class Predict(C.Structure):
+    _fields_ = [("max_step_ns", C.c_int64), ("end_epoch_ns", C.c_int64), ("deviation_tracking", C.c_int32),
+                ("n_process_noise", C.c_int32), ("process_noise", ProcessNoiseC * MAX_PROCESS_NOISE)]
+
+
+class Estimates(C.Structure):
+    _fields_ = [("covar", c_double_p), ("state_dev", c_double_p)]
+
+
+class PredictHistory(C.Structure):
+    _fields_ = [("capacity", C.c_int64), ("epoch_ns", c_int64_p), ("state", c_double_p), ("stm", c_double_p),
+                ("covar", c_double_p), ("state_dev", c_double_p), ("n_updates", c_int32_p)]
+
+
 class TrajBatch:
     """Dense output of a batch: entry k of trajectory i at [k, i]; k = 0 is the start state (step-major, as the ABI)."""
 
@@ -305,6 +327,7 @@ EXPORTS = [
     "nyx_hip_last_kernel_ms", "nyx_hip_last_error", "nyx_hip_load_cof", "nyx_hip_load_shadr", "nyx_hip_free",
     "nyx_hip_propagate_batch_with_traj", "nyx_hip_propagate_batch_with_traj_device",
     "nyx_hip_traj_at", "nyx_hip_traj_every", "nyx_hip_traj_at_device", "nyx_hip_traj_every_device",
+    "nyx_hip_predict_until",
 ]
 
 
@@ -343,6 +366,9 @@ def load_library():
     lib.nyx_hip_traj_at_device.restype = C.c_int32
     lib.nyx_hip_traj_every_device.argtypes = [C.c_void_p, C.POINTER(Traj), C.c_int64, C.c_int64, C.POINTER(Traj), C.c_void_p]
     lib.nyx_hip_traj_every_device.restype = C.c_int32
+    lib.nyx_hip_predict_until.argtypes = [C.c_void_p, C.POINTER(States), C.POINTER(Predict), C.POINTER(Estimates), C.POINTER(States),
+                                          C.POINTER(StepStats), C.POINTER(PredictHistory)]
+    lib.nyx_hip_predict_until.restype = C.c_int32
     lib.nyx_hip_propagate_until_epoch.argtypes = [C.c_void_p, C.POINTER(States), C.c_int64, C.POINTER(States), C.POINTER(StepStats)]
     lib.nyx_hip_propagate_until_epoch.restype = C.c_int32
     lib.nyx_hip_ctx_set_column_waves.argtypes = [C.c_void_p, C.c_int32]

@@ -14,9 +14,12 @@
 #include "../../include/nyx_hip.h"
 #include "butcher.h"
 #include "devcfg.h"
+#include "predict_args.h"
 #include "traj_args.h"
 
 extern "C" size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles, int stm);
+extern "C" hipError_t nyx_launch_predict_init(const PredictArgs *a, const int64_t *epoch0, hipStream_t stream);
+extern "C" hipError_t nyx_launch_time_update(const PredictArgs *a, hipStream_t stream);
 extern "C" hipError_t nyx_launch_traj_eval(const TrajEvalArgs *args, hipStream_t stream);
 extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg, const HarmEntry *htab,
                                            const ColHdr *cols, const double *records, int n_waves, int rec_lds_doubles,
@@ -495,7 +498,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
 
 static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t *out, nyx_hip_step_stats_t *st,
                   int64_t duration_ns, int64_t end_epoch_ns, int use_end, hipStream_t stream, bool time_it,
-                  const nyx_hip_traj_t *traj = nullptr) {
+                  const nyx_hip_traj_t *traj = nullptr, const int64_t *dur_ns = nullptr) {
     const int nw = pick_waves(ctx, in->n);
     if (nw != ctx->host_cfg.n_waves) {
         build_schedule(ctx, nw);
@@ -509,6 +512,7 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
     bt.x = in->x_km; bt.y = in->y_km; bt.z = in->z_km; bt.vx = in->vx_km_s; bt.vy = in->vy_km_s; bt.vz = in->vz_km_s;
     bt.cr = in->cr; bt.cd = in->cd; bt.mprop = in->prop_mass_kg; bt.mdry = in->dry_mass_kg; bt.mextra = in->extra_mass_kg;
     bt.asrp = in->srp_area_m2; bt.adrag = in->drag_area_m2; bt.step_in = in->step_ns;
+    bt.dur_ns = dur_ns;
     if (ctx->host_cfg.flags & NYX_HIP_FLAG_STM) {
         if (!in->stm || !out->stm) { nyx_set_error("STM context: in->stm and out->stm are mandatory"); return NYX_HIP_RC_BAD_ARG; }
         bt.stm = in->stm; bt.o_stm = out->stm;
@@ -572,6 +576,83 @@ extern "C" int32_t nyx_hip_propagate_batch_with_traj_device(nyx_hip_ctx *ctx, co
     return launch(ctx, in, out, stats, duration_ns, 0, 0, (hipStream_t)hip_stream, true, traj);
 }
 
+// Device views of a staged host batch: `din` lives in ctx->in, `dout` / `dst` in ctx->out.
+struct Staged {
+    nyx_hip_states_t din, dout;
+    nyx_hip_step_stats_t dst;
+    bool stm = false;
+};
+
+// H2D of a host batch through the pinned mirror (one copy for the SoA block, one for the STMs).
+// `upload_stm` false leaves ctx->in.stm allocated but unwritten (covariance mapping starts from identity).
+static int stage_batch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, const nyx_hip_states_t *out, Staged &sg, bool upload_stm = true) {
+    const int64_t n = in->n;
+    if (int rc = ensure_arrays(ctx->in, n, false)) return rc;
+    if (int rc = ensure_arrays(ctx->out, n, true)) return rc;
+    DevArrays &di = ctx->in, &dq = ctx->out;
+    const double *hin[13] = {in->x_km, in->y_km, in->z_km, in->vx_km_s, in->vy_km_s, in->vz_km_s, in->cr, in->cd,
+                             in->prop_mass_kg, in->dry_mass_kg, in->extra_mass_kg, in->srp_area_m2, in->drag_area_m2};
+    std::memcpy(di.host(di.epoch), in->epoch_ns, n * sizeof(int64_t));
+    for (int k = 0; k < 13; ++k)
+        if (hin[k]) std::memcpy(di.host(di.f[k]), hin[k], n * sizeof(double));
+    if (in->step_ns) std::memcpy(di.host(di.step), in->step_ns, n * sizeof(int64_t));
+    HIP_TRY(hipMemcpy(di.dblock, di.hblock, (size_t)((char *)(di.f[12] + di.cap) - di.dblock), hipMemcpyHostToDevice));
+    sg.stm = (ctx->host_cfg.flags & NYX_HIP_FLAG_STM) != 0;
+    if (sg.stm) {
+        if (upload_stm && (!in->stm || !out->stm)) { nyx_set_error("STM context: in->stm and out->stm are mandatory"); return NYX_HIP_RC_BAD_ARG; }
+        for (DevArrays *d : {&di, &dq}) {
+            if (d->stm_cap < n) {
+                hipFree(d->stm);
+                d->stm = nullptr;
+                HIP_TRY(hipMalloc(&d->stm, (size_t)std::max<int64_t>(n, 1024) * 81 * sizeof(double)));
+                d->stm_cap = std::max<int64_t>(n, 1024);
+            }
+        }
+        if (upload_stm) HIP_TRY(hipMemcpy(di.stm, in->stm, (size_t)n * 81 * sizeof(double), hipMemcpyHostToDevice));
+    }
+    nyx_hip_states_t &din = sg.din;
+    std::memset(&din, 0, sizeof din);
+    din.n = n; din.epoch_ns = di.epoch;
+    double **dinf[13] = {&din.x_km, &din.y_km, &din.z_km, &din.vx_km_s, &din.vy_km_s, &din.vz_km_s, &din.cr, &din.cd,
+                         &din.prop_mass_kg, &din.dry_mass_kg, &din.extra_mass_kg, &din.srp_area_m2, &din.drag_area_m2};
+    for (int k = 0; k < 13; ++k) *dinf[k] = hin[k] ? di.f[k] : nullptr;
+    din.step_ns = in->step_ns ? di.step : nullptr;
+    din.stm = sg.stm ? di.stm : nullptr;
+    nyx_hip_states_t &dout = sg.dout;
+    std::memset(&dout, 0, sizeof dout);
+    dout.n = n; dout.epoch_ns = dq.epoch;
+    double **doutf[13] = {&dout.x_km, &dout.y_km, &dout.z_km, &dout.vx_km_s, &dout.vy_km_s, &dout.vz_km_s, &dout.cr, &dout.cd,
+                          &dout.prop_mass_kg, &dout.dry_mass_kg, &dout.extra_mass_kg, &dout.srp_area_m2, &dout.drag_area_m2};
+    for (int k = 0; k < 13; ++k) *doutf[k] = dq.f[k];
+    dout.step_ns = dq.step;
+    dout.stm = sg.stm ? dq.stm : nullptr;
+    sg.dst = {dq.status, dq.last_step, dq.last_error, dq.last_attempts, dq.n_acc, dq.n_rej, dq.n_evals};
+    return NYX_HIP_RC_OK;
+}
+
+// D2H of ctx->out (states + stats) through the pinned mirror, unpacked into the caller's arrays.
+static int fetch_batch(nyx_hip_ctx *ctx, int64_t n, bool stm, nyx_hip_states_t *out, nyx_hip_step_stats_t *stats) {
+    DevArrays &dq = ctx->out;
+    HIP_TRY(hipMemcpy(dq.hblock, dq.dblock, dq.bytes, hipMemcpyDeviceToHost));
+    double *hout[13] = {out->x_km, out->y_km, out->z_km, out->vx_km_s, out->vy_km_s, out->vz_km_s, out->cr, out->cd,
+                        out->prop_mass_kg, out->dry_mass_kg, out->extra_mass_kg, out->srp_area_m2, out->drag_area_m2};
+    std::memcpy(out->epoch_ns, dq.host(dq.epoch), n * sizeof(int64_t));
+    for (int k = 0; k < 13; ++k)
+        if (hout[k]) std::memcpy(hout[k], dq.host(dq.f[k]), n * sizeof(double));
+    if (out->step_ns) std::memcpy(out->step_ns, dq.host(dq.step), n * sizeof(int64_t));
+    if (stm && out->stm) HIP_TRY(hipMemcpy(out->stm, dq.stm, (size_t)n * 81 * sizeof(double), hipMemcpyDeviceToHost));
+    if (stats) {
+        if (stats->status) std::memcpy(stats->status, dq.host(dq.status), n * sizeof(int32_t));
+        if (stats->last_step_ns) std::memcpy(stats->last_step_ns, dq.host(dq.last_step), n * sizeof(int64_t));
+        if (stats->last_error) std::memcpy(stats->last_error, dq.host(dq.last_error), n * sizeof(double));
+        if (stats->last_attempts) std::memcpy(stats->last_attempts, dq.host(dq.last_attempts), n * sizeof(int32_t));
+        if (stats->n_accepted) std::memcpy(stats->n_accepted, dq.host(dq.n_acc), n * sizeof(int64_t));
+        if (stats->n_rejected) std::memcpy(stats->n_rejected, dq.host(dq.n_rej), n * sizeof(int64_t));
+        if (stats->n_evals) std::memcpy(stats->n_evals, dq.host(dq.n_evals), n * sizeof(int64_t));
+    }
+    return NYX_HIP_RC_OK;
+}
+
 static int host_propagate(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t duration_ns, int64_t end_epoch_ns, int use_end,
                           nyx_hip_states_t *out, nyx_hip_step_stats_t *stats, nyx_hip_traj_t *traj = nullptr) {
     if (!ctx) { nyx_set_error("null ctx"); return NYX_HIP_RC_BAD_ARG; }
@@ -581,49 +662,8 @@ static int host_propagate(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t 
     if (n == 0) return NYX_HIP_RC_OK;
     if (out->n < n) { nyx_set_error("out batch smaller than in batch"); return NYX_HIP_RC_BAD_ARG; }
     HIP_TRY(hipSetDevice(ctx->device));
-    if (int rc = ensure_arrays(ctx->in, n, false)) return rc;
-    if (int rc = ensure_arrays(ctx->out, n, true)) return rc;
-    DevArrays &di = ctx->in, &dq = ctx->out;
-    const double *hin[13] = {in->x_km, in->y_km, in->z_km, in->vx_km_s, in->vy_km_s, in->vz_km_s, in->cr, in->cd,
-                             in->prop_mass_kg, in->dry_mass_kg, in->extra_mass_kg, in->srp_area_m2, in->drag_area_m2};
-    // pack into the pinned mirror, one H2D for the whole batch
-    std::memcpy(di.host(di.epoch), in->epoch_ns, n * sizeof(int64_t));
-    for (int k = 0; k < 13; ++k)
-        if (hin[k]) std::memcpy(di.host(di.f[k]), hin[k], n * sizeof(double));
-    if (in->step_ns) std::memcpy(di.host(di.step), in->step_ns, n * sizeof(int64_t));
-    HIP_TRY(hipMemcpy(di.dblock, di.hblock, (size_t)((char *)(di.f[12] + di.cap) - di.dblock), hipMemcpyHostToDevice));
-    const bool stm = (ctx->host_cfg.flags & NYX_HIP_FLAG_STM) != 0;
-    if (stm) {
-        if (!in->stm || !out->stm) { nyx_set_error("STM context: in->stm and out->stm are mandatory"); return NYX_HIP_RC_BAD_ARG; }
-        for (DevArrays *d : {&di, &dq}) {
-            if (d->stm_cap < n) {
-                hipFree(d->stm);
-                d->stm = nullptr;
-                HIP_TRY(hipMalloc(&d->stm, (size_t)std::max<int64_t>(n, 1024) * 81 * sizeof(double)));
-                d->stm_cap = std::max<int64_t>(n, 1024);
-            }
-        }
-        HIP_TRY(hipMemcpy(di.stm, in->stm, (size_t)n * 81 * sizeof(double), hipMemcpyHostToDevice));
-    }
-
-    nyx_hip_states_t din;
-    std::memset(&din, 0, sizeof din);
-    din.n = n; din.epoch_ns = di.epoch;
-    double **dinf[13] = {&din.x_km, &din.y_km, &din.z_km, &din.vx_km_s, &din.vy_km_s, &din.vz_km_s, &din.cr, &din.cd,
-                         &din.prop_mass_kg, &din.dry_mass_kg, &din.extra_mass_kg, &din.srp_area_m2, &din.drag_area_m2};
-    for (int k = 0; k < 13; ++k) *dinf[k] = hin[k] ? di.f[k] : nullptr;
-    din.step_ns = in->step_ns ? di.step : nullptr;
-    din.stm = stm ? di.stm : nullptr;
-
-    nyx_hip_states_t dout;
-    std::memset(&dout, 0, sizeof dout);
-    dout.n = n; dout.epoch_ns = dq.epoch;
-    double **doutf[13] = {&dout.x_km, &dout.y_km, &dout.z_km, &dout.vx_km_s, &dout.vy_km_s, &dout.vz_km_s, &dout.cr, &dout.cd,
-                          &dout.prop_mass_kg, &dout.dry_mass_kg, &dout.extra_mass_kg, &dout.srp_area_m2, &dout.drag_area_m2};
-    for (int k = 0; k < 13; ++k) *doutf[k] = dq.f[k];
-    dout.step_ns = dq.step;
-    dout.stm = stm ? dq.stm : nullptr;
-    nyx_hip_step_stats_t dst = {dq.status, dq.last_step, dq.last_error, dq.last_attempts, dq.n_acc, dq.n_rej, dq.n_evals};
+    Staged sg;
+    if (int rc = stage_batch(ctx, in, out, sg)) return rc;
 
     nyx_hip_traj_t dtraj;
     std::memset(&dtraj, 0, sizeof dtraj);
@@ -638,7 +678,7 @@ static int host_propagate(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t 
         dtraj.vx_km_s = base + 3 * slots; dtraj.vy_km_s = base + 4 * slots; dtraj.vz_km_s = base + 5 * slots;
         dtraj.len = (int32_t *)(base + 6 * slots);
     }
-    if (int rc = launch(ctx, &din, &dout, &dst, duration_ns, end_epoch_ns, use_end, nullptr, true, traj_block ? &dtraj : nullptr)) {
+    if (int rc = launch(ctx, &sg.din, &sg.dout, &sg.dst, duration_ns, end_epoch_ns, use_end, nullptr, true, traj_block ? &dtraj : nullptr)) {
         if (traj_block) (void)hipFree(traj_block);
         return rc;
     }
@@ -656,25 +696,7 @@ static int host_propagate(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t 
         float ms = 0.f;
         ctx->last_ms = (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ? ms : -1.0;
     }
-    // one D2H for states + stats, then unpack from the pinned mirror
-    HIP_TRY(hipMemcpy(dq.hblock, dq.dblock, dq.bytes, hipMemcpyDeviceToHost));
-    double *hout[13] = {out->x_km, out->y_km, out->z_km, out->vx_km_s, out->vy_km_s, out->vz_km_s, out->cr, out->cd,
-                        out->prop_mass_kg, out->dry_mass_kg, out->extra_mass_kg, out->srp_area_m2, out->drag_area_m2};
-    std::memcpy(out->epoch_ns, dq.host(dq.epoch), n * sizeof(int64_t));
-    for (int k = 0; k < 13; ++k)
-        if (hout[k]) std::memcpy(hout[k], dq.host(dq.f[k]), n * sizeof(double));
-    if (out->step_ns) std::memcpy(out->step_ns, dq.host(dq.step), n * sizeof(int64_t));
-    if (stm) HIP_TRY(hipMemcpy(out->stm, dq.stm, (size_t)n * 81 * sizeof(double), hipMemcpyDeviceToHost));
-    if (stats) {
-        if (stats->status) std::memcpy(stats->status, dq.host(dq.status), n * sizeof(int32_t));
-        if (stats->last_step_ns) std::memcpy(stats->last_step_ns, dq.host(dq.last_step), n * sizeof(int64_t));
-        if (stats->last_error) std::memcpy(stats->last_error, dq.host(dq.last_error), n * sizeof(double));
-        if (stats->last_attempts) std::memcpy(stats->last_attempts, dq.host(dq.last_attempts), n * sizeof(int32_t));
-        if (stats->n_accepted) std::memcpy(stats->n_accepted, dq.host(dq.n_acc), n * sizeof(int64_t));
-        if (stats->n_rejected) std::memcpy(stats->n_rejected, dq.host(dq.n_rej), n * sizeof(int64_t));
-        if (stats->n_evals) std::memcpy(stats->n_evals, dq.host(dq.n_evals), n * sizeof(int64_t));
-    }
-    return NYX_HIP_RC_OK;
+    return fetch_batch(ctx, n, sg.stm, out, stats);
 }
 
 extern "C" int32_t nyx_hip_propagate_batch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t duration_ns,
@@ -829,6 +851,112 @@ extern "C" int32_t nyx_hip_traj_at(nyx_hip_ctx *ctx, const nyx_hip_traj_t *traj,
 
 extern "C" int32_t nyx_hip_traj_every(nyx_hip_ctx *ctx, const nyx_hip_traj_t *traj, int64_t n, int64_t step_ns, nyx_hip_traj_t *out) {
     return traj_eval_host(ctx, traj, n, nullptr, 0, step_ns, out, nullptr, TRAJ_MODE_EVERY);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Covariance mapping (od/process/mod.rs:440-486): segment launches + predict_kernel.hip, one stream, no host round trip
+// ---------------------------------------------------------------------------------------------
+struct DevBuf {  // RAII device allocation
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) {
+        if (hipMalloc(&p, std::max<size_t>(bytes, 8)) != hipSuccess) {
+            p = nullptr;
+            nyx_set_error("hipMalloc of %zu bytes failed", bytes);
+            return NYX_HIP_RC_HIP_ERROR;
+        }
+        return NYX_HIP_RC_OK;
+    }
+    template <typename T> T *as() const { return (T *)p; }
+};
+
+extern "C" int32_t nyx_hip_predict_until(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, const nyx_hip_predict_t *cfg,
+                                         nyx_hip_estimates_t *est, nyx_hip_states_t *out, nyx_hip_step_stats_t *stats,
+                                         nyx_hip_predict_history_t *hist) {
+    if (!ctx || !cfg || !est || !est->covar) { nyx_set_error("predict: ctx, cfg and est->covar are mandatory"); return NYX_HIP_RC_BAD_ARG; }
+    if (!(ctx->host_cfg.flags & NYX_HIP_FLAG_STM)) { nyx_set_error("predict: the context must be created with NYX_HIP_FLAG_STM"); return NYX_HIP_RC_BAD_ARG; }
+    if (cfg->max_step_ns <= 0) { nyx_set_error("predict: max_step_ns must be > 0"); return NYX_HIP_RC_BAD_ARG; }
+    if (cfg->n_process_noise < 0 || cfg->n_process_noise > NYX_HIP_MAX_PROCESS_NOISE) { nyx_set_error("predict: n_process_noise out of range"); return NYX_HIP_RC_BAD_ARG; }
+    if (hist && (hist->capacity < 0 || !hist->n_updates)) { nyx_set_error("predict: hist->n_updates is mandatory, capacity >= 0"); return NYX_HIP_RC_BAD_ARG; }
+    if (int rc = check_states(in, "in")) return rc;
+    if (int rc = check_states(out, "out")) return rc;
+    const int64_t n = in->n;
+    if (n == 0) return NYX_HIP_RC_OK;
+    if (out->n < n) { nyx_set_error("out batch smaller than in batch"); return NYX_HIP_RC_BAD_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    Staged sg;
+    if (int rc = stage_batch(ctx, in, out, sg, /*upload_stm=*/false)) return rc;
+    // segments needed: the longest trajectory decides (the others idle with duration 0)
+    int64_t n_seg = 1;
+    for (int64_t i = 0; i < n; ++i) {
+        const int64_t span = cfg->end_epoch_ns - in->epoch_ns[i];
+        if (span > 0) n_seg = std::max(n_seg, (span + cfg->max_step_ns - 1) / cfg->max_step_ns);
+    }
+    const int64_t cap = hist ? hist->capacity : 0;
+    const size_t slots = (size_t)cap * (size_t)n;
+    DevBuf covar, sdev, work, h_epoch, h_state, h_stm, h_covar, h_sdev;
+    // work: prev_epoch, dur, acc x3 (int64) then status, n_updates (int32)
+    if (int rc = covar.alloc((size_t)n * 81 * 8)) return rc;
+    if (int rc = sdev.alloc((size_t)n * 9 * 8)) return rc;
+    if (int rc = work.alloc((size_t)n * (5 * 8 + 2 * 4))) return rc;
+    HIP_TRY(hipMemcpy(covar.p, est->covar, (size_t)n * 81 * 8, hipMemcpyHostToDevice));
+    if (est->state_dev) HIP_TRY(hipMemcpy(sdev.p, est->state_dev, (size_t)n * 9 * 8, hipMemcpyHostToDevice));
+    else HIP_TRY(hipMemset(sdev.p, 0, (size_t)n * 9 * 8));
+    PredictArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.n = n; a.cfg = *cfg;
+    a.epoch = sg.dout.epoch_ns;
+    const double *s9[9] = {sg.dout.x_km, sg.dout.y_km, sg.dout.z_km, sg.dout.vx_km_s, sg.dout.vy_km_s, sg.dout.vz_km_s,
+                           sg.dout.cr, sg.dout.cd, sg.dout.prop_mass_kg};
+    for (int k = 0; k < 9; ++k) a.s9[k] = s9[k];
+    a.seg_status = sg.dst.status; a.seg_n_acc = sg.dst.n_accepted; a.seg_n_rej = sg.dst.n_rejected; a.seg_n_evals = sg.dst.n_evals;
+    a.covar = covar.as<double>(); a.state_dev = sdev.as<double>();
+    int64_t *w64 = work.as<int64_t>();
+    a.prev_epoch = w64; a.dur = w64 + n; a.acc_n_acc = w64 + 2 * n; a.acc_n_rej = w64 + 3 * n; a.acc_n_evals = w64 + 4 * n;
+    a.status = (int32_t *)(w64 + 5 * n); a.hist.n_updates = a.status + n;
+    a.hist.capacity = cap;
+    if (hist && slots) {
+        if (hist->epoch_ns) { if (int rc = h_epoch.alloc(slots * 8)) return rc; a.hist.epoch_ns = h_epoch.as<int64_t>(); }
+        if (hist->state) { if (int rc = h_state.alloc(slots * 9 * 8)) return rc; a.hist.state = h_state.as<double>(); }
+        if (hist->stm) { if (int rc = h_stm.alloc(slots * 81 * 8)) return rc; a.hist.stm = h_stm.as<double>(); }
+        if (hist->covar) { if (int rc = h_covar.alloc(slots * 81 * 8)) return rc; a.hist.covar = h_covar.as<double>(); }
+        if (hist->state_dev) { if (int rc = h_sdev.alloc(slots * 9 * 8)) return rc; a.hist.state_dev = h_sdev.as<double>(); }
+    }
+    hipStream_t stream = nullptr;
+    HIP_TRY(hipEventRecord(ctx->ev0, stream));
+    // segment 0 reads the caller's states (ctx->in) with an identity STM and writes ctx->out; later segments run in place
+    a.stm = sg.din.stm;
+    HIP_TRY(nyx_launch_predict_init(&a, sg.din.epoch_ns, stream));
+    a.stm = sg.dout.stm;
+    for (int64_t s = 0; s < n_seg; ++s) {
+        const nyx_hip_states_t *src = s == 0 ? &sg.din : &sg.dout;
+        if (int rc = launch(ctx, src, &sg.dout, &sg.dst, 0, 0, 0, stream, false, nullptr, a.dur)) return rc;
+        HIP_TRY(nyx_launch_time_update(&a, stream));
+    }
+    HIP_TRY(hipEventRecord(ctx->ev1, stream));
+    HIP_TRY(hipDeviceSynchronize());
+    {
+        float ms = 0.f;
+        ctx->last_ms = (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ? ms : -1.0;
+    }
+    if (int rc = fetch_batch(ctx, n, true, out, stats)) return rc;
+    HIP_TRY(hipMemcpy(est->covar, covar.p, (size_t)n * 81 * 8, hipMemcpyDeviceToHost));
+    if (est->state_dev) HIP_TRY(hipMemcpy(est->state_dev, sdev.p, (size_t)n * 9 * 8, hipMemcpyDeviceToHost));
+    if (stats) {  // first failing status, counters summed over the segments
+        if (stats->status) HIP_TRY(hipMemcpy(stats->status, a.status, (size_t)n * 4, hipMemcpyDeviceToHost));
+        if (stats->n_accepted) HIP_TRY(hipMemcpy(stats->n_accepted, a.acc_n_acc, (size_t)n * 8, hipMemcpyDeviceToHost));
+        if (stats->n_rejected) HIP_TRY(hipMemcpy(stats->n_rejected, a.acc_n_rej, (size_t)n * 8, hipMemcpyDeviceToHost));
+        if (stats->n_evals) HIP_TRY(hipMemcpy(stats->n_evals, a.acc_n_evals, (size_t)n * 8, hipMemcpyDeviceToHost));
+    }
+    if (hist) {
+        HIP_TRY(hipMemcpy(hist->n_updates, a.hist.n_updates, (size_t)n * 4, hipMemcpyDeviceToHost));
+        if (a.hist.epoch_ns) HIP_TRY(hipMemcpy(hist->epoch_ns, a.hist.epoch_ns, slots * 8, hipMemcpyDeviceToHost));
+        if (a.hist.state) HIP_TRY(hipMemcpy(hist->state, a.hist.state, slots * 9 * 8, hipMemcpyDeviceToHost));
+        if (a.hist.stm) HIP_TRY(hipMemcpy(hist->stm, a.hist.stm, slots * 81 * 8, hipMemcpyDeviceToHost));
+        if (a.hist.covar) HIP_TRY(hipMemcpy(hist->covar, a.hist.covar, slots * 81 * 8, hipMemcpyDeviceToHost));
+        if (a.hist.state_dev) HIP_TRY(hipMemcpy(hist->state_dev, a.hist.state_dev, slots * 9 * 8, hipMemcpyDeviceToHost));
+    }
+    return NYX_HIP_RC_OK;
 }
 
 // Introspection for tests / DESIGN.md: column schedule of the current context.

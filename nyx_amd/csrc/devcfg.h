@@ -100,6 +100,7 @@ struct DevBatch { /* device pointers of one launch */
     const int64_t *epoch_ns;
     const double *x, *y, *z, *vx, *vy, *vz, *cr, *cd, *mprop, *mdry, *mextra, *asrp, *adrag;
     const int64_t *step_in;
+    const int64_t *dur_ns; /* optional per-trajectory duration (covariance-mapping segments); overrides duration_ns */
     const double *stm; /* [n][81] column-major per trajectory, or NULL */
     double *o_stm;
     int64_t *o_epoch_ns;

@@ -805,7 +805,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
         c.y[6] = bt.cr ? bt.cr[idx] : 0.0;
         c.y[7] = bt.cd ? bt.cd[idx] : 0.0;
         c.y[8] = bt.mprop ? bt.mprop[idx] : 0.0;
-        const int64_t duration = bt.use_end_epoch ? (bt.end_epoch_ns - c.epoch) : bt.duration_ns;
+        const int64_t duration = bt.dur_ns ? bt.dur_ns[idx] : (bt.use_end_epoch ? (bt.end_epoch_ns - c.epoch) : bt.duration_ns);
         c.stop = c.epoch + duration;
         c.backprop = duration < 0;
         c.step_size = (bt.step_in && bt.step_in[idx] != 0) ? bt.step_in[idx] : cfg->init_step_ns;

@@ -1052,10 +1052,9 @@ typedef struct {
     const nyx_hip_traj_t *traj;
 } job_t;
 
-static void run_one(const job_t *jb, inst_t *s, int64_t i) {
-    const nyx_hip_config_t *cfg = jb->p->cfg;
-    const nyx_hip_states_t *in = jb->in;
-    s->p = jb->p;
+static void inst_init(inst_t *s, const prepared_t *p, const nyx_hip_states_t *in, int64_t i) {
+    const nyx_hip_config_t *cfg = p->cfg;
+    s->p = p;
     s->tab = &ORC_TABLEAUX[cfg->opts.method];
     s->opts = cfg->opts;
     s->has_stm = (cfg->flags & NYX_HIP_FLAG_STM) && in->stm;
@@ -1078,12 +1077,10 @@ static void run_one(const job_t *jb, inst_t *s, int64_t i) {
     s->det_error = 0.0;
     s->det_attempts = 1;
     s->n_acc = s->n_rej = s->n_evals = 0;
-    s->traj = jb->traj; s->traj_n = in->n; s->traj_i = i;
-    traj_push(s);
+    s->traj = NULL; s->traj_n = in->n; s->traj_i = i;
+}
 
-    int st = propagate(s, jb->duration_ns);
-
-    nyx_hip_states_t *o = jb->out;
+static void inst_store(const inst_t *s, nyx_hip_states_t *o, nyx_hip_step_stats_t *t, int64_t i, int st) {
     o->epoch_ns[i] = s->epoch_ns;
     o->x_km[i] = s->y[0]; o->y_km[i] = s->y[1]; o->z_km[i] = s->y[2];
     o->vx_km_s[i] = s->y[3]; o->vy_km_s[i] = s->y[4]; o->vz_km_s[i] = s->y[5];
@@ -1096,7 +1093,6 @@ static void run_one(const job_t *jb, inst_t *s, int64_t i) {
     if (o->drag_area_m2) o->drag_area_m2[i] = s->sc.drag_area;
     if (o->stm && s->has_stm) memcpy(o->stm + 81 * i, s->y + 9, 81 * sizeof(double));
     if (o->step_ns) o->step_ns[i] = s->step_size_ns;
-    nyx_hip_step_stats_t *t = jb->stats;
     if (t) {
         if (t->status) t->status[i] = st;
         if (t->last_step_ns) t->last_step_ns[i] = s->det_step_ns;
@@ -1106,6 +1102,14 @@ static void run_one(const job_t *jb, inst_t *s, int64_t i) {
         if (t->n_rejected) t->n_rejected[i] = s->n_rej;
         if (t->n_evals) t->n_evals[i] = s->n_evals;
     }
+}
+
+static void run_one(const job_t *jb, inst_t *s, int64_t i) {
+    inst_init(s, jb->p, jb->in, i);
+    s->traj = jb->traj;
+    traj_push(s);
+    const int st = propagate(s, jb->duration_ns);
+    inst_store(s, jb->out, jb->stats, i, st);
 }
 
 static void *worker(void *arg) {
@@ -1252,6 +1256,102 @@ int32_t nyx_oracle_traj_every(const nyx_hip_traj_t *traj, int64_t n, int64_t ste
             out->len[i] = (int32_t)(k + 1);
         }
     }
+    return NYX_HIP_RC_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Covariance mapping: KalmanODProcess::predict_until (od/process/mod.rs:440-486) with
+ * KalmanFilter::time_update (od/kalman/filtering.rs:59-99) and ProcessNoise::propagate (od/snc.rs:165-283).
+ * 9x9 matrices are column-major (nalgebra storage); products accumulate k ascending, multiply then add, as
+ * nalgebra's gemv/axcpy loop does for statically sized matrices.
+ * --------------------------------------------------------------------------------------------- */
+static void mat9_mul(const double *a, const double *b, int b_transposed, double *out) {
+    for (int c = 0; c < 9; ++c)
+        for (int r = 0; r < 9; ++r) {
+            double acc = a[r] * (b_transposed ? b[c] : b[c * 9]);
+            for (int k = 1; k < 9; ++k) acc = acc + a[k * 9 + r] * (b_transposed ? b[k * 9 + c] : b[c * 9 + k]);
+            out[c * 9 + r] = acc;
+        }
+}
+
+int32_t nyx_oracle_predict_until(const nyx_hip_config_t *cfg, const nyx_hip_states_t *in, const nyx_hip_predict_t *pc,
+                                 nyx_hip_estimates_t *est, nyx_hip_states_t *out, nyx_hip_step_stats_t *stats,
+                                 nyx_hip_predict_history_t *hist) {
+    if (!cfg || !in || !out || !pc || !est || !est->covar || !(cfg->flags & NYX_HIP_FLAG_STM) || pc->max_step_ns <= 0)
+        return NYX_HIP_RC_BAD_ARG;
+    prepared_t p;
+    prepared_init(&p, cfg);
+    inst_t *s = malloc(sizeof *s);
+    scratch_init(&s->w, &p);
+    double *ident = calloc((size_t)in->n * 81, sizeof(double));
+    for (int64_t i = 0; i < in->n; ++i)
+        for (int k = 0; k < 9; ++k) ident[i * 81 + k * 10] = 1.0;
+    nyx_hip_states_t in_stm = *in;
+    in_stm.stm = ident; /* nominal_state().with_stm() (mod.rs:452) */
+    for (int64_t i = 0; i < in->n; ++i) {
+        scratch_t keep = s->w;
+        inst_init(s, &p, &in_stm, i);
+        double *covar = est->covar + 81 * i;
+        double dev[9];
+        for (int k = 0; k < 9; ++k) dev[k] = est->state_dev ? est->state_dev[9 * i + k] : 0.0;
+        int64_t prev_epoch = s->epoch_ns;
+        int32_t n_up = 0;
+        int st = NYX_HIP_OK;
+        for (;;) {
+            st = propagate(s, pc->max_step_ns);
+            if (st) break;
+            const double *stm = s->y + 9;
+            double m[81], cb[81];
+            mat9_mul(stm, covar, 0, m);
+            mat9_mul(m, stm, 1, cb);
+            const int64_t delta_ns = s->epoch_ns - prev_epoch;
+            for (int q = pc->n_process_noise - 1; q >= 0; --q) {
+                const nyx_hip_process_noise_t *pn = &pc->process_noise[q];
+                if (pn->has_start_time && pn->start_time_ns > s->epoch_ns) continue;
+                if (delta_ns > pn->disable_time_ns) continue;
+                const double dt = nyx_oracle_ns_to_seconds(delta_ns);
+                const double half_dt2 = (dt * dt) / 2.0;
+                for (int c = 0; c < 6; ++c)
+                    for (int r = 0; r < 6; ++r)
+                        if (r % 3 == c % 3) {
+                            const double g_r = r < 3 ? half_dt2 : dt, g_c = c < 3 ? half_dt2 : dt;
+                            cb[c * 9 + r] = cb[c * 9 + r] + (g_r * pn->diag[r % 3]) * g_c;
+                        }
+                break;
+            }
+            double sb[9];
+            for (int r = 0; r < 9; ++r) {
+                sb[r] = 0.0;
+                if (pc->deviation_tracking) {
+                    sb[r] = stm[r] * dev[0];
+                    for (int k = 1; k < 9; ++k) sb[r] = sb[r] + stm[k * 9 + r] * dev[k];
+                }
+            }
+            if (hist && n_up < hist->capacity) {
+                const int64_t slot = (int64_t)n_up * in->n + i;
+                if (hist->epoch_ns) hist->epoch_ns[slot] = s->epoch_ns;
+                if (hist->state) memcpy(hist->state + slot * 9, s->y, 9 * sizeof(double));
+                if (hist->stm) memcpy(hist->stm + slot * 81, stm, 81 * sizeof(double));
+                if (hist->covar) memcpy(hist->covar + slot * 81, cb, 81 * sizeof(double));
+                if (hist->state_dev) memcpy(hist->state_dev + slot * 9, sb, 9 * sizeof(double));
+            }
+            memcpy(covar, cb, sizeof cb);
+            memcpy(dev, sb, sizeof sb);
+            n_up += 1;
+            prev_epoch = s->epoch_ns;
+            memset(s->y + 9, 0, 81 * sizeof(double)); /* reset_stm() (mod.rs:479) */
+            for (int k = 0; k < 9; ++k) s->y[9 + k * 10] = 1.0;
+            if (s->epoch_ns >= pc->end_epoch_ns) break;
+        }
+        if (est->state_dev) memcpy(est->state_dev + 9 * i, dev, sizeof dev);
+        if (hist && hist->n_updates) hist->n_updates[i] = n_up;
+        inst_store(s, out, stats, i, st);
+        s->w = keep;
+    }
+    free(ident);
+    scratch_free(&s->w);
+    free(s);
+    prepared_free(&p);
     return NYX_HIP_RC_OK;
 }
 

@@ -61,6 +61,11 @@ int32_t nyx_oracle_hermite_eval(const double *xs, const double *ys, const double
 int32_t nyx_oracle_traj_at(const nyx_hip_traj_t *traj, int64_t n, int64_t i, int64_t epoch_ns, double *state6);
 int32_t nyx_oracle_traj_every(const nyx_hip_traj_t *traj, int64_t n, int64_t step_ns, nyx_hip_traj_t *out);
 
+/* KalmanODProcess::predict_until (od/process/mod.rs:440-486): oracle twin of nyx_hip_predict_until (one thread). */
+int32_t nyx_oracle_predict_until(const nyx_hip_config_t *cfg, const nyx_hip_states_t *in, const nyx_hip_predict_t *pc,
+                                 nyx_hip_estimates_t *est, nyx_hip_states_t *out, nyx_hip_step_stats_t *stats,
+                                 nyx_hip_predict_history_t *hist);
+
 /* hifitime conversions as restated (see nyx_oracle.c). */
 int64_t nyx_oracle_seconds_to_ns(double s);
 double nyx_oracle_ns_to_seconds(int64_t ns);

@@ -50,6 +50,9 @@ def load():
     lib.nyx_oracle_ns_to_seconds.argtypes = [C.c_int64]
     lib.nyx_oracle_ns_to_seconds.restype = C.c_double
     lib.nyx_oracle_set_ns_rounding.argtypes = [C.c_int32]
+    lib.nyx_oracle_predict_until.argtypes = [C.POINTER(_abi.Config), C.POINTER(_abi.States), C.POINTER(_abi.Predict), C.POINTER(_abi.Estimates),
+                                             C.POINTER(_abi.States), C.POINTER(_abi.StepStats), C.POINTER(_abi.PredictHistory)]
+    lib.nyx_oracle_predict_until.restype = C.c_int32
     lib.nyx_oracle_hermite_eval.argtypes = [_abi.c_double_p, _abi.c_double_p, _abi.c_double_p, C.c_int32, C.c_double,
                                             _abi.c_double_p, _abi.c_double_p]
     lib.nyx_oracle_hermite_eval.restype = C.c_int32
@@ -133,3 +136,11 @@ def traj_every(traj, step_ns, capacity):
     rc = lib.nyx_oracle_traj_every(C.byref(cin), traj.n, int(step_ns), C.byref(cout))
     assert rc == 0
     return out
+
+
+def predict_until(compiled, batch, covar, end_epoch_ns, max_step_ns, **kw):
+    """Oracle twin of nyx_amd.od.predict_until (same arguments, same result object)."""
+    from nyx_amd import od
+    lib = load()
+    return od.predict_until(None, batch, covar, end_epoch_ns, max_step_ns,
+                            _call=lambda *a: lib.nyx_oracle_predict_until(C.byref(compiled.cfg), *a), **kw)
