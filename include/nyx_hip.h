@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NYX_HIP_ABI_VERSION 1
+#define NYX_HIP_ABI_VERSION 2
 
 /* ---- IntegratorMethod: nyx-core/src/propagators/rk_methods/mod.rs:65-79 ---- */
 enum nyx_hip_method {
@@ -163,9 +163,22 @@ typedef struct nyx_hip_drag {
     nyx_hip_rotation_t rotation; /* drag frame (IAU Earth) */
 } nyx_hip_drag_t;
 
+/* SolidTides (dynamics/solid_tides.rs:43-72): IERS-2010 degree-2/3 deformation of the central body raised by the
+ * perturbers, evaluated as time-varying delta-C/S on a body-fixed frame of the central body. */
+typedef struct nyx_hip_solid_tides {
+    double k2, k3;               /* Love numbers (earth_moon_system: 0.3019, 0.093; solid_tides.rs:189-218) */
+    double mu_km3_s2;            /* frame.mu_km3_s2() of the tidal (body-fixed) frame */
+    double eq_radius_km;         /* frame.mean_equatorial_radius_km() */
+    nyx_hip_rotation_t rotation; /* orientation of the tidal frame */
+    int32_t n_perturbers;
+    int32_t perturber_body[NYX_HIP_MAX_BODIES];   /* TidalPerturber.frame as an index into bodies[] (its mu is used) */
+    int32_t compute_degree_3[NYX_HIP_MAX_BODIES]; /* TidalPerturber.compute_degree_3 */
+    int32_t _pad;
+} nyx_hip_solid_tides_t;
+
 /* PropagatorConfig{dynamics, method, options}: dynamics/sequence/config.rs:96-169.
  * Model order is the reference's `Dynamics::build` order: two-body, point
- * masses, gravity field; then SRP, drag. */
+ * masses, gravity field, solid tides; then SRP, drag. */
 typedef struct nyx_hip_config {
     uint32_t abi_version; /* NYX_HIP_ABI_VERSION */
     uint32_t flags;       /* NYX_HIP_FLAG_* */
@@ -187,6 +200,8 @@ typedef struct nyx_hip_config {
     const nyx_hip_drag_t *drag;             /* NULL => none */
 
     double speed_of_light_km_s; /* anise::constants::SPEED_OF_LIGHT_KM_S (cosmic/mod.rs:179-180) */
+
+    const nyx_hip_solid_tides_t *tides; /* NULL => none (accel_models.solid_tides, config.rs:116-118) */
 } nyx_hip_config_t;
 
 /* flags */

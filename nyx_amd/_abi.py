@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 MAX_CHAIN = 4
 MAX_BODIES = 8
 MAX_SEGMENTS = 16
@@ -108,6 +108,20 @@ class Drag(C.Structure):
     ]
 
 
+class SolidTidesC(C.Structure):
+    _fields_ = [
+        ("k2", C.c_double),
+        ("k3", C.c_double),
+        ("mu_km3_s2", C.c_double),
+        ("eq_radius_km", C.c_double),
+        ("rotation", Rotation),
+        ("n_perturbers", C.c_int32),
+        ("perturber_body", C.c_int32 * MAX_BODIES),
+        ("compute_degree_3", C.c_int32 * MAX_BODIES),
+        ("_pad", C.c_int32),
+    ]
+
+
 class Config(C.Structure):
     _fields_ = [
         ("abi_version", C.c_uint32),
@@ -124,6 +138,7 @@ class Config(C.Structure):
         ("srp", C.POINTER(Srp)),
         ("drag", C.POINTER(Drag)),
         ("speed_of_light_km_s", C.c_double),
+        ("tides", C.POINTER(SolidTidesC)),
     ]
 
 
@@ -318,7 +333,8 @@ LIB_NAME = "libnyx_hip.so"
 
 
 def lib_path() -> str:
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+    """In-tree build; NYX_HIP_LIB selects another build of the same library (kernel tuning experiments)."""
+    return os.environ.get("NYX_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
 
 
 EXPORTS = [

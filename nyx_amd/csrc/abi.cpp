@@ -136,6 +136,10 @@ extern "C" int64_t nyx_hip_abi_sizeof(int32_t which) {
     case 8: return sizeof(nyx_hip_states_t);
     case 9: return sizeof(nyx_hip_step_stats_t);
     case 10: return sizeof(nyx_hip_traj_t);
+    case 11: return sizeof(nyx_hip_solid_tides_t);
+    case 12: return sizeof(nyx_hip_predict_t);
+    case 13: return sizeof(nyx_hip_predict_history_t);
+    case 14: return sizeof(nyx_hip_process_noise_t);
     default: return -1;
     }
 }
@@ -285,7 +289,7 @@ static int pick_waves(const nyx_hip_ctx *ctx, int64_t n) {
     }
     if (ctx->forced_waves > 0) return std::min(ctx->forced_waves, DEV_MAX_WAVES);
     // no harmonics: integrator + almanac + perturbation waves form a 3-stage pipeline
-    if (!ctx->host_cfg.has_grav) return (ctx->host_cfg.n_slots > 0 || ctx->host_cfg.has_drag) ? 3 : 1;
+    if (!ctx->host_cfg.has_grav) return (ctx->host_cfg.n_slots > 0 || ctx->host_cfg.has_drag || ctx->host_cfg.has_tides) ? 3 : 1;
     // Fill the 256 CUs: workgroups = ceil(n/64); with fewer than ~2 workgroups per CU the column
     // split is what creates the waves that keep the SIMDs busy.
     const int64_t wgs = (n + DEV_LANES - 1) / DEV_LANES;
@@ -349,6 +353,18 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
     if (cfg->drag && cfg->gravity && std::memcmp(&cfg->drag->rotation, &cfg->gravity->rotation, sizeof(nyx_hip_rotation_t)) != 0) {
         nyx_set_error("device path: the drag frame must be the gravity-field frame when both are present");
         return NYX_HIP_RC_UNSUPPORTED;
+    }
+    if (cfg->tides) {
+        const nyx_hip_rotation_t *other = cfg->gravity ? &cfg->gravity->rotation : (cfg->drag ? &cfg->drag->rotation : nullptr);
+        if (other && std::memcmp(&cfg->tides->rotation, other, sizeof(nyx_hip_rotation_t)) != 0) {
+            nyx_set_error("device path: the tidal frame must be the gravity-field / drag frame when they are present");
+            return NYX_HIP_RC_UNSUPPORTED;
+        }
+        if (cfg->tides->n_perturbers < 0 || cfg->tides->n_perturbers > NYX_HIP_MAX_BODIES || !(cfg->tides->mu_km3_s2 > 0.0) ||
+            !(cfg->tides->eq_radius_km > 0.0)) {
+            nyx_set_error("bad solid-tides model");
+            return NYX_HIP_RC_BAD_ARG;
+        }
     }
     if (nyx_hip_device_count() <= device || device < 0) { nyx_set_error("no HIP device %d", device); return NYX_HIP_RC_NO_DEVICE; }
     HIP_TRY(hipSetDevice(device));
@@ -417,6 +433,23 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
             dc.shadow_slot[k] = sb;
         }
     }
+    if (cfg->tides) {
+        const nyx_hip_solid_tides_t *td = cfg->tides;
+        dc.has_tides = 1;
+        dc.t_k2_5 = td->k2 / (2.0 * 2.0 + 1.0);
+        dc.t_k3_7 = td->k3 / (2.0 * 3.0 + 1.0);
+        dc.t_mu = td->mu_km3_s2; dc.t_re = td->eq_radius_km;
+        for (int k = 0; k < 3; ++k) { dc.t_rot.ra[k] = td->rotation.ra_deg[k]; dc.t_rot.dec[k] = td->rotation.dec_deg[k]; dc.t_rot.w[k] = td->rotation.w_deg[k]; }
+        for (int j = 0; j < td->n_perturbers; ++j) {
+            const int b = td->perturber_body[j];
+            const int sl = slot_for(b);
+            if (sl < 0) { delete ctx; nyx_set_error("tidal perturbers must be non-central bodies with an ephemeris (and fit the %d slots)", DEV_MAX_SLOTS); return NYX_HIP_RC_BAD_ARG; }
+            dc.t_slot[dc.t_n] = sl;
+            dc.t_deg3[dc.t_n] = td->compute_degree_3[j] ? 1 : 0;
+            dc.t_gm_ratio[dc.t_n] = cfg->bodies[b].mu_km3_s2 / td->mu_km3_s2;
+            dc.t_n++;
+        }
+    }
     // ---- segments
     if (cfg->n_segments > DEV_MAX_SEG) { delete ctx; nyx_set_error("too many ephemeris segments"); return NYX_HIP_RC_BAD_ARG; }
     std::vector<double> records;
@@ -463,7 +496,8 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
         for (int s = 0; s < dc.n_slots; ++s) nseg_eval += dc.slot[s].n_chain;
         ctx->role_handicap[0] = 15.0;
         ctx->role_handicap[1] = 12.0 * nseg_eval + (dc.has_grav ? 18.0 : 0.0);
-        ctx->role_handicap[2] = 6.0 * dc.n_pm + (dc.has_srp ? 6.0 + 6.0 * dc.n_shadow : 0.0) + (dc.has_drag ? 10.0 : 0.0);
+        ctx->role_handicap[2] = 6.0 * dc.n_pm + (dc.has_srp ? 6.0 + 6.0 * dc.n_shadow : 0.0) + (dc.has_drag ? 10.0 : 0.0) +
+                                (dc.has_tides ? 14.0 + 8.0 * dc.t_n : 0.0);
         if (const char *e = std::getenv("NYX_HIP_ROLE_HANDICAP")) {
             double h0, h1, h2;
             if (std::sscanf(e, "%lf,%lf,%lf", &h0, &h1, &h2) == 3) { ctx->role_handicap[0] = h0; ctx->role_handicap[1] = h1; ctx->role_handicap[2] = h2; }

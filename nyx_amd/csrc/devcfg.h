@@ -64,6 +64,14 @@ struct DevCfg {
     double drag_rho0, drag_r0, drag_ref_alt_m, drag_max_alt_m, drag_re;
     DevRot d_rot;
 
+    /* SolidTides (solid_tides.rs): perturber j = slot t_slot[j], GM ratio, degree-3 switch */
+    int32_t has_tides, t_n;
+    int32_t t_slot[DEV_MAX_SLOTS], t_deg3[DEV_MAX_SLOTS];
+    double t_gm_ratio[DEV_MAX_SLOTS];
+    double t_k2_5, t_k3_7; /* k2 / 5, k3 / 7 */
+    double t_mu, t_re;
+    DevRot t_rot;
+
     /* --- column schedule: wave w walks n_ranges[w] contiguous column ranges --- */
     int32_t n_waves;
     int32_t merge_roles; /* almanac and perturbation duties share wave 1 */

@@ -117,10 +117,11 @@ template <typename P>
 DEVFN int epoch_data(CfgPtr cfg, P records, int64_t epoch_ns, double *slot, int lane) {
     const double et = ns_to_seconds(epoch_ns);
     int status = NYX_HIP_OK;
-    if (cfg->has_grav || cfg->has_drag) {  // (ctx_create requires the drag frame == the gravity frame when both exist)
+    if (cfg->has_grav || cfg->has_drag || cfg->has_tides) {  // (ctx_create requires these body-fixed frames to coincide)
         double m[9];
         if (cfg->has_grav) rotation_dcm(cfg->g_rot, et, m);
-        else rotation_dcm(cfg->d_rot, et, m);
+        else if (cfg->has_drag) rotation_dcm(cfg->d_rot, et, m);
+        else rotation_dcm(cfg->t_rot, et, m);
 #pragma unroll
         for (int q = 0; q < 9; ++q) slot[q * DEV_LANES + lane] = m[q];
     }
@@ -355,6 +356,142 @@ DEVFN double gzero(double) { return 0.0; }
 DEVFN D3 gzero(D3) { return d3c(0.0); }
 DEVFN double gone(double) { return 1.0; }
 DEVFN D3 gone(D3) { return d3c(1.0); }
+DEVFN double gdiv(double a, double b) { return a / b; }
+DEVFN D3 gdiv(D3 a, D3 b) { return d3div(a, b); }
+DEVFN double gnorm3(double a, double b, double c) { return norm3(a, b, c); }
+DEVFN D3 gnorm3(D3 a, D3 b, D3 c) { return d3norm(a, b, c); }
+DEVFN double glift(double v, double) { return v; }
+DEVFN D3 glift(double v, D3) { return d3c(v); }
+
+// SolidTides (reference dynamics/solid_tides.rs): delta-C/S of degrees 2-3 raised by the perturbers
+// (TidalPerturber::compute_pert, :74-175) and the degree-3 evaluation at the spacecraft (eom :238-385; gradient
+// :387-559 when T = D3, the deltas being functions of the epoch only).  `ed` holds this stage's DCM inertial ->
+// body-fixed and the perturber positions.  r and acc are inertial; with T = D3 the partials are w.r.t. inertial r.
+// The derived-Legendre table is walked column by column (only the 11 entries the two degrees touch are formed).
+template <typename T>
+DEVFN void tides_accel(CfgPtr cfg, const double *ed, int lane, const T (&r)[3], T (&acc)[3]) {
+    double m[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) m[q] = ed[q * DEV_LANES + lane];
+    double c2[3] = {0.0, 0.0, 0.0}, s2[3] = {0.0, 0.0, 0.0}, c3[4] = {0.0, 0.0, 0.0, 0.0}, s3[4] = {0.0, 0.0, 0.0, 0.0};
+    const int np = cfg->t_n;
+#pragma unroll
+    for (int j = 0; j < DEV_MAX_SLOTS; ++j) {
+        if (j < np) {
+            const int sl = cfg->t_slot[j];
+            const double p0 = ED_BP(ed, sl, 0), p1 = ED_BP(ed, sl, 1), p2 = ED_BP(ed, sl, 2);
+            const double b0 = m[0] * p0 + m[1] * p1 + m[2] * p2;
+            const double b1 = m[3] * p0 + m[4] * p1 + m[5] * p2;
+            const double b2 = m[6] * p0 + m[7] * p1 + m[8] * p2;
+            const double r_body = norm3(b0, b1, b2);
+            const double s_body = b0 / r_body, t_body = b1 / r_body, sin_phi = b2 / r_body;
+            const double cos_phi = sqrt(fmax(1.0 - sin_phi * sin_phi, 0.0));
+            const double cl = cos_phi > 1e-12 ? s_body / cos_phi : 1.0;
+            const double sn = cos_phi > 1e-12 ? t_body / cos_phi : 0.0;
+            const double gm = cfg->t_gm_ratio[j];
+            const double rr = cfg->t_re / r_body;
+            const double cl2 = cl * cl, sn2 = sn * sn;
+            const double cos2 = cl2 - sn2, sin2 = 2.0 * sn * cl;
+            {
+                const double common = cfg->t_k2_5 * gm * powi_dev(rr, 3);
+                const double p20 = 0.5 * (3.0 * (sin_phi * sin_phi) - 1.0) * sqrt(5.0);
+                const double p21 = 3.0 * sin_phi * cos_phi * sqrt(5.0 / 3.0);
+                const double p22 = 3.0 * (cos_phi * cos_phi) * sqrt(5.0 / 12.0);
+                c2[0] += common * p20;
+                c2[1] += common * p21 * cl;  s2[1] += common * p21 * sn;
+                c2[2] += common * p22 * cos2; s2[2] += common * p22 * sin2;
+            }
+            if (cfg->t_deg3[j]) {
+                const double common = cfg->t_k3_7 * gm * powi_dev(rr, 4);
+                const double p30 = 0.5 * (5.0 * powi_dev(sin_phi, 3) - 3.0 * sin_phi) * sqrt(7.0);
+                const double p31 = 1.5 * (5.0 * (sin_phi * sin_phi) - 1.0) * cos_phi * sqrt(7.0 / 6.0);
+                const double p32 = 15.0 * sin_phi * (cos_phi * cos_phi) * sqrt(7.0 / 60.0);
+                const double p33 = 15.0 * powi_dev(cos_phi, 3) * sqrt(7.0 / 360.0);
+                const double cos3 = cl * (cl2 - 3.0 * sn2), sin3 = sn * (3.0 * cl2 - sn2);
+                c3[0] += common * p30;
+                c3[1] += common * p31 * cl;   s3[1] += common * p31 * sn;
+                c3[2] += common * p32 * cos2; s3[2] += common * p32 * sin2;
+                c3[3] += common * p33 * cos3; s3[3] += common * p33 * sin3;
+            }
+        }
+    }
+    // ---- spacecraft side
+    const T rb0 = r[0] * m[0] + r[1] * m[1] + r[2] * m[2];
+    const T rb1 = r[0] * m[3] + r[1] * m[4] + r[2] * m[5];
+    const T rb2 = r[0] * m[6] + r[1] * m[7] + r[2] * m[8];
+    const T rmag = gnorm3(rb0, rb1, rb2);
+    const T s_ = gdiv(rb0, rmag), t_ = gdiv(rb1, rmag), u_ = gdiv(rb2, rmag);
+    // diagonal a[n][n] = sqrt(1 + 1/(2n)) a[n-1][n-1]: position-independent
+    const double d1 = sqrt(1.5), d2 = sqrt(1.25) * d1, d3 = sqrt(1.0 + 1.0 / 6.0) * d2, d4 = sqrt(1.125) * d3;
+    // b(n, m), c(n, m) of solid_tides.rs:266-276
+#define TB(n, m) sqrt(((2.0 * (n) + 1.0) * (2.0 * (n) - 1.0)) / (((n) + (m)) * (double)((n) - (m))))
+#define TC(n, m) sqrt(((2.0 * (n) + 1.0) * ((n) + (m) - 1.0) * ((n) - (m) - 1.0)) / (((n) - (m)) * (double)((n) + (m)) * (2.0 * (n) - 3.0)))
+    // (column 0 never enters: m * a[n][0] = 0, and the z / w sums read columns m + 1)
+    const T a21 = u_ * (sqrt(5.0) * d1);
+    const T a31 = (u_ * TB(3, 1)) * a21 - glift(TC(3, 1) * d1, u_);
+    const T a41 = (u_ * TB(4, 1)) * a31 - a21 * TC(4, 1);
+    const T a32 = u_ * (sqrt(7.0) * d2);
+    const T a42 = (u_ * TB(4, 2)) * a32 - glift(TC(4, 2) * d2, u_);
+    const T a43 = u_ * (3.0 * d3);
+#undef TB
+#undef TC
+    const T r2 = s_ * s_ - t_ * t_, i2 = s_ * t_ + t_ * s_;
+    const T r3 = s_ * r2 - t_ * i2, i3 = s_ * i2 + t_ * r2;
+    const double SQ2 = 1.41421356237309504880;
+    // vr01(n, m) = sqrt((n-m)(n+m+1)) [/ sqrt2 for m = 0], vr11(n, m) = sqrt((2n+1)(n+m+2)(n+m+1)/(2n+3)) [/ sqrt2]
+#define VR01(n, m) (sqrt(((n) - (m)) * ((n) + (m) + 1.0)) / ((m) == 0 ? SQ2 : 1.0))
+#define VR11(n, m) (sqrt(((2.0 * (n) + 1.0) * ((n) + (m) + 2.0) * ((n) + (m) + 1.0)) / (2.0 * (n) + 3.0)) / ((m) == 0 ? SQ2 : 1.0))
+    // degree 2
+    T x2, y2, z2, w2;
+    {
+        const T dd0 = glift(c2[0] * SQ2, u_);                                   // (C r_0 + S i_0) sqrt2, r_0 = 1, i_0 = 0
+        const T dd1 = (s_ * c2[1] + t_ * s2[1]) * SQ2;
+        const T dd2 = (r2 * c2[2] + i2 * s2[2]) * SQ2;
+        const double e1 = c2[1] * SQ2, f1 = s2[1] * SQ2;                        // m = 1: r_0, i_0
+        const T e2 = (s_ * c2[2] + t_ * s2[2]) * SQ2, f2 = (s_ * s2[2] - t_ * c2[2]) * SQ2;
+        x2 = a21 * e1 + e2 * (2.0 * d2);                                        // sum m a[2][m] e_m, a22 = d2
+        y2 = a21 * f1 + f2 * (2.0 * d2);
+        z2 = a21 * dd0 * VR01(2, 0) + dd1 * (VR01(2, 1) * d2);                  // a[2][3] = 0
+        w2 = -(a31 * dd0 * VR11(2, 0) + a32 * dd1 * VR11(2, 1) + dd2 * (VR11(2, 2) * d3));
+    }
+    // degree 3
+    T x3, y3, z3, w3;
+    {
+        const T dd0 = glift(c3[0] * SQ2, u_);
+        const T dd1 = (s_ * c3[1] + t_ * s3[1]) * SQ2;
+        const T dd2 = (r2 * c3[2] + i2 * s3[2]) * SQ2;
+        const T dd3 = (r3 * c3[3] + i3 * s3[3]) * SQ2;
+        const double e1 = c3[1] * SQ2, f1 = s3[1] * SQ2;
+        const T e2 = (s_ * c3[2] + t_ * s3[2]) * SQ2, f2 = (s_ * s3[2] - t_ * c3[2]) * SQ2;
+        const T e3 = (r2 * c3[3] + i2 * s3[3]) * SQ2, f3 = (r2 * s3[3] - i2 * c3[3]) * SQ2;
+        x3 = a31 * e1 + a32 * e2 * 2.0 + e3 * (3.0 * d3);
+        y3 = a31 * f1 + a32 * f2 * 2.0 + f3 * (3.0 * d3);
+        z3 = a31 * dd0 * VR01(3, 0) + a32 * dd1 * VR01(3, 1) + dd2 * (VR01(3, 2) * d3);   // a[3][4] = 0
+        w3 = -(a41 * dd0 * VR11(3, 0) + a42 * dd1 * VR11(3, 1) + a43 * dd2 * VR11(3, 2) + dd3 * (VR11(3, 3) * d4));
+    }
+#undef VR01
+#undef VR11
+    const T rho = gdiv(glift(cfg->t_re, u_), rmag);
+    const T rho3 = gdiv(glift(cfg->t_mu, u_), rmag) * rho * rho * rho;  // rho_np1 at n = 2
+    const T rho4 = rho3 * rho;
+    const double inv_re = 1.0 / cfg->t_re;
+    const T k2 = rho3 * inv_re, k3 = rho4 * inv_re;
+    const T ax = k2 * x2 + k3 * x3, ay = k2 * y2 + k3 * y3, az = k2 * z2 + k3 * z3, aw = k2 * w2 + k3 * w3;
+    const T l0 = ax + aw * s_, l1 = ay + aw * t_, l2 = az + aw * u_;
+    acc[0] = l0 * m[0] + l1 * m[3] + l2 * m[6];
+    acc[1] = l0 * m[1] + l1 * m[4] + l2 * m[7];
+    acc[2] = l0 * m[2] + l1 * m[5] + l2 * m[8];
+}
+
+// Out of line on purpose (like harmonics_partial): inlined, the model's ~60 live doubles perturb the register
+// allocation of the whole perturbation role and cost 3 % of the north-star run even when no tides are configured.
+static __device__ __attribute__((noinline)) void tides_into_pert(CfgPtr cfg, const double *ed, int lane, const double *ys, double *pert) {
+    const double r[3] = {ys[0 * DEV_LANES + lane], ys[1 * DEV_LANES + lane], ys[2 * DEV_LANES + lane]};
+    double a[3];
+    tides_accel<double>(cfg, ed, lane, r, a);
+#pragma unroll
+    for (int e = 0; e < 3; ++e) pert[e * DEV_LANES + lane] = pert[e * DEV_LANES + lane] + a[e];
+}
 
 template <typename T>
 DEVFN void cpow_uniform(T zr, T zi, int e, T &pr, T &pi) {
@@ -575,7 +712,7 @@ static __device__ __attribute__((noinline)) Partial4 fold_partials(LdsCPtr part,
 // PointMasses::gradient (orbital.rs:249-308) and SolarPressure::gradient (solarpressure.rs:167-232, k frozen).
 // out[27][64]: a_pm(3), G_pm(9 row-major), f_srp/m(3), G_srp/m(9), c = (F/Cr)/m (3, zero unless `estimate`).
 DEVFN void pert_gradients(CfgPtr cfg, const double *ed, int lane, const double *r, double cr, double area, double mass,
-                          bool has_pm, bool has_srp, double *out) {
+                          bool has_pm, bool has_srp, bool has_tides, double *out) {
     double o[27];
 #pragma unroll
     for (int q = 0; q < 27; ++q) o[q] = 0.0;
@@ -597,6 +734,16 @@ DEVFN void pert_gradients(CfgPtr cfg, const double *ed, int lane, const double *
                     o[3 + 3 * i + 0] += t.x; o[3 + 3 * i + 1] += t.y; o[3 + 3 * i + 2] += t.z;
                 }
             }
+        }
+    }
+    if (has_tides) {  // SolidTides::gradient: added to the orbital (point-mass) block
+        const D3 rd[3] = {{r[0], 1.0, 0.0, 0.0}, {r[1], 0.0, 1.0, 0.0}, {r[2], 0.0, 0.0, 1.0}};
+        D3 at[3];
+        tides_accel<D3>(cfg, ed, lane, rd, at);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            o[i] += at[i].v;
+            o[3 + 3 * i + 0] += at[i].x; o[3 + 3 * i + 1] += at[i].y; o[3 + 3 * i + 2] += at[i].z;
         }
     }
     if (has_srp) {
@@ -778,7 +925,12 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     const bool has_srp = cfg->has_srp != 0;
     const bool has_pm = cfg->n_pm > 0;
     const bool has_drag = cfg->has_drag != 0;
-    const bool need_almanac = has_grav || has_drag || cfg->n_slots > 0;
+#ifdef NYX_NO_TIDES
+    const bool has_tides = false;
+#else
+    const bool has_tides = cfg->has_tides != 0;
+#endif
+    const bool need_almanac = has_grav || has_drag || has_tides || cfg->n_slots > 0;
     const bool rec_in_lds = cfg->rec_in_lds != 0;
     const bool dbg_skip_serial = (cfg->flags & DBG_SKIP_SERIAL) != 0;
     const bool dbg_skip_harm = (cfg->flags & DBG_SKIP_HARMONICS) != 0;
@@ -963,7 +1115,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     st = rec_in_lds ? epoch_data(cfg, (const double *)L.rec, ep, edn, lane) : epoch_data(cfg, records, ep, edn, lane);
                 L.edst[((i + 1) & 1) * DEV_LANES + lane] = st;
             }
-            if (PERT && (has_pm || has_srp || has_drag)) {
+            if (PERT && (has_pm || has_srp || has_drag || has_tides)) {
                 // position-dependent third-body and SRP terms of THIS stage
                 double r[3] = {L.ys[0 * DEV_LANES + lane], L.ys[1 * DEV_LANES + lane], L.ys[2 * DEV_LANES + lane]};
                 double a3[3] = {0.0, 0.0, 0.0}, f3[3] = {0.0, 0.0, 0.0};
@@ -982,7 +1134,10 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
 #pragma unroll
                     for (int e = 0; e < 3; ++e) L.pert[(6 + e) * DEV_LANES + lane] = d3f[e] / p_mass;
                 }
-                if (STM) pert_gradients(cfg, edc, lane, r, p_cr, p_area, p_mass, has_pm, has_srp, L.pertD);
+                if (STM) pert_gradients(cfg, edc, lane, r, p_cr, p_area, p_mass, has_pm, has_srp, has_tides, L.pertD);
+                // third accel model (dynamics/sequence/config.rs:116-118): added to the point-mass slot, last, so that no
+                // live value of this role crosses the call
+                if (has_tides && !STM) tides_into_pert(cfg, edc, lane, L.ys, L.pert);
             }
             double acc[3] = {0.0, 0.0, 0.0};
             if (INTEG) {
@@ -1034,7 +1189,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
 
             if (INTEG) {
                 // ---- Phase C: assemble the derivative in the reference's order (orbital.rs:80-114, spacecraft.rs:227-243)
-                if (!STM && has_pm) {
+                if (!STM && (has_pm || has_tides)) {
                     acc[0] += L.pert[0 * DEV_LANES + lane]; acc[1] += L.pert[1 * DEV_LANES + lane]; acc[2] += L.pert[2 * DEV_LANES + lane];
                 }
                 if (!STM && has_grav) {
@@ -1067,7 +1222,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                         const D3 a = rad[q] * fac;
                         acc[q] = a.v; G[3 * q + 0] = a.x; G[3 * q + 1] = a.y; G[3 * q + 2] = a.z;
                     }
-                    if (has_pm) {
+                    if (has_pm || has_tides) {
 #pragma unroll
                         for (int q = 0; q < 3; ++q) acc[q] += L.pertD[q * DEV_LANES + lane];
 #pragma unroll

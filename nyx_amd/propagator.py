@@ -308,6 +308,29 @@ class Drag:
 
 
 @dataclass
+class TidalPerturber:
+    """solid_tides.rs:65-72: the body raising the tide (NAIF id; its GM comes from the almanac's planetary data)."""
+
+    naif_id: int
+    compute_degree_3: bool
+
+
+@dataclass
+class SolidTides:
+    """solid_tides.rs:43-63: IERS-2010 solid tides of the central body; `frame` is its body-fixed frame."""
+
+    frame: Frame
+    k2: float
+    k3: float
+    perturbers: List[TidalPerturber]
+
+    @classmethod
+    def earth_moon_system(cls, earth_frame: Frame, moon_id: int = 301, sun_id: int = 10):
+        """solid_tides.rs:181-219: Moon (degrees 2 and 3) and Sun (degree 2), k2 = 0.3019, k3 = 0.093."""
+        return cls(earth_frame, 0.3019, 0.093, [TidalPerturber(moon_id, True), TidalPerturber(sun_id, False)])
+
+
+@dataclass
 class OrbitalDynamics:
     accel_models: list = field(default_factory=list)
 
@@ -429,11 +452,12 @@ def compile_config(dynamics: SpacecraftDynamics, method: IntegratorMethod, opts:
     gf = [m for m in dynamics.orbital_dyn.accel_models if isinstance(m, GravityFieldData)]
     srp = [m for m in dynamics.force_models if isinstance(m, SolarPressure)]
     drag = [m for m in dynamics.force_models if isinstance(m, Drag)]
-    if len(pm) > 1 or len(gf) > 1 or len(srp) > 1 or len(drag) > 1:
+    tides = [m for m in dynamics.orbital_dyn.accel_models if isinstance(m, SolidTides)]
+    if len(pm) > 1 or len(gf) > 1 or len(srp) > 1 or len(drag) > 1 or len(tides) > 1:
         raise NotImplementedError("the device path takes at most one model of each kind")
-    known = len(pm) + len(gf)
+    known = len(pm) + len(gf) + len(tides)
     if known != len(dynamics.orbital_dyn.accel_models) or len(srp) + len(drag) != len(dynamics.force_models):
-        raise NotImplementedError("unsupported model on the device path (guidance/solid tides fall back to the CPU reference)")
+        raise NotImplementedError("unsupported model on the device path (guidance laws fall back to the CPU reference)")
 
     cfg.n_point_masses = 0
     if pm:
@@ -475,6 +499,23 @@ def compile_config(dynamics: SpacecraftDynamics, method: IntegratorMethod, opts:
         fill_rot(gs.rotation, g.frame.rotation)
         keep.append(gs)
         cfg.gravity = C.pointer(gs)
+
+    if tides:
+        t = tides[0]
+        if t.frame.naif_id != central.naif_id:
+            raise NotImplementedError("solid tides of a non-central body are not on the device path")
+        ts = _abi.SolidTidesC()
+        ts.k2, ts.k3 = float(t.k2), float(t.k3)
+        ts.mu_km3_s2, ts.eq_radius_km = float(t.frame.mu_km3_s2), float(t.frame.mean_equatorial_radius_km)
+        fill_rot(ts.rotation, t.frame.rotation)
+        if len(t.perturbers) > _abi.MAX_BODIES:
+            raise ValueError("too many tidal perturbers")
+        ts.n_perturbers = len(t.perturbers)
+        for k, pert in enumerate(t.perturbers):
+            ts.perturber_body[k] = body_of(pert.naif_id)
+            ts.compute_degree_3[k] = int(bool(pert.compute_degree_3))
+        keep.append(ts)
+        cfg.tides = C.pointer(ts)
 
     if drag:
         d = drag[0]

@@ -453,6 +453,217 @@ static void gravity_gradient(const nyx_hip_gravity_field_t *g, const grav_tables
 }
 
 /* ------------------------------------------------------------------------- */
+/* SolidTides, dynamics/solid_tides.rs:65-559                                   */
+/* ------------------------------------------------------------------------- */
+
+/* TidalPerturber::compute_pert (:74-175) for every perturber (accumulate_deltas :221-235) */
+static int tides_deltas(const nyx_hip_config_t *cfg, double et_s, const double dcm[3][3], double dc[4][4], double ds[4][4]) {
+    const nyx_hip_solid_tides_t *td = cfg->tides;
+    memset(dc, 0, 16 * sizeof(double));
+    memset(ds, 0, 16 * sizeof(double));
+    for (int j = 0; j < td->n_perturbers; ++j) {
+        const int b = td->perturber_body[j];
+        double pin[3], rb[3];
+        int st = body_position(cfg, b, et_s, pin);
+        if (st) return st;
+        /* almanac.transform(perturber, tidal frame): origin of the perturber seen in the body-fixed frame */
+        for (int i = 0; i < 3; ++i) rb[i] = dcm[i][0] * pin[0] + dcm[i][1] * pin[1] + dcm[i][2] * pin[2];
+        const double r_body = norm3(rb);
+        const double s_body = rb[0] / r_body, t_body = rb[1] / r_body, u_body = rb[2] / r_body;
+        const double sin_phi = u_body;
+        const double cos_phi = sqrt(fmax(1.0 - powi_(sin_phi, 2), 0.0));
+        const double cos_lambda = cos_phi > 1e-12 ? s_body / cos_phi : 1.0;
+        const double sin_lambda = cos_phi > 1e-12 ? t_body / cos_phi : 0.0;
+        const double p2[3] = {0.5 * (3.0 * powi_(sin_phi, 2) - 1.0) * sqrt(5.0), 3.0 * sin_phi * cos_phi * sqrt(5.0 / 3.0),
+                              3.0 * powi_(cos_phi, 2) * sqrt(5.0 / 12.0)};
+        const double p3[4] = {0.5 * (5.0 * powi_(sin_phi, 3) - 3.0 * sin_phi) * sqrt(7.0),
+                              1.5 * (5.0 * powi_(sin_phi, 2) - 1.0) * cos_phi * sqrt(7.0 / 6.0),
+                              15.0 * sin_phi * powi_(cos_phi, 2) * sqrt(7.0 / 60.0), 15.0 * powi_(cos_phi, 3) * sqrt(7.0 / 360.0)};
+        const double gm_ratio = cfg->bodies[b].mu_km3_s2 / td->mu_km3_s2;
+        const double r_ratio = td->eq_radius_km / r_body;
+        const int top = td->compute_degree_3[j] ? 3 : 2;
+        for (int n = 2; n <= top; ++n) {
+            const double kn = n == 2 ? td->k2 : td->k3;
+            const double common = kn / (2.0 * (double)n + 1.0) * gm_ratio * powi_(r_ratio, n + 1);
+            for (int m = 0; m <= n; ++m) {
+                const double p_nm = n == 2 ? p2[m] : p3[m];
+                double cos_ml, sin_ml;
+                switch (m) {
+                case 0: cos_ml = 1.0; sin_ml = 0.0; break;
+                case 1: cos_ml = cos_lambda; sin_ml = sin_lambda; break;
+                case 2: cos_ml = powi_(cos_lambda, 2) - powi_(sin_lambda, 2); sin_ml = 2.0 * sin_lambda * cos_lambda; break;
+                default:
+                    cos_ml = cos_lambda * (powi_(cos_lambda, 2) - 3.0 * powi_(sin_lambda, 2));
+                    sin_ml = sin_lambda * (3.0 * powi_(cos_lambda, 2) - powi_(sin_lambda, 2));
+                }
+                dc[n][m] += common * p_nm * cos_ml;
+                ds[n][m] += common * p_nm * sin_ml;
+            }
+        }
+    }
+    return NYX_HIP_OK;
+}
+
+static double tide_b(int n, int m) {
+    const double nf = n, mf = m;
+    return sqrt(((2.0 * nf + 1.0) * (2.0 * nf - 1.0)) / ((nf + mf) * (nf - mf)));
+}
+static double tide_c(int n, int m) {
+    const double nf = n, mf = m;
+    return sqrt(((2.0 * nf + 1.0) * (nf + mf - 1.0) * (nf - mf - 1.0)) / ((nf - mf) * (nf + mf) * (2.0 * nf - 3.0)));
+}
+static double tide_vr01(int n, int m) {
+    double v = sqrt(((double)n - (double)m) * ((double)n + (double)m + 1.0));
+    if (m == 0) v /= sqrt(2.0);
+    return v;
+}
+static double tide_vr11(int n, int m) {
+    const double nf = n, mf = m;
+    double v = sqrt(((2.0 * nf + 1.0) * (nf + mf + 2.0) * (nf + mf + 1.0)) / (2.0 * nf + 3.0));
+    if (m == 0) v /= sqrt(2.0);
+    return v;
+}
+
+/* SolidTides::eom (:238-385) */
+static int tides_eom(const nyx_hip_config_t *cfg, double et_s, const double *r_in, double *acc) {
+    const nyx_hip_solid_tides_t *td = cfg->tides;
+    double dcm[3][3], dc[4][4], ds[4][4];
+    rotation_dcm(&td->rotation, et_s, dcm);
+    int st = tides_deltas(cfg, et_s, dcm, dc, ds);
+    if (st) return st;
+    double rb[3];
+    for (int i = 0; i < 3; ++i) rb[i] = dcm[i][0] * r_in[0] + dcm[i][1] * r_in[1] + dcm[i][2] * r_in[2];
+    const double r_ = norm3(rb);
+    const double s_ = rb[0] / r_, t_ = rb[1] / r_, u_ = rb[2] / r_;
+    double a[6][6];
+    memset(a, 0, sizeof a);
+    a[0][0] = 1.0;
+    for (int n = 1; n <= 4; ++n) a[n][n] = sqrt(1.0 + 1.0 / (2.0 * (double)n)) * a[n - 1][n - 1];
+    a[1][0] = u_ * sqrt(3.0);
+    for (int n = 1; n <= 4; ++n) a[n + 1][n] = sqrt(2.0 * (double)n + 3.0) * u_ * a[n][n];
+    for (int m = 0; m <= 3; ++m)
+        for (int n = m + 2; n <= 4; ++n) a[n][m] = u_ * tide_b(n, m) * a[n - 1][m] - tide_c(n, m) * a[n - 2][m];
+    double rm[4], im[4];
+    rm[0] = 1.0; im[0] = 0.0;
+    for (int m = 1; m <= 3; ++m) {
+        rm[m] = s_ * rm[m - 1] - t_ * im[m - 1];
+        im[m] = s_ * im[m - 1] + t_ * rm[m - 1];
+    }
+    const double rho = td->eq_radius_km / r_;
+    double rho_np1 = td->mu_km3_s2 / r_ * rho;
+    double a4[4] = {0, 0, 0, 0};
+    const double sqrt2 = sqrt(2.0);
+    for (int n = 1; n <= 3; ++n) {
+        rho_np1 *= rho;
+        if (n < 2) continue;
+        double sum[4] = {0, 0, 0, 0};
+        for (int m = 0; m <= n; ++m) {
+            const double c_val = dc[n][m], s_val = ds[n][m];
+            const double d_ = (c_val * rm[m] + s_val * im[m]) * sqrt2;
+            const double e_ = m == 0 ? 0.0 : (c_val * rm[m - 1] + s_val * im[m - 1]) * sqrt2;
+            const double f_ = m == 0 ? 0.0 : (s_val * rm[m - 1] - c_val * im[m - 1]) * sqrt2;
+            sum[0] += (double)m * a[n][m] * e_;
+            sum[1] += (double)m * a[n][m] * f_;
+            sum[2] += tide_vr01(n, m) * a[n][m + 1] * d_;
+            sum[3] -= tide_vr11(n, m) * a[n + 1][m + 1] * d_;
+        }
+        const double k = rho_np1 / td->eq_radius_km;
+        for (int q = 0; q < 4; ++q) a4[q] += k * sum[q];
+    }
+    const double al[3] = {a4[0] + a4[3] * s_, a4[1] + a4[3] * t_, a4[2] + a4[3] * u_};
+    /* almanac.rotate(tidal frame -> integration frame) = dcm^T */
+    for (int i = 0; i < 3; ++i) acc[i] = dcm[0][i] * al[0] + dcm[1][i] * al[1] + dcm[2][i] * al[2];
+    return NYX_HIP_OK;
+}
+
+/* SolidTides::gradient (:387-559): the same evaluation on position duals, deltas constant */
+static int tides_gradient(const nyx_hip_config_t *cfg, double et_s, const double *r_in, double *acc, double grad[3][3]) {
+    const nyx_hip_solid_tides_t *td = cfg->tides;
+    double dcm[3][3], dc[4][4], ds[4][4];
+    rotation_dcm(&td->rotation, et_s, dcm);
+    int st = tides_deltas(cfg, et_s, dcm, dc, ds);
+    if (st) return st;
+    double rb[3];
+    for (int i = 0; i < 3; ++i) rb[i] = dcm[i][0] * r_in[0] + dcm[i][1] * r_in[1] + dcm[i][2] * r_in[2];
+    d3 rad[3];
+    for (int i = 0; i < 3; ++i) { rad[i] = d3c(rb[i]); rad[i].d[i] = 1.0; }
+    const d3 r_ = d3norm(rad);
+    const d3 s_ = d3div(rad[0], r_), t_ = d3div(rad[1], r_), u_ = d3div(rad[2], r_);
+    d3 a[6][6];
+    for (int i = 0; i < 6; ++i)
+        for (int j = 0; j < 6; ++j) a[i][j] = d3c(0.0);
+    a[0][0] = d3c(1.0);
+    for (int n = 1; n <= 4; ++n) a[n][n] = d3mul(d3c(sqrt(1.0 + 1.0 / (2.0 * (double)n))), a[n - 1][n - 1]);
+    a[1][0] = d3mul(u_, d3c(sqrt(3.0)));
+    for (int n = 1; n <= 4; ++n) a[n + 1][n] = d3mul(d3mul(d3c(sqrt(2.0 * (double)n + 3.0)), u_), a[n][n]);
+    for (int m = 0; m <= 3; ++m)
+        for (int n = m + 2; n <= 4; ++n)
+            a[n][m] = d3sub(d3mul(d3mul(u_, d3c(tide_b(n, m))), a[n - 1][m]), d3mul(d3c(tide_c(n, m)), a[n - 2][m]));
+    d3 rm[4], im[4];
+    rm[0] = d3c(1.0); im[0] = d3c(0.0);
+    for (int m = 1; m <= 3; ++m) {
+        rm[m] = d3sub(d3mul(s_, rm[m - 1]), d3mul(t_, im[m - 1]));
+        im[m] = d3add(d3mul(s_, im[m - 1]), d3mul(t_, rm[m - 1]));
+    }
+    const d3 eq = d3c(td->eq_radius_km);
+    const d3 rho = d3div(eq, r_);
+    d3 rho_np1 = d3mul(d3div(d3c(td->mu_km3_s2), r_), rho);
+    d3 a0 = d3c(0.0), a1 = d3c(0.0), a2 = d3c(0.0), a3 = d3c(0.0);
+    const d3 sqrt2 = d3c(sqrt(2.0));
+    for (int n = 1; n <= 3; ++n) {
+        rho_np1 = d3mul(rho_np1, rho);
+        if (n < 2) continue;
+        d3 s0 = d3c(0.0), s1 = d3c(0.0), s2 = d3c(0.0), s3 = d3c(0.0);
+        for (int m = 0; m <= n; ++m) {
+            const d3 c_val = d3c(dc[n][m]), s_val = d3c(ds[n][m]);
+            const d3 d_ = d3mul(d3add(d3mul(c_val, rm[m]), d3mul(s_val, im[m])), sqrt2);
+            const d3 e_ = m == 0 ? d3c(0.0) : d3mul(d3add(d3mul(c_val, rm[m - 1]), d3mul(s_val, im[m - 1])), sqrt2);
+            const d3 f_ = m == 0 ? d3c(0.0) : d3mul(d3sub(d3mul(s_val, rm[m - 1]), d3mul(c_val, im[m - 1])), sqrt2);
+            s0 = d3add(s0, d3mul(d3mul(d3c((double)m), a[n][m]), e_));
+            s1 = d3add(s1, d3mul(d3mul(d3c((double)m), a[n][m]), f_));
+            s2 = d3add(s2, d3mul(d3mul(d3c(tide_vr01(n, m)), a[n][m + 1]), d_));
+            s3 = d3add(s3, d3mul(d3mul(d3c(tide_vr11(n, m)), a[n + 1][m + 1]), d_));
+        }
+        const d3 rr = d3div(rho_np1, eq);
+        a0 = d3add(a0, d3mul(rr, s0));
+        a1 = d3add(a1, d3mul(rr, s1));
+        a2 = d3add(a2, d3mul(rr, s2));
+        a3 = d3sub(a3, d3mul(rr, s3));
+    }
+    const d3 al[3] = {d3add(a0, d3mul(a3, s_)), d3add(a1, d3mul(a3, t_)), d3add(a2, d3mul(a3, u_))};
+    for (int i = 0; i < 3; ++i) acc[i] = dcm[0][i] * al[0].v + dcm[1][i] * al[1].v + dcm[2][i] * al[2].v;
+    double tmp[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) tmp[i][j] = dcm[0][i] * al[0].d[j] + dcm[1][i] * al[1].d[j] + dcm[2][i] * al[2].d[j];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) grad[i][j] = tmp[i][0] * dcm[0][j] + tmp[i][1] * dcm[1][j] + tmp[i][2] * dcm[2][j];
+    return NYX_HIP_OK;
+}
+
+int32_t nyx_oracle_tides_accel(const nyx_hip_config_t *cfg, int64_t epoch_ns, const double *r3, double *a3, double *grad9_rowmajor,
+                               double *dc16, double *ds16) {
+    if (!cfg || !cfg->tides) return NYX_HIP_RC_BAD_ARG;
+    const double et = nyx_oracle_ns_to_seconds(epoch_ns);
+    int st = tides_eom(cfg, et, r3, a3);
+    if (st) return st;
+    if (grad9_rowmajor) {
+        double acc[3], g[3][3];
+        st = tides_gradient(cfg, et, r3, acc, g);
+        if (st) return st;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) grad9_rowmajor[3 * i + j] = g[i][j];
+    }
+    if (dc16 && ds16) {
+        double dcm[3][3], dc[4][4], ds[4][4];
+        rotation_dcm(&cfg->tides->rotation, et, dcm);
+        st = tides_deltas(cfg, et, dcm, dc, ds);
+        memcpy(dc16, dc, sizeof dc);
+        memcpy(ds16, ds, sizeof ds);
+    }
+    return st;
+}
+
+/* ------------------------------------------------------------------------- */
 /* Osculating spacecraft rebuilt from the state vector                         */
 /* (Spacecraft::set, cosmic/spacecraft.rs:477-497)                             */
 /* ------------------------------------------------------------------------- */
@@ -690,6 +901,15 @@ static int dual_eom(const prepared_t *p, double et_s, const double *y9, const sc
             for (int j = 0; j < 3; ++j) G(i + 3, j) += g3[i][j];
         }
     }
+    if (cfg->tides) {
+        double acc[3], g3[3][3];
+        int st = tides_gradient(cfg, et_s, r, acc, g3);
+        if (st) return st;
+        for (int i = 0; i < 3; ++i) {
+            fx[i + 3] += acc[i];
+            for (int j = 0; j < 3; ++j) G(i + 3, j) += g3[i][j];
+        }
+    }
     /* force models (spacecraft.rs:339-360) */
     const double cr = clamp02(y9[6]);
     const double total_mass = sc->dry + y9[8] + sc->extra;
@@ -752,6 +972,12 @@ static int sc_eom(const prepared_t *p, int64_t ctx_epoch_ns, double dt_s, const 
     if (cfg->gravity) {
         double a[3];
         gravity_eom(cfg->gravity, &p->gt, et_s, r, a, w->a_work, w->rm, w->im);
+        for (int c = 0; c < 3; ++c) dy[3 + c] += a[c];
+    }
+    if (cfg->tides) { /* third accel model of Dynamics::build (dynamics/sequence/config.rs:105-118) */
+        double a[3];
+        int st = tides_eom(cfg, et_s, r, a);
+        if (st) return st;
         for (int c = 0; c < 3; ++c) dy[3 + c] += a[c];
     }
     if (cfg->srp) {

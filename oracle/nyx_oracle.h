@@ -51,6 +51,9 @@ int32_t nyx_oracle_dual_eom(const nyx_hip_config_t *cfg, int64_t epoch_ns, const
 void nyx_oracle_body_position(const nyx_hip_config_t *cfg, int32_t body, int64_t epoch_ns, double *r3, int32_t *status);
 void nyx_oracle_rotation_dcm(const nyx_hip_rotation_t *rot, int64_t epoch_ns, double *dcm9_rowmajor);
 void nyx_oracle_gravity_accel(const nyx_hip_gravity_field_t *g, int64_t epoch_ns, const double *r3, double *a3);
+/* SolidTides::eom / gradient (dynamics/solid_tides.rs:238-559); grad and the delta tables ([n][m], 4x4) are optional. */
+int32_t nyx_oracle_tides_accel(const nyx_hip_config_t *cfg, int64_t epoch_ns, const double *r3, double *a3, double *grad9_rowmajor,
+                               double *dc16, double *ds16);
 double nyx_oracle_occultation_factor(const nyx_hip_config_t *cfg, int32_t eclipsing_body, int32_t sun_body,
                                      int64_t epoch_ns, const double *r3, int32_t *status);
 double nyx_oracle_error_estimate(int32_t error_ctrl, int32_t nv, const double *err, const double *cand, const double *cur);

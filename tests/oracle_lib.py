@@ -53,6 +53,9 @@ def load():
     lib.nyx_oracle_predict_until.argtypes = [C.POINTER(_abi.Config), C.POINTER(_abi.States), C.POINTER(_abi.Predict), C.POINTER(_abi.Estimates),
                                              C.POINTER(_abi.States), C.POINTER(_abi.StepStats), C.POINTER(_abi.PredictHistory)]
     lib.nyx_oracle_predict_until.restype = C.c_int32
+    lib.nyx_oracle_tides_accel.argtypes = [C.POINTER(_abi.Config), C.c_int64, _abi.c_double_p, _abi.c_double_p, _abi.c_double_p,
+                                           _abi.c_double_p, _abi.c_double_p]
+    lib.nyx_oracle_tides_accel.restype = C.c_int32
     lib.nyx_oracle_hermite_eval.argtypes = [_abi.c_double_p, _abi.c_double_p, _abi.c_double_p, C.c_int32, C.c_double,
                                             _abi.c_double_p, _abi.c_double_p]
     lib.nyx_oracle_hermite_eval.restype = C.c_int32
@@ -144,3 +147,14 @@ def predict_until(compiled, batch, covar, end_epoch_ns, max_step_ns, **kw):
     lib = load()
     return od.predict_until(None, batch, covar, end_epoch_ns, max_step_ns,
                             _call=lambda *a: lib.nyx_oracle_predict_until(C.byref(compiled.cfg), *a), **kw)
+
+
+def tides_accel(compiled, epoch_ns, r3):
+    """(accel[3], gradient[3, 3], delta_c[4, 4], delta_s[4, 4]) of the solid-tides model of `compiled`."""
+    lib = load()
+    r3 = np.ascontiguousarray(r3, dtype=np.float64)
+    a, g, dc, ds = np.zeros(3), np.zeros(9), np.zeros(16), np.zeros(16)
+    p = lambda x: x.ctypes.data_as(_abi.c_double_p)
+    st = lib.nyx_oracle_tides_accel(C.byref(compiled.cfg), int(epoch_ns), p(r3), p(a), p(g), p(dc), p(ds))
+    assert st == 0, st
+    return a, g.reshape(3, 3), dc.reshape(4, 4), ds.reshape(4, 4)

@@ -56,7 +56,7 @@ def iau_earth_frame(mu=ephem.MU_EARTH):
 
 
 def leo_full_setup(degree=70, order=None, point_masses=(nx.SUN, nx.MOON), srp=True, method=nx.IntegratorMethod.RungeKutta89,
-                   opts=None, drag=None):
+                   opts=None, drag=None, tides=False):
     """(Propagator, Almanac, central Frame) for the north-star force model."""
     order = degree if order is None else order
     almanac = almanac_earth()
@@ -66,6 +66,8 @@ def leo_full_setup(degree=70, order=None, point_masses=(nx.SUN, nx.MOON), srp=Tr
         accel.append(nx.PointMasses(list(point_masses)))
     if degree and degree > 0:
         accel.append(nx.GravityFieldData.from_packed_file(JGM3_PATH, iau_earth_frame(), degree, order))
+    if tides:  # third accel model of Dynamics::build (dynamics/sequence/config.rs:116-118)
+        accel.append(nx.SolidTides.earth_moon_system(iau_earth_frame(), nx.MOON, nx.SUN))
     forces = [nx.SolarPressure.default_flux(nx.EARTH)] if srp else []
     if drag == "exp":
         forces.append(nx.Drag.earth_exp(iau_earth_frame()))          # drag.rs:128-143

@@ -27,7 +27,8 @@ def test_library_loads_and_exports_every_declared_symbol():
 def test_struct_layouts_match_the_header():
     lib = _abi.load_library()
     mirror = [_abi.IntegOpts, _abi.ChebySegment, _abi.Body, _abi.Rotation, _abi.GravityField, _abi.Srp, _abi.Drag,
-              _abi.Config, _abi.States, _abi.StepStats, _abi.Traj]
+              _abi.Config, _abi.States, _abi.StepStats, _abi.Traj, _abi.SolidTidesC, _abi.Predict, _abi.PredictHistory,
+              _abi.ProcessNoiseC]
     for which, cls in enumerate(mirror):
         assert lib.nyx_hip_abi_sizeof(which) == C.sizeof(cls), cls.__name__
 

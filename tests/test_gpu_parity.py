@@ -392,3 +392,58 @@ def test_step_controller_corner_cases(case):
         if case == "max_step_clip":
             assert (np.abs(out.step_ns) <= nx.seconds(20.0)).all() and (np.sign(out.step_ns) == 1).all()
     ctx.close()
+
+
+@pytest.mark.parametrize("degree,point_masses,srp", [(8, (nx.SUN, nx.MOON), True), (0, (), False), (70, (nx.SUN, nx.MOON), True)])
+def test_solid_tides_vs_oracle(degree, point_masses, srp):
+    """SolidTides (dynamics/solid_tides.rs), the third accel model of `Dynamics::build`: device vs oracle within the
+    parity bar, with and without a gravity field (the body-fixed DCM then comes from the tidal frame), and an effect
+    of the expected size."""
+    prop, almanac, central = leo_full_setup(degree=degree, point_masses=point_masses, srp=srp, tides=True)
+    compiled = prop.compile(almanac, central)
+    b = dispersed_leo_batch(70, seed=31 + degree)
+    ctx = nx.GpuContext(compiled)
+    dur = 3 * 3600 * nx.NS_PER_S
+    out, st = ctx.propagate(b, dur)
+    ref, rst = oracle_lib.propagate(compiled, b, dur, n_threads=NCPU)
+    assert (st.status == 0).all() and (rst.status == 0).all()
+    dr, dv = pos_vel_errors(out, ref)
+    p0, a0, c0 = leo_full_setup(degree=degree, point_masses=point_masses, srp=srp)
+    plain, _ = oracle_lib.propagate(p0.compile(a0, c0), b, dur, n_threads=NCPU)
+    effect = np.linalg.norm((ref.rv() - plain.rv())[:, :3], axis=1)
+    print(f"tides deg {degree}: dr {dr.max()*1e3:.3e} m dv {dv.max()*1e6:.3e} mm/s; tide effect {effect.min()*1e3:.2e}..{effect.max()*1e3:.2e} m, "
+          f"kernel {ctx.last_kernel_ms():.1f} ms")
+    assert dr.max() < 1e-3 and dv.max() < 1e-6
+    assert effect.min() > 1e-6 and effect.max() < 0.1         # millimetres to tens of metres after 3 h
+    ctx.close()
+
+
+def test_solid_tides_stm_and_frame_rule():
+    prop, almanac, central = leo_full_setup(degree=8, opts=nx.IntegratorOptions.with_fixed_step_s(30.0), tides=True)
+    compiled = prop.compile(almanac, central, stm=True)
+    n = 6
+    b = dispersed_leo_batch(n, seed=2)
+    b.stm = np.zeros((n, 81))
+    b.reset_stm()
+    ctx = nx.GpuContext(compiled)
+    out, st = ctx.propagate(b, 1800 * nx.NS_PER_S)
+    ref, rst = oracle_lib.propagate(compiled, b, 1800 * nx.NS_PER_S, n_threads=NCPU)
+    assert (st.status == 0).all() and (rst.status == 0).all()
+    dr, dv = pos_vel_errors(out, ref)
+    scale = np.maximum(np.abs(ref.stm), 1e-6 * np.abs(ref.stm).max(axis=1, keepdims=True))
+    e = (np.abs(out.stm - ref.stm) / scale).max()
+    # the tide gradient is really in Phi: compare with the oracle WITHOUT tides
+    p0, a0, c0 = leo_full_setup(degree=8, opts=nx.IntegratorOptions.with_fixed_step_s(30.0))
+    plain, _ = oracle_lib.propagate(p0.compile(a0, c0, stm=True), b, 1800 * nx.NS_PER_S, n_threads=NCPU)
+    contrib = (np.abs(ref.stm - plain.stm) / scale).max()
+    print(f"tides STM: dr {dr.max()*1e3:.2e} m, Phi rel err {e:.2e}, tide contribution to Phi {contrib:.2e}")
+    assert dr.max() < 1e-3 and dv.max() < 1e-6 and e < 1e-9 and contrib > 1e-9
+    ctx.close()
+    # a tidal frame that is not the gravity-field frame is refused (one body-fixed DCM per stage on the device)
+    from scenarios import iau_earth_frame
+    other = iau_earth_frame()
+    other = nx.Frame(other.naif_id, other.mu_km3_s2, other.mean_equatorial_radius_km,
+                     nx.Rotation(other.rotation.ra_deg, other.rotation.dec_deg, [other.rotation.w_deg[0] + 1.0] + list(other.rotation.w_deg[1:])))
+    prop.dynamics.orbital_dyn.accel_models[-1] = nx.SolidTides.earth_moon_system(other, nx.MOON, nx.SUN)
+    with pytest.raises(RuntimeError, match="tidal frame"):
+        nx.GpuContext(prop.compile(almanac, central))
