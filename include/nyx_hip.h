@@ -63,7 +63,9 @@ enum nyx_hip_status {
     NYX_HIP_ERR_MASSLESS = 2,       /* MasslessSpacecraft, dynamics/spacecraft.rs:201-203 */
     NYX_HIP_ERR_FUEL_EXHAUSTED = 3, /* FuelExhausted, dynamics/spacecraft.rs:163-168 */
     NYX_HIP_ERR_EPHEM_RANGE = 4,    /* almanac lookup outside the loaded segments   */
-    NYX_HIP_ERR_UNSUPPORTED = 5     /* model combination the device path refuses   */
+    NYX_HIP_ERR_UNSUPPORTED = 5,    /* model combination the device path refuses   */
+    NYX_HIP_ERR_EVENT_NOT_FOUND = 6, /* NthEventError: max_duration reached first (propagators/event.rs:170-176) */
+    NYX_HIP_ERR_EVENT_SEARCH = 7    /* PropagationError::Analysis / TrajectoryEvent: the root search in the bracket failed */
 };
 
 /* ---- library-level return codes ---- */
@@ -315,6 +317,41 @@ int32_t nyx_hip_traj_every_device(nyx_hip_ctx *ctx, const nyx_hip_traj_t *traj, 
 /* Per-trajectory epochs variant of until_epoch (instance.rs:279-282): duration_i = end_epoch_ns - epoch_i. */
 int32_t nyx_hip_propagate_until_epoch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t end_epoch_ns,
                                       nyx_hip_states_t *out, nyx_hip_step_stats_t *stats);
+
+/* ---- stop conditions: PropInstance::until_nth_event (propagators/event.rs:88-211) ----
+ * The event is `Event{scalar, Condition::Equals(desired)}` evaluated on the integration-frame orbit (event_frame =
+ * None).  After every accepted step except the final fixed one the scalar is evaluated (event.rs:108-146): a sign
+ * change between consecutive states is a crossing (for angles: opposite signs AND |delta| < 180 deg, the event value
+ * being the difference wrapped to [-180, 180)); the propagation stops at the end of the step in which crossing number
+ * `trigger` happened, WITHOUT publishing that state; the root is then searched with Brent's method on the 13-state
+ * Hermite interpolant between the last published state and the end state (event.rs:178-197), and the state returned
+ * is `traj.at(event_epoch)`.  The scalars and the root search live in the absent anise crate (`analysis`): they are
+ * restated (see oracle/nyx_oracle.c) and their precisions are explicit here. */
+enum nyx_hip_event_scalar {
+    NYX_HIP_EV_TRUE_ANOMALY_DEG = 0, /* OrbitalElement::TrueAnomaly, an angle: Event::apoapsis() = Equals(180), periapsis() = Equals(0) */
+    NYX_HIP_EV_RMAG_KM = 1,
+    NYX_HIP_EV_VMAG_KM_S = 2,
+    NYX_HIP_EV_SMA_KM = 3,
+    NYX_HIP_EV_ECC = 4,
+    NYX_HIP_EV_X_KM = 5, NYX_HIP_EV_Y_KM = 6, NYX_HIP_EV_Z_KM = 7,
+    NYX_HIP_EV_VX_KM_S = 8, NYX_HIP_EV_VY_KM_S = 9, NYX_HIP_EV_VZ_KM_S = 10
+};
+typedef struct nyx_hip_event {
+    int32_t scalar;             /* enum nyx_hip_event_scalar */
+    int32_t trigger;            /* 1-based occurrence to stop at (until_event = 1) */
+    double desired;             /* Condition::Equals(desired) */
+    double value_precision;     /* the search ends when |event value| is below this */
+    int64_t epoch_precision_ns; /* ... or when the bracket is narrower than this (then: not found in the bracket) */
+} nyx_hip_event_t;
+
+/* Batch form of `prop.with(state, almanac).until_nth_event(max_duration, &event, None, trigger)` (host arrays).
+ * `out`: the interpolated state at the event (epoch_ns = event epoch); `traj` (mandatory, capacity >= 2): the states
+ * recorded up to and including the end of the step where the event occurred, as the reference returns it; `crossings`
+ * (n, may be NULL): sign changes counted.  stats->status: 0, NYX_HIP_ERR_EVENT_NOT_FOUND (out = state after
+ * max_duration), NYX_HIP_ERR_EVENT_SEARCH, or a propagation error. */
+int32_t nyx_hip_propagate_until_event(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t max_duration_ns,
+                                      const nyx_hip_event_t *event, nyx_hip_states_t *out, nyx_hip_step_stats_t *stats,
+                                      nyx_hip_traj_t *traj, int32_t *crossings);
 
 /* ---- covariance mapping: KalmanODProcess::predict_until (od/process/mod.rs:440-486) for the batch ----
  * Per trajectory, repeated until epoch >= end_epoch_ns (at least once):

@@ -20,8 +20,9 @@ RK89, DP78, DP45, RK4, CASHKARP45, VERNER56 = range(6)
 # enum nyx_hip_error_ctrl  (reference: propagators/error_ctrl.rs:30-76)
 RSS_CARTESIAN_STATE, RSS_CARTESIAN_STEP, RSS_STATE, RSS_STEP, LARGEST_ERROR, LARGEST_STATE, LARGEST_STEP = range(7)
 # enum nyx_hip_status
-OK, ERR_NAN, ERR_MASSLESS, ERR_FUEL_EXHAUSTED, ERR_EPHEM_RANGE, ERR_UNSUPPORTED = range(6)
-STATUS_NAMES = ["Ok", "PropMathError(NaN)", "MasslessSpacecraft", "FuelExhausted", "EphemerisOutOfRange", "Unsupported"]
+OK, ERR_NAN, ERR_MASSLESS, ERR_FUEL_EXHAUSTED, ERR_EPHEM_RANGE, ERR_UNSUPPORTED, ERR_EVENT_NOT_FOUND, ERR_EVENT_SEARCH = range(8)
+STATUS_NAMES = ["Ok", "PropMathError(NaN)", "MasslessSpacecraft", "FuelExhausted", "EphemerisOutOfRange", "Unsupported",
+                "NthEventError", "EventSearchFailed"]
 # enum nyx_hip_interp_status
 INTERP_OK, INTERP_NO_DATA, INTERP_MATH = range(3)
 # flags
@@ -187,6 +188,15 @@ class Traj(C.Structure):
 
 
 MAX_PROCESS_NOISE = 4
+# enum nyx_hip_event_scalar
+(EV_TRUE_ANOMALY_DEG, EV_RMAG_KM, EV_VMAG_KM_S, EV_SMA_KM, EV_ECC, EV_X_KM, EV_Y_KM, EV_Z_KM, EV_VX_KM_S, EV_VY_KM_S,
+ EV_VZ_KM_S) = range(11)
+
+
+class EventC(C.Structure):
+    _fields_ = [("scalar", C.c_int32), ("trigger", C.c_int32), ("desired", C.c_double), ("value_precision", C.c_double),
+                ("epoch_precision_ns", C.c_int64)]
+
 
 
 class ProcessNoiseC(C.Structure):
@@ -343,7 +353,7 @@ EXPORTS = [
     "nyx_hip_last_kernel_ms", "nyx_hip_last_error", "nyx_hip_load_cof", "nyx_hip_load_shadr", "nyx_hip_free",
     "nyx_hip_propagate_batch_with_traj", "nyx_hip_propagate_batch_with_traj_device",
     "nyx_hip_traj_at", "nyx_hip_traj_every", "nyx_hip_traj_at_device", "nyx_hip_traj_every_device",
-    "nyx_hip_predict_until",
+    "nyx_hip_predict_until", "nyx_hip_propagate_until_event",
 ]
 
 
@@ -382,6 +392,9 @@ def load_library():
     lib.nyx_hip_traj_at_device.restype = C.c_int32
     lib.nyx_hip_traj_every_device.argtypes = [C.c_void_p, C.POINTER(Traj), C.c_int64, C.c_int64, C.POINTER(Traj), C.c_void_p]
     lib.nyx_hip_traj_every_device.restype = C.c_int32
+    lib.nyx_hip_propagate_until_event.argtypes = [C.c_void_p, C.POINTER(States), C.c_int64, C.POINTER(EventC), C.POINTER(States),
+                                                  C.POINTER(StepStats), C.POINTER(Traj), c_int32_p]
+    lib.nyx_hip_propagate_until_event.restype = C.c_int32
     lib.nyx_hip_predict_until.argtypes = [C.c_void_p, C.POINTER(States), C.POINTER(Predict), C.POINTER(Estimates), C.POINTER(States),
                                           C.POINTER(StepStats), C.POINTER(PredictHistory)]
     lib.nyx_hip_predict_until.restype = C.c_int32

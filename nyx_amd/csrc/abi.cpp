@@ -20,6 +20,7 @@
 extern "C" size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles, int stm);
 extern "C" hipError_t nyx_launch_predict_init(const PredictArgs *a, const int64_t *epoch0, hipStream_t stream);
 extern "C" hipError_t nyx_launch_time_update(const PredictArgs *a, hipStream_t stream);
+extern "C" hipError_t nyx_launch_event_search(const EventSearchArgs *args, hipStream_t stream);
 extern "C" hipError_t nyx_launch_traj_eval(const TrajEvalArgs *args, hipStream_t stream);
 extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg, const HarmEntry *htab,
                                            const ColHdr *cols, const double *records, int n_waves, int rec_lds_doubles,
@@ -532,7 +533,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
 
 static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t *out, nyx_hip_step_stats_t *st,
                   int64_t duration_ns, int64_t end_epoch_ns, int use_end, hipStream_t stream, bool time_it,
-                  const nyx_hip_traj_t *traj = nullptr, const int64_t *dur_ns = nullptr) {
+                  const nyx_hip_traj_t *traj = nullptr, const int64_t *dur_ns = nullptr, const DevBatch *ev = nullptr) {
     const int nw = pick_waves(ctx, in->n);
     if (nw != ctx->host_cfg.n_waves) {
         build_schedule(ctx, nw);
@@ -547,6 +548,10 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
     bt.cr = in->cr; bt.cd = in->cd; bt.mprop = in->prop_mass_kg; bt.mdry = in->dry_mass_kg; bt.mextra = in->extra_mass_kg;
     bt.asrp = in->srp_area_m2; bt.adrag = in->drag_area_m2; bt.step_in = in->step_ns;
     bt.dur_ns = dur_ns;
+    if (ev) {  // stop condition: only the ev_* fields of `ev` are read
+        bt.ev_on = 1; bt.ev_scalar = ev->ev_scalar; bt.ev_trigger = ev->ev_trigger; bt.ev_desired = ev->ev_desired; bt.ev_mu = ev->ev_mu;
+        bt.ev_prev = ev->ev_prev; bt.ev_count = ev->ev_count; bt.ev_found = ev->ev_found;
+    }
     if (ctx->host_cfg.flags & NYX_HIP_FLAG_STM) {
         if (!in->stm || !out->stm) { nyx_set_error("STM context: in->stm and out->stm are mandatory"); return NYX_HIP_RC_BAD_ARG; }
         bt.stm = in->stm; bt.o_stm = out->stm;
@@ -887,9 +892,6 @@ extern "C" int32_t nyx_hip_traj_every(nyx_hip_ctx *ctx, const nyx_hip_traj_t *tr
     return traj_eval_host(ctx, traj, n, nullptr, 0, step_ns, out, nullptr, TRAJ_MODE_EVERY);
 }
 
-// ---------------------------------------------------------------------------------------------
-// Covariance mapping (od/process/mod.rs:440-486): segment launches + predict_kernel.hip, one stream, no host round trip
-// ---------------------------------------------------------------------------------------------
 struct DevBuf {  // RAII device allocation
     void *p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
@@ -903,6 +905,63 @@ struct DevBuf {  // RAII device allocation
     }
     template <typename T> T *as() const { return (T *)p; }
 };
+
+// ---------------------------------------------------------------------------------------------
+// Stop conditions (propagators/event.rs:88-211): propagation with the crossing counter, then the root search
+// ---------------------------------------------------------------------------------------------
+extern "C" int32_t nyx_hip_propagate_until_event(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t max_duration_ns,
+                                                 const nyx_hip_event_t *event, nyx_hip_states_t *out, nyx_hip_step_stats_t *stats,
+                                                 nyx_hip_traj_t *traj, int32_t *crossings) {
+    if (!ctx || !event) { nyx_set_error("until_event: ctx and event are mandatory"); return NYX_HIP_RC_BAD_ARG; }
+    if (event->scalar < NYX_HIP_EV_TRUE_ANOMALY_DEG || event->scalar > NYX_HIP_EV_VZ_KM_S || event->trigger < 1 ||
+        event->epoch_precision_ns < 0 || !(event->value_precision >= 0.0)) {
+        nyx_set_error("until_event: bad event (scalar, trigger >= 1, precisions >= 0)");
+        return NYX_HIP_RC_BAD_ARG;
+    }
+    if (int rc = check_traj(traj, "traj", true)) return rc;
+    if (traj->capacity < 2) { nyx_set_error("until_event: traj->capacity >= 2 required (the search needs the bracket)"); return NYX_HIP_RC_BAD_ARG; }
+    if (int rc = check_states(in, "in")) return rc;
+    if (int rc = check_states(out, "out")) return rc;
+    const int64_t n = in->n;
+    if (n == 0) return NYX_HIP_RC_OK;
+    if (out->n < n) { nyx_set_error("out batch smaller than in batch"); return NYX_HIP_RC_BAD_ARG; }
+    HIP_TRY(hipSetDevice(ctx->device));
+    Staged sg;
+    if (int rc = stage_batch(ctx, in, out, sg)) return rc;
+    DevTraj dtraj;
+    if (int rc = dtraj.alloc(traj->capacity, n)) return rc;
+    DevBuf evbuf;  // prev (f64), count, found (i32)
+    if (int rc = evbuf.alloc((size_t)n * 16)) return rc;
+    DevBatch ev;
+    std::memset(&ev, 0, sizeof ev);
+    ev.ev_scalar = event->scalar; ev.ev_trigger = event->trigger; ev.ev_desired = event->desired;
+    ev.ev_mu = ctx->host_cfg.mu_central;
+    ev.ev_prev = evbuf.as<double>();
+    ev.ev_count = (int32_t *)(evbuf.as<double>() + n);
+    ev.ev_found = ev.ev_count + n;
+    HIP_TRY(hipMemset(evbuf.p, 0, (size_t)n * 16));
+    if (int rc = launch(ctx, &sg.din, &sg.dout, &sg.dst, max_duration_ns, 0, 0, nullptr, true, &dtraj.t, nullptr, &ev)) return rc;
+    EventSearchArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.traj = dtraj.t; a.n = n; a.ev = *event; a.mu = ctx->host_cfg.mu_central;
+    a.found = ev.ev_found; a.status = sg.dst.status; a.epoch_ns = sg.dout.epoch_ns;
+    double *st6[6] = {sg.dout.x_km, sg.dout.y_km, sg.dout.z_km, sg.dout.vx_km_s, sg.dout.vy_km_s, sg.dout.vz_km_s};
+    for (int c = 0; c < 6; ++c) a.state[c] = st6[c];
+    HIP_TRY(nyx_launch_event_search(&a, nullptr));
+    HIP_TRY(hipDeviceSynchronize());
+    {
+        float ms = 0.f;
+        ctx->last_ms = (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) ? ms : -1.0;
+    }
+    if (int rc = fetch_batch(ctx, n, sg.stm, out, stats)) return rc;
+    if (int rc = dtraj.download(traj)) return rc;
+    if (crossings) HIP_TRY(hipMemcpy(crossings, ev.ev_count, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return NYX_HIP_RC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Covariance mapping (od/process/mod.rs:440-486): segment launches + predict_kernel.hip, one stream, no host round trip
+// ---------------------------------------------------------------------------------------------
 
 extern "C" int32_t nyx_hip_predict_until(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, const nyx_hip_predict_t *cfg,
                                          nyx_hip_estimates_t *est, nyx_hip_states_t *out, nyx_hip_step_stats_t *stats,

@@ -108,6 +108,12 @@ struct DevBatch { /* device pointers of one launch */
     const int64_t *epoch_ns;
     const double *x, *y, *z, *vx, *vy, *vz, *cr, *cd, *mprop, *mdry, *mextra, *asrp, *adrag;
     const int64_t *step_in;
+    /* stop condition (propagators/event.rs:88-146); ev_on = 0 => none */
+    int32_t ev_on, ev_scalar, ev_trigger, _pad2;
+    double ev_desired, ev_mu;
+    double *ev_prev;   /* [n] event value of the previous accepted state */
+    int32_t *ev_count; /* [n] crossings so far */
+    int32_t *ev_found; /* [n] 1 when the propagation stopped on the event */
     const int64_t *dur_ns; /* optional per-trajectory duration (covariance-mapping segments); overrides duration_ns */
     const double *stm; /* [n][81] column-major per trajectory, or NULL */
     double *o_stm;

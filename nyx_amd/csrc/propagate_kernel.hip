@@ -33,6 +33,7 @@
 #include "../../include/nyx_hip.h"
 #include "devcfg.h"
 #include "hifitime_dev.h"
+#include "event_dev.h"
 
 #define CAS __attribute__((address_space(4)))
 typedef const CAS DevCfg *CfgPtr;
@@ -813,6 +814,20 @@ DEVFN bool stm_update(double *phi, double h, const double *sacc, int lane, doubl
 // Integrator state that is only touched between attempts lives in LDS (per lane, field-major), not in
 // registers: the stage loop then keeps ~30 VGPRs of integrator state live instead of ~90 (no scratch spills).
 #define CS_FIELDS 21
+// The `enough_crossings` closure of until_nth_event (propagators/event.rs:108-146) for one accepted state: the event
+// state (previous value, crossings) lives in global memory, touched once per accepted step and only when a stop
+// condition is set; out of line so that the integrator's register allocation does not see it.
+static __device__ __attribute__((noinline)) bool event_step(int scalar, int trigger, double desired, double mu, double *prev, int32_t *count,
+                                                            double y0, double y1, double y2, double y3, double y4, double y5) {
+    const double y[6] = {y0, y1, y2, y3, y4, y5};
+    const double y_next = ev_eval(scalar, desired, mu, y);
+    int n = *count;
+    if (ev_crossing(scalar, *prev, y_next)) n += 1;
+    *prev = y_next;
+    *count = n;
+    return n >= trigger;
+}
+
 struct ColdState {
     int64_t epoch, stop, step_size, prev_step, det_step, n_acc, n_rej, n_evals;
     double y[9];
@@ -972,6 +987,12 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
         const double mass = (bt.mdry ? bt.mdry[idx] : 0.0) + c.y[8] + (bt.mextra ? bt.mextra[idx] : 0.0);
         c.massless = (has_srp || has_drag) && !(mass > 0.0);  // MasslessSpacecraft (spacecraft.rs:201-203)
         cold_store(L.cs, lane, c);
+        if (bt.ev_on && valid) {  // y_prev of the start state (event.rs:104-106)
+            const double y0[6] = {c.y[0], c.y[1], c.y[2], c.y[3], c.y[4], c.y[5]};
+            bt.ev_prev[gid] = ev_eval(bt.ev_scalar, bt.ev_desired, bt.ev_mu, y0);
+            bt.ev_count[gid] = 0;
+            bt.ev_found[gid] = 0;
+        }
         if (bt.traj_cap > 0 && valid) {  // dense output: the start state is entry 0 (instance.rs:319-321)
             bt.t_epoch[gid] = c.epoch;
 #pragma unroll
@@ -1347,7 +1368,17 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     y[6] = clamp02(y[6]);
                     c.n_acc += 1;
                     c.det_attempts = c.attempts;
-                    if (bt.traj_cap > 0 && valid) {  // chan.send(self.state) after every accepted step, final one included
+                    // stop condition: checked after every step but the final fixed one; the triggering state is returned,
+                    // not published (instance.rs:243-252)
+                    bool ev_hit = false;
+                    if (bt.ev_on && valid && !c.is_final)
+                        ev_hit = event_step(bt.ev_scalar, bt.ev_trigger, bt.ev_desired, bt.ev_mu, bt.ev_prev + gid, bt.ev_count + gid, y[0], y[1],
+                                            y[2], y[3], y[4], y[5]);
+                    if (ev_hit) {
+                        bt.ev_found[gid] = 1;
+                        c.done = true;
+                    }
+                    if (bt.traj_cap > 0 && valid && !ev_hit) {  // chan.send(self.state) after every accepted step, final one included
                         if (c.n_acc < bt.traj_cap) {
                             const int64_t at = c.n_acc * bt.n + gid;
                             bt.t_epoch[at] = c.epoch;

@@ -17,3 +17,16 @@ struct TrajEvalArgs {
     int32_t mode;
     int64_t samples_per_block;  // filled by the launcher
 };
+
+// nyx_event_search_kernel: Brent on the interpolant between the last published state and the end state
+// (propagators/event.rs:178-197), then out = traj.at(event epoch).
+struct EventSearchArgs {
+    nyx_hip_traj_t traj;  // device; the end state is appended here (event.rs:179)
+    int64_t n;
+    nyx_hip_event_t ev;
+    double mu;
+    const int32_t *found;  // [n] set by the propagation kernel
+    int32_t *status;       // [n] in: propagation status; out: + EVENT_NOT_FOUND / EVENT_SEARCH
+    int64_t *epoch_ns;     // [n] in: end-state epoch; out: event epoch
+    double *state[6];      // [n] in: end state; out: interpolated state at the event
+};

@@ -21,6 +21,7 @@
 #include "../../include/nyx_hip.h"
 #include "hifitime_dev.h"
 #include "traj_args.h"
+#include "event_dev.h"
 
 #define DEVFN static __device__ __forceinline__
 
@@ -259,6 +260,105 @@ __global__ __launch_bounds__(LANES) void nyx_traj_eval_kernel(TrajEvalArgs a) {
         }
     }
     if (a.mode == TRAJ_MODE_AT && live && n_ok) atomicAdd(&a.dst.len[i], n_ok);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Event search (propagators/event.rs:178-197).  brent_solver is anise's (absent crate): restated from the `roots`
+// crate's Brent as earlier Nyx releases embedded it; the oracle carries an independent copy of the same restatement.
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+DEVFN int ev_at(const nyx_hip_traj_t &traj, const View &v, const nyx_hip_event_t &ev, double mu, int64_t epoch_ns, double &value) {
+    double s6[6];
+    const int st = traj_at(traj, v, epoch_ns, s6);
+    value = ev_eval(ev.scalar, ev.desired, mu, s6);
+    return st;
+}
+
+// 0 = found, 1 = not in the bracket, 2 = evaluation failed, 3 = iteration cap
+DEVFN int brent_event(const nyx_hip_traj_t &traj, const View &v, const nyx_hip_event_t &ev, double mu, int64_t start_ns, int64_t end_ns,
+                      int64_t &event_ns) {
+    const double EPS = 2.220446049250313e-16;
+    const double eps_t = ns_to_seconds(ev.epoch_precision_ns);
+    const double eps_v = fabs(ev.value_precision);
+    double xa = 0.0, xb = ns_to_seconds(end_ns - start_ns);
+    double ya, yb;
+    if (ev_at(traj, v, ev, mu, start_ns, ya) | ev_at(traj, v, ev, mu, end_ns, yb)) return 2;
+    if (fabs(ya) <= eps_v) { event_ns = start_ns; return 0; }
+    if (fabs(yb) <= eps_v) { event_ns = end_ns; return 0; }
+    double xc = xa, yc = ya, xd = xa;
+    bool flag = true;
+    for (int it = 0; it < 50; ++it) {
+        if (fabs(ya) < eps_v) { event_ns = start_ns + seconds_to_ns(xa); return 0; }
+        if (fabs(yb) < eps_v) { event_ns = start_ns + seconds_to_ns(xb); return 0; }
+        if (fabs(xa - xb) <= eps_t) return 1;
+        double sx;
+        if (fabs(ya - yc) > EPS && fabs(yb - yc) > EPS)
+            sx = xa * yb * yc / ((ya - yb) * (ya - yc)) + xb * ya * yc / ((yb - ya) * (yb - yc)) + xc * ya * yb / ((yc - ya) * (yc - yb));
+        else
+            sx = xb - yb * (xb - xa) / (yb - ya);
+        const bool cond1 = (sx - xb) * (sx - (3.0 * xa + xb) / 4.0) > 0.0;
+        const bool cond2 = flag && fabs(sx - xb) >= fabs(xb - xc) / 2.0;
+        const bool cond3 = !flag && fabs(sx - xb) >= fabs(xc - xd) / 2.0;
+        const bool cond4 = flag && fabs(xb - xc) <= eps_t;
+        const bool cond5 = !flag && fabs(xc - xd) <= eps_t;
+        if (cond1 || cond2 || cond3 || cond4 || cond5) { sx = (xa + xb) / 2.0; flag = true; } else { flag = false; }
+        double ys;
+        if (ev_at(traj, v, ev, mu, start_ns + seconds_to_ns(sx), ys)) return 2;
+        xd = xc; xc = xb; yc = yb;
+        if (ya * ys < 0.0) {  // root between a and s
+            if (fabs(ya) > fabs(ys)) { xb = sx; yb = ys; } else { xb = xa; yb = ya; xa = sx; ya = ys; }
+        } else {              // root between s and b
+            if (fabs(ys) > fabs(yb)) { xa = sx; ya = ys; } else { xa = xb; ya = yb; xb = sx; yb = ys; }
+        }
+    }
+    return 3;
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(LANES) void nyx_event_search_kernel(EventSearchArgs a) {
+    const int64_t i = (int64_t)blockIdx.x * LANES + threadIdx.x;
+    if (i >= a.n) return;
+    if (a.status[i] != NYX_HIP_OK) return;  // propagation error: reported as it is
+    if (!a.found[i]) {                      // end_state == last published state (event.rs:170-176)
+        a.status[i] = NYX_HIP_ERR_EVENT_NOT_FOUND;
+        return;
+    }
+    const int64_t len = a.traj.len[i];
+    if (len >= a.traj.capacity || len < 1) {  // the bracket does not fit the caller's buffer
+        a.status[i] = NYX_HIP_ERR_EVENT_SEARCH;
+        return;
+    }
+    // traj.states.push(end_state) (event.rs:179)
+    const int64_t at = len * a.n + i;
+    const int64_t end_ns = a.epoch_ns[i];
+    a.traj.epoch_ns[at] = end_ns;
+    a.traj.x_km[at] = a.state[0][i]; a.traj.y_km[at] = a.state[1][i]; a.traj.z_km[at] = a.state[2][i];
+    a.traj.vx_km_s[at] = a.state[3][i]; a.traj.vy_km_s[at] = a.state[4][i]; a.traj.vz_km_s[at] = a.state[5][i];
+    a.traj.len[i] = (int32_t)(len + 1);
+    __threadfence();
+    View v;
+    v.epoch = a.traj.epoch_ns; v.n = a.n; v.i = i; v.len = len + 1;
+    v.desc = end_ns < a.traj.epoch_ns[i];
+    // `traj.states.last()` AFTER finalize() sorted the states by epoch (event.rs:165-168): the last published state when
+    // propagating forward, but the START state of a back-propagation (the bracket is then the whole arc)
+    const int64_t start_ns = v.desc ? a.traj.epoch_ns[i] : a.traj.epoch_ns[(len - 1) * a.n + i];
+    int64_t ev_ns = 0;
+    double s6[6];
+    if (brent_event(a.traj, v, a.ev, a.mu, start_ns, end_ns, ev_ns) != 0 || traj_at(a.traj, v, ev_ns, s6) != NYX_HIP_INTERP_OK) {
+        a.status[i] = NYX_HIP_ERR_EVENT_SEARCH;
+        return;
+    }
+    a.epoch_ns[i] = ev_ns;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) a.state[c][i] = s6[c];
+}
+
+extern "C" hipError_t nyx_launch_event_search(const EventSearchArgs *args, hipStream_t stream) {
+    if (args->n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(nyx_event_search_kernel, dim3((unsigned)((args->n + LANES - 1) / LANES)), dim3(LANES), 0, stream, *args);
+    return hipGetLastError();
 }
 
 extern "C" hipError_t nyx_launch_traj_eval(const TrajEvalArgs *args, hipStream_t stream) {

@@ -632,6 +632,20 @@ class GpuContext:
             raise RuntimeError(f"nyx_hip_propagate_batch_with_traj failed (rc={rc}): {_abi.last_error()}")
         return out, stats, traj
 
+    def propagate_until_event(self, batch: _abi.StateBatch, max_duration_ns: int, event: "Event", trigger: int = 1, capacity: int = 4096):
+        """Batch form of `until_nth_event` (propagators/event.rs:88-211): (states at the event, stats, TrajBatch, crossings).
+        stats.status is ERR_EVENT_NOT_FOUND where `max_duration_ns` elapsed first (the reference's NthEventError)."""
+        out = batch.copy()
+        stats = _abi.StatsBatch(batch.n)
+        traj = _abi.TrajBatch(batch.n, int(capacity))
+        crossings = np.zeros(batch.n, dtype=np.int32)
+        cin, cout, cst, ctr, cev = batch.as_c(), out.as_c(), stats.as_c(), traj.as_c(), event.as_c(trigger)
+        rc = self._lib.nyx_hip_propagate_until_event(self._h, C.byref(cin), int(max_duration_ns), C.byref(cev), C.byref(cout), C.byref(cst),
+                                                     C.byref(ctr), crossings.ctypes.data_as(_abi.c_int32_p))
+        if rc != 0:
+            raise RuntimeError(f"nyx_hip_propagate_until_event failed (rc={rc}): {_abi.last_error()}")
+        return out, stats, traj, crossings
+
     def traj_at(self, traj: _abi.TrajBatch, epochs_ns):
         """`Traj::at(epoch)` (traj.rs:82-127) of every trajectory of the batch at the shared epochs:
         (states[m, n, 6], status[m, n]) with status = nyx_hip_interp_status; failed samples are NaN."""
@@ -704,8 +718,43 @@ class PropInstance:
         self.state = unpack_spacecraft(out, [self.state])[0]
         return self.state, Traj(self._ctx, traj, 0)
 
+    def until_nth_event(self, max_duration_ns: int, event: "Event", trigger: int, capacity: int = 1 << 16):
+        """event.rs:88-211: (state at the event, Traj up to the end of the step where it occurred)."""
+        batch = pack_spacecraft([self.state], False)
+        batch.step_ns[0] = self.step_size
+        out, st, traj, _ = self._ctx.propagate_until_event(batch, int(max_duration_ns), event, trigger, capacity)
+        if st.status[0] != _abi.OK:
+            raise PropagationError(int(st.status[0]))
+        self.state = unpack_spacecraft(out, [self.state])[0]
+        return self.state, Traj(self._ctx, traj, 0)
+
+    def until_event(self, max_duration_ns: int, event: "Event", capacity: int = 1 << 16):
+        return self.until_nth_event(max_duration_ns, event, 1, capacity)
+
     def latest_details(self):
         return dict(self.details)
+
+
+@dataclass
+class Event:
+    """anise `Event{scalar, Condition::Equals(desired)}` as the stop condition of `until_nth_event`
+    (propagators/event.rs:88-211).  The precisions of the root search are explicit (anise keeps them in the Event)."""
+
+    scalar: int                       # _abi.EV_*
+    desired: float
+    value_precision: float = 1e-7           # deg / km / km/s: tight enough for the reference's own 1e-6 deg assertions
+    epoch_precision_ns: int = 1_000         # 1 us: a bracket narrower than this without a hit is "not found"
+
+    @classmethod
+    def apoapsis(cls):
+        return cls(_abi.EV_TRUE_ANOMALY_DEG, 180.0)
+
+    @classmethod
+    def periapsis(cls):
+        return cls(_abi.EV_TRUE_ANOMALY_DEG, 0.0)
+
+    def as_c(self, trigger: int) -> "_abi.EventC":
+        return _abi.EventC(int(self.scalar), int(trigger), float(self.desired), float(self.value_precision), int(self.epoch_precision_ns))
 
 
 class TrajError(Exception):
@@ -811,6 +860,20 @@ class Propagator:
     def with_(self, state: Spacecraft, almanac: Almanac) -> PropInstance:
         """``Propagator::with`` (propagator.rs:88-108)."""
         return PropInstance(self, state, almanac)
+
+    def many_until_event(self, spacecraft: Sequence[Spacecraft], almanac: Almanac, max_duration_ns: int, event: "Event", trigger: int = 1,
+                         drop_failed: bool = True, capacity: int = 4096):
+        """``Propagator.many_until_event`` (nyx-py/src/py_md.rs:324-370): the states at the n-th event; like the reference,
+        runs that fail (event not found included) are dropped unless ``drop_failed=False``."""
+        if len(spacecraft) == 0:
+            return []
+        ctx = self._context(almanac, spacecraft[0].frame, False)
+        batch = pack_spacecraft(list(spacecraft), False)
+        out, st, _, _ = ctx.propagate_until_event(batch, int(max_duration_ns), event, trigger, capacity)
+        res = unpack_spacecraft(out, spacecraft)
+        if drop_failed:
+            return [r for r, s in zip(res, st.status) if s == _abi.OK]
+        return [r if s == _abi.OK else PropagationError(int(s), i) for i, (r, s) in enumerate(zip(res, st.status))]
 
     def many_for_duration(self, spacecraft: Sequence[Spacecraft], almanac: Almanac, duration_ns: int, drop_failed: bool = True):
         """``Propagator.many_for_duration`` (nyx-py/src/py_md.rs:275-321): like the reference, failed runs

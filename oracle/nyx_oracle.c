@@ -1136,12 +1136,80 @@ typedef struct {
     /* dense output (for_duration_with_traj, instance.rs:297-326) */
     const nyx_hip_traj_t *traj;
     int64_t traj_n, traj_i;
+    /* stop condition (propagators/event.rs:108-146) */
+    const nyx_hip_event_t *ev;
+    double ev_prev;
+    int ev_count, ev_found;
 } inst_t;
+
+/* ---------------------------------------------------------------------------------------------
+ * Event evaluation.  `Event`, `ScalarExpr::evaluate` and `brent_solver` belong to anise 0.10.2 (feature
+ * "analysis"), absent from /root/reference: PARITY UNPINNED.  Restated from the classical definitions
+ * (Vallado RV2COE for the elements, the `roots` crate's Brent as used by earlier Nyx releases) and anchored
+ * on what nyx-core itself fixes: the crossing rule (propagators/event.rs:124-141) and the assertions of
+ * tests/propagation/stopcond.rs (third apoapsis inside [2P, 3P], |180 - TA| < 1e-6 deg, ...).
+ * --------------------------------------------------------------------------------------------- */
+static int ev_is_angle(int scalar) { return scalar == NYX_HIP_EV_TRUE_ANOMALY_DEG; }
+
+static double ev_scalar(int scalar, double mu, const double *y) {
+    const double *r = y, *v = y + 3;
+    const double rmag = norm3(r), vmag = norm3(v);
+    switch (scalar) {
+    case NYX_HIP_EV_RMAG_KM: return rmag;
+    case NYX_HIP_EV_VMAG_KM_S: return vmag;
+    case NYX_HIP_EV_X_KM: case NYX_HIP_EV_Y_KM: case NYX_HIP_EV_Z_KM: return y[scalar - NYX_HIP_EV_X_KM];
+    case NYX_HIP_EV_VX_KM_S: case NYX_HIP_EV_VY_KM_S: case NYX_HIP_EV_VZ_KM_S: return y[3 + scalar - NYX_HIP_EV_VX_KM_S];
+    case NYX_HIP_EV_SMA_KM: {
+        const double energy = vmag * vmag / 2.0 - mu / rmag;
+        return -mu / (2.0 * energy);
+    }
+    default: break;
+    }
+    /* eccentricity vector: ((v^2 - mu/r) r - (r.v) v) / mu */
+    const double rv = r[0] * v[0] + r[1] * v[1] + r[2] * v[2];
+    const double k = vmag * vmag - mu / rmag;
+    double e[3];
+    for (int i = 0; i < 3; ++i) e[i] = (k * r[i] - rv * v[i]) / mu;
+    const double ecc = norm3(e);
+    if (scalar == NYX_HIP_EV_ECC) return ecc;
+    /* true anomaly in [0, 360): atan2 of (sin, cos) projected on the orbit plane.  The textbook acos(e.r / (|e||r|)) loses
+     * half the digits at the apsides (1e-6 deg), exactly where Event::apoapsis / periapsis need it. */
+    const double h[3] = {r[1] * v[2] - r[2] * v[1], r[2] * v[0] - r[0] * v[2], r[0] * v[1] - r[1] * v[0]};
+    const double exr[3] = {e[1] * r[2] - e[2] * r[1], e[2] * r[0] - e[0] * r[2], e[0] * r[1] - e[1] * r[0]};
+    const double sin_part = (exr[0] * h[0] + exr[1] * h[1] + exr[2] * h[2]) / norm3(h);
+    const double cos_part = e[0] * r[0] + e[1] * r[1] + e[2] * r[2];
+    const double deg = atan2(sin_part, cos_part) * (180.0 / 3.14159265358979323846);
+    return deg < 0.0 ? deg + 360.0 : deg;
+}
+
+/* Event::eval for Condition::Equals: value - desired, wrapped to [-180, 180) for angles */
+static double ev_eval(const nyx_hip_event_t *ev, double mu, const double *y) {
+    const double d = ev_scalar(ev->scalar, mu, y) - ev->desired;
+    if (!ev_is_angle(ev->scalar)) return d;
+    double w = fmod(d + 180.0, 360.0);
+    if (w < 0.0) w += 360.0;
+    return w - 180.0;
+}
+
+static double signum_(double x) { return x != x ? x : (signbit(x) ? -1.0 : 1.0); } /* f64::signum */
+
+/* the `enough_crossings` closure (event.rs:108-146) */
+static int ev_step(inst_t *s) {
+    const double y_next = ev_eval(s->ev, s->p->cfg->central_mu_km3_s2, s->y);
+    const double delta = fabs(y_next - s->ev_prev);
+    if (ev_is_angle(s->ev->scalar)) {
+        if (signum_(s->ev_prev) != signum_(y_next) && delta < 180.0) s->ev_count += 1;
+    } else if (s->ev_prev * y_next < 0.0) {
+        s->ev_count += 1;
+    }
+    s->ev_prev = y_next;
+    return s->ev_count >= s->ev->trigger;
+}
 
 static void traj_push(inst_t *s) {
     const nyx_hip_traj_t *t = s->traj;
     if (!t) return;
-    const int64_t k = s->n_acc; /* 0 = start state */
+    const int64_t k = t->len[s->traj_i]; /* 0 = start state (len is reset by the caller) */
     if (k < t->capacity) {
         const int64_t at = k * s->traj_n + s->traj_i;
         t->epoch_ns[at] = s->epoch_ns;
@@ -1233,7 +1301,6 @@ static int single_step(inst_t *s) {
     memcpy(s->y, next, sizeof(double) * (size_t)s->nv);
     s->y[6] = clamp02(s->y[6]);
     s->n_acc += 1;
-    traj_push(s); /* chan.send(self.state) (instance.rs:188-193, 254-259) */
     return finally_(s);
 }
 
@@ -1254,6 +1321,7 @@ static int propagate(inst_t *s, int64_t duration_ns) {
             s->fixed_step = 1;
             st = single_step(s);
             if (st) return st;
+            traj_push(s); /* chan.send(self.state) (instance.rs:188-193) */
             s->step_size_ns = prev_step;
             s->fixed_step = prev_kind;
             if (backprop) s->step_size_ns = -s->step_size_ns;
@@ -1261,6 +1329,9 @@ static int propagate(inst_t *s, int64_t duration_ns) {
         }
         st = single_step(s);
         if (st) return st;
+        /* stop condition: the triggering state is NOT published (instance.rs:243-252) */
+        if (s->ev && ev_step(s)) { s->ev_found = 1; return NYX_HIP_OK; }
+        traj_push(s); /* chan.send(self.state) (instance.rs:254-259) */
     }
 }
 
@@ -1304,6 +1375,7 @@ static void inst_init(inst_t *s, const prepared_t *p, const nyx_hip_states_t *in
     s->det_attempts = 1;
     s->n_acc = s->n_rej = s->n_evals = 0;
     s->traj = NULL; s->traj_n = in->n; s->traj_i = i;
+    s->ev = NULL; s->ev_prev = 0.0; s->ev_count = 0; s->ev_found = 0;
 }
 
 static void inst_store(const inst_t *s, nyx_hip_states_t *o, nyx_hip_step_stats_t *t, int64_t i, int st) {
@@ -1333,6 +1405,7 @@ static void inst_store(const inst_t *s, nyx_hip_states_t *o, nyx_hip_step_stats_
 static void run_one(const job_t *jb, inst_t *s, int64_t i) {
     inst_init(s, jb->p, jb->in, i);
     s->traj = jb->traj;
+    if (jb->traj) jb->traj->len[i] = 0;
     traj_push(s);
     const int st = propagate(s, jb->duration_ns);
     inst_store(s, jb->out, jb->stats, i, st);
@@ -1482,6 +1555,112 @@ int32_t nyx_oracle_traj_every(const nyx_hip_traj_t *traj, int64_t n, int64_t ste
             out->len[i] = (int32_t)(k + 1);
         }
     }
+    return NYX_HIP_RC_OK;
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * until_nth_event (propagators/event.rs:88-211): propagate with the stop condition, then Brent on the
+ * interpolant between the last published state and the end state.  brent_solver is anise's (absent):
+ * restated from the `roots` crate's Brent as earlier Nyx releases embedded it — PARITY UNPINNED.
+ * --------------------------------------------------------------------------------------------- */
+static int ev_at(const nyx_hip_traj_t *traj, int64_t n, int64_t i, const nyx_hip_event_t *ev, double mu, int64_t epoch_ns,
+                 double *value) {
+    double s6[6];
+    const int st = nyx_oracle_traj_at(traj, n, i, epoch_ns, s6);
+    if (st != NYX_HIP_INTERP_OK) return st;
+    *value = ev_eval(ev, mu, s6);
+    return NYX_HIP_INTERP_OK;
+}
+
+/* returns 0 and the event epoch, or 1 = not found in the bracket / 2 = evaluation failed / 3 = max iterations */
+static int brent_event(const nyx_hip_traj_t *traj, int64_t n, int64_t i, const nyx_hip_event_t *ev, double mu, int64_t start_ns,
+                       int64_t end_ns, int64_t *event_ns) {
+    const double eps_t = nyx_oracle_ns_to_seconds(ev->epoch_precision_ns);
+    const double eps_v = fabs(ev->value_precision);
+    double xa = 0.0, xb = nyx_oracle_ns_to_seconds(end_ns - start_ns);
+    double ya, yb;
+    if (ev_at(traj, n, i, ev, mu, start_ns, &ya) || ev_at(traj, n, i, ev, mu, end_ns, &yb)) return 2;
+    if (fabs(ya) <= eps_v) { *event_ns = start_ns; return 0; }
+    if (fabs(yb) <= eps_v) { *event_ns = end_ns; return 0; }
+    double xc = xa, yc = ya, xd = xa;
+    int flag = 1;
+    for (int it = 0; it < 50; ++it) {
+        if (fabs(ya) < eps_v) { *event_ns = start_ns + nyx_oracle_seconds_to_ns(xa); return 0; }
+        if (fabs(yb) < eps_v) { *event_ns = start_ns + nyx_oracle_seconds_to_ns(xb); return 0; }
+        if (fabs(xa - xb) <= eps_t) return 1;
+        double sx;
+        if (fabs(ya - yc) > DBL_EPSILON && fabs(yb - yc) > DBL_EPSILON)
+            sx = xa * yb * yc / ((ya - yb) * (ya - yc)) + xb * ya * yc / ((yb - ya) * (yb - yc)) + xc * ya * yb / ((yc - ya) * (yc - yb));
+        else
+            sx = xb - yb * (xb - xa) / (yb - ya);
+        const int cond1 = (sx - xb) * (sx - (3.0 * xa + xb) / 4.0) > 0.0;
+        const int cond2 = flag && fabs(sx - xb) >= fabs(xb - xc) / 2.0;
+        const int cond3 = !flag && fabs(sx - xb) >= fabs(xc - xd) / 2.0;
+        const int cond4 = flag && fabs(xb - xc) <= eps_t;
+        const int cond5 = !flag && fabs(xc - xd) <= eps_t;
+        if (cond1 || cond2 || cond3 || cond4 || cond5) { sx = (xa + xb) / 2.0; flag = 1; } else { flag = 0; }
+        double ys;
+        if (ev_at(traj, n, i, ev, mu, start_ns + nyx_oracle_seconds_to_ns(sx), &ys)) return 2;
+        xd = xc; xc = xb; yc = yb;
+        if (ya * ys < 0.0) { /* root between a and s */
+            if (fabs(ya) > fabs(ys)) { xb = sx; yb = ys; } else { xb = xa; yb = ya; xa = sx; ya = ys; }
+        } else {             /* root between s and b */
+            if (fabs(ys) > fabs(yb)) { xa = sx; ya = ys; } else { xa = xb; ya = yb; xb = sx; yb = ys; }
+        }
+    }
+    return 3;
+}
+
+int32_t nyx_oracle_until_event(const nyx_hip_config_t *cfg, const nyx_hip_states_t *in, int64_t max_duration_ns,
+                               const nyx_hip_event_t *ev, nyx_hip_states_t *out, nyx_hip_step_stats_t *stats,
+                               nyx_hip_traj_t *traj, int32_t *crossings) {
+    if (!cfg || !in || !out || !ev || !traj || traj->capacity < 2 || ev->trigger < 1) return NYX_HIP_RC_BAD_ARG;
+    prepared_t p;
+    prepared_init(&p, cfg);
+    inst_t *s = malloc(sizeof *s);
+    scratch_init(&s->w, &p);
+    double *oc[6] = {out->x_km, out->y_km, out->z_km, out->vx_km_s, out->vy_km_s, out->vz_km_s};
+    for (int64_t i = 0; i < in->n; ++i) {
+        scratch_t keep = s->w;
+        inst_init(s, &p, in, i);
+        s->traj = traj;
+        traj->len[i] = 0;
+        traj_push(s);
+        s->ev = ev;
+        s->ev_prev = ev_eval(ev, cfg->central_mu_km3_s2, s->y); /* y_prev of the start state (event.rs:104-106) */
+        int st = propagate(s, max_duration_ns);
+        inst_store(s, out, stats, i, st);
+        if (crossings) crossings[i] = s->ev_count;
+        if (st == NYX_HIP_OK) {
+            if (!s->ev_found) {
+                st = NYX_HIP_ERR_EVENT_NOT_FOUND; /* end_state == last_traj_state (event.rs:170-176) */
+            } else {
+                const int64_t last = traj->len[i] - 1;
+                if (traj->len[i] >= traj->capacity) {
+                    st = NYX_HIP_ERR_EVENT_SEARCH; /* the bracket does not fit the caller's buffer */
+                } else {
+                    /* traj.states.last() after finalize() sorted by epoch (event.rs:165-168): for a back-propagation
+                     * that is the START state, and the bracket is the whole arc */
+                    const int64_t start_ns = max_duration_ns < 0 ? traj->epoch_ns[i] : traj->epoch_ns[last * in->n + i];
+                    traj_push(s); /* traj.states.push(end_state) (event.rs:179) */
+                    int64_t ev_ns = 0;
+                    double s6[6];
+                    if (brent_event(traj, in->n, i, ev, cfg->central_mu_km3_s2, start_ns, s->epoch_ns, &ev_ns) != 0 ||
+                        nyx_oracle_traj_at(traj, in->n, i, ev_ns, s6) != NYX_HIP_INTERP_OK) {
+                        st = NYX_HIP_ERR_EVENT_SEARCH;
+                    } else {
+                        out->epoch_ns[i] = ev_ns;
+                        for (int c = 0; c < 6; ++c) oc[c][i] = s6[c];
+                    }
+                }
+            }
+            if (stats && stats->status) stats->status[i] = st;
+        }
+        s->w = keep;
+    }
+    scratch_free(&s->w);
+    free(s);
+    prepared_free(&p);
     return NYX_HIP_RC_OK;
 }
 

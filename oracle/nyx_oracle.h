@@ -64,6 +64,11 @@ int32_t nyx_oracle_hermite_eval(const double *xs, const double *ys, const double
 int32_t nyx_oracle_traj_at(const nyx_hip_traj_t *traj, int64_t n, int64_t i, int64_t epoch_ns, double *state6);
 int32_t nyx_oracle_traj_every(const nyx_hip_traj_t *traj, int64_t n, int64_t step_ns, nyx_hip_traj_t *out);
 
+/* PropInstance::until_nth_event (propagators/event.rs:88-211): oracle twin of nyx_hip_propagate_until_event. */
+int32_t nyx_oracle_until_event(const nyx_hip_config_t *cfg, const nyx_hip_states_t *in, int64_t max_duration_ns,
+                               const nyx_hip_event_t *ev, nyx_hip_states_t *out, nyx_hip_step_stats_t *stats,
+                               nyx_hip_traj_t *traj, int32_t *crossings);
+
 /* KalmanODProcess::predict_until (od/process/mod.rs:440-486): oracle twin of nyx_hip_predict_until (one thread). */
 int32_t nyx_oracle_predict_until(const nyx_hip_config_t *cfg, const nyx_hip_states_t *in, const nyx_hip_predict_t *pc,
                                  nyx_hip_estimates_t *est, nyx_hip_states_t *out, nyx_hip_step_stats_t *stats,

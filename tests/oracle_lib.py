@@ -56,6 +56,9 @@ def load():
     lib.nyx_oracle_tides_accel.argtypes = [C.POINTER(_abi.Config), C.c_int64, _abi.c_double_p, _abi.c_double_p, _abi.c_double_p,
                                            _abi.c_double_p, _abi.c_double_p]
     lib.nyx_oracle_tides_accel.restype = C.c_int32
+    lib.nyx_oracle_until_event.argtypes = [C.POINTER(_abi.Config), C.POINTER(_abi.States), C.c_int64, C.POINTER(_abi.EventC), C.POINTER(_abi.States),
+                                           C.POINTER(_abi.StepStats), C.POINTER(_abi.Traj), _abi.c_int32_p]
+    lib.nyx_oracle_until_event.restype = C.c_int32
     lib.nyx_oracle_hermite_eval.argtypes = [_abi.c_double_p, _abi.c_double_p, _abi.c_double_p, C.c_int32, C.c_double,
                                             _abi.c_double_p, _abi.c_double_p]
     lib.nyx_oracle_hermite_eval.restype = C.c_int32
@@ -158,3 +161,17 @@ def tides_accel(compiled, epoch_ns, r3):
     st = lib.nyx_oracle_tides_accel(C.byref(compiled.cfg), int(epoch_ns), p(r3), p(a), p(g), p(dc), p(ds))
     assert st == 0, st
     return a, g.reshape(3, 3), dc.reshape(4, 4), ds.reshape(4, 4)
+
+
+def propagate_until_event(compiled, batch, max_duration_ns, event, trigger=1, capacity=4096):
+    """Oracle twin of GpuContext.propagate_until_event."""
+    lib = load()
+    out = batch.copy()
+    stats = _abi.StatsBatch(batch.n)
+    traj = _abi.TrajBatch(batch.n, capacity)
+    crossings = np.zeros(batch.n, dtype=np.int32)
+    cin, cout, cst, ctr, cev = batch.as_c(), out.as_c(), stats.as_c(), traj.as_c(), event.as_c(trigger)
+    rc = lib.nyx_oracle_until_event(C.byref(compiled.cfg), C.byref(cin), int(max_duration_ns), C.byref(cev), C.byref(cout), C.byref(cst),
+                                    C.byref(ctr), crossings.ctypes.data_as(_abi.c_int32_p))
+    assert rc == 0
+    return out, stats, traj, crossings

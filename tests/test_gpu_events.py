@@ -1,0 +1,97 @@
+"""Device until_nth_event (stop condition inside the propagation kernel + Brent search kernel on the interpolant) against
+the oracle and against the reference's own assertions (tests/propagation/stopcond.rs)."""
+import numpy as np
+import pytest
+
+import nyx_amd as nx
+import oracle_lib
+from nyx_amd import _abi
+from scenarios import EPOCH0_NS, dispersed_leo_batch, leo_full_setup
+from test_oracle_events import MU, STATE, period_ns, setup, true_anomaly_deg
+
+pytestmark = pytest.mark.gpu
+S = nx.NS_PER_S
+
+
+@pytest.mark.parametrize("event,target", [(nx.Event.apoapsis(), 180.0), (nx.Event.periapsis(), 0.0)])
+def test_third_apsis_two_body_matches_the_oracle(event, target):
+    compiled, batch = setup(n=70)
+    ctx = nx.GpuContext(compiled)
+    p = period_ns(batch.rv()[0])
+    out, st, traj, cr = ctx.propagate_until_event(batch, 5 * p, event, trigger=3, capacity=512)
+    ref, rst, rtraj, rcr = oracle_lib.propagate_until_event(compiled, batch, 5 * p, event, trigger=3, capacity=512)
+    assert (st.status == 0).all() and (rst.status == 0).all()
+    np.testing.assert_array_equal(cr, rcr)
+    np.testing.assert_array_equal(traj.len, rtraj.len)            # two-body: bit-identical step sequences
+    np.testing.assert_array_equal(st.n_accepted, rst.n_accepted)
+    for i in (0, 33, 69):
+        m = int(traj.len[i])
+        np.testing.assert_array_equal(traj.epoch_ns[:m, i], rtraj.epoch_ns[:m, i])
+        np.testing.assert_array_equal(traj.state[:, :m, i], rtraj.state[:, :m, i])
+    # same bracket, same interpolant, same Brent: the event epochs agree to the nanosecond grid of the search
+    assert np.abs(out.epoch_ns - ref.epoch_ns).max() <= 2
+    assert np.abs(out.rv() - ref.rv())[:, :3].max() < 1e-7 and np.abs(out.rv() - ref.rv())[:, 3:].max() < 1e-10
+    for i in range(70):                                             # stopcond.rs:70-90
+        pi = period_ns(batch.rv()[i])
+        assert EPOCH0_NS + 2 * pi < out.epoch_ns[i] <= EPOCH0_NS + 3 * pi + 1
+        ta = true_anomaly_deg(out.rv()[i])
+        assert min(abs(ta - target), abs(ta - target - 360.0), abs(ta - target + 360.0)) < 1e-6
+    ctx.close()
+
+
+def test_full_model_events_not_found_and_mixed_outcomes():
+    prop, almanac, central = leo_full_setup(degree=8)
+    compiled = prop.compile(almanac, central)
+    ctx = nx.GpuContext(compiled)
+    b = dispersed_leo_batch(130, seed=14)
+    ev = nx.Event.apoapsis()
+    dur = 3 * 3600 * S
+    out, st, traj, cr = ctx.propagate_until_event(b, dur, ev, trigger=2, capacity=400)
+    ref, rst, rtraj, rcr = oracle_lib.propagate_until_event(compiled, b, dur, ev, trigger=2, capacity=400)
+    np.testing.assert_array_equal(st.status, rst.status)
+    np.testing.assert_array_equal(cr, rcr)
+    assert (st.status == 0).all()
+    # Perturbed dynamics: the event sits in the LAST interval of the recorded trajectory, where the reference's 12-state
+    # one-sided Hermite window is only good to ~1e-4 km / 5e-6 km/s and amplifies the 0.12 us abscissa grid differently
+    # for every node placement; with e ~ 0.018 that moves the osculating apoapsis by tens of milliseconds
+    # between two runs whose states agree to micrometres (the oracle against itself shows the same scatter).  So: epochs
+    # within 0.5 s, and the device's event state against the oracle PROPAGATED to the device's event epoch.
+    assert np.abs(out.epoch_ns - ref.epoch_ns).max() < 500_000_000
+    for i in range(0, 130, 13):
+        one = _abi.StateBatch(1)
+        for f in ["epoch_ns"] + _abi.F64_FIELDS:
+            getattr(one, f)[:] = getattr(b, f)[i]
+        truth, tst = oracle_lib.propagate(compiled, one, int(out.epoch_ns[i] - EPOCH0_NS))
+        assert np.linalg.norm(out.rv()[i, :3] - truth.rv()[0, :3]) < 1e-3 and np.linalg.norm(out.rv()[i, 3:] - truth.rv()[0, 3:]) < 2e-5
+        ta = true_anomaly_deg(out.rv()[i], central.mu_km3_s2)
+        assert abs(ta - 180.0) < 1e-5                                   # the event condition holds on the returned state
+    # too short a window: NthEventError for every run, the end state is the plain propagation
+    out2, st2, _, cr2 = ctx.propagate_until_event(b, 20 * 60 * S, ev, trigger=2, capacity=400)
+    plain, _ = ctx.propagate(b, 20 * 60 * S)
+    assert (st2.status == _abi.ERR_EVENT_NOT_FOUND).all() and (cr2 < 2).all()
+    np.testing.assert_array_equal(out2.rv(), plain.rv())
+    # a dense-output buffer too small for the bracket is reported, not overrun
+    out3, st3, small, _ = ctx.propagate_until_event(b, dur, ev, trigger=2, capacity=8)
+    assert (st3.status == _abi.ERR_EVENT_SEARCH).all() and (small.len > 8).all()
+    ctx.close()
+
+
+def test_front_ends_mirror_the_reference():
+    # (no SRP here: a shadow crossing makes the step controller cluster states a few seconds apart, and when such a
+    # cluster falls in the 12-state window of the LAST interval - where the event is searched - the reference's
+    # interpolant is off by kilometres and the search fails with EventSearchFailed on device and oracle alike)
+    prop, almanac, central = leo_full_setup(degree=2, srp=False)
+    b = dispersed_leo_batch(5, seed=1)
+    scs = [nx.Spacecraft(EPOCH0_NS, b.rv()[i], central, dry_mass_kg=100.0, srp_area_m2=1.0, cr=1.8) for i in range(5)]
+    # PropInstance::until_event (event.rs:48-60): (state at the event, trajectory)
+    inst = prop.with_(scs[0], almanac)
+    state, traj = inst.until_event(3 * 3600 * S, nx.Event.periapsis())
+    assert traj.epochs_ns[0] == EPOCH0_NS and traj.epochs_ns[-2] <= state.epoch_ns <= traj.epochs_ns[-1]
+    np.testing.assert_array_equal(traj.at(state.epoch_ns), state.rv)
+    with pytest.raises(nx.PropagationError, match="NthEventError"):
+        prop.with_(scs[0], almanac).until_nth_event(600 * S, nx.Event.periapsis(), 5)
+    # Propagator.many_until_event (py_md.rs:324-370): failed runs are dropped
+    got = prop.many_until_event(scs, almanac, 3 * 3600 * S, nx.Event(_abi.EV_RMAG_KM, 6700.0, value_precision=1e-6))
+    assert len(got) == 5 and all(abs(np.linalg.norm(g.rv[:3]) - 6700.0) < 1e-6 for g in got)
+    none = prop.many_until_event(scs, almanac, 3 * 3600 * S, nx.Event(_abi.EV_RMAG_KM, 9000.0))
+    assert none == []

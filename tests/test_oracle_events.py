@@ -1,0 +1,90 @@
+"""Oracle checks of until_nth_event (propagators/event.rs:88-211) against the assertions of the reference's own tests
+(tests/propagation/stopcond.rs:29-150): the n-th apsis falls in the right orbit, the event value is met, successive
+events are one period apart; plus the bookkeeping nyx-core fixes (the triggering state is not published, NthEventError)."""
+import numpy as np
+import pytest
+
+import nyx_amd as nx
+import oracle_lib
+from nyx_amd import _abi
+from scenarios import EPOCH0_NS, GOLDEN, earth_frame
+
+S = nx.NS_PER_S
+MU = GOLDEN["mu_gmat"]
+STATE = [-2436.45, -2436.45, 6891.037, 5.088611, -5.088611, 0.01]      # stopcond.rs:33-35
+
+
+def setup(n=1):
+    central = earth_frame(MU)
+    prop = nx.Propagator.default(nx.SpacecraftDynamics.new(nx.OrbitalDynamics.two_body()))
+    compiled = prop.compile(nx.Almanac(), central)
+    scs = [nx.Spacecraft(EPOCH0_NS, np.array(STATE) * (1 + 1e-3 * i), central) for i in range(n)]
+    return compiled, nx.pack_spacecraft(scs, False)
+
+
+def period_ns(rv):
+    r, v = np.linalg.norm(rv[:3]), np.linalg.norm(rv[3:])
+    a = -MU / (2 * (v * v / 2 - MU / r))
+    return int(2 * np.pi * np.sqrt(a ** 3 / MU) * 1e9)
+
+
+def true_anomaly_deg(rv, mu=MU):
+    """Independent of the implementation under test: numpy, atan2 form (acos has a 1e-6 deg noise floor at the apsides)."""
+    r, v = rv[:3], rv[3:]
+    e = ((v @ v - mu / np.linalg.norm(r)) * r - (r @ v) * v) / mu
+    h = np.cross(r, v)
+    ta = np.degrees(np.arctan2(np.cross(e, r) @ h / np.linalg.norm(h), e @ r))
+    return ta + 360.0 if ta < 0 else ta
+
+
+@pytest.mark.parametrize("event,target", [(nx.Event.apoapsis(), 180.0), (nx.Event.periapsis(), 0.0)])
+def test_third_apsis_like_the_reference(event, target):
+    compiled, batch = setup()
+    p = period_ns(batch.rv()[0])
+    out, st, traj, crossings = oracle_lib.propagate_until_event(compiled, batch, 5 * p, event, trigger=3)
+    assert st.status[0] == 0 and crossings[0] == 3
+    # stopcond.rs:70-86: the third apsis lies in the third orbit
+    assert out.epoch_ns[0] - (EPOCH0_NS + 2 * p) >= 1 and out.epoch_ns[0] - (EPOCH0_NS + 3 * p) <= 1
+    ta = true_anomaly_deg(out.rv()[0])
+    assert min(abs(ta - target), abs(ta - target - 360.0), abs(ta - target + 360.0)) < 1e-6      # stopcond.rs:87-90
+    # the trajectory ends with the END state of the triggering step (event.rs:179), the event lies in its last interval
+    ep, xs = traj.trajectory(0)
+    assert ep[-2] <= out.epoch_ns[0] <= ep[-1] and traj.len[0] == st.n_accepted[0] + 1
+    # successive events one period apart (stopcond.rs:56-63: 0.5 s)
+    first, st1, _, _ = oracle_lib.propagate_until_event(compiled, batch, 5 * p, event, trigger=1)
+    second, st2, _, _ = oracle_lib.propagate_until_event(compiled, batch, 5 * p, event, trigger=2)
+    assert abs((second.epoch_ns[0] - first.epoch_ns[0]) - p) < 0.5 * S and abs((out.epoch_ns[0] - second.epoch_ns[0]) - p) < 0.5 * S
+
+
+def test_not_found_is_reported_with_the_crossings_seen():
+    compiled, batch = setup()
+    p = period_ns(batch.rv()[0])
+    out, st, traj, crossings = oracle_lib.propagate_until_event(compiled, batch, int(1.5 * p), nx.Event.apoapsis(), trigger=3)
+    assert st.status[0] == _abi.ERR_EVENT_NOT_FOUND and crossings[0] in (1, 2)      # NthEventError{nth: 3, found: < 3}
+    plain, _ = oracle_lib.propagate(compiled, batch, int(1.5 * p))
+    np.testing.assert_array_equal(out.rv(), plain.rv())                             # the propagation itself ran to max_duration
+    assert out.epoch_ns[0] == EPOCH0_NS + int(1.5 * p)
+
+
+def test_non_angle_scalars_and_batches():
+    compiled, batch = setup(n=3)
+    p = period_ns(batch.rv()[0])
+    rmag0 = np.linalg.norm(batch.rv()[:, :3], axis=1)
+    target = float(rmag0.max() + 2.0)
+    ev = nx.Event(_abi.EV_RMAG_KM, target)
+    out, st, traj, crossings = oracle_lib.propagate_until_event(compiled, batch, 2 * p, ev, trigger=2)
+    ok = st.status == 0
+    assert ok.any() and (crossings[ok] == 2).all() and (st.status[~ok] == _abi.ERR_EVENT_NOT_FOUND).all()
+    assert np.abs(np.linalg.norm(out.rv()[ok, :3], axis=1) - target).max() < 1e-6
+    # equator crossings.  The interpolant is evaluated at f64 seconds past J2000 (0.12 us grid): with dz/dt ~ 7 km/s the
+    # event value moves in steps of ~1e-6 km, so that is the precision that can be asked for (a tighter one ends as
+    # "not found in the bracket", status ERR_EVENT_SEARCH)
+    z = nx.Event(_abi.EV_Z_KM, 0.0, value_precision=1e-5)
+    out, st, _, _ = oracle_lib.propagate_until_event(compiled, batch, 2 * p, z, trigger=1)
+    assert (st.status == 0).all() and np.abs(out.rv()[:, 2]).max() < 1e-5
+    tight = nx.Event(_abi.EV_Z_KM, 0.0, value_precision=1e-12)
+    _, st_t, _, _ = oracle_lib.propagate_until_event(compiled, batch, 2 * p, tight, trigger=1)
+    assert (st_t.status == _abi.ERR_EVENT_SEARCH).any()
+    sma = nx.Event(_abi.EV_SMA_KM, 1.0)                                              # never crossed: constant of the motion
+    out, st, _, crossings = oracle_lib.propagate_until_event(compiled, batch, p // 2, sma)
+    assert (st.status == _abi.ERR_EVENT_NOT_FOUND).all() and (crossings == 0).all()
