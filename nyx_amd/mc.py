@@ -118,7 +118,28 @@ class MonteCarlo:
                                dist=None) -> Results:
         """montecarlo.rs:208-273.  With `dist` (an initialised torch.distributed module) the runs are sharded by
         contiguous index range over the ranks and every rank returns the complete, index-sorted Results."""
-        from .propagator import PropagationError, pack_spacecraft, unpack_spacecraft
+
+        def run(ctx, batch):
+            return ctx.propagate_until_epoch(batch, int(end_epoch_ns))
+
+        return self._run(prop, almanac, skip, num_runs, dist, run, int(end_epoch_ns))
+
+    def run_until_nth_event(self, prop: Propagator, almanac: Almanac, max_duration_ns: int, event, trigger: int, num_runs: int) -> Results:
+        """montecarlo.rs:93-110."""
+        return self.resume_run_until_nth_event(prop, almanac, 0, max_duration_ns, event, trigger, num_runs)
+
+    def resume_run_until_nth_event(self, prop: Propagator, almanac: Almanac, skip: int, max_duration_ns: int, event, trigger: int,
+                                   num_runs: int, dist=None, capacity: int = 4096) -> Results:
+        """montecarlo.rs:115-186: every run stops at the `trigger`-th occurrence of `event` (or fails with NthEventError)."""
+
+        def run(ctx, batch):
+            out, st, _, _ = ctx.propagate_until_event(batch, int(max_duration_ns), event, trigger, capacity)
+            return out, st
+
+        return self._run(prop, almanac, skip, num_runs, dist, run, ("event", int(max_duration_ns), event, trigger))
+
+    def _run(self, prop, almanac, skip, num_runs, dist, run, fn_arg) -> Results:
+        from .propagator import PropagationError, pack_spacecraft
 
         states = self.generate_states(skip, num_runs, self.seed)
         rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
@@ -126,10 +147,9 @@ class MonteCarlo:
         mine = states[lo:hi]
         batch = pack_spacecraft([s for _, s in mine], False)
         if self.propagate_fn is not None:
-            out, st = self.propagate_fn(batch, int(end_epoch_ns))
+            out, st = self.propagate_fn(batch, fn_arg)
         else:
-            ctx = prop._context(almanac, self.random_state.template.frame, False)
-            out, st = ctx.propagate_until_epoch(batch, int(end_epoch_ns))
+            out, st = run(prop._context(almanac, self.random_state.template.frame, False), batch)
         payload = np.concatenate([out.rv(), out.cr[:, None], out.cd[:, None], out.prop_mass_kg[:, None],
                                   np.ascontiguousarray(out.epoch_ns, dtype=np.int64).view(np.float64)[:, None],  # bit pattern: ns past J2000 exceed 2^53
                                   st.status[:, None].astype(np.float64)], axis=1)

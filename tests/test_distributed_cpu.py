@@ -31,8 +31,11 @@ def _build():
     template = nx.Spacecraft(EPOCH0_NS, leo_nominal(), central, dry_mass_kg=100.0, srp_area_m2=1.0, cr=1.8)
     mvn = nx.MvnSpacecraft.from_sigmas(template, [1.0, 1.0, 1.0, 1e-3, 1e-3, 1e-3])
 
-    def fn(batch, end_epoch_ns):
-        return oracle_lib.propagate(compiled, batch, end_epoch_ns - int(batch.epoch_ns[0]))
+    def fn(batch, arg):
+        if isinstance(arg, tuple):  # ("event", max_duration, event, trigger): run_until_nth_event
+            out, st, _, _ = oracle_lib.propagate_until_event(compiled, batch, arg[1], arg[2], arg[3], capacity=512)
+            return out, st
+        return oracle_lib.propagate(compiled, batch, arg - int(batch.epoch_ns[0]))
 
     return prop, almanac, nx.MonteCarlo(mvn, seed=7, propagate_fn=fn)
 
@@ -44,6 +47,9 @@ def _worker(rank, world, port, out_dir):
     prop, almanac, mc = _build()
     res = mc.resume_run_until_epoch(prop, almanac, 0, EPOCH0_NS + 600 * nx.NS_PER_S, 11, dist=dist)
     np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array([[r.index, *r.result.rv] for r in res.runs]))
+    ev = mc.resume_run_until_nth_event(prop, almanac, 0, 2 * 3600 * nx.NS_PER_S, nx.Event(nx._abi.EV_Z_KM, 0.0, value_precision=1e-5), 2, 7,
+                                       dist=dist)
+    np.save(os.path.join(out_dir, f"e{rank}.npy"), np.array([[r.index, r.result.epoch_ns - EPOCH0_NS, r.result.rv[2]] for r in ev.runs]))
     dist.destroy_process_group()
 
 
@@ -66,6 +72,10 @@ def test_two_rank_gloo_monte_carlo(tmp_path):
     np.testing.assert_array_equal(r0[:, 1:], single.final_rv())  # sharding does not change any trajectory
     # integer-ns epochs survive the gather exactly (they exceed 2^53, so they travel as bit patterns)
     assert all(r.result.epoch_ns == EPOCH0_NS + 600 * nx.NS_PER_S for r in single.runs)
+    # the event-terminated ensemble: sharded the same way, per-run event epochs survive the gather bit for bit
+    e0, e1 = np.load(tmp_path / "e0.npy"), np.load(tmp_path / "e1.npy")
+    np.testing.assert_array_equal(e0, e1)
+    assert list(e0[:, 0]) == list(range(7)) and (np.abs(e0[:, 2]) < 1e-5).all() and len(set(e0[:, 1])) == 7
     # resume(skip) reproduces the tail of the stream (montecarlo.rs:208-224)
     tail = mc.resume_run_until_epoch(prop, almanac, 5, EPOCH0_NS + 600 * nx.NS_PER_S, 6)
     assert [r.index for r in tail.runs] == list(range(5, 11))

@@ -66,6 +66,20 @@ def test_monte_carlo_run_until_epoch_on_gpu():
     np.testing.assert_array_equal(tail.final_rv(), rslts.final_rv()[6:])
 
 
+def test_monte_carlo_run_until_nth_event_on_gpu():
+    # MonteCarlo::run_until_nth_event (montecarlo.rs:93-186): every run stops at its own 2nd apoapsis; failures keep
+    # their index (NthEventError) like `Run.result: Err(..)`
+    prop, almanac, central = leo_full_setup(degree=4, srp=False)
+    template = nx.Spacecraft(EPOCH0_NS, leo_nominal(), central, dry_mass_kg=100.0)
+    mc = nx.MonteCarlo(nx.MvnSpacecraft.from_sigmas(template, [1.0, 1.0, 1.0, 1e-3, 1e-3, 1e-3]), seed=3)
+    rslts = mc.run_until_nth_event(prop, almanac, 4 * 3600 * nx.NS_PER_S, nx.Event.apoapsis(), 2, 12)
+    assert [r.index for r in rslts.runs] == list(range(12)) and all(isinstance(r.result, nx.Spacecraft) for r in rslts.runs)
+    epochs = np.array([r.result.epoch_ns for r in rslts.runs])
+    assert len(set(epochs)) == 12 and ((epochs - EPOCH0_NS) > 1.4 * 5400 * nx.NS_PER_S).all()    # per-run event epochs
+    short = mc.run_until_nth_event(prop, almanac, 600 * nx.NS_PER_S, nx.Event.apoapsis(), 2, 5)
+    assert all(isinstance(r.result, nx.PropagationError) and r.result.status == nx._abi.ERR_EVENT_NOT_FOUND for r in short.runs)
+
+
 def test_dense_output_matches_the_oracle_trajectory():
     """for_duration_with_traj (instance.rs:297-326): start state + every accepted state (the final fixed step included)."""
     prop, almanac, central = leo_full_setup(degree=8)
