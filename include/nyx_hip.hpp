@@ -7,7 +7,12 @@
 //   prop.with(state, almanac).for_duration(d)             prop.with(state).for_duration(d)
 //   prop.with(state, almanac).until_epoch(e)              prop.with(state).until_epoch(e)
 //   states.par_iter().map(|s| prop.with(s).for_duration)  prop.many_for_duration(batch, d)
-//   (propagators/propagator.rs:34-121, instance.rs:62-352, mc/montecarlo.rs:233-253)
+//   prop.with(state, almanac).for_duration_with_traj(d)   prop.many_for_duration_with_traj(batch, d, ...) -> nyx::TrajBatch
+//   traj.at(epoch) / traj.every(step)                     trajs.at(prop, epochs, ...) / trajs.every(prop, step, capacity)
+//   prop.with(..).until_nth_event(max, &event, None, n)   prop.many_until_event(batch, max, event, ...)
+//   odp.predict_until(estimate, end_epoch)                prop.predict_until(batch, cfg, covar, ...)
+//   (propagators/propagator.rs:34-121, instance.rs:62-352, event.rs:88-211, md/trajectory/traj.rs:82-162,
+//    mc/montecarlo.rs:93-253, od/process/mod.rs:440-486)
 #ifndef NYX_HIP_HPP
 #define NYX_HIP_HPP
 
@@ -97,6 +102,33 @@ struct RunStats {
 
 class GpuPropagator;
 
+// Traj<Spacecraft> of every run of a batch (md/trajectory/traj.rs:40-162): step-major storage, as the ABI.
+class TrajBatch {
+  public:
+    TrajBatch(int64_t n, int64_t capacity) : n_(n), cap_(capacity), epoch_((size_t)(n * capacity)), len_((size_t)n, 0) {
+        for (auto &f : f_) f.assign((size_t)(n * capacity), 0.0);
+    }
+    int64_t size() const { return n_; }
+    int64_t capacity() const { return cap_; }
+    int32_t len(int64_t i) const { return len_[i]; }
+    int64_t epoch_ns(int64_t k, int64_t i) const { return epoch_[(size_t)(k * n_ + i)]; }
+    double state(int64_t k, int64_t i, int c) const { return f_[c][(size_t)(k * n_ + i)]; }
+    nyx_hip_traj_t view() {
+        return nyx_hip_traj_t{cap_, epoch_.data(), f_[0].data(), f_[1].data(), f_[2].data(), f_[3].data(), f_[4].data(), f_[5].data(),
+                              len_.data()};
+    }
+    // Traj::at for every run at shared epochs; status[q * n + i] = nyx_hip_interp_status
+    TrajBatch at(GpuPropagator &prop, const std::vector<int64_t> &epochs_ns, std::vector<int32_t> &status);
+    // Traj::every(step) for every run
+    TrajBatch every(GpuPropagator &prop, int64_t step_ns, int64_t capacity);
+
+  private:
+    int64_t n_, cap_;
+    std::vector<int64_t> epoch_;
+    std::vector<double> f_[6];
+    std::vector<int32_t> len_;
+};
+
 // PropInstance (propagators/instance.rs:62-352) for one state: a batch of one on the device.
 class PropInstance {
   public:
@@ -133,12 +165,55 @@ class GpuPropagator {
         nyx_hip_step_stats_t vs = stats.view();
         if (nyx_hip_propagate_until_epoch(ctx_, &vi, end_epoch_ns, &vo, &vs) != NYX_HIP_RC_OK) throw std::runtime_error(nyx_hip_last_error());
     }
+    // for_duration_with_traj for the batch (instance.rs:297-326)
+    void many_for_duration_with_traj(StateBatch &in, int64_t duration_ns, StateBatch &out, RunStats &stats, TrajBatch &traj) {
+        nyx_hip_states_t vi = in.view(), vo = out.view();
+        nyx_hip_step_stats_t vs = stats.view();
+        nyx_hip_traj_t vt = traj.view();
+        if (nyx_hip_propagate_batch_with_traj(ctx_, &vi, duration_ns, &vo, &vs, &vt) != NYX_HIP_RC_OK) throw std::runtime_error(nyx_hip_last_error());
+    }
+    // until_nth_event for the batch (event.rs:88-211; MonteCarlo::run_until_nth_event, montecarlo.rs:93-186): `out` holds the
+    // states at the event, stats.status NYX_HIP_ERR_EVENT_NOT_FOUND where max_duration elapsed first
+    void many_until_event(StateBatch &in, int64_t max_duration_ns, const nyx_hip_event_t &event, StateBatch &out, RunStats &stats,
+                          TrajBatch &traj, std::vector<int32_t> *crossings = nullptr) {
+        nyx_hip_states_t vi = in.view(), vo = out.view();
+        nyx_hip_step_stats_t vs = stats.view();
+        nyx_hip_traj_t vt = traj.view();
+        if (crossings) crossings->assign((size_t)in.size(), 0);
+        if (nyx_hip_propagate_until_event(ctx_, &vi, max_duration_ns, &event, &vo, &vs, &vt, crossings ? crossings->data() : nullptr) !=
+            NYX_HIP_RC_OK)
+            throw std::runtime_error(nyx_hip_last_error());
+    }
+    // KalmanODProcess::predict_until for the batch (od/process/mod.rs:440-486); covar: n * 81, column-major, in/out
+    void predict_until(StateBatch &in, const nyx_hip_predict_t &cfg, std::vector<double> &covar, StateBatch &out, RunStats &stats,
+                       nyx_hip_predict_history_t *history = nullptr, std::vector<double> *state_deviation = nullptr) {
+        nyx_hip_states_t vi = in.view(), vo = out.view();
+        nyx_hip_step_stats_t vs = stats.view();
+        nyx_hip_estimates_t est{covar.data(), state_deviation ? state_deviation->data() : nullptr};
+        if (nyx_hip_predict_until(ctx_, &vi, &cfg, &est, &vo, &vs, history) != NYX_HIP_RC_OK) throw std::runtime_error(nyx_hip_last_error());
+    }
     nyx_hip_ctx *raw() { return ctx_; }
 
   private:
     nyx_hip_ctx *ctx_ = nullptr;
     int64_t init_step_;
 };
+
+inline TrajBatch TrajBatch::at(GpuPropagator &prop, const std::vector<int64_t> &epochs_ns, std::vector<int32_t> &status) {
+    const int64_t m = (int64_t)epochs_ns.size();
+    TrajBatch out(n_, m > 0 ? m : 1);
+    status.assign((size_t)((m > 0 ? m : 1) * n_), 0);
+    nyx_hip_traj_t vi = view(), vo = out.view();
+    if (nyx_hip_traj_at(prop.raw(), &vi, n_, epochs_ns.data(), m, &vo, status.data()) != NYX_HIP_RC_OK) throw std::runtime_error(nyx_hip_last_error());
+    return out;
+}
+
+inline TrajBatch TrajBatch::every(GpuPropagator &prop, int64_t step_ns, int64_t capacity) {
+    TrajBatch out(n_, capacity);
+    nyx_hip_traj_t vi = view(), vo = out.view();
+    if (nyx_hip_traj_every(prop.raw(), &vi, n_, step_ns, &vo) != NYX_HIP_RC_OK) throw std::runtime_error(nyx_hip_last_error());
+    return out;
+}
 
 inline Spacecraft PropInstance::for_duration(int64_t duration_ns) {
     StateBatch b(1), o(1);
