@@ -78,8 +78,10 @@ def cpu_baseline(compiled, n_per_gpu, hours, seed):
     t0 = time.time()
     oracle_lib.propagate(compiled, probe, int(0.25 * 3600) * nx.NS_PER_S, n_threads=cores)
     per_traj_hour = (time.time() - t0) / 0.25  # seconds of wall per (cores trajectories) per hour of propagation
-    budget_s = 20.0
-    rounds = max(1, min(8, int(budget_s / max(per_traj_hour * hours, 1e-3))))
+    # one round = `cores` full-length trajectories, one per thread (~13 s for 24 h on this class of host); the short probe
+    # underestimates it (caches, clocks), so at most two rounds: 10-30 s of CPU work whatever the probe says
+    budget_s = 25.0
+    rounds = max(1, min(2, int(budget_s / max(per_traj_hour * hours, 1e-3))))
     n = cores * rounds
     sample = dispersed_leo_batch(n, seed=seed)
     t0 = time.time()
