@@ -189,3 +189,62 @@ def test_traj_object_mirrors_the_reference_accessors(leo):
     truth = prop.with_(sc, almanac).for_duration(2000 * nx.NS_PER_S)
     dr, dv = np.linalg.norm(mid[:3] - truth.rv[:3]), np.linalg.norm(mid[3:] - truth.rv[3:])
     assert dr < 2e-6 and dv < 1e-7, (dr, dv)
+
+
+def test_device_resident_pipeline_on_a_stream(leo):
+    """propagate_with_traj_device -> traj_every_device on one HIP stream, every buffer a device tensor, no host round trip in
+    between: the flavour a resident Monte Carlo uses.  Same results as the host-array entry points."""
+    import ctypes as C
+    import torch
+    prop, almanac, central, compiled, ctx = leo
+    lib = nx._abi.load_library()
+    dev = torch.device("cuda", 0)
+    n, cap, step, count = 200, 160, 60 * nx.NS_PER_S, 61
+    b = dispersed_leo_batch(n, seed=21)
+    dur = 3600 * nx.NS_PER_S
+
+    def dev_states(batch):
+        t = {"epoch_ns": torch.from_numpy(batch.epoch_ns).to(dev), "step_ns": torch.zeros(n, dtype=torch.int64, device=dev)}
+        for f in nx._abi.F64_FIELDS:
+            t[f] = torch.from_numpy(getattr(batch, f)).to(dev)
+        s = nx._abi.States()
+        s.n = n
+        s.epoch_ns = C.cast(t["epoch_ns"].data_ptr(), nx._abi.c_int64_p)
+        s.step_ns = C.cast(t["step_ns"].data_ptr(), nx._abi.c_int64_p)
+        for f in nx._abi.F64_FIELDS:
+            setattr(s, f, C.cast(t[f].data_ptr(), nx._abi.c_double_p))
+        return t, s
+
+    def dev_traj(capacity):
+        t = {"epoch": torch.zeros((capacity, n), dtype=torch.int64, device=dev), "state": torch.zeros((6, capacity, n), dtype=torch.float64, device=dev),
+             "len": torch.zeros(n, dtype=torch.int32, device=dev)}
+        s = nx._abi.Traj()
+        s.capacity = capacity
+        s.epoch_ns = C.cast(t["epoch"].data_ptr(), nx._abi.c_int64_p)
+        for k, f in enumerate(["x_km", "y_km", "z_km", "vx_km_s", "vy_km_s", "vz_km_s"]):
+            setattr(s, f, C.cast(t["state"][k].data_ptr(), nx._abi.c_double_p))
+        s.len = C.cast(t["len"].data_ptr(), nx._abi.c_int32_p)
+        return t, s
+
+    tin, sin = dev_states(b)
+    tout, sout = dev_states(b)
+    status = torch.zeros(n, dtype=torch.int32, device=dev)
+    sst = nx._abi.StepStats()
+    sst.status = C.cast(status.data_ptr(), nx._abi.c_int32_p)
+    ttraj, straj = dev_traj(cap)
+    tev, sev = dev_traj(count)
+    stream = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(stream):
+        h = C.c_void_p(stream.cuda_stream)
+        assert lib.nyx_hip_propagate_batch_with_traj_device(ctx._h, C.byref(sin), dur, C.byref(sout), C.byref(sst), C.byref(straj), h) == 0
+        assert lib.nyx_hip_traj_every_device(ctx._h, C.byref(straj), n, step, C.byref(sev), h) == 0
+    stream.synchronize()
+    assert int((status != 0).sum()) == 0
+    # host-array twins
+    out, st, traj = ctx.propagate_with_traj(b, dur, capacity=cap)
+    ev = ctx.traj_every(traj, step, capacity=count)
+    np.testing.assert_array_equal(ttraj["len"].cpu().numpy(), traj.len)
+    np.testing.assert_array_equal(tev["len"].cpu().numpy(), ev.len)
+    np.testing.assert_array_equal(tev["epoch"].cpu().numpy(), ev.epoch_ns)
+    np.testing.assert_array_equal(tev["state"].cpu().numpy(), ev.state)
+    np.testing.assert_array_equal(tout["x_km"].cpu().numpy(), out.x_km)
