@@ -405,6 +405,11 @@ int32_t nyx_hip_predict_until(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, cons
  * 64-trajectory workgroup (0 = pick automatically from n). */
 int32_t nyx_hip_ctx_set_column_waves(nyx_hip_ctx *ctx, int32_t waves);
 
+/* Number of helper workgroups of the last propagate launch on this ctx (0 = every workgroup worked alone).  Cooperative
+ * mode is chosen automatically when the 64-trajectory workgroups leave CUs idle (propagate_kernel.hip); NYX_HIP_COOP=0
+ * in the environment disables it. */
+int32_t nyx_hip_last_coop_helpers(nyx_hip_ctx *ctx);
+
 /* Elapsed device time (ms) of the kernels launched by the last propagate call on
  * this ctx, measured with HIP events on the launch stream; <0 if unavailable. */
 double nyx_hip_last_kernel_ms(nyx_hip_ctx *ctx);

@@ -353,7 +353,7 @@ EXPORTS = [
     "nyx_hip_last_kernel_ms", "nyx_hip_last_error", "nyx_hip_load_cof", "nyx_hip_load_shadr", "nyx_hip_free",
     "nyx_hip_propagate_batch_with_traj", "nyx_hip_propagate_batch_with_traj_device",
     "nyx_hip_traj_at", "nyx_hip_traj_every", "nyx_hip_traj_at_device", "nyx_hip_traj_every_device",
-    "nyx_hip_predict_until", "nyx_hip_propagate_until_event",
+    "nyx_hip_predict_until", "nyx_hip_propagate_until_event", "nyx_hip_last_coop_helpers",
 ]
 
 
@@ -402,6 +402,8 @@ def load_library():
     lib.nyx_hip_propagate_until_epoch.restype = C.c_int32
     lib.nyx_hip_ctx_set_column_waves.argtypes = [C.c_void_p, C.c_int32]
     lib.nyx_hip_ctx_set_column_waves.restype = C.c_int32
+    lib.nyx_hip_last_coop_helpers.argtypes = [C.c_void_p]
+    lib.nyx_hip_last_coop_helpers.restype = C.c_int32
     lib.nyx_hip_last_kernel_ms.argtypes = [C.c_void_p]
     lib.nyx_hip_last_kernel_ms.restype = C.c_double
     lib.nyx_hip_last_error.restype = C.c_char_p

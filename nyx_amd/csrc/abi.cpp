@@ -81,6 +81,10 @@ struct nyx_hip_ctx {
     double role_handicap[3] = {0.0, 0.0, 0.0};  // integrator, almanac, perturbations (harmonics-term units)
     DevArrays in, out;
     int64_t *d_prof = nullptr;
+    CoopBox *d_coop = nullptr;  // cooperative-mode mailboxes, one per trajectory-owning workgroup
+    int64_t coop_cap = 0;
+    int n_cu = 0;
+    int last_coop_helpers = 0;  // helpers of the last launch (0 = solo)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_ms = -1.0;
 };
@@ -221,23 +225,13 @@ static void build_harmonics(const nyx_hip_gravity_field_t *g, std::vector<HarmEn
 // topped up with short columns from the high-c end — so that one complex power per range suffices.
 // Waves 0/1/2 also carry the integrator / almanac / perturbation duties (`role_handicap`, in units of
 // one harmonics term), so they receive a reduced share of the columns, possibly none.
-static void build_schedule(nyx_hip_ctx *ctx, int n_waves) {
-    DevCfg &dc = ctx->host_cfg;
-    const int nc = dc.n_cols;
-    for (int w = 0; w < DEV_MAX_WAVES; ++w) dc.n_ranges[w] = 0;
-    dc.n_waves = n_waves;
-    dc.merge_roles = (std::getenv("NYX_HIP_MERGE_ROLES") && n_waves >= 8) ? 1 : 0;
-    if (!dc.has_grav || nc == 0) return;
+// Water-filling of the columns [c_lo, c_hi] over `n_waves` waves with per-wave handicaps hc[] (work a wave does besides
+// its columns, in harmonics-term units) and SIMD age weights.  Wave 0 takes what is left.
+static void fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, int c_lo, int c_hi, const double *hc) {
+    for (int w = 0; w < DEV_MAX_WAVES; ++w) sd.n_ranges[w] = 0;
+    if (c_lo > c_hi) return;
     double terms = 0.0;
-    for (int c = 1; c <= nc; ++c) terms += ctx->col_len[c];
-    // role handicaps of this workgroup shape (merged roles when there are fewer than three waves)
-    double hc[DEV_MAX_WAVES] = {0};
-    if (n_waves == 1) hc[0] = ctx->role_handicap[0] + ctx->role_handicap[1] + ctx->role_handicap[2];
-    else if (n_waves == 2) { hc[0] = ctx->role_handicap[0]; hc[1] = ctx->role_handicap[1] + ctx->role_handicap[2]; }
-    else if (dc.merge_roles) { hc[0] = ctx->role_handicap[0]; hc[1] = ctx->role_handicap[1] + ctx->role_handicap[2]; }
-    else { hc[0] = ctx->role_handicap[0]; hc[1] = ctx->role_handicap[1]; hc[2] = ctx->role_handicap[2]; }
-    // with enough column workers the integrator keeps its window free: its serial phases A / C gate every other wave
-    if (n_waves >= 8 && !std::getenv("NYX_HIP_ROLE_HANDICAP")) hc[0] = 1e9;
+    for (int c = c_lo; c <= c_hi; ++c) terms += ctx->col_len[c];
     // Age weights: the four waves that share a SIMD (w, w+4, w+8, w+12) are arbitrated oldest-first, so with equal shares
     // the oldest finishes early and the youngest runs the tail alone, with nothing to hide its scalar-load latency.
     // Larger shares for the older waves make the four finish together.
@@ -248,20 +242,22 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves) {
     // water-filling: level such that sum_w max(0, level * weight_w - hc[w]) = terms
     double level = 0.0;
     {
-        double lo = 0.0, hi = 4.0 * (terms + std::min(hc[0], 1e6) + hc[1] + hc[2]);
+        double hsum = 0.0;
+        for (int w = 0; w < n_waves; ++w) hsum += std::min(hc[w], 1e6);
+        double lo = 0.0, hi = 4.0 * (terms + hsum);
         for (int it = 0; it < 80; ++it) {
             level = 0.5 * (lo + hi);
-            double s = 0.0;
-            for (int w = 0; w < n_waves; ++w) s += std::max(0.0, level * wgt(w) - hc[w]);
-            if (s < terms) lo = level; else hi = level;
+            double sum = 0.0;
+            for (int w = 0; w < n_waves; ++w) sum += std::max(0.0, level * wgt(w) - hc[w]);
+            if (sum < terms) lo = level; else hi = level;
         }
     }
-    int lo = 1, hi = nc;
+    int lo = c_lo, hi = c_hi;
     // plain column workers first (highest wave index), role waves last so they take what is left
     for (int w = n_waves - 1; w >= 0; --w) {
         const double tgt = std::max(0.0, level * wgt(w) - hc[w]);
         if (w == 0) {
-            if (lo <= hi) { dc.range_c0[0][0] = lo; dc.range_cnt[0][0] = hi - lo + 1; dc.n_ranges[0] = 1; }
+            if (lo <= hi) { sd.range_c0[0][0] = lo; sd.range_cnt[0][0] = hi - lo + 1; sd.n_ranges[0] = 1; }
             break;
         }
         double load = 0.0;
@@ -276,9 +272,43 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves) {
             --hi; ++bcnt;
         }
         int nr = 0;
-        if (acnt) { dc.range_c0[w][nr] = a0; dc.range_cnt[w][nr] = acnt; ++nr; }
-        if (bcnt) { dc.range_c0[w][nr] = bend - bcnt + 1; dc.range_cnt[w][nr] = bcnt; ++nr; }
-        dc.n_ranges[w] = nr;
+        if (acnt) { sd.range_c0[w][nr] = a0; sd.range_cnt[w][nr] = acnt; ++nr; }
+        if (bcnt) { sd.range_c0[w][nr] = bend - bcnt + 1; sd.range_cnt[w][nr] = bcnt; ++nr; }
+        sd.n_ranges[w] = nr;
+    }
+}
+
+static void build_schedule(nyx_hip_ctx *ctx, int n_waves) {
+    DevCfg &dc = ctx->host_cfg;
+    const int nc = dc.n_cols;
+    for (int k = 0; k < DEV_N_SCHED; ++k)
+        for (int w = 0; w < DEV_MAX_WAVES; ++w) dc.sched[k].n_ranges[w] = 0;
+    dc.n_waves = n_waves;
+    dc.merge_roles = (std::getenv("NYX_HIP_MERGE_ROLES") && n_waves >= 8) ? 1 : 0;
+    if (!dc.has_grav || nc == 0) return;
+    // role handicaps of this workgroup shape (merged roles when there are fewer than three waves)
+    double hc[DEV_MAX_WAVES] = {0};
+    if (n_waves == 1) hc[0] = ctx->role_handicap[0] + ctx->role_handicap[1] + ctx->role_handicap[2];
+    else if (n_waves == 2) { hc[0] = ctx->role_handicap[0]; hc[1] = ctx->role_handicap[1] + ctx->role_handicap[2]; }
+    else if (dc.merge_roles) { hc[0] = ctx->role_handicap[0]; hc[1] = ctx->role_handicap[1] + ctx->role_handicap[2]; }
+    else { hc[0] = ctx->role_handicap[0]; hc[1] = ctx->role_handicap[1]; hc[2] = ctx->role_handicap[2]; }
+    // with enough column workers the integrator keeps its window free: its serial phases A / C gate every other wave
+    if (n_waves >= 8 && !std::getenv("NYX_HIP_ROLE_HANDICAP")) hc[0] = 1e9;
+    fill_schedule(ctx, dc.sched[DEV_SCHED_SOLO], n_waves, 1, nc, hc);
+    // cooperative mode (16-wave workgroups only): the helper takes the LONG columns 1..c_split (fewest columns for its share)
+    if (n_waves == DEV_MAX_WAVES && nc >= 8) {
+        double terms = 0.0, acc = 0.0;
+        for (int c = 1; c <= nc; ++c) terms += ctx->col_len[c];
+        int c_split = 0;
+        while (c_split < nc - 1 && acc + 0.5 * ctx->col_len[c_split + 1] <= dc.coop_frac * terms) acc += ctx->col_len[++c_split];
+        if (c_split >= 1) {
+            fill_schedule(ctx, dc.sched[DEV_SCHED_PRIMARY], n_waves, c_split + 1, nc, hc);
+            double hh[DEV_MAX_WAVES] = {0};
+            hh[0] = 8.0;  // the helper's wave 0 also polls, folds and answers
+            fill_schedule(ctx, dc.sched[DEV_SCHED_HELPER], n_waves, 1, c_split, hh);
+            DevSched &fb = dc.sched[DEV_SCHED_FALLBACK];
+            fb.n_ranges[0] = 1; fb.range_c0[0][0] = 1; fb.range_cnt[0][0] = c_split;
+        }
     }
 }
 
@@ -309,6 +339,8 @@ extern "C" int32_t nyx_hip_ctx_set_column_waves(nyx_hip_ctx *ctx, int32_t waves)
     return NYX_HIP_RC_OK;
 }
 
+extern "C" int32_t nyx_hip_last_coop_helpers(nyx_hip_ctx *ctx) { return ctx ? ctx->last_coop_helpers : 0; }
+
 extern "C" double nyx_hip_last_kernel_ms(nyx_hip_ctx *ctx) {
     if (!ctx || !ctx->ev1) return -1.0;
     if (hipEventSynchronize(ctx->ev1) != hipSuccess) return -1.0;
@@ -331,6 +363,7 @@ extern "C" void nyx_hip_ctx_destroy(nyx_hip_ctx *ctx) {
     hipFree(ctx->d_cfg); hipFree(ctx->d_htab); hipFree(ctx->d_cols); hipFree(ctx->d_records);
     free_arrays(ctx->in);
     free_arrays(ctx->out);
+    (void)hipFree(ctx->d_coop);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     delete ctx;
@@ -508,6 +541,12 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
     dc.rec_doubles = (int32_t)records.size();
     dc.rec_in_lds = (records.size() * sizeof(double) <= 24 * 1024) ? 1 : 0;
     if ((cfg->flags & NYX_HIP_FLAG_STM) && nyx_kernel_lds_bytes(DEV_MAX_WAVES_STM, dc.rec_doubles, 1) > 160 * 1024) dc.rec_in_lds = 0;
+    dc.coop_frac = 0.30;  // measured optimum with two owners per helper (10 000 trajectories, 70x70): 0.28-0.33 is flat
+    if (const char *e = std::getenv("NYX_HIP_COOP_FRAC")) dc.coop_frac = std::min(0.9, std::max(0.05, std::atof(e)));
+    {
+        hipDeviceProp_t prop;
+        ctx->n_cu = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 0;
+    }
     build_schedule(ctx, 1);
 
     // ---- upload
@@ -572,6 +611,39 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
     if (st) {
         bt.status = st->status; bt.last_step_ns = st->last_step_ns; bt.last_error = st->last_error;
         bt.last_attempts = st->last_attempts; bt.n_acc = st->n_accepted; bt.n_rej = st->n_rejected; bt.n_evals = st->n_evals;
+    }
+    // Cooperative mode: when the trajectory-owning workgroups leave CUs idle, helper workgroups take over a share of
+    // the harmonics columns (propagate_kernel.hip).  Owners and helpers that talk to each other get block indices that
+    // agree modulo 8 (round-robin XCD dispatch: same L2); every owner needs a helper for the split to pay off.
+    ctx->last_coop_helpers = 0;
+    {
+        const char *e = std::getenv("NYX_HIP_COOP");
+        const bool want = e ? std::atoi(e) != 0 : true;  // on by default; NYX_HIP_COOP=0 forces one workgroup per 64 trajectories to work alone
+        const int64_t n_own = (in->n + DEV_LANES - 1) / DEV_LANES;
+        const int64_t base = (n_own + 7) / 8 * 8;
+        const bool stm_ctx = (ctx->host_cfg.flags & NYX_HIP_FLAG_STM) != 0;
+        if (want && !stm_ctx && ctx->host_cfg.has_grav && nw == DEV_MAX_WAVES && ctx->host_cfg.sched[DEV_SCHED_FALLBACK].n_ranges[0] > 0 &&
+            base + 8 <= ctx->n_cu) {
+            int64_t helpers = std::min<int64_t>(n_own, (ctx->n_cu - base) / 8 * 8);
+            if (helpers >= 8 && 2 * helpers >= n_own) {
+                if (ctx->coop_cap < n_own) {
+                    (void)hipFree(ctx->d_coop);
+                    ctx->d_coop = nullptr;
+                    // uncached device memory: the mailboxes are coherent across the XCDs' L2s without any cache
+                    // write-back / invalidate in the kernel (those would also flush the harmonics table out of L2)
+                    if (hipExtMallocWithFlags((void **)&ctx->d_coop, (size_t)std::max<int64_t>(n_own, 256) * sizeof(CoopBox),
+                                              hipDeviceMallocUncached) != hipSuccess) {
+                        ctx->d_coop = nullptr;
+                        nyx_set_error("hipExtMallocWithFlags(uncached) failed for the cooperative-mode mailboxes");
+                        return NYX_HIP_RC_HIP_ERROR;
+                    }
+                    ctx->coop_cap = std::max<int64_t>(n_own, 256);
+                }
+                HIP_TRY(hipMemsetAsync(ctx->d_coop, 0, (size_t)n_own * sizeof(CoopBox), stream));
+                bt.coop_helpers = (int32_t)helpers; bt.coop_base = (int32_t)base; bt.coop_box = ctx->d_coop;
+                ctx->last_coop_helpers = (int)helpers;
+            }
+        }
     }
     if (std::getenv("NYX_HIP_PROFILE")) {
         if (!ctx->d_prof) HIP_TRY(hipMalloc(&ctx->d_prof, 16 * 8 * sizeof(int64_t)));
@@ -1059,8 +1131,9 @@ extern "C" int32_t nyx_hip_debug_schedule(nyx_hip_ctx *ctx, int32_t n_waves, int
     build_schedule(ctx, n_waves);
     for (int w = 0; w < DEV_MAX_WAVES; ++w) {
         int l = 0;
-        for (int q = 0; q < ctx->host_cfg.n_ranges[w]; ++q)
-            for (int c = ctx->host_cfg.range_c0[w][q]; c < ctx->host_cfg.range_c0[w][q] + ctx->host_cfg.range_cnt[w][q]; ++c) l += ctx->col_len[c];
+        const DevSched &sd = ctx->host_cfg.sched[DEV_SCHED_SOLO];
+        for (int q = 0; q < sd.n_ranges[w]; ++q)
+            for (int c = sd.range_c0[w][q]; c < sd.range_c0[w][q] + sd.range_cnt[w][q]; ++c) l += ctx->col_len[c];
         loads[w] = l;
     }
     build_schedule(ctx, keep);

@@ -26,6 +26,18 @@ struct DevSlot { /* one evaluated body: position w.r.t. the integration centre =
     double sign[4];
 };
 
+/* One assignment of harmonics columns to the waves of a workgroup. */
+struct DevSched {
+    int32_t n_ranges[DEV_MAX_WAVES];
+    int32_t range_c0[DEV_MAX_WAVES][DEV_MAX_RANGES];
+    int32_t range_cnt[DEV_MAX_WAVES][DEV_MAX_RANGES];
+};
+/* SOLO: one workgroup does every column (all configurations).  Cooperative mode (idle CUs lend a hand, see
+ * propagate_kernel.hip): PRIMARY = the columns the trajectory-owning workgroup keeps, HELPER = the columns a helper
+ * workgroup on another CU evaluates, FALLBACK = the helper's columns on wave 0 (primary does them itself if the
+ * helper does not answer). */
+enum { DEV_SCHED_SOLO = 0, DEV_SCHED_PRIMARY = 1, DEV_SCHED_HELPER = 2, DEV_SCHED_FALLBACK = 3, DEV_N_SCHED = 4 };
+
 struct DevRot {
     double ra[3], dec[3], w[3];
 };
@@ -72,12 +84,11 @@ struct DevCfg {
     double t_mu, t_re;
     DevRot t_rot;
 
-    /* --- column schedule: wave w walks n_ranges[w] contiguous column ranges --- */
+    /* --- column schedules: wave w walks n_ranges[w] contiguous column ranges --- */
     int32_t n_waves;
     int32_t merge_roles; /* almanac and perturbation duties share wave 1 */
-    int32_t n_ranges[DEV_MAX_WAVES];
-    int32_t range_c0[DEV_MAX_WAVES][DEV_MAX_RANGES];
-    int32_t range_cnt[DEV_MAX_WAVES][DEV_MAX_RANGES];
+    DevSched sched[DEV_N_SCHED];
+    double coop_frac; /* share of the harmonics terms a helper workgroup takes over (cooperative mode) */
 };
 
 /* Column header (32 B = one s_load_dwordx8): rows of column c start at htab[start] and come in
@@ -99,6 +110,18 @@ struct HarmEntry {
     double bb, cc, t1, t2, t3, t4, t5, t6;
 };
 
+/* Mailbox between a trajectory-owning workgroup and its helper (global memory).  The owner posts the harmonics inputs
+ * of evaluation `posted` (1, 2, ...); the helper answers with the partial sums of its columns and `done = posted`. */
+struct CoopBox {
+    double in[5][DEV_LANES];
+    double out[4][DEV_LANES];
+    uint32_t posted;   /* written by the owner */
+    uint32_t finished; /* owner: left the kernel or stopped posting */
+    uint32_t pad0[14];
+    uint32_t done;     /* written by the helper (its own 64-byte line) */
+    uint32_t pad1[15];
+};
+
 struct DevBatch { /* device pointers of one launch */
     int64_t n;
     int64_t duration_ns;
@@ -114,6 +137,9 @@ struct DevBatch { /* device pointers of one launch */
     double *ev_prev;   /* [n] event value of the previous accepted state */
     int32_t *ev_count; /* [n] crossings so far */
     int32_t *ev_found; /* [n] 1 when the propagation stopped on the event */
+    /* cooperative mode: workgroups [0, ceil(n/64)) own trajectories, [coop_base, coop_base + coop_helpers) help */
+    int32_t coop_helpers, coop_base;
+    struct CoopBox *coop_box; /* one mailbox per trajectory-owning workgroup, zeroed before the launch */
     const int64_t *dur_ns; /* optional per-trajectory duration (covariance-mapping segments); overrides duration_ns */
     const double *stm; /* [n][81] column-major per trajectory, or NULL */
     double *o_stm;

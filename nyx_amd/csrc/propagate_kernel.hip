@@ -549,13 +549,15 @@ typedef Partial4T<double> Partial4;
 // VGPRs under the device-function ABI, so the wave-uniform ones are re-scalarised with v_readfirstlane.
 // T = double: accelerations only; T = D3: accelerations and their body-fixed position partials (STM path).
 template <typename T>
-DEVFN Partial4T<T> harmonics_core(CfgPtr cfg, HarmPtr htab, ColPtr cols, const int wave, T zr, T zi, T rho_u, T rho, T inv_rho) {
+DEVFN Partial4T<T> harmonics_core(CfgPtr cfg, HarmPtr htab, ColPtr cols, const int wave, const int sched, T zr, T zi, T rho_u, T rho,
+                                  T inv_rho) {
     T px = gzero(zr), py = gzero(zr), pz = gzero(zr), pw = gzero(zr);
     const T rho2 = gmul(rho, rho);
-    const int nr = cfg->n_ranges[wave];
+    const CAS DevSched &sd = cfg->sched[sched];
+    const int nr = sd.n_ranges[wave];
     for (int q = 0; q < nr; ++q) {
-        const int c0 = cfg->range_c0[wave][q];
-        const int cnt = cfg->range_cnt[wave][q];
+        const int c0 = sd.range_c0[wave][q];
+        const int cnt = sd.range_cnt[wave][q];
         T rc, ic;
         cpow_uniform(zr, zi, c0 - 1, rc, ic);
         ColHdr hd = load_hdr(cols, c0);  // the next column's header is fetched under this column's batches
@@ -592,12 +594,14 @@ DEVFN Partial4T<T> harmonics_core(CfgPtr cfg, HarmPtr htab, ColPtr cols, const i
 }
 
 static __device__ __attribute__((noinline)) Partial4 harmonics_partial(uint64_t cfg_u, uint64_t htab_u, uint64_t cols_u, int wave_v,
-                                                                     double zr, double zi, double rho_u, double rho, double inv_rho) {
+                                                                     int sched_v, double zr, double zi, double rho_u, double rho,
+                                                                     double inv_rho) {
     CfgPtr cfg = (CfgPtr)uniform_u64(cfg_u);
     HarmPtr htab = (HarmPtr)uniform_u64(htab_u);
     ColPtr cols = (ColPtr)uniform_u64(cols_u);
     const int wave = __builtin_amdgcn_readfirstlane(wave_v);
-    return harmonics_core<double>(cfg, htab, cols, wave, zr, zi, rho_u, rho, inv_rho);
+    const int sched = __builtin_amdgcn_readfirstlane(sched_v);
+    return harmonics_core<double>(cfg, htab, cols, wave, sched, zr, zi, rho_u, rho, inv_rho);
 }
 
 // Dual variant: inputs and outputs go through LDS (20 + 16 doubles per lane) instead of the register ABI.
@@ -613,12 +617,128 @@ static __device__ __attribute__((noinline)) void harmonics_partial_dual(uint64_t
         in[q].v = inbD[(4 * q + 0) * DEV_LANES + lane]; in[q].x = inbD[(4 * q + 1) * DEV_LANES + lane];
         in[q].y = inbD[(4 * q + 2) * DEV_LANES + lane]; in[q].z = inbD[(4 * q + 3) * DEV_LANES + lane];
     }
-    const Partial4T<D3> pd = harmonics_core<D3>(cfg, htab, cols, wave, in[0], in[1], in[2], in[3], in[4]);
+    const Partial4T<D3> pd = harmonics_core<D3>(cfg, htab, cols, wave, DEV_SCHED_SOLO, in[0], in[1], in[2], in[3], in[4]);
     const D3 o4[4] = {pd.x, pd.y, pd.z, pd.w};
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         outD[(4 * q + 0) * DEV_LANES + lane] = o4[q].v; outD[(4 * q + 1) * DEV_LANES + lane] = o4[q].x;
         outD[(4 * q + 2) * DEV_LANES + lane] = o4[q].y; outD[(4 * q + 3) * DEV_LANES + lane] = o4[q].z;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cooperative mode: idle CUs lend a hand.
+//
+// A workgroup holds 64 trajectories and fills one CU; an ensemble of 10 000 therefore occupies 157 of the 256 CUs.
+// When workgroups are fewer than CUs, the launch adds HELPER workgroups on the idle CUs.  For every force evaluation
+// the trajectory-owning workgroup posts the five per-lane inputs of the column recursion (2.5 KB) in a mailbox in
+// global memory, keeps the columns of DEV_SCHED_PRIMARY for itself, and its helper evaluates the columns of
+// DEV_SCHED_HELPER for the same 64 lanes and answers with four partial sums per lane (2 KB).  The exchange overlaps
+// the owner's own window; what it costs is two device-scope fences per evaluation on either side.
+// Deadlock-free without any residency assumption: the owner waits a bounded time for an answer, and if none comes it
+// evaluates the helper's columns itself (DEV_SCHED_FALLBACK) and goes back to DEV_SCHED_SOLO for the rest of the
+// launch; helpers leave when every workgroup they serve has finished.  The owner adds the helper's partial after its
+// own sixteen, in a fixed order: results are deterministic for a given split.
+// ---------------------------------------------------------------------------------------------
+// The mailboxes live in UNCACHED device memory and are only touched with device-scope relaxed atomics (loads and stores
+// that go past the L1 / the XCD's L2), ordered by workgroup-scope fences, i.e. s_waitcnt on the wave's own accesses: no
+// cache write-back or invalidate anywhere (a device-scope fence per evaluation also throws the harmonics table out of
+// L2 and doubled the run time).
+DEVFN uint32_t coop_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEVFN void coop_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEVFN double coop_loadd(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEVFN void coop_stored(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEVFN void coop_release() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }  // (inline asm: never elided by the compiler)
+DEVFN void coop_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+#define COOP_TIMEOUT_TICKS 200000LL  /* 2 ms of the 100 MHz realtime counter */
+
+// Posting happens after barrier B1, from the LDS copy of the inputs, when the integrator wave is idle anyway: the
+// owner's critical path never waits for memory.
+static __device__ __attribute__((noinline)) void coop_post(CoopBox *box, int lane, uint32_t seq, const double *inb) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) coop_stored(&box->in[q][lane], inb[q * DEV_LANES + lane]);
+    coop_release();  // the inputs have reached memory before the sequence number is written
+    if (lane == 0) coop_store(&box->posted, seq);
+}
+
+struct CoopAnswer {
+    double x, y, z, w;
+    int ok;
+};
+static __device__ __attribute__((noinline)) CoopAnswer coop_wait(CoopBox *box, int lane, uint32_t seq) {
+    CoopAnswer a = {0.0, 0.0, 0.0, 0.0, 0};
+    const int64_t t0 = (int64_t)__builtin_amdgcn_s_memrealtime();
+    for (;;) {
+        if (coop_load(&box->done) == seq) break;
+        if ((int64_t)__builtin_amdgcn_s_memrealtime() - t0 > COOP_TIMEOUT_TICKS) return a;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    coop_acquire();
+    a.x = coop_loadd(&box->out[0][lane]); a.y = coop_loadd(&box->out[1][lane]); a.z = coop_loadd(&box->out[2][lane]);
+    a.w = coop_loadd(&box->out[3][lane]);
+    a.ok = 1;
+    return a;
+}
+
+// Helper workgroup: serves the owners h and h + n_helpers.  LDS: [16][4][64] partials + the job word.
+DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols, char *smem, int lane, int wave) {
+    double *part = (double *)smem;
+    volatile int *job = (volatile int *)(part + DEV_MAX_WAVES * 4 * DEV_LANES);
+    const int h = (int)blockIdx.x - bt.coop_base;
+    const int64_t n_own = (bt.n + DEV_LANES - 1) / DEV_LANES;
+    const int64_t own[2] = {h, (int64_t)h + bt.coop_helpers};
+    const bool served[2] = {own[0] < n_own, own[1] < n_own};
+    uint32_t last[2] = {0u, 0u};
+    int rr = 0;
+    for (;;) {
+        if (wave == 0) {
+            int which = -2;
+            uint32_t seq = 0;
+            const int64_t t0 = (int64_t)__builtin_amdgcn_s_memrealtime();
+            for (;;) {
+                bool all_fin = true;
+                for (int k = 0; k < 2; ++k) {
+                    const int kk = (rr + k) & 1;
+                    if (!served[kk]) continue;
+                    CoopBox *b = bt.coop_box + own[kk];
+                    const uint32_t posted = coop_load(&b->posted);
+                    if (posted != last[kk]) { which = kk; seq = posted; break; }
+                    if (!coop_load(&b->finished)) all_fin = false;
+                }
+                if (which >= 0) break;
+                if (all_fin) { which = -1; break; }
+                if ((int64_t)__builtin_amdgcn_s_memrealtime() - t0 > 5000 * COOP_TIMEOUT_TICKS) { which = -1; break; }  // 10 s: never spin forever
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (lane == 0) { job[0] = which; job[1] = (int)seq; }
+            if (which >= 0) last[which] = seq;
+            rr ^= 1;
+        }
+        __syncthreads();
+        const int which = job[0];
+        const uint32_t seq = (uint32_t)job[1];
+        if (which < 0) break;
+        CoopBox *b = bt.coop_box + own[which];
+        coop_acquire();  // the inputs were posted before `seq`
+        const double v0 = coop_loadd(&b->in[0][lane]), v1 = coop_loadd(&b->in[1][lane]), v2 = coop_loadd(&b->in[2][lane]),
+                     v3 = coop_loadd(&b->in[3][lane]), v4 = coop_loadd(&b->in[4][lane]);
+        const Partial4 pr = harmonics_partial((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, DEV_SCHED_HELPER, v0, v1, v2, v3, v4);
+        double *pp = part + wave * 4 * DEV_LANES;
+        pp[0 * DEV_LANES + lane] = pr.x; pp[1 * DEV_LANES + lane] = pr.y; pp[2 * DEV_LANES + lane] = pr.z; pp[3 * DEV_LANES + lane] = pr.w;
+        __syncthreads();
+        if (wave == DEV_MAX_WAVES - 1) {  // the last wave answers while wave 0 is already polling for the next job
+            double o[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int w = 0; w < DEV_MAX_WAVES; ++w) {  // fixed wave order
+#pragma unroll
+                for (int q = 0; q < 4; ++q) o[q] += part[(w * 4 + q) * DEV_LANES + lane];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) coop_stored(&b->out[q][lane], o[q]);
+            coop_release();
+            if (lane == 0) coop_store(&b->done, seq);
+        }
+        // no barrier here: every wave read job[] before the barrier above, and part[] is not rewritten before the last wave
+        // (the one that is reading it) has arrived at the next job barrier
     }
 }
 
@@ -1012,6 +1132,11 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
         p_mass = (bt.mdry ? bt.mdry[idx] : 0.0) + (bt.mprop ? bt.mprop[idx] : 0.0) + (bt.mextra ? bt.mextra[idx] : 0.0);
     }
     __syncthreads();
+    // cooperative mode (see above): the integrator owns the conversation with the helper
+    CoopBox *const cbox = bt.coop_box + blockIdx.x;
+    bool coop_on = !STM && ((volatile int *)L.ctl)[1] != 0;
+    const bool coop_started = coop_on;
+    uint32_t coop_seq = 0;
 
     for (;;) {  // one iteration = one RK attempt for every live lane (derive(), instance.rs:368-414)
         double h = 0.0;
@@ -1127,6 +1252,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             const int64_t ptw_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;
 
             // ---- window --------------------------------------------------------------------------
+            if (INTEG && !STM && coop_on && has_grav) coop_post(cbox, lane, ++coop_seq, L.inb);
             if (ALMANAC && need_almanac && i + 1 < stages) {
                 // epoch-only data of the NEXT stage
                 const int64_t ep = __double_as_longlong(L.step[lane]) + seconds_to_ns(C_COEF(i + 1) * L.step[DEV_LANES + lane]);
@@ -1190,7 +1316,8 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             if (STM && has_grav)
                 harmonics_partial_dual((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, L.inbD, L.partD + wave * 16 * DEV_LANES, lane);
             if (!STM && has_grav && !dbg_skip_harm) {
-                const Partial4 pr = harmonics_partial((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, L.inb[0 * DEV_LANES + lane],
+                const int sched = ((volatile int *)L.ctl)[1] ? DEV_SCHED_PRIMARY : DEV_SCHED_SOLO;  // (ctl[1] only changes between B2 and B1)
+                const Partial4 pr = harmonics_partial((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, sched, L.inb[0 * DEV_LANES + lane],
                                                       L.inb[1 * DEV_LANES + lane], L.inb[2 * DEV_LANES + lane],
                                                       L.inb[3 * DEV_LANES + lane], L.inb[4 * DEV_LANES + lane]);
                 px = pr.x; py = pr.y; pz = pr.z; pw = pr.w;
@@ -1219,6 +1346,20 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     {
                         const Partial4 f4 = fold_partials((LdsCPtr)L.part, lane, px, py, pz, pw);
                         px = f4.x; py = f4.y; pz = f4.z; pw = f4.w;
+                    }
+                    if (coop_on) {  // + the helper's columns
+                        const CoopAnswer ans = coop_wait(cbox, lane, coop_seq);
+                        if (ans.ok) {
+                            px += ans.x; py += ans.y; pz += ans.z; pw += ans.w;
+                        } else {  // no answer in time: do the helper's columns here, then carry on alone
+                            const Partial4 fb = harmonics_partial((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, 0, DEV_SCHED_FALLBACK,
+                                                                  L.inb[0 * DEV_LANES + lane], L.inb[1 * DEV_LANES + lane],
+                                                                  L.inb[2 * DEV_LANES + lane], L.inb[3 * DEV_LANES + lane],
+                                                                  L.inb[4 * DEV_LANES + lane]);
+                            px += fb.x; py += fb.y; pz += fb.z; pw += fb.w;
+                            coop_on = false;
+                            if (lane == 0) { L.ctl[1] = 0; coop_store(&cbox->finished, 1u); }
+                        }
                     }
                     px *= kfac; py *= kfac; pz *= kfac; pw *= kfac;
                     const double al0 = px + pw * s_, al1 = py + pw * t_, al2 = pz + pw * u_;
@@ -1414,6 +1555,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
         for (int q = 0; q < 8; ++q) bt.prof[wave * 8 + q] = prof_acc[q];
     }
 
+    if (INTEG && coop_started && lane == 0) coop_store(&cbox->finished, 1u);
     if (INTEG && valid) {
         ColdState c;
         cold_load(L.cs, lane, c);
@@ -1451,6 +1593,15 @@ DEVFN void propagate_body(const DevBatch &bt, const DevCfg *cfg_g, const HarmEnt
     HarmPtr htab = (HarmPtr)htab_g;
     ColPtr cols = (ColPtr)cols_g;
 
+    // cooperative mode: blocks past the trajectory-owning ones are padding (up to coop_base) or helpers
+    if (!STM && bt.coop_helpers > 0) {
+        const int64_t n_own = (bt.n + DEV_LANES - 1) / DEV_LANES;
+        if ((int64_t)blockIdx.x >= n_own) {
+            if ((int)blockIdx.x >= bt.coop_base) helper_body(bt, cfg, htab, cols, smem, lane, wave);
+            return;
+        }
+    }
+
     const int stages = cfg->stages;
     const bool rec_in_lds = cfg->rec_in_lds != 0;
 
@@ -1471,7 +1622,11 @@ DEVFN void propagate_body(const DevBatch &bt, const DevCfg *cfg_g, const HarmEnt
         }
         tabl[q] = v;
     }
-    if (threadIdx.x == 0) L.ctl[0] = 0;
+    if (threadIdx.x == 0) {
+        L.ctl[0] = 0;
+        // ctl[1]: 1 while this workgroup shares its columns with a helper (owners h and h + n_helpers are served)
+        L.ctl[1] = (!STM && bt.coop_helpers > 0 && cfg->has_grav && (int)blockIdx.x < 2 * bt.coop_helpers) ? 1 : 0;
+    }
     for (int q = (int)threadIdx.x; q < DEV_MAX_WAVES * 4 * DEV_LANES; q += (int)blockDim.x) L.part[q] = 0.0;
 
     // ---- role dispatch (wave-uniform): merged roles when the workgroup has fewer than three waves
@@ -1525,8 +1680,10 @@ extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg
     if (stm)
         hipLaunchKernelGGL(nyx_propagate_kernel_stm, dim3((unsigned)blocks), dim3((unsigned)(n_waves * DEV_LANES)), lds, stream, bt, cfg,
                            htab, cols, records);
-    else
-        hipLaunchKernelGGL(nyx_propagate_kernel, dim3((unsigned)blocks), dim3((unsigned)(n_waves * DEV_LANES)), lds, stream, bt, cfg,
+    else {
+        const int64_t grid = bt.coop_helpers > 0 ? (int64_t)bt.coop_base + bt.coop_helpers : blocks;
+        hipLaunchKernelGGL(nyx_propagate_kernel, dim3((unsigned)grid), dim3((unsigned)(n_waves * DEV_LANES)), lds, stream, bt, cfg,
                            htab, cols, records);
+    }
     return hipGetLastError();
 }

@@ -609,6 +609,10 @@ class GpuContext:
     def set_column_waves(self, waves: int):
         self._lib.nyx_hip_ctx_set_column_waves(self._h, int(waves))
 
+    def last_coop_helpers(self) -> int:
+        """Helper workgroups of the last launch (0 = no cooperative mode)."""
+        return int(self._lib.nyx_hip_last_coop_helpers(self._h))
+
     def last_kernel_ms(self) -> float:
         return float(self._lib.nyx_hip_last_kernel_ms(self._h))
 

@@ -447,3 +447,36 @@ def test_solid_tides_stm_and_frame_rule():
     prop.dynamics.orbital_dyn.accel_models[-1] = nx.SolidTides.earth_moon_system(other, nx.MOON, nx.SUN)
     with pytest.raises(RuntimeError, match="tidal frame"):
         nx.GpuContext(prop.compile(almanac, central))
+
+
+def test_cooperative_mode_matches_solo_and_oracle(monkeypatch):
+    """10 000 trajectories leave 99 of the 256 CUs idle: helper workgroups take over a share of the harmonics columns
+    (propagate_kernel.hip, cooperative mode).  Same physics: against the solo launch the states agree to the level of a
+    different summation order, against the oracle within the parity bar; and the exchange is deterministic."""
+    prop, almanac, central = leo_full_setup(degree=70)
+    compiled = prop.compile(almanac, central)
+    ctx = nx.GpuContext(compiled)
+    b = dispersed_leo_batch(10_000, seed=0)
+    dur = 2 * 3600 * nx.NS_PER_S
+    monkeypatch.setenv("NYX_HIP_COOP", "0")
+    solo, sst = ctx.propagate(b, dur)
+    assert ctx.last_coop_helpers() == 0
+    solo_ms = ctx.last_kernel_ms()
+    monkeypatch.setenv("NYX_HIP_COOP", "1")
+    coop, cst = ctx.propagate(b, dur)
+    assert ctx.last_coop_helpers() == 96          # ceil(10000/64) = 157 owners, base 160, 96 helpers on the idle CUs
+    coop_ms = ctx.last_kernel_ms()
+    again, ast = ctx.propagate(b, dur)
+    assert (sst.status == 0).all() and (cst.status == 0).all()
+    np.testing.assert_array_equal(coop.rv(), again.rv())            # deterministic
+    np.testing.assert_array_equal(cst.n_evals, ast.n_evals)
+    dr, dv = pos_vel_errors(coop, solo)
+    print(f"cooperative vs solo: kernel {coop_ms:.1f} vs {solo_ms:.1f} ms, max dr {dr.max()*1e3:.2e} m, dv {dv.max()*1e6:.2e} mm/s, "
+          f"evals {cst.n_evals.sum()} vs {sst.n_evals.sum()}")
+    assert dr.max() < 1e-6 and dv.max() < 1e-9                       # 1 mm / 1e-3 mm/s: summation order and step noise only
+    head = b.slice(0, 256)
+    ref, rst = oracle_lib.propagate(compiled, head, dur, n_threads=NCPU)
+    dr, dv = pos_vel_errors(coop.slice(0, 256), ref)
+    assert dr.max() < 1e-3 and dv.max() < 1e-6
+    assert coop_ms < solo_ms                                          # and it is what it is for
+    ctx.close()
