@@ -641,6 +641,7 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
                 }
                 HIP_TRY(hipMemsetAsync(ctx->d_coop, 0, (size_t)n_own * sizeof(CoopBox), stream));
                 bt.coop_helpers = (int32_t)helpers; bt.coop_base = (int32_t)base; bt.coop_box = ctx->d_coop;
+                bt.coop_mute = std::getenv("NYX_HIP_COOP_MUTE") ? 1 : 0;
                 ctx->last_coop_helpers = (int)helpers;
             }
         }

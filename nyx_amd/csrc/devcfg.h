@@ -139,6 +139,7 @@ struct DevBatch { /* device pointers of one launch */
     int32_t *ev_found; /* [n] 1 when the propagation stopped on the event */
     /* cooperative mode: workgroups [0, ceil(n/64)) own trajectories, [coop_base, coop_base + coop_helpers) help */
     int32_t coop_helpers, coop_base;
+    int32_t coop_mute, _pad3; /* test switch (NYX_HIP_COOP_MUTE): helpers exit at once, as if they had never become resident */
     struct CoopBox *coop_box; /* one mailbox per trajectory-owning workgroup, zeroed before the launch */
     const int64_t *dur_ns; /* optional per-trajectory duration (covariance-mapping segments); overrides duration_ns */
     const double *stm; /* [n][81] column-major per trajectory, or NULL */

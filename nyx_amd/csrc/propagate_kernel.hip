@@ -1137,6 +1137,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     bool coop_on = !STM && ((volatile int *)L.ctl)[1] != 0;
     const bool coop_started = coop_on;
     uint32_t coop_seq = 0;
+    bool coop_drop = false;  // fallback taken: the workers go back to DEV_SCHED_SOLO from the next evaluation on
 
     for (;;) {  // one iteration = one RK attempt for every live lane (derive(), instance.rs:368-414)
         double h = 0.0;
@@ -1308,6 +1309,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             if (prof_on) prof_acc[1] += (int64_t)__builtin_readcyclecounter() - ptw_;
             const int64_t pth_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;
             double px = 0.0, py = 0.0, pz = 0.0, pw = 0.0;
+            double coop_x = 0.0, coop_y = 0.0, coop_z = 0.0, coop_w = 0.0;
             if (has_grav && dbg_skip_harm && !INTEG) {
                 double *pp = L.part + wave * 4 * DEV_LANES;
                 pp[0 * DEV_LANES + lane] = 0.0; pp[1 * DEV_LANES + lane] = 0.0;
@@ -1325,6 +1327,21 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     double *pp = L.part + wave * 4 * DEV_LANES;
                     pp[0 * DEV_LANES + lane] = px; pp[1 * DEV_LANES + lane] = py;
                     pp[2 * DEV_LANES + lane] = pz; pp[3 * DEV_LANES + lane] = pw;
+                }
+            }
+            if (INTEG && !STM && coop_on && has_grav) {
+                // the helper's answer is collected INSIDE the window (this wave has nothing else to do): phase C never waits
+                const CoopAnswer ans = coop_wait(cbox, lane, coop_seq);
+                if (ans.ok) {
+                    coop_x = ans.x; coop_y = ans.y; coop_z = ans.z; coop_w = ans.w;
+                } else {  // no answer in time: do the helper's columns here, then carry on alone
+                    const Partial4 fb = harmonics_partial((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, 0, DEV_SCHED_FALLBACK,
+                                                          L.inb[0 * DEV_LANES + lane], L.inb[1 * DEV_LANES + lane], L.inb[2 * DEV_LANES + lane],
+                                                          L.inb[3 * DEV_LANES + lane], L.inb[4 * DEV_LANES + lane]);
+                    coop_x = fb.x; coop_y = fb.y; coop_z = fb.z; coop_w = fb.w;
+                    coop_on = false;
+                    coop_drop = true;
+                    if (lane == 0) coop_store(&cbox->finished, 1u);
                 }
             }
             if (prof_on) prof_acc[2] += (int64_t)__builtin_readcyclecounter() - pth_;
@@ -1347,19 +1364,10 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                         const Partial4 f4 = fold_partials((LdsCPtr)L.part, lane, px, py, pz, pw);
                         px = f4.x; py = f4.y; pz = f4.z; pw = f4.w;
                     }
-                    if (coop_on) {  // + the helper's columns
-                        const CoopAnswer ans = coop_wait(cbox, lane, coop_seq);
-                        if (ans.ok) {
-                            px += ans.x; py += ans.y; pz += ans.z; pw += ans.w;
-                        } else {  // no answer in time: do the helper's columns here, then carry on alone
-                            const Partial4 fb = harmonics_partial((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, 0, DEV_SCHED_FALLBACK,
-                                                                  L.inb[0 * DEV_LANES + lane], L.inb[1 * DEV_LANES + lane],
-                                                                  L.inb[2 * DEV_LANES + lane], L.inb[3 * DEV_LANES + lane],
-                                                                  L.inb[4 * DEV_LANES + lane]);
-                            px += fb.x; py += fb.y; pz += fb.z; pw += fb.w;
-                            coop_on = false;
-                            if (lane == 0) { L.ctl[1] = 0; coop_store(&cbox->finished, 1u); }
-                        }
+                    px += coop_x; py += coop_y; pz += coop_z; pw += coop_w;  // + the helper's columns (0 when working alone)
+                    if (coop_drop) {  // (between B2 and the next B1: no worker is reading ctl[1])
+                        if (lane == 0) L.ctl[1] = 0;
+                        coop_drop = false;
                     }
                     px *= kfac; py *= kfac; pz *= kfac; pw *= kfac;
                     const double al0 = px + pw * s_, al1 = py + pw * t_, al2 = pz + pw * u_;
@@ -1597,7 +1605,7 @@ DEVFN void propagate_body(const DevBatch &bt, const DevCfg *cfg_g, const HarmEnt
     if (!STM && bt.coop_helpers > 0) {
         const int64_t n_own = (bt.n + DEV_LANES - 1) / DEV_LANES;
         if ((int64_t)blockIdx.x >= n_own) {
-            if ((int)blockIdx.x >= bt.coop_base) helper_body(bt, cfg, htab, cols, smem, lane, wave);
+            if ((int)blockIdx.x >= bt.coop_base && !bt.coop_mute) helper_body(bt, cfg, htab, cols, smem, lane, wave);
             return;
         }
     }
