@@ -626,23 +626,28 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
             base + 8 <= ctx->n_cu) {
             int64_t helpers = std::min<int64_t>(n_own, (ctx->n_cu - base) / 8 * 8);
             if (helpers >= 8 && 2 * helpers >= n_own) {
-                if (ctx->coop_cap < n_own) {
+                bool have_boxes = ctx->coop_cap >= n_own;
+                if (!have_boxes) {
                     (void)hipFree(ctx->d_coop);
                     ctx->d_coop = nullptr;
+                    ctx->coop_cap = 0;
                     // uncached device memory: the mailboxes are coherent across the XCDs' L2s without any cache
                     // write-back / invalidate in the kernel (those would also flush the harmonics table out of L2)
                     if (hipExtMallocWithFlags((void **)&ctx->d_coop, (size_t)std::max<int64_t>(n_own, 256) * sizeof(CoopBox),
-                                              hipDeviceMallocUncached) != hipSuccess) {
-                        ctx->d_coop = nullptr;
-                        nyx_set_error("hipExtMallocWithFlags(uncached) failed for the cooperative-mode mailboxes");
-                        return NYX_HIP_RC_HIP_ERROR;
+                                              hipDeviceMallocUncached) == hipSuccess) {
+                        ctx->coop_cap = std::max<int64_t>(n_own, 256);
+                        have_boxes = true;
+                    } else {
+                        ctx->d_coop = nullptr;  // no such memory here: every workgroup works alone
+                        (void)hipGetLastError();
                     }
-                    ctx->coop_cap = std::max<int64_t>(n_own, 256);
                 }
-                HIP_TRY(hipMemsetAsync(ctx->d_coop, 0, (size_t)n_own * sizeof(CoopBox), stream));
-                bt.coop_helpers = (int32_t)helpers; bt.coop_base = (int32_t)base; bt.coop_box = ctx->d_coop;
-                bt.coop_mute = std::getenv("NYX_HIP_COOP_MUTE") ? 1 : 0;
-                ctx->last_coop_helpers = (int)helpers;
+                if (have_boxes) {
+                    HIP_TRY(hipMemsetAsync(ctx->d_coop, 0, (size_t)n_own * sizeof(CoopBox), stream));
+                    bt.coop_helpers = (int32_t)helpers; bt.coop_base = (int32_t)base; bt.coop_box = ctx->d_coop;
+                    bt.coop_mute = std::getenv("NYX_HIP_COOP_MUTE") ? 1 : 0;
+                    ctx->last_coop_helpers = (int)helpers;
+                }
             }
         }
     }
