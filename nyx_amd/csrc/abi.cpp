@@ -81,7 +81,7 @@ struct nyx_hip_ctx {
     double role_handicap[3] = {0.0, 0.0, 0.0};  // integrator, almanac, perturbations (harmonics-term units)
     DevArrays in, out;
     int64_t *d_prof = nullptr;
-    CoopBox *d_coop = nullptr;  // cooperative-mode mailboxes, one per trajectory-owning workgroup
+    CoopBox *d_coop = nullptr;  // cooperative-mode mailboxes, one per trajectory-owning workgroup, then the packed scan words
     int64_t coop_cap = 0;
     int n_cu = 0;
     int last_coop_helpers = 0;  // helpers of the last launch (0 = solo)
@@ -624,8 +624,21 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
         const bool stm_ctx = (ctx->host_cfg.flags & NYX_HIP_FLAG_STM) != 0;
         if (want && !stm_ctx && ctx->host_cfg.has_grav && nw == DEV_MAX_WAVES && ctx->host_cfg.sched[DEV_SCHED_FALLBACK].n_ranges[0] > 0 &&
             base + 8 <= ctx->n_cu) {
-            int64_t helpers = std::min<int64_t>(n_own, (ctx->n_cu - base) / 8 * 8);
-            if (helpers >= 8 && 2 * helpers >= n_own) {
+            const int64_t helpers = std::min<int64_t>(n_own, (ctx->n_cu - base) / 8 * 8);
+            if (helpers >= 8 && 4 * helpers >= n_own) {
+                // share of the terms the helpers take: owners keep (1 - x), each helper does x * owners / helpers jobs' worth
+                // per evaluation period, plus its hand-off overhead: x ~ 0.92 r / (1 + r) with r = helpers / owners
+                if (!std::getenv("NYX_HIP_COOP_FRAC")) {
+                    const double r = (double)helpers / (double)n_own;
+                    const double x = std::min(0.55, std::max(0.10, 0.92 * r / (1.0 + r)));
+                    if (std::fabs(x - ctx->host_cfg.coop_frac) > 0.01) {
+                        ctx->host_cfg.coop_frac = x;
+                        build_schedule(ctx, nw);
+                        HIP_TRY(hipMemcpyAsync(ctx->d_cfg, &ctx->host_cfg, sizeof(DevCfg), hipMemcpyHostToDevice, stream));
+                    }
+                }
+                const int64_t want_cap = std::max<int64_t>(n_own, 256);
+                const size_t cap_bytes = (size_t)want_cap * sizeof(CoopBox) + 3 * (size_t)(want_cap + 64) * sizeof(uint32_t);  // sets of 16: <= cap + 16 words
                 bool have_boxes = ctx->coop_cap >= n_own;
                 if (!have_boxes) {
                     (void)hipFree(ctx->d_coop);
@@ -633,8 +646,7 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
                     ctx->coop_cap = 0;
                     // uncached device memory: the mailboxes are coherent across the XCDs' L2s without any cache
                     // write-back / invalidate in the kernel (those would also flush the harmonics table out of L2)
-                    if (hipExtMallocWithFlags((void **)&ctx->d_coop, (size_t)std::max<int64_t>(n_own, 256) * sizeof(CoopBox),
-                                              hipDeviceMallocUncached) == hipSuccess) {
+                    if (hipExtMallocWithFlags((void **)&ctx->d_coop, cap_bytes, hipDeviceMallocUncached) == hipSuccess) {
                         ctx->coop_cap = std::max<int64_t>(n_own, 256);
                         have_boxes = true;
                     } else {
@@ -642,9 +654,12 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
                         (void)hipGetLastError();
                     }
                 }
-                if (have_boxes) {
-                    HIP_TRY(hipMemsetAsync(ctx->d_coop, 0, (size_t)n_own * sizeof(CoopBox), stream));
+                if (have_boxes && ctx->host_cfg.sched[DEV_SCHED_FALLBACK].n_ranges[0] > 0) {
+                    HIP_TRY(hipMemsetAsync(ctx->d_coop, 0, (size_t)ctx->coop_cap * sizeof(CoopBox) + 3 * (size_t)(ctx->coop_cap + 64) * sizeof(uint32_t), stream));
                     bt.coop_helpers = (int32_t)helpers; bt.coop_base = (int32_t)base; bt.coop_box = ctx->d_coop;
+                    uint32_t *words = (uint32_t *)(ctx->d_coop + ctx->coop_cap);
+                    bt.coop_posted = words; bt.coop_claimed = words + (ctx->coop_cap + 64); bt.coop_finished = words + 2 * (ctx->coop_cap + 64);
+                    bt.coop_sets = (int32_t)((n_own + 15) / 16);
                     bt.coop_mute = std::getenv("NYX_HIP_COOP_MUTE") ? 1 : 0;
                     ctx->last_coop_helpers = (int)helpers;
                 }

@@ -110,16 +110,16 @@ struct HarmEntry {
     double bb, cc, t1, t2, t3, t4, t5, t6;
 };
 
-/* Mailbox between a trajectory-owning workgroup and its helper (global memory).  The owner posts the harmonics inputs
- * of evaluation `posted` (1, 2, ...); the helper answers with the partial sums of its columns and `done = posted`. */
+/* Mailbox of a trajectory-owning workgroup (uncached global memory).  The owner writes the harmonics inputs of
+ * evaluation `seq` (1, 2, ...) and then posted[owner] = seq; a helper claims the job by moving claimed[owner] from
+ * seq - 1 to seq (compare-and-swap), evaluates its columns and answers with the partial sums and done = seq.  The
+ * words the helpers scan (posted, claimed, finished) are packed per set of 16 owners (one 64-byte line per set and
+ * kind: word index = set * 16 + slot, owner = set + slot * n_sets), so one load scans a set. */
 struct CoopBox {
     double in[5][DEV_LANES];
     double out[4][DEV_LANES];
-    uint32_t posted;   /* written by the owner */
-    uint32_t finished; /* owner: left the kernel or stopped posting */
-    uint32_t pad0[14];
-    uint32_t done;     /* written by the helper (its own 64-byte line) */
-    uint32_t pad1[15];
+    uint32_t done; /* written by the helper that claimed the job */
+    uint32_t pad[15];
 };
 
 struct DevBatch { /* device pointers of one launch */
@@ -139,8 +139,9 @@ struct DevBatch { /* device pointers of one launch */
     int32_t *ev_found; /* [n] 1 when the propagation stopped on the event */
     /* cooperative mode: workgroups [0, ceil(n/64)) own trajectories, [coop_base, coop_base + coop_helpers) help */
     int32_t coop_helpers, coop_base;
-    int32_t coop_mute, _pad3; /* test switch (NYX_HIP_COOP_MUTE): helpers exit at once, as if they had never become resident */
+    int32_t coop_mute, coop_sets; /* coop_sets: owners are dealt into this many sets of <= 16, each watched by its own helpers */ /* test switch (NYX_HIP_COOP_MUTE): helpers exit at once, as if they had never become resident */
     struct CoopBox *coop_box; /* one mailbox per trajectory-owning workgroup, zeroed before the launch */
+    uint32_t *coop_posted, *coop_claimed, *coop_finished; /* [owners] packed scan words, zeroed before the launch */
     const int64_t *dur_ns; /* optional per-trajectory duration (covariance-mapping segments); overrides duration_ns */
     const double *stm; /* [n][81] column-major per trajectory, or NULL */
     double *o_stm;

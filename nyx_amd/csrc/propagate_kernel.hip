@@ -651,14 +651,15 @@ DEVFN void coop_stored(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_
 DEVFN void coop_release() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }  // (inline asm: never elided by the compiler)
 DEVFN void coop_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 #define COOP_TIMEOUT_TICKS 200000LL  /* 2 ms of the 100 MHz realtime counter */
+#define COOP_SET 16                  /* owners per set */
 
 // Posting happens after barrier B1, from the LDS copy of the inputs, when the integrator wave is idle anyway: the
 // owner's critical path never waits for memory.
-static __device__ __attribute__((noinline)) void coop_post(CoopBox *box, int lane, uint32_t seq, const double *inb) {
+static __device__ __attribute__((noinline)) void coop_post(CoopBox *box, uint32_t *posted, int lane, uint32_t seq, const double *inb) {
 #pragma unroll
     for (int q = 0; q < 5; ++q) coop_stored(&box->in[q][lane], inb[q * DEV_LANES + lane]);
     coop_release();  // the inputs have reached memory before the sequence number is written
-    if (lane == 0) coop_store(&box->posted, seq);
+    if (lane == 0) coop_store(posted, seq);
 }
 
 struct CoopAnswer {
@@ -680,45 +681,60 @@ static __device__ __attribute__((noinline)) CoopAnswer coop_wait(CoopBox *box, i
     return a;
 }
 
-// Helper workgroup: serves the owners h and h + n_helpers.  LDS: [16][4][64] partials + the job word.
+// Helper workgroup.  Jobs are CLAIMED, not assigned: the owners are dealt into sets of at most 16, a helper watches
+// one set (lane l < 16 of its wave 0 <-> one owner: two 64-byte loads scan the set), and whichever helper of the set is
+// free takes the next posted job with a compare-and-swap on claimed[owner].  The load evens out by itself whatever the
+// ratio of helpers to owners.  LDS: [16][4][64] partials + the job words.
 DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols, char *smem, int lane, int wave) {
     double *part = (double *)smem;
     volatile int *job = (volatile int *)(part + DEV_MAX_WAVES * 4 * DEV_LANES);
     const int h = (int)blockIdx.x - bt.coop_base;
     const int64_t n_own = (bt.n + DEV_LANES - 1) / DEV_LANES;
-    const int64_t own[2] = {h, (int64_t)h + bt.coop_helpers};
-    const bool served[2] = {own[0] < n_own, own[1] < n_own};
-    uint32_t last[2] = {0u, 0u};
-    int rr = 0;
+    const int n_sets = bt.coop_sets;
+    const int set = h % n_sets;
+    const int64_t mine = (int64_t)set + (int64_t)lane * n_sets;  // the owner this lane watches (lanes 0..15)
+    const bool has = lane < COOP_SET && mine < n_own;
+    const int widx = set * COOP_SET + lane;                       // its scan words
+    unsigned turn = (unsigned)h;
     for (;;) {
         if (wave == 0) {
-            int which = -2;
+            int owner = -1;
             uint32_t seq = 0;
             const int64_t t0 = (int64_t)__builtin_amdgcn_s_memrealtime();
             for (;;) {
-                bool all_fin = true;
-                for (int k = 0; k < 2; ++k) {
-                    const int kk = (rr + k) & 1;
-                    if (!served[kk]) continue;
-                    CoopBox *b = bt.coop_box + own[kk];
-                    const uint32_t posted = coop_load(&b->posted);
-                    if (posted != last[kk]) { which = kk; seq = posted; break; }
-                    if (!coop_load(&b->finished)) all_fin = false;
+                const uint32_t posted = has ? coop_load(bt.coop_posted + widx) : 0u;
+                const uint32_t claimed = has ? coop_load(bt.coop_claimed + widx) : 0u;
+                const uint64_t cand = __ballot(has && posted != claimed);
+                if (cand) {
+                    // first candidate at or after a rotating start lane, so that the helpers of a set spread over the jobs
+                    const unsigned rot = turn++ & 63u;
+                    const uint64_t hi = cand >> rot;
+                    const int pick = hi ? (int)rot + __builtin_ctzll(hi) : __builtin_ctzll(cand);
+                    int won = 0;
+                    if (lane == pick) {
+                        uint32_t expect = claimed;
+                        won = __hip_atomic_compare_exchange_strong(bt.coop_claimed + widx, &expect, posted, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                                   __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+                    }
+                    if (__shfl(won, pick)) {
+                        owner = (int)__shfl((int)mine, pick);
+                        seq = (uint32_t)__shfl((int)posted, pick);
+                        break;
+                    }
+                    continue;  // another helper was faster: look again
                 }
-                if (which >= 0) break;
-                if (all_fin) { which = -1; break; }
-                if ((int64_t)__builtin_amdgcn_s_memrealtime() - t0 > 5000 * COOP_TIMEOUT_TICKS) { which = -1; break; }  // 10 s: never spin forever
-                __builtin_amdgcn_s_sleep(1);
+                const uint32_t fin = has ? coop_load(bt.coop_finished + widx) : 1u;
+                if (__all(fin != 0u)) { owner = -1; break; }
+                if ((int64_t)__builtin_amdgcn_s_memrealtime() - t0 > 5000 * COOP_TIMEOUT_TICKS) { owner = -1; break; }  // 10 s: never spin forever
+                __builtin_amdgcn_s_sleep(8);  // ~0.2 us between scans: the set's words are one memory line shared by ~10 helpers
             }
-            if (lane == 0) { job[0] = which; job[1] = (int)seq; }
-            if (which >= 0) last[which] = seq;
-            rr ^= 1;
+            if (lane == 0) { job[0] = owner; job[1] = (int)seq; }
         }
         __syncthreads();
-        const int which = job[0];
+        const int owner = job[0];
         const uint32_t seq = (uint32_t)job[1];
-        if (which < 0) break;
-        CoopBox *b = bt.coop_box + own[which];
+        if (owner < 0) break;
+        CoopBox *b = bt.coop_box + owner;
         coop_acquire();  // the inputs were posted before `seq`
         const double v0 = coop_loadd(&b->in[0][lane]), v1 = coop_loadd(&b->in[1][lane]), v2 = coop_loadd(&b->in[2][lane]),
                      v3 = coop_loadd(&b->in[3][lane]), v4 = coop_loadd(&b->in[4][lane]);
@@ -726,7 +742,7 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
         double *pp = part + wave * 4 * DEV_LANES;
         pp[0 * DEV_LANES + lane] = pr.x; pp[1 * DEV_LANES + lane] = pr.y; pp[2 * DEV_LANES + lane] = pr.z; pp[3 * DEV_LANES + lane] = pr.w;
         __syncthreads();
-        if (wave == DEV_MAX_WAVES - 1) {  // the last wave answers while wave 0 is already polling for the next job
+        if (wave == DEV_MAX_WAVES - 1) {  // the last wave answers while wave 0 is already looking for the next job
             double o[4] = {0.0, 0.0, 0.0, 0.0};
             for (int w = 0; w < DEV_MAX_WAVES; ++w) {  // fixed wave order
 #pragma unroll
@@ -1134,6 +1150,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     __syncthreads();
     // cooperative mode (see above): the integrator owns the conversation with the helper
     CoopBox *const cbox = bt.coop_box + blockIdx.x;
+    const int coop_widx = bt.coop_sets > 0 ? ((int)blockIdx.x % bt.coop_sets) * COOP_SET + (int)blockIdx.x / bt.coop_sets : 0;
     bool coop_on = !STM && ((volatile int *)L.ctl)[1] != 0;
     const bool coop_started = coop_on;
     uint32_t coop_seq = 0;
@@ -1253,7 +1270,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             const int64_t ptw_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;
 
             // ---- window --------------------------------------------------------------------------
-            if (INTEG && !STM && coop_on && has_grav) coop_post(cbox, lane, ++coop_seq, L.inb);
+            if (INTEG && !STM && coop_on && has_grav) coop_post(cbox, bt.coop_posted + coop_widx, lane, ++coop_seq, L.inb);
             if (ALMANAC && need_almanac && i + 1 < stages) {
                 // epoch-only data of the NEXT stage
                 const int64_t ep = __double_as_longlong(L.step[lane]) + seconds_to_ns(C_COEF(i + 1) * L.step[DEV_LANES + lane]);
@@ -1341,7 +1358,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     coop_x = fb.x; coop_y = fb.y; coop_z = fb.z; coop_w = fb.w;
                     coop_on = false;
                     coop_drop = true;
-                    if (lane == 0) coop_store(&cbox->finished, 1u);
+                    if (lane == 0) coop_store(bt.coop_finished + coop_widx, 1u);
                 }
             }
             if (prof_on) prof_acc[2] += (int64_t)__builtin_readcyclecounter() - pth_;
@@ -1563,7 +1580,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
         for (int q = 0; q < 8; ++q) bt.prof[wave * 8 + q] = prof_acc[q];
     }
 
-    if (INTEG && coop_started && lane == 0) coop_store(&cbox->finished, 1u);
+    if (INTEG && coop_started && lane == 0) coop_store(bt.coop_finished + coop_widx, 1u);
     if (INTEG && valid) {
         ColdState c;
         cold_load(L.cs, lane, c);
@@ -1632,8 +1649,8 @@ DEVFN void propagate_body(const DevBatch &bt, const DevCfg *cfg_g, const HarmEnt
     }
     if (threadIdx.x == 0) {
         L.ctl[0] = 0;
-        // ctl[1]: 1 while this workgroup shares its columns with a helper (owners h and h + n_helpers are served)
-        L.ctl[1] = (!STM && bt.coop_helpers > 0 && cfg->has_grav && (int)blockIdx.x < 2 * bt.coop_helpers) ? 1 : 0;
+        // ctl[1]: 1 while this workgroup shares its columns with the helpers
+        L.ctl[1] = (!STM && bt.coop_helpers > 0 && cfg->has_grav) ? 1 : 0;
     }
     for (int q = (int)threadIdx.x; q < DEV_MAX_WAVES * 4 * DEV_LANES; q += (int)blockDim.x) L.part[q] = 0.0;
 

@@ -296,7 +296,7 @@ def test_config5_lunar_150x150_vs_oracle(method):
     ctx.close()
 
 
-def test_full_size_properties_config2():
+def test_full_size_properties_config2(monkeypatch):
     """BASELINE size (10 000 x 70x70, 3 h slice): index stability under re-batching, determinism, and the two-body
     energy drift bound when the perturbations are switched off."""
     prop, almanac, central = leo_full_setup(degree=70)
@@ -306,11 +306,19 @@ def test_full_size_properties_config2():
     out, st = ctx.propagate(b, dur)
     assert (st.status == 0).all() and (out.epoch_ns == b.epoch_ns + dur).all()
     again, _ = ctx.propagate(b, dur)
-    np.testing.assert_array_equal(out.rv(), again.rv())  # deterministic: fixed fold order, no atomics
-    # a shard run alone reproduces its slice exactly (contiguous index shards)
+    np.testing.assert_array_equal(out.rv(), again.rv())  # deterministic: fixed fold order, whichever helper takes a job
+    # a shard run alone reproduces its slice (contiguous index shards).  Bit for bit when the launch has the
+    # same shape (one workgroup per 64 trajectories working alone); in cooperative mode the owner / helper split follows
+    # the number of idle CUs, i.e. the batch size, and the harmonics sums associate differently: sub-millimetre
     lo, hi = nx.shard_bounds(10_000, 3, 8)
     part, _ = ctx.propagate(b.slice(lo, hi), dur)
-    np.testing.assert_array_equal(part.rv(), out.rv()[lo:hi])
+    dr, dv = pos_vel_errors(part, out.slice(lo, hi))
+    assert dr.max() < 1e-6 and dv.max() < 1e-9
+    monkeypatch.setenv("NYX_HIP_COOP", "0")
+    solo, _ = ctx.propagate(b, dur)
+    part, _ = ctx.propagate(b.slice(lo, hi), dur)
+    np.testing.assert_array_equal(part.rv(), solo.rv()[lo:hi])
+    monkeypatch.delenv("NYX_HIP_COOP")
     ctx.close()
     # two-body only, full day, full ensemble: specific orbital energy conserved to ~1e-12 relative
     from scenarios import GOLDEN as G, two_body_setup
