@@ -227,18 +227,35 @@ static void build_harmonics(const nyx_hip_gravity_field_t *g, std::vector<HarmEn
 // one harmonics term), so they receive a reduced share of the columns, possibly none.
 // Water-filling of the columns [c_lo, c_hi] over `n_waves` waves with per-wave handicaps hc[] (work a wave does besides
 // its columns, in harmonics-term units) and SIMD age weights.  Wave 0 takes what is left.
-static void fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, int c_lo, int c_hi, const double *hc) {
+// `list`: the columns to distribute, ascending (= longest first).  Returns false if a wave would need more than
+// DEV_MAX_RANGES contiguous ranges.
+static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, const std::vector<int> &list, const double *hc) {
     for (int w = 0; w < DEV_MAX_WAVES; ++w) sd.n_ranges[w] = 0;
-    if (c_lo > c_hi) return;
+    if (list.empty()) return true;
     double terms = 0.0;
-    for (int c = c_lo; c <= c_hi; ++c) terms += ctx->col_len[c];
-    // Age weights: the four waves that share a SIMD (w, w+4, w+8, w+12) are arbitrated oldest-first, so with equal shares
-    // the oldest finishes early and the youngest runs the tail alone, with nothing to hide its scalar-load latency.
-    // Larger shares for the older waves make the four finish together.
-    double aw[4] = {1.0, 1.0, 1.0, 1.0};
-    if (n_waves == 16) { aw[0] = 1.30; aw[1] = 1.10; aw[2] = 0.90; aw[3] = 0.70; }
-    if (const char *e = std::getenv("NYX_HIP_AGE_WEIGHTS")) std::sscanf(e, "%lf,%lf,%lf,%lf", &aw[0], &aw[1], &aw[2], &aw[3]);
-    auto wgt = [&](int w) { return n_waves == 16 ? aw[w / 4] : 1.0; };
+    for (int c : list) terms += ctx->col_len[c];
+    // Per-wave weights of a 16-wave workgroup.  The four waves that share a SIMD (w, w+4, w+8, w+12) are arbitrated
+    // oldest-first, so with equal shares the oldest finishes early and the youngest runs the tail alone, with nothing to
+    // hide its scalar-load latency; SIMD 0 also hosts the integrator wave, which carries no columns, so its column waves
+    // (4, 8, 12) can take more.  Calibrated on the device with tools/tune_wave_weights.py (in-kernel cycle accounting of the
+    // north-star force model): the waves of a workgroup then finish their window within ~10 % of each other.
+    static const double tuned16[DEV_MAX_WAVES] = {1.0000, 1.3959, 1.3248, 1.5513, 1.5890, 1.1944, 1.1728, 1.3383,
+                                                  1.3085, 0.8969, 0.9070, 0.9179, 0.8464, 0.5319, 0.5459, 0.5545};
+    double per_wave[DEV_MAX_WAVES];
+    for (int w = 0; w < DEV_MAX_WAVES; ++w) per_wave[w] = n_waves == 16 ? tuned16[w] : 1.0;
+    if (const char *e = std::getenv("NYX_HIP_AGE_WEIGHTS")) {  // coarse knob: one weight per age class
+        double aw[4] = {1.0, 1.0, 1.0, 1.0};
+        if (std::sscanf(e, "%lf,%lf,%lf,%lf", &aw[0], &aw[1], &aw[2], &aw[3]) == 4 && n_waves == 16)
+            for (int w = 0; w < DEV_MAX_WAVES; ++w) per_wave[w] = aw[w / 4];
+    }
+    if (const char *e = std::getenv("NYX_HIP_WAVE_WEIGHTS")) {  // tuning: 16 comma-separated weights (tools/tune_wave_weights.py)
+        const char *p = e;
+        for (int w = 0; w < DEV_MAX_WAVES && *p; ++w) {
+            per_wave[w] = std::strtod(p, (char **)&p);
+            if (*p == ',') ++p;
+        }
+    }
+    auto wgt = [&](int w) { return per_wave[w]; };
     // water-filling: level such that sum_w max(0, level * weight_w - hc[w]) = terms
     double level = 0.0;
     {
@@ -252,30 +269,34 @@ static void fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, int
             if (sum < terms) lo = level; else hi = level;
         }
     }
-    int lo = c_lo, hi = c_hi;
+    int lo = 0, hi = (int)list.size() - 1;  // indices into `list`
     // plain column workers first (highest wave index), role waves last so they take what is left
     for (int w = n_waves - 1; w >= 0; --w) {
         const double tgt = std::max(0.0, level * wgt(w) - hc[w]);
+        std::vector<int> mine;
         if (w == 0) {
-            if (lo <= hi) { sd.range_c0[0][0] = lo; sd.range_cnt[0][0] = hi - lo + 1; sd.n_ranges[0] = 1; }
-            break;
+            for (int k = lo; k <= hi; ++k) mine.push_back(list[k]);
+            lo = hi + 1;
+        } else {
+            double load = 0.0;
+            while (lo <= hi && load + 0.5 * ctx->col_len[list[lo]] <= tgt) { load += ctx->col_len[list[lo]]; mine.push_back(list[lo++]); }
+            std::vector<int> tail;
+            while (lo <= hi && load + 0.5 * ctx->col_len[list[hi]] <= tgt) { load += ctx->col_len[list[hi]]; tail.push_back(list[hi--]); }
+            mine.insert(mine.end(), tail.rbegin(), tail.rend());
         }
-        double load = 0.0;
-        int a0 = lo, acnt = 0;
-        while (lo <= hi && load + 0.5 * ctx->col_len[lo] <= tgt) {
-            load += ctx->col_len[lo];
-            ++lo; ++acnt;
-        }
-        int bend = hi, bcnt = 0;
-        while (lo <= hi && load + 0.5 * ctx->col_len[hi] <= tgt) {
-            load += ctx->col_len[hi];
-            --hi; ++bcnt;
-        }
+        // contiguous runs of column numbers -> ranges
         int nr = 0;
-        if (acnt) { sd.range_c0[w][nr] = a0; sd.range_cnt[w][nr] = acnt; ++nr; }
-        if (bcnt) { sd.range_c0[w][nr] = bend - bcnt + 1; sd.range_cnt[w][nr] = bcnt; ++nr; }
+        for (size_t k = 0; k < mine.size();) {
+            size_t e = k + 1;
+            while (e < mine.size() && mine[e] == mine[e - 1] + 1) ++e;
+            if (nr >= DEV_MAX_RANGES) return false;
+            sd.range_c0[w][nr] = mine[k]; sd.range_cnt[w][nr] = (int)(e - k); ++nr;
+            k = e;
+        }
         sd.n_ranges[w] = nr;
+        if (w == 0) break;
     }
+    return true;
 }
 
 static void build_schedule(nyx_hip_ctx *ctx, int n_waves) {
@@ -294,21 +315,36 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves) {
     else { hc[0] = ctx->role_handicap[0]; hc[1] = ctx->role_handicap[1]; hc[2] = ctx->role_handicap[2]; }
     // with enough column workers the integrator keeps its window free: its serial phases A / C gate every other wave
     if (n_waves >= 8 && !std::getenv("NYX_HIP_ROLE_HANDICAP")) hc[0] = 1e9;
-    fill_schedule(ctx, dc.sched[DEV_SCHED_SOLO], n_waves, 1, nc, hc);
-    // cooperative mode (16-wave workgroups only): the helper takes the LONG columns 1..c_split (fewest columns for its share)
+    std::vector<int> all;
+    for (int c = 1; c <= nc; ++c) all.push_back(c);
+    (void)fill_schedule(ctx, dc.sched[DEV_SCHED_SOLO], n_waves, all, hc);
+    // Cooperative mode (16-wave workgroups only).  The helper takes the LONGEST columns, at most one per wave: its job
+    // time is then one long column (~18 batches), which is within 17 % of the ideal x * terms / 16 for x <= 0.35, and the
+    // owner keeps the many short columns that let it balance its fifteen waves.  (Interleaving the two sets column by
+    // column was measured 10-25 % slower: the helper's waves then hold a long AND a short column each.)
     if (n_waves == DEV_MAX_WAVES && nc >= 8) {
-        double terms = 0.0, acc = 0.0;
+        double terms = 0.0, given = 0.0;
         for (int c = 1; c <= nc; ++c) terms += ctx->col_len[c];
-        int c_split = 0;
-        while (c_split < nc - 1 && acc + 0.5 * ctx->col_len[c_split + 1] <= dc.coop_frac * terms) acc += ctx->col_len[++c_split];
-        if (c_split >= 1) {
-            fill_schedule(ctx, dc.sched[DEV_SCHED_PRIMARY], n_waves, c_split + 1, nc, hc);
-            double hh[DEV_MAX_WAVES] = {0};
-            hh[0] = 8.0;  // the helper's wave 0 also polls, folds and answers
-            fill_schedule(ctx, dc.sched[DEV_SCHED_HELPER], n_waves, 1, c_split, hh);
-            DevSched &fb = dc.sched[DEV_SCHED_FALLBACK];
-            fb.n_ranges[0] = 1; fb.range_c0[0][0] = 1; fb.range_cnt[0][0] = c_split;
+        std::vector<int> own, help;
+        for (int c = 1; c <= nc; ++c) {
+            if ((int)help.size() < DEV_MAX_WAVES && c < nc - 1 && given + 0.5 * ctx->col_len[c] <= dc.coop_frac * terms) {
+                help.push_back(c);
+                given += ctx->col_len[c];
+            } else {
+                own.push_back(c);
+            }
         }
+        double hh[DEV_MAX_WAVES] = {0};
+        hh[0] = 8.0;  // the helper's wave 0 also scans the mailboxes and claims the job
+        if (!help.empty() && !own.empty() && fill_schedule(ctx, dc.sched[DEV_SCHED_PRIMARY], n_waves, own, hc) &&
+            fill_schedule(ctx, dc.sched[DEV_SCHED_HELPER], n_waves, help, hh)) {
+            dc.coop_ok = 1;
+        } else {
+            dc.coop_ok = 0;
+            for (int w = 0; w < DEV_MAX_WAVES; ++w) dc.sched[DEV_SCHED_PRIMARY].n_ranges[w] = dc.sched[DEV_SCHED_HELPER].n_ranges[w] = 0;
+        }
+    } else {
+        dc.coop_ok = 0;
     }
 }
 
@@ -622,7 +658,7 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
         const int64_t n_own = (in->n + DEV_LANES - 1) / DEV_LANES;
         const int64_t base = (n_own + 7) / 8 * 8;
         const bool stm_ctx = (ctx->host_cfg.flags & NYX_HIP_FLAG_STM) != 0;
-        if (want && !stm_ctx && ctx->host_cfg.has_grav && nw == DEV_MAX_WAVES && ctx->host_cfg.sched[DEV_SCHED_FALLBACK].n_ranges[0] > 0 &&
+        if (want && !stm_ctx && ctx->host_cfg.has_grav && nw == DEV_MAX_WAVES && ctx->host_cfg.coop_ok &&
             base + 8 <= ctx->n_cu) {
             const int64_t helpers = std::min<int64_t>(n_own, (ctx->n_cu - base) / 8 * 8);
             if (helpers >= 8 && 4 * helpers >= n_own) {
@@ -654,7 +690,7 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
                         (void)hipGetLastError();
                     }
                 }
-                if (have_boxes && ctx->host_cfg.sched[DEV_SCHED_FALLBACK].n_ranges[0] > 0) {
+                if (have_boxes && ctx->host_cfg.coop_ok) {
                     HIP_TRY(hipMemsetAsync(ctx->d_coop, 0, (size_t)ctx->coop_cap * sizeof(CoopBox) + 3 * (size_t)(ctx->coop_cap + 64) * sizeof(uint32_t), stream));
                     bt.coop_helpers = (int32_t)helpers; bt.coop_base = (int32_t)base; bt.coop_box = ctx->d_coop;
                     uint32_t *words = (uint32_t *)(ctx->d_coop + ctx->coop_cap);

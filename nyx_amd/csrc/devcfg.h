@@ -34,9 +34,9 @@ struct DevSched {
 };
 /* SOLO: one workgroup does every column (all configurations).  Cooperative mode (idle CUs lend a hand, see
  * propagate_kernel.hip): PRIMARY = the columns the trajectory-owning workgroup keeps, HELPER = the columns a helper
- * workgroup on another CU evaluates, FALLBACK = the helper's columns on wave 0 (primary does them itself if the
- * helper does not answer). */
-enum { DEV_SCHED_SOLO = 0, DEV_SCHED_PRIMARY = 1, DEV_SCHED_HELPER = 2, DEV_SCHED_FALLBACK = 3, DEV_N_SCHED = 4 };
+ * workgroup on another CU evaluates (the owner walks that schedule itself, wave slot by wave slot, if no helper
+ * answers). */
+enum { DEV_SCHED_SOLO = 0, DEV_SCHED_PRIMARY = 1, DEV_SCHED_HELPER = 2, DEV_N_SCHED = 3 };
 
 struct DevRot {
     double ra[3], dec[3], w[3];
@@ -89,6 +89,7 @@ struct DevCfg {
     int32_t merge_roles; /* almanac and perturbation duties share wave 1 */
     DevSched sched[DEV_N_SCHED];
     double coop_frac; /* share of the harmonics terms a helper workgroup takes over (cooperative mode) */
+    int32_t coop_ok, _pad4; /* PRIMARY / HELPER schedules are valid */
 };
 
 /* Column header (32 B = one s_load_dwordx8): rows of column c start at htab[start] and come in

@@ -636,7 +636,7 @@ static __device__ __attribute__((noinline)) void harmonics_partial_dual(uint64_t
 // DEV_SCHED_HELPER for the same 64 lanes and answers with four partial sums per lane (2 KB).  The exchange overlaps
 // the owner's own window; what it costs is two device-scope fences per evaluation on either side.
 // Deadlock-free without any residency assumption: the owner waits a bounded time for an answer, and if none comes it
-// evaluates the helper's columns itself (DEV_SCHED_FALLBACK) and goes back to DEV_SCHED_SOLO for the rest of the
+// evaluates the helper's columns itself (walking DEV_SCHED_HELPER) and goes back to DEV_SCHED_SOLO for the rest of the
 // launch; helpers leave when every workgroup they serve has finished.  The owner adds the helper's partial after its
 // own sixteen, in a fixed order: results are deterministic for a given split.
 // ---------------------------------------------------------------------------------------------
@@ -679,6 +679,20 @@ static __device__ __attribute__((noinline)) CoopAnswer coop_wait(CoopBox *box, i
     a.w = coop_loadd(&box->out[3][lane]);
     a.ok = 1;
     return a;
+}
+
+// What the owner does when no helper answers: the helper's sixteen wave slots one after the other, summed in the
+// helper's fold order, i.e. bit for bit the answer it did not get.  Out of line: a rare path must not cost the
+// integrator role registers.
+static __device__ __attribute__((noinline)) Partial4 coop_fallback(uint64_t cfg_u, uint64_t htab_u, uint64_t cols_u, const double *inb, int lane) {
+    const double v0 = inb[0 * DEV_LANES + lane], v1 = inb[1 * DEV_LANES + lane], v2 = inb[2 * DEV_LANES + lane],
+                 v3 = inb[3 * DEV_LANES + lane], v4 = inb[4 * DEV_LANES + lane];
+    Partial4 o = {0.0, 0.0, 0.0, 0.0};
+    for (int hw = 0; hw < DEV_MAX_WAVES; ++hw) {
+        const Partial4 p = harmonics_partial(cfg_u, htab_u, cols_u, hw, DEV_SCHED_HELPER, v0, v1, v2, v3, v4);
+        o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+    }
+    return o;
 }
 
 // Helper workgroup.  Jobs are CLAIMED, not assigned: the owners are dealt into sets of at most 16, a helper watches
@@ -1352,9 +1366,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 if (ans.ok) {
                     coop_x = ans.x; coop_y = ans.y; coop_z = ans.z; coop_w = ans.w;
                 } else {  // no answer in time: do the helper's columns here, then carry on alone
-                    const Partial4 fb = harmonics_partial((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, 0, DEV_SCHED_FALLBACK,
-                                                          L.inb[0 * DEV_LANES + lane], L.inb[1 * DEV_LANES + lane], L.inb[2 * DEV_LANES + lane],
-                                                          L.inb[3 * DEV_LANES + lane], L.inb[4 * DEV_LANES + lane]);
+                    const Partial4 fb = coop_fallback((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, L.inb, lane);
                     coop_x = fb.x; coop_y = fb.y; coop_z = fb.z; coop_w = fb.w;
                     coop_on = false;
                     coop_drop = true;
