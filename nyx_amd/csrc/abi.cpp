@@ -193,31 +193,39 @@ static void build_harmonics(const nyx_hip_gravity_field_t *g, std::vector<HarmEn
     tab.clear();
     for (int c = 1; c <= n_cols; ++c) {
         const int rows = N + 2 - c;
-        const int nb = (rows + 3) / 4;
+        const int nb = (rows + HARM_BATCH - 1) / HARM_BATCH;
         cols[c].start = (int32_t)tab.size();
         cols[c].nb = nb;
         cols[c].scale = (double)c * SQ2;
         cols[c].diag = diag[c];
-        col_len[c] = 4 * nb;
+        col_len[c] = HARM_BATCH * nb;
+        double B = 1.0;  // prod of b[k][c], k = c+1 .. n: the scale of the carried recursion variable (see HarmEntry)
         for (int n = c; n <= N + 1; ++n) {
             HarmEntry e;
-            e.bb = (n == c) ? 0.0 : bnm(n, c);
-            e.cc = (n == c) ? -1.0 : ((n == c + 1) ? 0.0 : cnm(n, c));
-            e.t1 = C(n, c);
-            e.t2 = S(n, c);
+            if (n == c) {
+                e.g = -1.0;
+            } else if (n == c + 1) {
+                e.g = 0.0;
+                B *= bnm(n, c);
+            } else {
+                e.g = cnm(n, c) / (bnm(n, c) * bnm(n - 1, c));
+                B *= bnm(n, c);
+            }
+            e.t1 = B * C(n, c);
+            e.t2 = B * S(n, c);
             // z: (n, m = c-1), n in 1..N
             const bool zok = (n >= 1 && n <= N);
-            e.t3 = zok ? SQ2 * vr01(n, c - 1) * C(n, c - 1) : 0.0;
-            e.t4 = zok ? SQ2 * vr01(n, c - 1) * S(n, c - 1) : 0.0;
+            e.t3 = zok ? B * (SQ2 * vr01(n, c - 1) * C(n, c - 1)) : 0.0;
+            e.t4 = zok ? B * (SQ2 * vr01(n, c - 1) * S(n, c - 1)) : 0.0;
             // w: (n-1, m = c-1), n-1 in 1..N
             const bool wok = (n - 1 >= 1 && n - 1 <= N && n - 1 >= c - 1);
-            e.t5 = wok ? SQ2 * vr11(n - 1, c - 1) * C(n - 1, c - 1) : 0.0;
-            e.t6 = wok ? SQ2 * vr11(n - 1, c - 1) * S(n - 1, c - 1) : 0.0;
+            e.t5 = wok ? B * (SQ2 * vr11(n - 1, c - 1) * C(n - 1, c - 1)) : 0.0;
+            e.t6 = wok ? B * (SQ2 * vr11(n - 1, c - 1) * S(n - 1, c - 1)) : 0.0;
             tab.push_back(e);
         }
         HarmEntry z;
         std::memset(&z, 0, sizeof z);
-        for (int k = rows; k < 4 * nb; ++k) tab.push_back(z);  // neutral padding rows
+        for (int k = rows; k < HARM_BATCH * nb; ++k) tab.push_back(z);  // neutral padding rows
     }
 }
 
@@ -318,7 +326,7 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves) {
     std::vector<int> all;
     for (int c = 1; c <= nc; ++c) all.push_back(c);
     (void)fill_schedule(ctx, dc.sched[DEV_SCHED_SOLO], n_waves, all, hc);
-    // Cooperative mode (16-wave workgroups only).  The helper takes the LONGEST columns, at most one per wave: its job
+    // Cooperative mode (16-wave workgroups only).  The helper takes the LONGEST columns, at most one per column wave: its job
     // time is then one long column (~18 batches), which is within 17 % of the ideal x * terms / 16 for x <= 0.35, and the
     // owner keeps the many short columns that let it balance its fifteen waves.  (Interleaving the two sets column by
     // column was measured 10-25 % slower: the helper's waves then hold a long AND a short column each.)
@@ -327,17 +335,22 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves) {
         for (int c = 1; c <= nc; ++c) terms += ctx->col_len[c];
         std::vector<int> own, help;
         for (int c = 1; c <= nc; ++c) {
-            if ((int)help.size() < DEV_MAX_WAVES && c < nc - 1 && given + 0.5 * ctx->col_len[c] <= dc.coop_frac * terms) {
+            if ((int)help.size() < DEV_MAX_WAVES - 1 && c < nc - 1 && given + 0.5 * ctx->col_len[c] <= dc.coop_frac * terms) {
                 help.push_back(c);
                 given += ctx->col_len[c];
             } else {
                 own.push_back(c);
             }
         }
-        double hh[DEV_MAX_WAVES] = {0};
-        hh[0] = 8.0;  // the helper's wave 0 also scans the mailboxes and claims the job
-        if (!help.empty() && !own.empty() && fill_schedule(ctx, dc.sched[DEV_SCHED_PRIMARY], n_waves, own, hc) &&
-            fill_schedule(ctx, dc.sched[DEV_SCHED_HELPER], n_waves, help, hh)) {
+        // helper: one column per wave; wave 0 keeps none: it only scans the
+        // mailboxes and claims jobs (with a column of its own the claims come late and every owner waits: +12 % run time)
+        DevSched &hs = dc.sched[DEV_SCHED_HELPER];
+        for (int w = 0; w < DEV_MAX_WAVES; ++w) hs.n_ranges[w] = 0;
+        for (size_t k = 0; k < help.size(); ++k) {
+            const int w = 1 + (int)k;  // oldest wave slots (served first by the SIMD arbiter) take the longest columns
+            hs.range_c0[w][0] = help[k]; hs.range_cnt[w][0] = 1; hs.n_ranges[w] = 1;
+        }
+        if (!help.empty() && !own.empty() && fill_schedule(ctx, dc.sched[DEV_SCHED_PRIMARY], n_waves, own, hc)) {
             dc.coop_ok = 1;
         } else {
             dc.coop_ok = 0;

@@ -93,7 +93,8 @@ struct DevCfg {
 };
 
 /* Column header (32 B = one s_load_dwordx8): rows of column c start at htab[start] and come in
- * `nb` batches of 4 entries (zero-padded); the recursion is seeded with a2 = diag / rho, a1 = 0. */
+ * `nb` batches of HARM_BATCH entries (zero-padded); the recursion is seeded with a2 = diag / rho, a1 = 0. */
+#define HARM_BATCH 5
 struct ColHdr {
     int32_t start, nb;
     double scale; /* c * sqrt(2) */
@@ -101,14 +102,16 @@ struct ColHdr {
     double _pad;
 };
 
-/* One (n', c) entry of the harmonics table, 64 B = one s_load_dwordx16:
- *   bb, cc : recursion coefficients b[n'][c], c[n'][c]; row n' = c has bb = 0, cc = -1 so that the
- *            generic step  a_n = (bb rho_u) a1 - (cc rho^2) a2  yields rho * diag from the seed
- *   t1, t2 : C, S of (n', c)                       -> x / y sums
- *   t3, t4 : sqrt2 * vr01[n'][c-1] * (C, S)[n'][c-1]   -> z sum
- *   t5, t6 : sqrt2 * vr11[n'-1][c-1] * (C, S)[n'-1][c-1] -> w sum */
+/* One (n', c) entry of the harmonics table: 56 B, seven scalar-register pairs; a batch of five is 70 SGPRs.
+ * The column recursion of the reference, a_n = u b_n a_{n-1} - c_n a_{n-2} with c_n = b_n / b_{n-1}, is carried on
+ * a~_n = a_n / B_n, B_n = prod_{k=c+1..n} b_k:  a~_n = (rho u) a~_{n-1} - rho^2 g_n a~_{n-2},  g_n = 1 / b_{n-1}^2 —
+ * ONE coefficient per row instead of two — and B_n is folded into the Stokes coefficients:
+ *   g      : g_n; row n' = c has g = -1 so that the generic step yields rho * diag from the seed, row c + 1 has g = 0
+ *   t1, t2 : B * (C, S) of (n', c)                            -> x / y sums
+ *   t3, t4 : B * sqrt2 * vr01[n'][c-1] * (C, S)[n'][c-1]      -> z sum
+ *   t5, t6 : B * sqrt2 * vr11[n'-1][c-1] * (C, S)[n'-1][c-1]  -> w sum */
 struct HarmEntry {
-    double bb, cc, t1, t2, t3, t4, t5, t6;
+    double g, t1, t2, t3, t4, t5, t6;
 };
 
 /* Mailbox of a trajectory-owning workgroup (uncached global memory).  The owner writes the harmonics inputs of

@@ -514,7 +514,7 @@ DEVFN void cpow_uniform(T zr, T zi, int e, T &pr, T &pi) {
 
 #define HARM_TERM(h)                                                                       \
     {                                                                                      \
-        const T an = gfma(rho_u * (h).bb, a1, -(gmul(rho2 * (h).cc, a2)));                 \
+        const T an = gfma(rho_u, a1, -(gmul(rho2 * (h).g, a2)));                           \
         s1 = sfma(an, (h).t1, s1);                                                         \
         s2 = sfma(an, (h).t2, s2);                                                         \
         s3 = sfma(an, (h).t3, s3);                                                         \
@@ -567,16 +567,18 @@ DEVFN Partial4T<T> harmonics_core(CfgPtr cfg, HarmPtr htab, ColPtr cols, const i
             const int nb = hd.nb;
             T a1 = gzero(zr), a2 = inv_rho * hd.diag;
             T s1 = gzero(zr), s2 = gzero(zr), s3 = gzero(zr), s4 = gzero(zr), s5 = gzero(zr), s6 = gzero(zr);
-            for (int b = 0; b < nb; ++b, e += 4) {
-                // four 64-byte entries per batch: 4 x s_load_dwordx16 in flight, then 40 f64 VALU ops (x4.5 with duals)
+            for (int b = 0; b < nb; ++b, e += HARM_BATCH) {
+                // five 56-byte entries per batch: 70 SGPRs of scalar loads in flight, then 45 f64 VALU ops (x4.5 with duals)
                 const HarmEntry CAS &h0 = e[0];
                 const HarmEntry CAS &h1 = e[1];
                 const HarmEntry CAS &h2 = e[2];
                 const HarmEntry CAS &h3 = e[3];
+                const HarmEntry CAS &h4 = e[4];
                 HARM_TERM(h0)
                 HARM_TERM(h1)
                 HARM_TERM(h2)
                 HARM_TERM(h3)
+                HARM_TERM(h4)
             }
             const T sc = rho * hd.scale;  // rho * c * sqrt(2)
             px = gfma(sc, gfma(rc, s1, gmul(ic, s2)), px);
