@@ -250,7 +250,10 @@ static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, con
     static const double tuned16[DEV_MAX_WAVES] = {1.0000, 1.3959, 1.3248, 1.5513, 1.5890, 1.1944, 1.1728, 1.3383,
                                                   1.3085, 0.8969, 0.9070, 0.9179, 0.8464, 0.5319, 0.5459, 0.5545};
     double per_wave[DEV_MAX_WAVES];
-    for (int w = 0; w < DEV_MAX_WAVES; ++w) per_wave[w] = n_waves == 16 ? tuned16[w] : 1.0;
+    // pipelined stage loop: the integrator wave now works beside the column waves of SIMD 0 (4, 8, 12), same calibration
+    static const double tuned16_pipe[DEV_MAX_WAVES] = {1.0000, 1.2871, 1.0928, 1.5517, 1.4983, 1.3248, 1.2956, 1.3168,
+                                                       1.2552, 0.8859, 0.9897, 1.0051, 0.8594, 0.5099, 0.5811, 0.5808};
+    for (int w = 0; w < DEV_MAX_WAVES; ++w) per_wave[w] = n_waves == 16 ? (ctx->host_cfg.pipe ? tuned16_pipe[w] : tuned16[w]) : 1.0;
     if (const char *e = std::getenv("NYX_HIP_AGE_WEIGHTS")) {  // coarse knob: one weight per age class
         double aw[4] = {1.0, 1.0, 1.0, 1.0};
         if (std::sscanf(e, "%lf,%lf,%lf,%lf", &aw[0], &aw[1], &aw[2], &aw[3]) == 4 && n_waves == 16)
@@ -314,6 +317,10 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves) {
         for (int w = 0; w < DEV_MAX_WAVES; ++w) dc.sched[k].n_ranges[w] = 0;
     dc.n_waves = n_waves;
     dc.merge_roles = (std::getenv("NYX_HIP_MERGE_ROLES") && n_waves >= 8) ? 1 : 0;
+    {
+        const char *e = std::getenv("NYX_HIP_PIPE");
+        dc.pipe = (n_waves == DEV_MAX_WAVES && !dc.merge_roles && (e ? std::atoi(e) != 0 : true)) ? 1 : 0;
+    }
     if (!dc.has_grav || nc == 0) return;
     // role handicaps of this workgroup shape (merged roles when there are fewer than three waves)
     double hc[DEV_MAX_WAVES] = {0};
@@ -334,21 +341,27 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves) {
         double terms = 0.0, given = 0.0;
         for (int c = 1; c <= nc; ++c) terms += ctx->col_len[c];
         std::vector<int> own, help;
+        const int col_waves = DEV_MAX_WAVES - 2;  // a helper's wave 0 claims jobs, its last wave answers
+        int max_cols = col_waves;
+        if (const char *e = std::getenv("NYX_HIP_COOP_COLS")) max_cols = std::min(2 * col_waves, std::max(1, std::atoi(e)));
         for (int c = 1; c <= nc; ++c) {
-            if ((int)help.size() < DEV_MAX_WAVES - 1 && c < nc - 1 && given + 0.5 * ctx->col_len[c] <= dc.coop_frac * terms) {
+            if ((int)help.size() < max_cols && c < nc - 1 && given + 0.5 * ctx->col_len[c] <= dc.coop_frac * terms) {
                 help.push_back(c);
                 given += ctx->col_len[c];
             } else {
                 own.push_back(c);
             }
         }
-        // helper: one column per wave; wave 0 keeps none: it only scans the
-        // mailboxes and claims jobs (with a column of its own the claims come late and every owner waits: +12 % run time)
+        // helper: one column per wave, longest first; the two SIMDs that also host the producer and the answering wave have
+        // three column waves (4 8 12 / 3 7 11) and take the six longest, the other two SIMDs four each
+        static const int wave_order[DEV_MAX_WAVES - 2] = {4, 3, 8, 7, 12, 11, 1, 2, 5, 6, 9, 10, 13, 14};
         DevSched &hs = dc.sched[DEV_SCHED_HELPER];
         for (int w = 0; w < DEV_MAX_WAVES; ++w) hs.n_ranges[w] = 0;
         for (size_t k = 0; k < help.size(); ++k) {
-            const int w = 1 + (int)k;  // oldest wave slots (served first by the SIMD arbiter) take the longest columns
-            hs.range_c0[w][0] = help[k]; hs.range_cnt[w][0] = 1; hs.n_ranges[w] = 1;
+            // a second round (NYX_HIP_COOP_COLS) is dealt in the opposite direction: every wave's pair has about the same length
+            const int w = (int)k < col_waves ? wave_order[k] : wave_order[2 * col_waves - 1 - (int)k];
+            const int r = hs.n_ranges[w]++;
+            hs.range_c0[w][r] = help[k]; hs.range_cnt[w][r] = 1;
         }
         if (!help.empty() && !own.empty() && fill_schedule(ctx, dc.sched[DEV_SCHED_PRIMARY], n_waves, own, hc)) {
             dc.coop_ok = 1;
@@ -399,10 +412,10 @@ extern "C" double nyx_hip_last_kernel_ms(nyx_hip_ctx *ctx) {
     return ms;
 }
 
-// Cycle accounting of workgroup 0 of the last launch (NYX_HIP_PROFILE=1): out[16][8], see the kernel.
+// Cycle accounting of workgroup 0 of the last launch (NYX_HIP_PROFILE=1): out[17][8], see the kernel (row 16: mailbox counters).
 extern "C" int32_t nyx_hip_debug_profile(nyx_hip_ctx *ctx, int64_t *out) {
     if (!ctx || !ctx->d_prof) return NYX_HIP_RC_BAD_ARG;
-    if (hipMemcpy(out, ctx->d_prof, 16 * 8 * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return NYX_HIP_RC_HIP_ERROR;
+    if (hipMemcpy(out, ctx->d_prof, 17 * 8 * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return NYX_HIP_RC_HIP_ERROR;
     return NYX_HIP_RC_OK;
 }
 
@@ -676,10 +689,10 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
             const int64_t helpers = std::min<int64_t>(n_own, (ctx->n_cu - base) / 8 * 8);
             if (helpers >= 8 && 4 * helpers >= n_own) {
                 // share of the terms the helpers take: owners keep (1 - x), each helper does x * owners / helpers jobs' worth
-                // per evaluation period, plus its hand-off overhead: x ~ 0.92 r / (1 + r) with r = helpers / owners
+                // per evaluation period, plus its hand-off overhead: x ~ 0.85 r / (1 + r) with r = helpers / owners
                 if (!std::getenv("NYX_HIP_COOP_FRAC")) {
                     const double r = (double)helpers / (double)n_own;
-                    const double x = std::min(0.55, std::max(0.10, 0.92 * r / (1.0 + r)));
+                    const double x = std::min(0.55, std::max(0.10, 0.85 * r / (1.0 + r)));
                     if (std::fabs(x - ctx->host_cfg.coop_frac) > 0.01) {
                         ctx->host_cfg.coop_frac = x;
                         build_schedule(ctx, nw);
@@ -716,8 +729,8 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
         }
     }
     if (std::getenv("NYX_HIP_PROFILE")) {
-        if (!ctx->d_prof) HIP_TRY(hipMalloc(&ctx->d_prof, 16 * 8 * sizeof(int64_t)));
-        HIP_TRY(hipMemsetAsync(ctx->d_prof, 0, 16 * 8 * sizeof(int64_t), stream));
+        if (!ctx->d_prof) HIP_TRY(hipMalloc(&ctx->d_prof, 17 * 8 * sizeof(int64_t)));
+        HIP_TRY(hipMemsetAsync(ctx->d_prof, 0, 17 * 8 * sizeof(int64_t), stream));
         bt.prof = ctx->d_prof;
     }
     if (time_it) HIP_TRY(hipEventRecord(ctx->ev0, stream));

@@ -87,6 +87,7 @@ struct DevCfg {
     /* --- column schedules: wave w walks n_ranges[w] contiguous column ranges --- */
     int32_t n_waves;
     int32_t merge_roles; /* almanac and perturbation duties share wave 1 */
+    int32_t pipe, _pad5; /* pipelined stage loop (16-wave workgroups): see role_loop */
     DevSched sched[DEV_N_SCHED];
     double coop_frac; /* share of the harmonics terms a helper workgroup takes over (cooperative mode) */
     int32_t coop_ok, _pad4; /* PRIMARY / HELPER schedules are valid */
@@ -119,11 +120,11 @@ struct HarmEntry {
  * seq - 1 to seq (compare-and-swap), evaluates its columns and answers with the partial sums and done = seq.  The
  * words the helpers scan (posted, claimed, finished) are packed per set of 16 owners (one 64-byte line per set and
  * kind: word index = set * 16 + slot, owner = set + slot * n_sets), so one load scans a set. */
-struct CoopBox {
-    double in[5][DEV_LANES];
-    double out[4][DEV_LANES];
-    uint32_t done; /* written by the helper that claimed the job */
-    uint32_t pad[15];
+struct CoopBox { /* double-buffered by the parity of `seq`: the next evaluation is posted before the previous answer is read */
+    double in[2][5][DEV_LANES];
+    double out[2][4][DEV_LANES];
+    uint32_t done[2]; /* written by the helper that claimed the job */
+    uint32_t pad[14];
 };
 
 struct DevBatch { /* device pointers of one launch */

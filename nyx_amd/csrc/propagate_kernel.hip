@@ -525,6 +525,33 @@ DEVFN void cpow_uniform(T zr, T zi, int e, T &pr, T &pi) {
         a1 = an;                                                                           \
     }
 
+// One batch of the table = 280 contiguous bytes = 70 SGPRs, fetched by six scalar loads behind a single wait.
+typedef int v16i __attribute__((ext_vector_type(16)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+struct HarmBatch {
+    v16i q0, q1, q2, q3;
+    v4i q4;
+    v2i q5;
+};
+static_assert(HARM_BATCH == 5 && sizeof(HarmEntry) == 56, "load_batch spells out five 56-byte entries");
+DEVFN void load_batch(HarmPtr e, HarmBatch &b) {
+    asm volatile(
+        "s_load_dwordx16 %0, %6, 0x0\n\t"
+        "s_load_dwordx16 %1, %6, 0x40\n\t"
+        "s_load_dwordx16 %2, %6, 0x80\n\t"
+        "s_load_dwordx16 %3, %6, 0xc0\n\t"
+        "s_load_dwordx4 %4, %6, 0x100\n\t"
+        "s_load_dwordx2 %5, %6, 0x110\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(b.q0), "=&s"(b.q1), "=&s"(b.q2), "=&s"(b.q3), "=&s"(b.q4), "=&s"(b.q5)
+        : "s"(e)
+        : "memory");
+}
+#define HB_D(v, i) __builtin_bit_cast(double, (v2i){(v)[(i)], (v)[(i) + 1]})
+#define HB_ENTRY(v0, v1, v2, v3, v4, v5, v6, i0, i1, i2, i3, i4, i5, i6) \
+    { HB_D(v0, i0), HB_D(v1, i1), HB_D(v2, i2), HB_D(v3, i3), HB_D(v4, i4), HB_D(v5, i5), HB_D(v6, i6) }
+
 DEVFN uint64_t uniform_u64(uint64_t v) {
     const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
     const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
@@ -568,12 +595,15 @@ DEVFN Partial4T<T> harmonics_core(CfgPtr cfg, HarmPtr htab, ColPtr cols, const i
             T a1 = gzero(zr), a2 = inv_rho * hd.diag;
             T s1 = gzero(zr), s2 = gzero(zr), s3 = gzero(zr), s4 = gzero(zr), s5 = gzero(zr), s6 = gzero(zr);
             for (int b = 0; b < nb; ++b, e += HARM_BATCH) {
-                // five 56-byte entries per batch: 70 SGPRs of scalar loads in flight, then 45 f64 VALU ops (x4.5 with duals)
-                const HarmEntry CAS &h0 = e[0];
-                const HarmEntry CAS &h1 = e[1];
-                const HarmEntry CAS &h2 = e[2];
-                const HarmEntry CAS &h3 = e[3];
-                const HarmEntry CAS &h4 = e[4];
+                // five 56-byte entries per batch: 70 SGPRs of scalar loads in flight behind ONE wait, then 45 f64 VALU ops per
+                // lane.  The loads are spelled out: left to the scheduler, instantiations under register pressure wait after every load.
+                HarmBatch hb;
+                load_batch(e, hb);
+                const HarmEntry h0 = HB_ENTRY(hb.q0, hb.q0, hb.q0, hb.q0, hb.q0, hb.q0, hb.q0, 0, 2, 4, 6, 8, 10, 12);
+                const HarmEntry h1 = HB_ENTRY(hb.q0, hb.q1, hb.q1, hb.q1, hb.q1, hb.q1, hb.q1, 14, 0, 2, 4, 6, 8, 10);
+                const HarmEntry h2 = HB_ENTRY(hb.q1, hb.q1, hb.q2, hb.q2, hb.q2, hb.q2, hb.q2, 12, 14, 0, 2, 4, 6, 8);
+                const HarmEntry h3 = HB_ENTRY(hb.q2, hb.q2, hb.q2, hb.q3, hb.q3, hb.q3, hb.q3, 10, 12, 14, 0, 2, 4, 6);
+                const HarmEntry h4 = HB_ENTRY(hb.q3, hb.q3, hb.q3, hb.q3, hb.q4, hb.q4, hb.q5, 8, 10, 12, 14, 0, 2, 0);
                 HARM_TERM(h0)
                 HARM_TERM(h1)
                 HARM_TERM(h2)
@@ -659,7 +689,7 @@ DEVFN void coop_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"
 // owner's critical path never waits for memory.
 static __device__ __attribute__((noinline)) void coop_post(CoopBox *box, uint32_t *posted, int lane, uint32_t seq, const double *inb) {
 #pragma unroll
-    for (int q = 0; q < 5; ++q) coop_stored(&box->in[q][lane], inb[q * DEV_LANES + lane]);
+    for (int q = 0; q < 5; ++q) coop_stored(&box->in[seq & 1u][q][lane], inb[q * DEV_LANES + lane]);
     coop_release();  // the inputs have reached memory before the sequence number is written
     if (lane == 0) coop_store(posted, seq);
 }
@@ -672,13 +702,13 @@ static __device__ __attribute__((noinline)) CoopAnswer coop_wait(CoopBox *box, i
     CoopAnswer a = {0.0, 0.0, 0.0, 0.0, 0};
     const int64_t t0 = (int64_t)__builtin_amdgcn_s_memrealtime();
     for (;;) {
-        if (coop_load(&box->done) == seq) break;
+        if (coop_load(&box->done[seq & 1u]) == seq) break;
         if ((int64_t)__builtin_amdgcn_s_memrealtime() - t0 > COOP_TIMEOUT_TICKS) return a;
         __builtin_amdgcn_s_sleep(1);
     }
     coop_acquire();
-    a.x = coop_loadd(&box->out[0][lane]); a.y = coop_loadd(&box->out[1][lane]); a.z = coop_loadd(&box->out[2][lane]);
-    a.w = coop_loadd(&box->out[3][lane]);
+    a.x = coop_loadd(&box->out[seq & 1u][0][lane]); a.y = coop_loadd(&box->out[seq & 1u][1][lane]);
+    a.z = coop_loadd(&box->out[seq & 1u][2][lane]); a.w = coop_loadd(&box->out[seq & 1u][3][lane]);
     a.ok = 1;
     return a;
 }
@@ -700,27 +730,59 @@ static __device__ __attribute__((noinline)) Partial4 coop_fallback(uint64_t cfg_
 // Helper workgroup.  Jobs are CLAIMED, not assigned: the owners are dealt into sets of at most 16, a helper watches
 // one set (lane l < 16 of its wave 0 <-> one owner: two 64-byte loads scan the set), and whichever helper of the set is
 // free takes the next posted job with a compare-and-swap on claimed[owner].  The load evens out by itself whatever the
-// ratio of helpers to owners.  LDS: [16][4][64] partials + the job words.
+// ratio of helpers to owners.
+//
+// Inside the workgroup the job is a two-slot software pipeline with no workgroup barrier: wave 0 is the PRODUCER (it
+// claims job j+1 and fetches its five input rows from the mailbox into LDS while the others work on job j), waves
+// 1..14 are the column waves (one column each), and wave 15 ANSWERS: it waits for the fourteen partial sums, folds
+// them in the fixed wave order and writes the answer.  So the two memory round trips of a job (inputs in, answer out,
+// ~2 us each on uncached memory) overlap the arithmetic of its neighbours: a helper's job period is its longest
+// column, not column + latencies.  LDS words: ready[s] / answered[s] = 1 + number of the job last published /
+// answered in slot s, cnt[s] = column waves that have delivered.
+#define HELPER_LDS_BYTES ((2 * DEV_MAX_WAVES * 4 * DEV_LANES + 2 * 5 * DEV_LANES) * 8 + 64 * 4)
 DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols, char *smem, int lane, int wave) {
-    double *part = (double *)smem;
-    volatile int *job = (volatile int *)(part + DEV_MAX_WAVES * 4 * DEV_LANES);
-    const int h = (int)blockIdx.x - bt.coop_base;
-    const int64_t n_own = (bt.n + DEV_LANES - 1) / DEV_LANES;
-    const int n_sets = bt.coop_sets;
-    const int set = h % n_sets;
-    const int64_t mine = (int64_t)set + (int64_t)lane * n_sets;  // the owner this lane watches (lanes 0..15)
-    const bool has = lane < COOP_SET && mine < n_own;
-    const int widx = set * COOP_SET + lane;                       // its scan words
-    unsigned turn = (unsigned)h;
-    for (;;) {
-        if (wave == 0) {
+    double *part = (double *)smem;                                 // [2][16][4][64]
+    double *inl = part + 2 * DEV_MAX_WAVES * 4 * DEV_LANES;        // [2][5][64]
+    int *ctl = (int *)(inl + 2 * 5 * DEV_LANES);
+    volatile int *ready = ctl, *answered = ctl + 2, *jown = ctl + 4, *jseq = ctl + 6;
+    int *cnt = ctl + 8;
+    const int answer_wave = (int)(blockDim.x / DEV_LANES) - 1;
+    const int n_col_waves = answer_wave - 1;
+    if (wave == 0 || wave == answer_wave) {
+        if (wave == 0 && lane < 16) ctl[lane] = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            part[(wave * 4 + q) * DEV_LANES + lane] = 0.0;
+            part[((DEV_MAX_WAVES + wave) * 4 + q) * DEV_LANES + lane] = 0.0;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int h = (int)blockIdx.x - bt.coop_base;
+        const int64_t n_own = (bt.n + DEV_LANES - 1) / DEV_LANES;
+        const int n_sets = bt.coop_sets;
+        const int set = h % n_sets;
+        const int64_t mine = (int64_t)set + (int64_t)lane * n_sets;  // the owner this lane watches (lanes 0..15)
+        const bool has = lane < COOP_SET && mine < n_own;
+        const int widx = set * COOP_SET + lane;                       // its scan words
+        unsigned turn = (unsigned)h;
+        for (int j = 0;; ++j) {
+            const int s = j & 1;
             int owner = -1;
             uint32_t seq = 0;
             const int64_t t0 = (int64_t)__builtin_amdgcn_s_memrealtime();
+            bool slot_free = j < 2;
             for (;;) {
+                if ((int64_t)__builtin_amdgcn_s_memrealtime() - t0 > 5000 * COOP_TIMEOUT_TICKS) { owner = -1; break; }  // 10 s: never spin forever
+                if (!slot_free) {  // the job that used this slot two rounds ago has been answered
+                    slot_free = answered[s] == j - 1;
+                    if (!slot_free) { __builtin_amdgcn_s_sleep(4); continue; }
+                }
+                // the two words are read by independent loads: a pair (old posted, new claimed) is possible and must not look
+                // like a job, hence "posted is AHEAD of claimed", not "differs from"
                 const uint32_t posted = has ? coop_load(bt.coop_posted + widx) : 0u;
                 const uint32_t claimed = has ? coop_load(bt.coop_claimed + widx) : 0u;
-                const uint64_t cand = __ballot(has && posted != claimed);
+                const uint64_t cand = __ballot(has && (int32_t)(posted - claimed) > 0);
                 if (cand) {
                     // first candidate at or after a rotating start lane, so that the helpers of a set spread over the jobs
                     const unsigned rot = turn++ & 63u;
@@ -728,49 +790,90 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
                     const int pick = hi ? (int)rot + __builtin_ctzll(hi) : __builtin_ctzll(cand);
                     int won = 0;
                     if (lane == pick) {
+                        // jobs are taken in order, one at a time: an owner may have two outstanding (the pipelined loop posts
+                        // stage i+1 before it has read the answer of stage i)
                         uint32_t expect = claimed;
-                        won = __hip_atomic_compare_exchange_strong(bt.coop_claimed + widx, &expect, posted, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                                   __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
+                        won = __hip_atomic_compare_exchange_strong(bt.coop_claimed + widx, &expect, claimed + 1u, __ATOMIC_RELAXED,
+                                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
                     }
                     if (__shfl(won, pick)) {
                         owner = (int)__shfl((int)mine, pick);
-                        seq = (uint32_t)__shfl((int)posted, pick);
+                        seq = (uint32_t)__shfl((int)claimed, pick) + 1u;
                         break;
                     }
                     continue;  // another helper was faster: look again
                 }
                 const uint32_t fin = has ? coop_load(bt.coop_finished + widx) : 1u;
                 if (__all(fin != 0u)) { owner = -1; break; }
-                if ((int64_t)__builtin_amdgcn_s_memrealtime() - t0 > 5000 * COOP_TIMEOUT_TICKS) { owner = -1; break; }  // 10 s: never spin forever
                 __builtin_amdgcn_s_sleep(8);  // ~0.2 us between scans: the set's words are one memory line shared by ~10 helpers
             }
-            if (lane == 0) { job[0] = owner; job[1] = (int)seq; }
-        }
-        __syncthreads();
-        const int owner = job[0];
-        const uint32_t seq = (uint32_t)job[1];
-        if (owner < 0) break;
-        CoopBox *b = bt.coop_box + owner;
-        coop_acquire();  // the inputs were posted before `seq`
-        const double v0 = coop_loadd(&b->in[0][lane]), v1 = coop_loadd(&b->in[1][lane]), v2 = coop_loadd(&b->in[2][lane]),
-                     v3 = coop_loadd(&b->in[3][lane]), v4 = coop_loadd(&b->in[4][lane]);
-        const Partial4 pr = harmonics_partial((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, DEV_SCHED_HELPER, v0, v1, v2, v3, v4);
-        double *pp = part + wave * 4 * DEV_LANES;
-        pp[0 * DEV_LANES + lane] = pr.x; pp[1 * DEV_LANES + lane] = pr.y; pp[2 * DEV_LANES + lane] = pr.z; pp[3 * DEV_LANES + lane] = pr.w;
-        __syncthreads();
-        if (wave == DEV_MAX_WAVES - 1) {  // the last wave answers while wave 0 is already looking for the next job
-            double o[4] = {0.0, 0.0, 0.0, 0.0};
-            for (int w = 0; w < DEV_MAX_WAVES; ++w) {  // fixed wave order
-#pragma unroll
-                for (int q = 0; q < 4; ++q) o[q] += part[(w * 4 + q) * DEV_LANES + lane];
+            if (owner >= 0) {
+                const CoopBox *b = bt.coop_box + owner;
+                coop_acquire();  // the inputs were posted before `seq`
+                const unsigned par = seq & 1u;
+                const double v0 = coop_loadd(&b->in[par][0][lane]), v1 = coop_loadd(&b->in[par][1][lane]), v2 = coop_loadd(&b->in[par][2][lane]),
+                             v3 = coop_loadd(&b->in[par][3][lane]), v4 = coop_loadd(&b->in[par][4][lane]);
+                double *il = inl + s * 5 * DEV_LANES;
+                il[0 * DEV_LANES + lane] = v0; il[1 * DEV_LANES + lane] = v1; il[2 * DEV_LANES + lane] = v2;
+                il[3 * DEV_LANES + lane] = v3; il[4 * DEV_LANES + lane] = v4;
             }
-#pragma unroll
-            for (int q = 0; q < 4; ++q) coop_stored(&b->out[q][lane], o[q]);
-            coop_release();
-            if (lane == 0) coop_store(&b->done, seq);
+            if (lane == 0) { jown[s] = owner; jseq[s] = (int)seq; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) ready[s] = j + 1;
+            if (owner < 0) break;
         }
-        // no barrier here: every wave read job[] before the barrier above, and part[] is not rewritten before the last wave
-        // (the one that is reading it) has arrived at the next job barrier
+        return;
+    }
+    for (int j = 0;; ++j) {
+        const int s = j & 1;
+        {
+            const int64_t t0 = (int64_t)__builtin_amdgcn_s_memrealtime();
+            while (ready[s] != j + 1) {
+                if ((int64_t)__builtin_amdgcn_s_memrealtime() - t0 > 6000 * COOP_TIMEOUT_TICKS) return;  // (the producer gives up after 10 s)
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const int owner = jown[s];
+        const uint32_t seq = (uint32_t)jseq[s];
+        if (owner < 0) break;
+        double *ps = part + s * DEV_MAX_WAVES * 4 * DEV_LANES;
+        if (wave != answer_wave) {
+            const double *il = inl + s * 5 * DEV_LANES;
+            const double v0 = il[0 * DEV_LANES + lane], v1 = il[1 * DEV_LANES + lane], v2 = il[2 * DEV_LANES + lane],
+                         v3 = il[3 * DEV_LANES + lane], v4 = il[4 * DEV_LANES + lane];
+            const Partial4 pr = harmonics_partial((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, DEV_SCHED_HELPER, v0, v1, v2, v3, v4);
+            double *pp = ps + wave * 4 * DEV_LANES;
+            pp[0 * DEV_LANES + lane] = pr.x; pp[1 * DEV_LANES + lane] = pr.y; pp[2 * DEV_LANES + lane] = pr.z; pp[3 * DEV_LANES + lane] = pr.w;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) (void)__hip_atomic_fetch_add(cnt + s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            continue;
+        }
+        // ---- the answering wave: wait for the column waves, fold in the fixed wave order (the slots of the producer and of
+        // this wave hold zeros), answer.  None of this is on a column wave's path.
+        {
+            const int64_t t0 = (int64_t)__builtin_amdgcn_s_memrealtime();
+            while (__hip_atomic_load(cnt + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != n_col_waves) {
+                if ((int64_t)__builtin_amdgcn_s_memrealtime() - t0 > 6000 * COOP_TIMEOUT_TICKS) return;
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        CoopBox *b = bt.coop_box + owner;
+        const unsigned par = seq & 1u;
+        double o[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int w = 0; w < DEV_MAX_WAVES; ++w) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] += ps[(w * 4 + q) * DEV_LANES + lane];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) coop_stored(&b->out[par][q][lane], o[q]);
+        if (lane == 0) __hip_atomic_store(cnt + s, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) answered[s] = j + 1;  // the slot may be refilled: its partial sums are in registers
+        coop_release();
+        if (lane == 0) coop_store(&b->done[par], seq);
+        if (lane == 0 && bt.prof != nullptr) atomicAdd((unsigned long long *)bt.prof + 16 * 8 + 4, 1ull);
     }
 }
 
@@ -1029,6 +1132,8 @@ struct LdsMap {
     int *pertst;    // [64]
     int *ctl;       // [16]
     double *rec;    // [rec_doubles]
+    // pipelined stage loop (non-STM): buffers of odd stages
+    double *ys2, *inb2, *pert2;
     // STM variant only
     double *inbD;   // [20][64]       5 dual inputs (zr, zi, rho_u, rho, 1/rho)
     double *pertD;  // [27][64]       a_pm(3) G_pm(9) f_srp/m(3) G_srp/m(9) c_srp(3)
@@ -1060,6 +1165,12 @@ DEVFN LdsMap carve_lds(char *smem, int n_waves, bool stm) {
         m.inb = p; p += NIN * DEV_LANES;
         m.pert = p; p += 9 * DEV_LANES;
     }
+    m.ys2 = m.ys; m.inb2 = m.inb; m.pert2 = m.pert;
+    if (!stm) {
+        m.ys2 = p; p += 6 * DEV_LANES;
+        m.inb2 = p; p += NIN * DEV_LANES;
+        m.pert2 = p; p += 9 * DEV_LANES;
+    }
     m.rec = p;
     return m;
 }
@@ -1068,7 +1179,7 @@ extern "C" size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles, int stm) {
     size_t d = (size_t)DEV_MAX_STAGES * 6 * DEV_LANES + DEV_MAX_STAGES * DEV_MAX_STAGES + 3 * DEV_MAX_STAGES + 6 * DEV_LANES +
                2 * ED_FIELDS * DEV_LANES + 2 * DEV_LANES + CS_FIELDS * DEV_LANES + (size_t)DEV_MAX_WAVES * 4 * DEV_LANES + DEV_LANES +
                DEV_LANES / 2 + 8 + (size_t)rec_doubles;
-    d += stm ? (size_t)(20 + 27 + 12) * DEV_LANES : (size_t)(NIN + 9) * DEV_LANES;
+    d += stm ? (size_t)(20 + 27 + 12) * DEV_LANES : (size_t)(NIN + 9 + 6 + NIN + 9) * DEV_LANES;
     (void)n_waves;
     return d * sizeof(double) + 64;
 }
@@ -1171,6 +1282,22 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     const bool coop_started = coop_on;
     uint32_t coop_seq = 0;
     bool coop_drop = false;  // fallback taken: the workers go back to DEV_SCHED_SOLO from the next evaluation on
+    // Pipelined stage loop.  What the column workers need for stage i+1 is its POSITION (the five recursion inputs), and
+    // that depends on the velocities of the stages up to i, i.e. on the accelerations up to stage i-1 only.  So the
+    // integrator wave, idle in window i, publishes position and inputs of stage i+1 there (second set of LDS buffers, by
+    // stage parity), the workers go from barrier B2(i) straight into the harmonics of stage i+1, and the integrator's
+    // phase C(i) + the velocity of stage i+1 run beside them instead of in front of them: one barrier per stage, nobody
+    // waits for the serial phases.  Two LDS words order the rest: ctl[2] = last stage whose epoch data the almanac wave
+    // has written, ctl[3] = number of stages whose partial sums the integrator has folded (a worker does not overwrite
+    // its slot before that).  Same arithmetic in the same order as the plain loop: bit-identical results.
+    const bool pipe = !STM && !(INTEG && (ALMANAC || PERT)) && cfg->pipe != 0 && has_grav && !has_drag;
+    double nx_pos[3] = {0.0, 0.0, 0.0}, nx_s = 0.0, nx_t = 0.0, nx_u = 0.0, nx_kfac = 0.0;
+    double m_cur[9], m_nx[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { m_cur[q] = 0.0; m_nx[q] = 0.0; }
+    uint32_t seq_cur = 0, seq_nx = 0;   // mailbox sequence numbers of this stage / the next one
+    unsigned long long dbg_answers = 0, dbg_fallbacks = 0, dbg_fb_seq = 0;  // (NYX_HIP_PROFILE: row 16 of the profile)
+    bool shared_cur = false, shared_nx = false;  // did the workers of this / the next stage leave columns to a helper?
 
     for (;;) {  // one iteration = one RK attempt for every live lane (derive(), instance.rs:368-414)
         double h = 0.0;
@@ -1216,6 +1343,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             int st = rec_in_lds ? epoch_data(cfg, (const double *)L.rec, ep, L.ed, lane) : epoch_data(cfg, records, ep, L.ed, lane);
             L.edst[lane] = st;
         }
+        if (INTEG && lane == 0) { L.ctl[2] = 0; L.ctl[3] = 0; }
         __syncthreads();  // Bp
 
         int st_att = NYX_HIP_OK;
@@ -1227,6 +1355,24 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             PROF_T0();
             if (INTEG) {
                 // ---- Phase A: stage state  y + h * sum_j a_ij k_j   (instance.rs:376-394)
+                double *const ysb = (pipe && (i & 1)) ? L.ys2 : L.ys;
+                double *const inbb = (pipe && (i & 1)) ? L.inb2 : L.inb;
+                if (pipe && i > 0) {
+                    // position and inputs of this stage were published in the previous window: only the velocity is left
+                    const double a_last = A_ROW(i, i - 1);
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) ys[e] = nx_pos[e];
+#pragma unroll
+                    for (int e = 3; e < 6; ++e) {
+                        const double wi = wpre[e] + a_last * KB(i - 1, e);
+                        ys[e] = CS_Y(e) + h * wi;
+                        ysb[e * DEV_LANES + lane] = ys[e];
+                    }
+                    s_ = nx_s; t_ = nx_t; u_ = nx_u; kfac = nx_kfac;
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) m_cur[q] = m_nx[q];
+                    seq_cur = seq_nx; shared_cur = shared_nx;
+                } else {
                 if (i == 0) {
 #pragma unroll
                     for (int e = 0; e < 6; ++e) ys[e] = CS_Y(e);
@@ -1241,24 +1387,26 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < 6; ++e) L.ys[e * DEV_LANES + lane] = ys[e];
+                for (int e = 0; e < 6; ++e) ysb[e * DEV_LANES + lane] = ys[e];
                 if (need_almanac && L.edst[(i & 1) * DEV_LANES + lane]) st_att = L.edst[(i & 1) * DEV_LANES + lane];
                 if (has_grav) {
                     // body-fixed position and the scaled inputs of the column recursion
-                    const double rb0 = edc[0 * DEV_LANES + lane] * ys[0] + edc[1 * DEV_LANES + lane] * ys[1] + edc[2 * DEV_LANES + lane] * ys[2];
-                    const double rb1 = edc[3 * DEV_LANES + lane] * ys[0] + edc[4 * DEV_LANES + lane] * ys[1] + edc[5 * DEV_LANES + lane] * ys[2];
-                    const double rb2 = edc[6 * DEV_LANES + lane] * ys[0] + edc[7 * DEV_LANES + lane] * ys[1] + edc[8 * DEV_LANES + lane] * ys[2];
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) m_cur[q] = edc[q * DEV_LANES + lane];
+                    const double rb0 = m_cur[0] * ys[0] + m_cur[1] * ys[1] + m_cur[2] * ys[2];
+                    const double rb1 = m_cur[3] * ys[0] + m_cur[4] * ys[1] + m_cur[5] * ys[2];
+                    const double rb2 = m_cur[6] * ys[0] + m_cur[7] * ys[1] + m_cur[8] * ys[2];
                     // one sqrt and one divide on the critical path; the rest are multiplies
                     const double r_ = norm3(rb0, rb1, rb2);
                     const double inv_r = 1.0 / r_;
                     s_ = rb0 * inv_r; t_ = rb1 * inv_r; u_ = rb2 * inv_r;
                     const double rho = cfg->g_re * inv_r;
                     kfac = (cfg->g_mu * inv_r) * cfg->g_inv_re;  // (mu / r) / R_eq
-                    L.inb[0 * DEV_LANES + lane] = rho * s_;
-                    L.inb[1 * DEV_LANES + lane] = rho * t_;
-                    L.inb[2 * DEV_LANES + lane] = rho * u_;
-                    L.inb[3 * DEV_LANES + lane] = rho;
-                    L.inb[4 * DEV_LANES + lane] = r_ * cfg->g_inv_re;
+                    inbb[0 * DEV_LANES + lane] = rho * s_;
+                    inbb[1 * DEV_LANES + lane] = rho * t_;
+                    inbb[2 * DEV_LANES + lane] = rho * u_;
+                    inbb[3 * DEV_LANES + lane] = rho;
+                    inbb[4 * DEV_LANES + lane] = r_ * cfg->g_inv_re;
                     if (STM) {
                         // the same quantities as duals seeded in the BODY-FIXED frame (gravity_field.rs:285-291)
                         const D3 x0 = {rb0, 1.0, 0.0, 0.0}, x1 = {rb1, 0.0, 1.0, 0.0}, x2 = {rb2, 0.0, 0.0, 1.0};
@@ -1276,17 +1424,25 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                         }
                     }
                 }
+                if (pipe) {  // stage 0 of an attempt: the workers' schedule for it is decided here, before B1
+                    shared_cur = coop_on;
+                    if (lane == 0) L.ctl[1] = coop_on ? 1 : 0;
+                }
+                }
             }
             PROF_ADD(0);
-            {
+            if (!pipe || i == 0) {
                 PROF_T0();
-                __syncthreads();  // B1: stage state and harmonics inputs published
+                __syncthreads();  // B1: stage state and harmonics inputs published (pipelined: stage 0 only)
                 PROF_ADD(6);
             }
             const int64_t ptw_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;
 
             // ---- window --------------------------------------------------------------------------
-            if (INTEG && !STM && coop_on && has_grav) coop_post(cbox, bt.coop_posted + coop_widx, lane, ++coop_seq, L.inb);
+            if (INTEG && !STM && coop_on && has_grav && (!pipe || i == 0)) {
+                seq_cur = ++coop_seq;
+                coop_post(cbox, bt.coop_posted + coop_widx, lane, seq_cur, L.inb);
+            }
             if (ALMANAC && need_almanac && i + 1 < stages) {
                 // epoch-only data of the NEXT stage
                 const int64_t ep = __double_as_longlong(L.step[lane]) + seconds_to_ns(C_COEF(i + 1) * L.step[DEV_LANES + lane]);
@@ -1295,10 +1451,16 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 if (!dbg_skip_serial || i == 0)  // (timing switch: reuse the data of stages 0/1)
                     st = rec_in_lds ? epoch_data(cfg, (const double *)L.rec, ep, edn, lane) : epoch_data(cfg, records, ep, edn, lane);
                 L.edst[((i + 1) & 1) * DEV_LANES + lane] = st;
+                if (pipe) {  // tell the integrator wave (which publishes the inputs of stage i+1 inside this window)
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (lane == 0) ((volatile int *)L.ctl)[2] = i + 1;
+                }
             }
             if (PERT && (has_pm || has_srp || has_drag || has_tides)) {
                 // position-dependent third-body and SRP terms of THIS stage
-                double r[3] = {L.ys[0 * DEV_LANES + lane], L.ys[1 * DEV_LANES + lane], L.ys[2 * DEV_LANES + lane]};
+                double *const ysp = (pipe && (i & 1)) ? L.ys2 : L.ys;
+                double *const pertp = (pipe && (i & 1)) ? L.pert2 : L.pert;
+                double r[3] = {ysp[0 * DEV_LANES + lane], ysp[1 * DEV_LANES + lane], ysp[2 * DEV_LANES + lane]};
                 double a3[3] = {0.0, 0.0, 0.0}, f3[3] = {0.0, 0.0, 0.0};
                 if (has_pm && !dbg_skip_serial) point_masses_accel(cfg, edc, lane, r, a3);
                 if (has_srp && !dbg_skip_serial) {
@@ -1306,19 +1468,19 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     f3[0] = f3[0] / p_mass; f3[1] = f3[1] / p_mass; f3[2] = f3[2] / p_mass;
                 }
 #pragma unroll
-                for (int e = 0; e < 3; ++e) { L.pert[e * DEV_LANES + lane] = a3[e]; L.pert[(3 + e) * DEV_LANES + lane] = f3[e]; }
+                for (int e = 0; e < 3; ++e) { pertp[e * DEV_LANES + lane] = a3[e]; pertp[(3 + e) * DEV_LANES + lane] = f3[e]; }
                 if (has_drag) {
-                    const double vv[3] = {L.ys[3 * DEV_LANES + lane], L.ys[4 * DEV_LANES + lane], L.ys[5 * DEV_LANES + lane]};
+                    const double vv[3] = {ysp[3 * DEV_LANES + lane], ysp[4 * DEV_LANES + lane], ysp[5 * DEV_LANES + lane]};
                     const int64_t ep = __double_as_longlong(L.step[lane]) + seconds_to_ns(C_COEF(i) * L.step[DEV_LANES + lane]);
                     double d3f[3];
                     drag_force(cfg, edc, lane, ns_to_seconds(ep), r, vv, p_cd, p_darea, d3f);
 #pragma unroll
-                    for (int e = 0; e < 3; ++e) L.pert[(6 + e) * DEV_LANES + lane] = d3f[e] / p_mass;
+                    for (int e = 0; e < 3; ++e) pertp[(6 + e) * DEV_LANES + lane] = d3f[e] / p_mass;
                 }
                 if (STM) pert_gradients(cfg, edc, lane, r, p_cr, p_area, p_mass, has_pm, has_srp, has_tides, L.pertD);
                 // third accel model (dynamics/sequence/config.rs:116-118): added to the point-mass slot, last, so that no
                 // live value of this role crosses the call
-                if (has_tides && !STM) tides_into_pert(cfg, edc, lane, L.ys, L.pert);
+                if (has_tides && !STM) tides_into_pert(cfg, edc, lane, ysp, pertp);
             }
             double acc[3] = {0.0, 0.0, 0.0};
             if (INTEG) {
@@ -1338,6 +1500,49 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                         }
                     }
                 }
+                if (pipe && i + 1 < stages) {
+                    // ---- position and recursion inputs of stage i+1, published inside the window of stage i.
+                    // k_i[0..2] is this stage's velocity, so  y + h (wpre + a_{i+1,i} k_i)  is complete for the position
+                    const double a_nl = A_ROW(i + 1, i);
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) {
+                        const double wi = wpre[e] + a_nl * ys[3 + e];
+                        nx_pos[e] = CS_Y(e) + h * wi;
+                    }
+                    double *const ysn = ((i + 1) & 1) ? L.ys2 : L.ys;
+                    double *const inbn = ((i + 1) & 1) ? L.inb2 : L.inb;
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) ysn[e * DEV_LANES + lane] = nx_pos[e];
+                    if (need_almanac) {  // the almanac wave writes the epoch data of stage i+1 early in this window
+                        // (bounded: a protocol error must end as a failed run, never as a hung GPU)
+                        int spin = 0;
+                        while (((volatile int *)L.ctl)[2] != i + 1 && ++spin < 4000000) __builtin_amdgcn_s_sleep(1);
+                        if (spin >= 4000000) st_att = NYX_HIP_ERR_NAN;
+                    }
+                    const double *const edn = L.ed + ((i + 1) & 1) * ED_FIELDS * DEV_LANES;
+                    if (need_almanac && L.edst[((i + 1) & 1) * DEV_LANES + lane]) st_att = L.edst[((i + 1) & 1) * DEV_LANES + lane];
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) m_nx[q] = edn[q * DEV_LANES + lane];
+                    const double rb0 = m_nx[0] * nx_pos[0] + m_nx[1] * nx_pos[1] + m_nx[2] * nx_pos[2];
+                    const double rb1 = m_nx[3] * nx_pos[0] + m_nx[4] * nx_pos[1] + m_nx[5] * nx_pos[2];
+                    const double rb2 = m_nx[6] * nx_pos[0] + m_nx[7] * nx_pos[1] + m_nx[8] * nx_pos[2];
+                    const double r_ = norm3(rb0, rb1, rb2);
+                    const double inv_r = 1.0 / r_;
+                    nx_s = rb0 * inv_r; nx_t = rb1 * inv_r; nx_u = rb2 * inv_r;
+                    const double rho = cfg->g_re * inv_r;
+                    nx_kfac = (cfg->g_mu * inv_r) * cfg->g_inv_re;
+                    inbn[0 * DEV_LANES + lane] = rho * nx_s;
+                    inbn[1 * DEV_LANES + lane] = rho * nx_t;
+                    inbn[2 * DEV_LANES + lane] = rho * nx_u;
+                    inbn[3 * DEV_LANES + lane] = rho;
+                    inbn[4 * DEV_LANES + lane] = r_ * cfg->g_inv_re;
+                    shared_nx = coop_on;
+                    if (lane == 0) L.ctl[1] = coop_on ? 1 : 0;  // the workers read it after B2(i), for stage i+1
+                    if (coop_on) {
+                        seq_nx = ++coop_seq;
+                        coop_post(cbox, bt.coop_posted + coop_widx, lane, seq_nx, inbn);
+                    }
+                }
             }
             if (prof_on) prof_acc[1] += (int64_t)__builtin_readcyclecounter() - ptw_;
             const int64_t pth_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;
@@ -1351,27 +1556,38 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             if (STM && has_grav)
                 harmonics_partial_dual((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, L.inbD, L.partD + wave * 16 * DEV_LANES, lane);
             if (!STM && has_grav && !dbg_skip_harm) {
-                const int sched = ((volatile int *)L.ctl)[1] ? DEV_SCHED_PRIMARY : DEV_SCHED_SOLO;  // (ctl[1] only changes between B2 and B1)
-                const Partial4 pr = harmonics_partial((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, sched, L.inb[0 * DEV_LANES + lane],
-                                                      L.inb[1 * DEV_LANES + lane], L.inb[2 * DEV_LANES + lane],
-                                                      L.inb[3 * DEV_LANES + lane], L.inb[4 * DEV_LANES + lane]);
+                // (ctl[1] is written before the barrier that precedes this read: B1 for stage 0, B2 of the previous stage otherwise;
+                //  the integrator wave itself carries no columns in a pipelined workgroup and uses whatever it just wrote)
+                const int sched = ((volatile int *)L.ctl)[1] ? DEV_SCHED_PRIMARY : DEV_SCHED_SOLO;
+                const double *const inbw = (pipe && (i & 1)) ? L.inb2 : L.inb;
+                Partial4 pr = {0.0, 0.0, 0.0, 0.0};
+                if (!(pipe && INTEG))
+                    pr = harmonics_partial((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, sched, inbw[0 * DEV_LANES + lane],
+                                           inbw[1 * DEV_LANES + lane], inbw[2 * DEV_LANES + lane], inbw[3 * DEV_LANES + lane],
+                                           inbw[4 * DEV_LANES + lane]);
                 px = pr.x; py = pr.y; pz = pr.z; pw = pr.w;
                 if (!INTEG) {
+                    if (pipe && i > 0) {  // the integrator folds the partials of stage i-1 at the start of this window
+                        int spin = 0;
+                        while (((volatile int *)L.ctl)[3] < i && ++spin < 4000000) __builtin_amdgcn_s_sleep(1);
+                    }
                     double *pp = L.part + wave * 4 * DEV_LANES;
                     pp[0 * DEV_LANES + lane] = px; pp[1 * DEV_LANES + lane] = py;
                     pp[2 * DEV_LANES + lane] = pz; pp[3 * DEV_LANES + lane] = pw;
                 }
             }
-            if (INTEG && !STM && coop_on && has_grav) {
+            if (INTEG && !STM && has_grav && (pipe ? shared_cur : coop_on)) {
                 // the helper's answer is collected INSIDE the window (this wave has nothing else to do): phase C never waits
-                const CoopAnswer ans = coop_wait(cbox, lane, coop_seq);
+                const CoopAnswer ans = coop_on ? coop_wait(cbox, lane, seq_cur) : CoopAnswer{0.0, 0.0, 0.0, 0.0, 0};
                 if (ans.ok) {
                     coop_x = ans.x; coop_y = ans.y; coop_z = ans.z; coop_w = ans.w;
-                } else {  // no answer in time: do the helper's columns here, then carry on alone
-                    const Partial4 fb = coop_fallback((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, L.inb, lane);
+                    ++dbg_answers;
+                } else {
+                    if (coop_on) { ++dbg_fallbacks; dbg_fb_seq = seq_cur; }  // no answer in time: do the helper's columns here, then carry on alone
+                    const Partial4 fb = coop_fallback((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, (pipe && (i & 1)) ? L.inb2 : L.inb, lane);
                     coop_x = fb.x; coop_y = fb.y; coop_z = fb.z; coop_w = fb.w;
                     coop_on = false;
-                    coop_drop = true;
+                    coop_drop = !pipe;  // (pipelined: ctl[1] is rewritten for every stage, nothing to undo)
                     if (lane == 0) coop_store(bt.coop_finished + coop_widx, 1u);
                 }
             }
@@ -1385,8 +1601,9 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
 
             if (INTEG) {
                 // ---- Phase C: assemble the derivative in the reference's order (orbital.rs:80-114, spacecraft.rs:227-243)
+                const double *const pertc = (pipe && (i & 1)) ? L.pert2 : L.pert;
                 if (!STM && (has_pm || has_tides)) {
-                    acc[0] += L.pert[0 * DEV_LANES + lane]; acc[1] += L.pert[1 * DEV_LANES + lane]; acc[2] += L.pert[2 * DEV_LANES + lane];
+                    acc[0] += pertc[0 * DEV_LANES + lane]; acc[1] += pertc[1 * DEV_LANES + lane]; acc[2] += pertc[2 * DEV_LANES + lane];
                 }
                 if (!STM && has_grav) {
                     // fixed wave order; all 15 slots are read unconditionally (slots of absent waves hold an exact
@@ -1395,6 +1612,10 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                         const Partial4 f4 = fold_partials((LdsCPtr)L.part, lane, px, py, pz, pw);
                         px = f4.x; py = f4.y; pz = f4.z; pw = f4.w;
                     }
+                    if (pipe) {  // the partial sums of stage i are in registers: the workers may overwrite their slots
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        if (lane == 0) ((volatile int *)L.ctl)[3] = i + 1;
+                    }
                     px += coop_x; py += coop_y; pz += coop_z; pw += coop_w;  // + the helper's columns (0 when working alone)
                     if (coop_drop) {  // (between B2 and the next B1: no worker is reading ctl[1])
                         if (lane == 0) L.ctl[1] = 0;
@@ -1402,15 +1623,16 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     }
                     px *= kfac; py *= kfac; pz *= kfac; pw *= kfac;
                     const double al0 = px + pw * s_, al1 = py + pw * t_, al2 = pz + pw * u_;
-                    acc[0] += edc[0 * DEV_LANES + lane] * al0 + edc[3 * DEV_LANES + lane] * al1 + edc[6 * DEV_LANES + lane] * al2;
-                    acc[1] += edc[1 * DEV_LANES + lane] * al0 + edc[4 * DEV_LANES + lane] * al1 + edc[7 * DEV_LANES + lane] * al2;
-                    acc[2] += edc[2 * DEV_LANES + lane] * al0 + edc[5 * DEV_LANES + lane] * al1 + edc[8 * DEV_LANES + lane] * al2;
+                    // DCM of THIS stage from registers: in the pipelined loop the almanac wave is already overwriting that LDS buffer
+                    acc[0] += m_cur[0] * al0 + m_cur[3] * al1 + m_cur[6] * al2;
+                    acc[1] += m_cur[1] * al0 + m_cur[4] * al1 + m_cur[7] * al2;
+                    acc[2] += m_cur[2] * al0 + m_cur[5] * al1 + m_cur[8] * al2;
                 }
                 if (!STM && has_srp) {
-                    acc[0] += L.pert[3 * DEV_LANES + lane]; acc[1] += L.pert[4 * DEV_LANES + lane]; acc[2] += L.pert[5 * DEV_LANES + lane];
+                    acc[0] += pertc[3 * DEV_LANES + lane]; acc[1] += pertc[4 * DEV_LANES + lane]; acc[2] += pertc[5 * DEV_LANES + lane];
                 }
                 if (!STM && has_drag) {
-                    acc[0] += L.pert[6 * DEV_LANES + lane]; acc[1] += L.pert[7 * DEV_LANES + lane]; acc[2] += L.pert[8 * DEV_LANES + lane];
+                    acc[0] += pertc[6 * DEV_LANES + lane]; acc[1] += pertc[7 * DEV_LANES + lane]; acc[2] += pertc[8 * DEV_LANES + lane];
                 }
                 if (STM) {
                     // dual path (dual_eom, spacecraft.rs:312-363): f(x) and A = df/dx; the derivative written to k_i is
@@ -1595,6 +1817,12 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     }
 
     if (INTEG && coop_started && lane == 0) coop_store(bt.coop_finished + coop_widx, 1u);
+    if (INTEG && bt.prof != nullptr && lane == 0) {
+        atomicAdd((unsigned long long *)bt.prof + 16 * 8 + 0, dbg_answers);
+        atomicAdd((unsigned long long *)bt.prof + 16 * 8 + 1, dbg_fallbacks);
+        atomicAdd((unsigned long long *)bt.prof + 16 * 8 + 2, dbg_fb_seq);
+        atomicAdd((unsigned long long *)bt.prof + 16 * 8 + 3, (unsigned long long)coop_seq);
+    }
     if (INTEG && valid) {
         ColdState c;
         cold_load(L.cs, lane, c);
@@ -1715,7 +1943,8 @@ extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg
         attr_set = true;
     }
     const bool stm = bt.o_stm != nullptr;
-    const size_t lds = nyx_kernel_lds_bytes(n_waves, rec_lds_doubles, stm ? 1 : 0);
+    size_t lds = nyx_kernel_lds_bytes(n_waves, rec_lds_doubles, stm ? 1 : 0);
+    if (!stm && bt.coop_helpers > 0 && lds < (size_t)HELPER_LDS_BYTES) lds = HELPER_LDS_BYTES;
     if (stm)
         hipLaunchKernelGGL(nyx_propagate_kernel_stm, dim3((unsigned)blocks), dim3((unsigned)(n_waves * DEV_LANES)), lds, stream, bt, cfg,
                            htab, cols, records);

@@ -35,10 +35,11 @@ print(f"n={n} hours={hours} deg={degree} waves={waves or 'auto'}: kernel {ms:.1f
       f"{n/ms*1e3*(24/hours):.1f} traj-days/s equiv, acc {st.n_accepted.sum()} rej {st.n_rejected.sum()} status!=0: {(st.status!=0).sum()}")
 if os.environ.get("NYX_HIP_PROFILE"):
     import ctypes as C
-    buf = (C.c_int64 * 128)()
+    buf = (C.c_int64 * 136)()
     ctx._lib.nyx_hip_debug_profile.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     if ctx._lib.nyx_hip_debug_profile(ctx._h, buf) == 0:
-        p = np.array(buf[:]).reshape(16, 8)
+        p = np.array(buf[:]).reshape(17, 8)
+        print('  mailbox: answers %d fallbacks %d fb_seq_sum %d posted %d helper_jobs %d' % tuple(p[16, :5]))
         ne = int(st.n_evals[:64].max())
         print("  wg0 cycles per eval (phaseA, duty, harmonics, phaseC, stepctl | total, barrier-wait) clock %.0f MHz" % (p[0, 5] / max(p[0, 7], 1) * 100.0))
         for w in range(16):

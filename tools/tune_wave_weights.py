@@ -32,10 +32,10 @@ for it in range(iters):
     for rep in range(2):
         out, st = ctx.propagate(batch, dur)
         ms.append(ctx.last_kernel_ms())
-    buf = (C.c_int64 * 128)()
+    buf = (C.c_int64 * 136)()
     ctx._lib.nyx_hip_debug_profile.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     ctx._lib.nyx_hip_debug_profile(ctx._h, buf)
-    p = np.array(buf[:]).reshape(16, 8).astype(float)
+    p = np.array(buf[:]).reshape(17, 8)[:16].astype(float)
     ne = float(st.n_evals[:64].max())
     t = (p[:, 1] + p[:, 2]) / ne          # duty + harmonics per evaluation
     t[0] = np.nan
