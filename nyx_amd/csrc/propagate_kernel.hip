@@ -1287,10 +1287,11 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     // integrator wave, idle in window i, publishes position and inputs of stage i+1 there (second set of LDS buffers, by
     // stage parity), the workers go from barrier B2(i) straight into the harmonics of stage i+1, and the integrator's
     // phase C(i) + the velocity of stage i+1 run beside them instead of in front of them: one barrier per stage, nobody
-    // waits for the serial phases.  Two LDS words order the rest: ctl[2] = last stage whose epoch data the almanac wave
+    // waits for the serial phases.  Three LDS words order the rest: ctl[2] = last stage whose epoch data the almanac wave
     // has written, ctl[3] = number of stages whose partial sums the integrator has folded (a worker does not overwrite
-    // its slot before that).  Same arithmetic in the same order as the plain loop: bit-identical results.
-    const bool pipe = !STM && !(INTEG && (ALMANAC || PERT)) && cfg->pipe != 0 && has_grav && !has_drag;
+    // its slot before that), ctl[4] = last stage whose velocity is published (drag is the one position-AND-velocity term
+    // of the perturbation wave).  Same arithmetic in the same order as the plain loop: bit-identical results.
+    const bool pipe = !STM && !(INTEG && (ALMANAC || PERT)) && cfg->pipe != 0 && has_grav;
     double nx_pos[3] = {0.0, 0.0, 0.0}, nx_s = 0.0, nx_t = 0.0, nx_u = 0.0, nx_kfac = 0.0;
     double m_cur[9], m_nx[9];
 #pragma unroll
@@ -1343,7 +1344,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             int st = rec_in_lds ? epoch_data(cfg, (const double *)L.rec, ep, L.ed, lane) : epoch_data(cfg, records, ep, L.ed, lane);
             L.edst[lane] = st;
         }
-        if (INTEG && lane == 0) { L.ctl[2] = 0; L.ctl[3] = 0; }
+        if (INTEG && lane == 0) { L.ctl[2] = 0; L.ctl[3] = 0; L.ctl[4] = 0; }
         __syncthreads();  // Bp
 
         int st_att = NYX_HIP_OK;
@@ -1367,6 +1368,10 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                         const double wi = wpre[e] + a_last * KB(i - 1, e);
                         ys[e] = CS_Y(e) + h * wi;
                         ysb[e * DEV_LANES + lane] = ys[e];
+                    }
+                    if (has_drag) {  // the perturbation wave is already in this stage's window; drag is the one term that wants the velocity
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) ((volatile int *)L.ctl)[4] = i + 1;
                     }
                     s_ = nx_s; t_ = nx_t; u_ = nx_u; kfac = nx_kfac;
 #pragma unroll
@@ -1470,6 +1475,11 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
 #pragma unroll
                 for (int e = 0; e < 3; ++e) { pertp[e * DEV_LANES + lane] = a3[e]; pertp[(3 + e) * DEV_LANES + lane] = f3[e]; }
                 if (has_drag) {
+                    if (pipe && i > 0) {  // velocity of this stage: written by phase A, which runs beside this window
+                        int spin = 0;
+                        while (((volatile int *)L.ctl)[4] != i + 1 && ++spin < 4000000) __builtin_amdgcn_s_sleep(1);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    }
                     const double vv[3] = {ysp[3 * DEV_LANES + lane], ysp[4 * DEV_LANES + lane], ysp[5 * DEV_LANES + lane]};
                     const int64_t ep = __double_as_longlong(L.step[lane]) + seconds_to_ns(C_COEF(i) * L.step[DEV_LANES + lane]);
                     double d3f[3];

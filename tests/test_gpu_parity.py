@@ -333,7 +333,7 @@ def test_full_size_properties_config2(monkeypatch):
     ctx2.close()
 
 
-@pytest.mark.parametrize("model,degree", [("exp", 4), ("stdatm", 0), ("const", 4)])
+@pytest.mark.parametrize("model,degree", [("exp", 4), ("stdatm", 0), ("const", 4), ("exp", 70)])  # (70: 16-wave workgroups, pipelined stage loop)
 def test_drag_vs_oracle(model, degree):
     """Drag::eom with its unit / frame quirks (drag.rs:181-284): the reference only smoke-tests drag
     (tests/mission_design/force_models.rs:257-385); here the device path is held to the oracle."""
