@@ -17,14 +17,14 @@
 #include "predict_args.h"
 #include "traj_args.h"
 
-extern "C" size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles, int stm);
+extern "C" size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles, int stm, int reuse_fields);
 extern "C" hipError_t nyx_launch_predict_init(const PredictArgs *a, const int64_t *epoch0, hipStream_t stream);
 extern "C" hipError_t nyx_launch_time_update(const PredictArgs *a, hipStream_t stream);
 extern "C" hipError_t nyx_launch_event_search(const EventSearchArgs *args, hipStream_t stream);
 extern "C" hipError_t nyx_launch_traj_eval(const TrajEvalArgs *args, hipStream_t stream);
 extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg, const HarmEntry *htab,
                                            const ColHdr *cols, const double *records, int n_waves, int rec_lds_doubles,
-                                           hipStream_t stream);
+                                           int reuse_fields, hipStream_t stream);
 
 // ---------------------------------------------------------------------------------------------
 // error reporting
@@ -602,7 +602,14 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
     records.resize(records.size() + 16, 0.0);  // padding for the 16-wide coefficient window
     dc.rec_doubles = (int32_t)records.size();
     dc.rec_in_lds = (records.size() * sizeof(double) <= 24 * 1024) ? 1 : 0;
-    if ((cfg->flags & NYX_HIP_FLAG_STM) && nyx_kernel_lds_bytes(DEV_MAX_WAVES_STM, dc.rec_doubles, 1) > 160 * 1024) dc.rec_in_lds = 0;
+    if ((cfg->flags & NYX_HIP_FLAG_STM) && nyx_kernel_lds_bytes(DEV_MAX_WAVES_STM, dc.rec_doubles, 1, 0) > 160 * 1024) dc.rec_in_lds = 0;
+    // stage-0 epoch data carried between attempts (see role_loop): needs an even stage count (the last stage's window
+    // then leaves buffer 0 free) and 9 + 3 * n_slots doubles + 20 bytes of LDS per lane
+    dc.ed_reuse = 0;
+    if (!(cfg->flags & NYX_HIP_FLAG_STM) && dc.stages % 2 == 0 && !(std::getenv("NYX_HIP_ED_REUSE") && std::atoi(std::getenv("NYX_HIP_ED_REUSE")) == 0)) {
+        const int nf = 9 + 3 * dc.n_slots;
+        if (nyx_kernel_lds_bytes(DEV_MAX_WAVES, dc.rec_in_lds ? dc.rec_doubles : 0, 0, nf) <= 160 * 1024) dc.ed_reuse = nf;
+    }
     dc.coop_frac = 0.30;  // measured optimum with two owners per helper (10 000 trajectories, 70x70): 0.28-0.33 is flat
     if (const char *e = std::getenv("NYX_HIP_COOP_FRAC")) dc.coop_frac = std::min(0.9, std::max(0.05, std::atof(e)));
     {
@@ -735,7 +742,7 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
     }
     if (time_it) HIP_TRY(hipEventRecord(ctx->ev0, stream));
     HIP_TRY(nyx_launch_propagate(bt, ctx->d_cfg, ctx->d_htab, ctx->d_cols, ctx->d_records, nw,
-                                 ctx->host_cfg.rec_in_lds ? ctx->host_cfg.rec_doubles : 0, stream));
+                                 ctx->host_cfg.rec_in_lds ? ctx->host_cfg.rec_doubles : 0, ctx->host_cfg.ed_reuse, stream));
     if (time_it) HIP_TRY(hipEventRecord(ctx->ev1, stream));
     return NYX_HIP_RC_OK;
 }

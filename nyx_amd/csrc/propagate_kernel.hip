@@ -1134,6 +1134,11 @@ struct LdsMap {
     double *rec;    // [rec_doubles]
     // pipelined stage loop (non-STM): buffers of odd stages
     double *ys2, *inb2, *pert2;
+    // epoch data carried between attempts (cfg->ed_reuse fields per lane), behind the ephemeris records
+    double *ed0;         // [ed_reuse][64]  stage-0 data of the current attempt (what a rejected attempt starts from again)
+    long long *ed0_ep;   // [64]            its epoch
+    long long *spec_ep;  // [64]            epoch of the data the almanac wave left in buffer 0 during the last window
+    int *ed0st;          // [64]
     // STM variant only
     double *inbD;   // [20][64]       5 dual inputs (zr, zi, rho_u, rho, 1/rho)
     double *pertD;  // [27][64]       a_pm(3) G_pm(9) f_srp/m(3) G_srp/m(9) c_srp(3)
@@ -1141,7 +1146,7 @@ struct LdsMap {
     double *partD;  // [P][16][64]    dual harmonics partials
 };
 
-DEVFN LdsMap carve_lds(char *smem, int n_waves, bool stm) {
+DEVFN LdsMap carve_lds(char *smem, int n_waves, bool stm, int rec_lds_doubles, int reuse_fields) {
     LdsMap m;
     double *p = (double *)smem;
     m.kbuf = p; p += DEV_MAX_STAGES * 6 * DEV_LANES;
@@ -1171,16 +1176,21 @@ DEVFN LdsMap carve_lds(char *smem, int n_waves, bool stm) {
         m.inb2 = p; p += NIN * DEV_LANES;
         m.pert2 = p; p += 9 * DEV_LANES;
     }
-    m.rec = p;
+    m.rec = p; p += rec_lds_doubles;
+    m.ed0 = p; p += reuse_fields * DEV_LANES;
+    m.ed0_ep = (long long *)p; p += DEV_LANES;
+    m.spec_ep = (long long *)p; p += DEV_LANES;
+    m.ed0st = (int *)p;
     return m;
 }
 
-extern "C" size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles, int stm) {
+extern "C" size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles, int stm, int reuse_fields) {
     size_t d = (size_t)DEV_MAX_STAGES * 6 * DEV_LANES + DEV_MAX_STAGES * DEV_MAX_STAGES + 3 * DEV_MAX_STAGES + 6 * DEV_LANES +
                2 * ED_FIELDS * DEV_LANES + 2 * DEV_LANES + CS_FIELDS * DEV_LANES + (size_t)DEV_MAX_WAVES * 4 * DEV_LANES + DEV_LANES +
                DEV_LANES / 2 + 8 + (size_t)rec_doubles;
     d += stm ? (size_t)(20 + 27 + 12) * DEV_LANES : (size_t)(NIN + 9 + 6 + NIN + 9) * DEV_LANES;
     (void)n_waves;
+    if (reuse_fields > 0) d += (size_t)reuse_fields * DEV_LANES + 2 * DEV_LANES + DEV_LANES / 2;
     return d * sizeof(double) + 64;
 }
 
@@ -1292,6 +1302,13 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     // its slot before that), ctl[4] = last stage whose velocity is published (drag is the one position-AND-velocity term
     // of the perturbation wave).  Same arithmetic in the same order as the plain loop: bit-identical results.
     const bool pipe = !STM && !(INTEG && (ALMANAC || PERT)) && cfg->pipe != 0 && has_grav;
+    // Epoch data carried between attempts (almanac wave, host-enabled when the stage count is even and LDS has room).
+    // Stage 0 of the next attempt sits at t + h if this attempt is accepted and at t again if it is rejected: the first
+    // is computed by the almanac wave in the LAST window (where it has no next stage to prepare; buffer 0 is free by
+    // then), the second is this attempt's own stage-0 data, kept aside.  Both are keyed by their integer epoch, so the
+    // prologue only has to compare epochs - whatever the step logic did - and falls back to computing.
+    const int reuse_nf = (!STM && ALMANAC && !INTEG && need_almanac) ? cfg->ed_reuse : 0;
+    if (reuse_nf > 0) { L.ed0_ep[lane] = INT64_MIN; L.spec_ep[lane] = INT64_MIN; }
     double nx_pos[3] = {0.0, 0.0, 0.0}, nx_s = 0.0, nx_t = 0.0, nx_u = 0.0, nx_kfac = 0.0;
     double m_cur[9], m_nx[9];
 #pragma unroll
@@ -1341,8 +1358,25 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
         // prologue: epoch data of stage 0
         if (ALMANAC && need_almanac) {
             const int64_t ep = __double_as_longlong(L.step[lane]);
-            int st = rec_in_lds ? epoch_data(cfg, (const double *)L.rec, ep, L.ed, lane) : epoch_data(cfg, records, ep, L.ed, lane);
-            L.edst[lane] = st;
+            bool compute = true;
+            if (reuse_nf > 0) {
+                const bool hit_spec = ep == (int64_t)L.spec_ep[lane];  // accepted: buffer 0 already holds this epoch
+                const bool hit_prev = ep == (int64_t)L.ed0_ep[lane];   // rejected (or finished): same epoch as last time
+                compute = __any(!(hit_spec || hit_prev)) != 0;
+                if (!compute && !hit_spec) {
+                    for (int f = 0; f < reuse_nf; ++f) L.ed[f * DEV_LANES + lane] = L.ed0[f * DEV_LANES + lane];
+                    L.edst[lane] = L.ed0st[lane];
+                }
+            }
+            if (compute) {
+                int st = rec_in_lds ? epoch_data(cfg, (const double *)L.rec, ep, L.ed, lane) : epoch_data(cfg, records, ep, L.ed, lane);
+                L.edst[lane] = st;
+            }
+            if (reuse_nf > 0) {
+                for (int f = 0; f < reuse_nf; ++f) L.ed0[f * DEV_LANES + lane] = L.ed[f * DEV_LANES + lane];
+                L.ed0st[lane] = L.edst[lane];
+                L.ed0_ep[lane] = ep;
+            }
         }
         if (INTEG && lane == 0) { L.ctl[2] = 0; L.ctl[3] = 0; L.ctl[4] = 0; }
         __syncthreads();  // Bp
@@ -1448,15 +1482,19 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 seq_cur = ++coop_seq;
                 coop_post(cbox, bt.coop_posted + coop_widx, lane, seq_cur, L.inb);
             }
-            if (ALMANAC && need_almanac && i + 1 < stages) {
-                // epoch-only data of the NEXT stage
-                const int64_t ep = __double_as_longlong(L.step[lane]) + seconds_to_ns(C_COEF(i + 1) * L.step[DEV_LANES + lane]);
+            const bool last_stage = i + 1 == stages;
+            if (ALMANAC && need_almanac && (!last_stage || reuse_nf > 0)) {
+                // epoch-only data of the NEXT stage; in the last window (carried epoch data, even stage count: parity 0 again)
+                // that is stage 0 of the next attempt should this one be accepted: epoch + seconds_to_ns(h), instance.rs:401
+                const double c_next = last_stage ? 1.0 : C_COEF(i + 1);
+                const int64_t ep = __double_as_longlong(L.step[lane]) + seconds_to_ns(c_next * L.step[DEV_LANES + lane]);
                 double *edn = L.ed + ((i + 1) & 1) * ED_FIELDS * DEV_LANES;
+                if (last_stage) L.spec_ep[lane] = ep;
                 int st = NYX_HIP_OK;
                 if (!dbg_skip_serial || i == 0)  // (timing switch: reuse the data of stages 0/1)
                     st = rec_in_lds ? epoch_data(cfg, (const double *)L.rec, ep, edn, lane) : epoch_data(cfg, records, ep, edn, lane);
                 L.edst[((i + 1) & 1) * DEV_LANES + lane] = st;
-                if (pipe) {  // tell the integrator wave (which publishes the inputs of stage i+1 inside this window)
+                if (pipe && !last_stage) {  // tell the integrator wave (which publishes the inputs of stage i+1 inside this window)
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if (lane == 0) ((volatile int *)L.ctl)[2] = i + 1;
                 }
@@ -1863,7 +1901,7 @@ DEVFN void propagate_body(const DevBatch &bt, const DevCfg *cfg_g, const HarmEnt
     const int lane = threadIdx.x & (DEV_LANES - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nw = (int)(blockDim.x >> 6);
-    const LdsMap L = carve_lds(smem, nw, STM);
+    const LdsMap L = carve_lds(smem, nw, STM, cfg_g->rec_in_lds ? cfg_g->rec_doubles : 0, STM ? 0 : cfg_g->ed_reuse);
     double *const kbuf = L.kbuf;
     double *const tabl = L.tabl;
     CfgPtr cfg = (CfgPtr)cfg_g;
@@ -1943,7 +1981,7 @@ extern "C" __global__ void __launch_bounds__(DEV_MAX_WAVES_STM *DEV_LANES)
 
 extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg, const HarmEntry *htab,
                                            const ColHdr *cols, const double *records, int n_waves, int rec_lds_doubles,
-                                           hipStream_t stream) {
+                                           int reuse_fields, hipStream_t stream) {
     const int64_t blocks = (bt.n + DEV_LANES - 1) / DEV_LANES;
     if (blocks == 0) return hipSuccess;
     static bool attr_set = false;
@@ -1953,7 +1991,7 @@ extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg
         attr_set = true;
     }
     const bool stm = bt.o_stm != nullptr;
-    size_t lds = nyx_kernel_lds_bytes(n_waves, rec_lds_doubles, stm ? 1 : 0);
+    size_t lds = nyx_kernel_lds_bytes(n_waves, rec_lds_doubles, stm ? 1 : 0, stm ? 0 : reuse_fields);
     if (!stm && bt.coop_helpers > 0 && lds < (size_t)HELPER_LDS_BYTES) lds = HELPER_LDS_BYTES;
     if (stm)
         hipLaunchKernelGGL(nyx_propagate_kernel_stm, dim3((unsigned)blocks), dim3((unsigned)(n_waves * DEV_LANES)), lds, stream, bt, cfg,
