@@ -622,6 +622,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
     HIP_TRY(hipMalloc(&ctx->d_cfg, sizeof(DevCfg)));
     HIP_TRY(hipMemcpy(ctx->d_cfg, &dc, sizeof(DevCfg), hipMemcpyHostToDevice));
     if (!tab.empty()) {
+        tab.resize(tab.size() + 4 * HARM_BATCH, HarmEntry{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0});  // the kernel touches a few batches ahead
         HIP_TRY(hipMalloc(&ctx->d_htab, tab.size() * sizeof(HarmEntry)));
         HIP_TRY(hipMemcpy(ctx->d_htab, tab.data(), tab.size() * sizeof(HarmEntry), hipMemcpyHostToDevice));
         HIP_TRY(hipMalloc(&ctx->d_cols, cols.size() * sizeof(ColHdr)));

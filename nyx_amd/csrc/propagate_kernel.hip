@@ -525,6 +525,9 @@ DEVFN void cpow_uniform(T zr, T zi, int e, T &pr, T &pi) {
         a1 = an;                                                                           \
     }
 
+#ifndef TOUCH_AHEAD
+#define TOUCH_AHEAD 1
+#endif
 // One batch of the table = 280 contiguous bytes = 70 SGPRs, fetched by six scalar loads behind a single wait.
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -548,6 +551,24 @@ DEVFN void load_batch(HarmPtr e, HarmBatch &b) {
         : "s"(e)
         : "memory");
 }
+// Touch the (up to six) 64-byte lines of the batch TOUCH_AHEAD batches further on (results discarded): by the time its
+// loads are issued the lines are in the scalar cache or on their way.  (The table is padded accordingly.)
+// `sink` is read and written so that the register stays allocated for as long as a touch can be in flight: until the
+// wait inside the next load_batch(), or touch_done() after the last batch of a column.
+DEVFN void touch_batch(HarmPtr e, int &sink) {
+    asm volatile(
+        "s_load_dword %0, %1, %2\n\t"
+        "s_load_dword %0, %1, %3\n\t"
+        "s_load_dword %0, %1, %4\n\t"
+        "s_load_dword %0, %1, %5\n\t"
+        "s_load_dword %0, %1, %6\n\t"
+        "s_load_dword %0, %1, %7"
+        : "+&s"(sink)
+        : "s"(e), "n"(TOUCH_AHEAD * 0x118), "n"(TOUCH_AHEAD * 0x118 + 0x40), "n"(TOUCH_AHEAD * 0x118 + 0x80), "n"(TOUCH_AHEAD * 0x118 + 0xc0),
+          "n"(TOUCH_AHEAD * 0x118 + 0x100), "n"(TOUCH_AHEAD * 0x118 + 0x114)
+        : "memory");
+}
+DEVFN void touch_done(int &sink) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sink) : : "memory"); }
 #define HB_D(v, i) __builtin_bit_cast(double, (v2i){(v)[(i)], (v)[(i) + 1]})
 #define HB_ENTRY(v0, v1, v2, v3, v4, v5, v6, i0, i1, i2, i3, i4, i5, i6) \
     { HB_D(v0, i0), HB_D(v1, i1), HB_D(v2, i2), HB_D(v3, i3), HB_D(v4, i4), HB_D(v5, i5), HB_D(v6, i6) }
@@ -594,11 +615,13 @@ DEVFN Partial4T<T> harmonics_core(CfgPtr cfg, HarmPtr htab, ColPtr cols, const i
             const int nb = hd.nb;
             T a1 = gzero(zr), a2 = inv_rho * hd.diag;
             T s1 = gzero(zr), s2 = gzero(zr), s3 = gzero(zr), s4 = gzero(zr), s5 = gzero(zr), s6 = gzero(zr);
+            int sink = 0;
             for (int b = 0; b < nb; ++b, e += HARM_BATCH) {
                 // five 56-byte entries per batch: 70 SGPRs of scalar loads in flight behind ONE wait, then 45 f64 VALU ops per
                 // lane.  The loads are spelled out: left to the scheduler, instantiations under register pressure wait after every load.
                 HarmBatch hb;
                 load_batch(e, hb);
+                if (TOUCH_AHEAD) touch_batch(e, sink);
                 const HarmEntry h0 = HB_ENTRY(hb.q0, hb.q0, hb.q0, hb.q0, hb.q0, hb.q0, hb.q0, 0, 2, 4, 6, 8, 10, 12);
                 const HarmEntry h1 = HB_ENTRY(hb.q0, hb.q1, hb.q1, hb.q1, hb.q1, hb.q1, hb.q1, 14, 0, 2, 4, 6, 8, 10);
                 const HarmEntry h2 = HB_ENTRY(hb.q1, hb.q1, hb.q2, hb.q2, hb.q2, hb.q2, hb.q2, 12, 14, 0, 2, 4, 6, 8);
@@ -610,6 +633,7 @@ DEVFN Partial4T<T> harmonics_core(CfgPtr cfg, HarmPtr htab, ColPtr cols, const i
                 HARM_TERM(h3)
                 HARM_TERM(h4)
             }
+            if (TOUCH_AHEAD) touch_done(sink);
             const T sc = rho * hd.scale;  // rho * c * sqrt(2)
             px = gfma(sc, gfma(rc, s1, gmul(ic, s2)), px);
             py = gfma(sc, gfma(rc, s2, -(gmul(ic, s1))), py);
