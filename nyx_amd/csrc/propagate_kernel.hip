@@ -854,7 +854,7 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
             const int64_t t0 = (int64_t)__builtin_amdgcn_s_memrealtime();
             while (ready[s] != j + 1) {
                 if ((int64_t)__builtin_amdgcn_s_memrealtime() - t0 > 6000 * COOP_TIMEOUT_TICKS) return;  // (the producer gives up after 10 s)
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(4);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -879,7 +879,7 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
             const int64_t t0 = (int64_t)__builtin_amdgcn_s_memrealtime();
             while (__hip_atomic_load(cnt + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != n_col_waves) {
                 if ((int64_t)__builtin_amdgcn_s_memrealtime() - t0 > 6000 * COOP_TIMEOUT_TICKS) return;
-                __builtin_amdgcn_s_sleep(2);
+                __builtin_amdgcn_s_sleep(8);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -1539,7 +1539,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 if (has_drag) {
                     if (pipe && i > 0) {  // velocity of this stage: written by phase A, which runs beside this window
                         int spin = 0;
-                        while (((volatile int *)L.ctl)[4] != i + 1 && ++spin < 4000000) __builtin_amdgcn_s_sleep(1);
+                        while (((volatile int *)L.ctl)[4] != i + 1 && ++spin < 4000000) __builtin_amdgcn_s_sleep(4);
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     }
                     const double vv[3] = {ysp[3 * DEV_LANES + lane], ysp[4 * DEV_LANES + lane], ysp[5 * DEV_LANES + lane]};
@@ -1588,7 +1588,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     if (need_almanac) {  // the almanac wave writes the epoch data of stage i+1 early in this window
                         // (bounded: a protocol error must end as a failed run, never as a hung GPU)
                         int spin = 0;
-                        while (((volatile int *)L.ctl)[2] != i + 1 && ++spin < 4000000) __builtin_amdgcn_s_sleep(1);
+                        while (((volatile int *)L.ctl)[2] != i + 1 && ++spin < 4000000) __builtin_amdgcn_s_sleep(4);
                         if (spin >= 4000000) st_att = NYX_HIP_ERR_NAN;
                     }
                     const double *const edn = L.ed + ((i + 1) & 1) * ED_FIELDS * DEV_LANES;
