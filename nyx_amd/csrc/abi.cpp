@@ -251,8 +251,8 @@ static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, con
                                                   1.3085, 0.8969, 0.9070, 0.9179, 0.8464, 0.5319, 0.5459, 0.5545};
     double per_wave[DEV_MAX_WAVES];
     // pipelined stage loop: the integrator wave now works beside the column waves of SIMD 0 (4, 8, 12), same calibration
-    static const double tuned16_pipe[DEV_MAX_WAVES] = {1.0000, 1.2871, 1.0928, 1.5517, 1.4983, 1.3248, 1.2956, 1.3168,
-                                                       1.2552, 0.8859, 0.9897, 1.0051, 0.8594, 0.5099, 0.5811, 0.5808};
+    static const double tuned16_pipe[DEV_MAX_WAVES] = {1.0000, 1.1768, 1.3204, 1.8145, 1.7397, 1.3918, 1.4247, 1.3479,
+                                                       1.2716, 0.8906, 0.8939, 0.9863, 0.8109, 0.4500, 0.5075, 0.5311};
     for (int w = 0; w < DEV_MAX_WAVES; ++w) per_wave[w] = n_waves == 16 ? (ctx->host_cfg.pipe ? tuned16_pipe[w] : tuned16[w]) : 1.0;
     if (const char *e = std::getenv("NYX_HIP_AGE_WEIGHTS")) {  // coarse knob: one weight per age class
         double aw[4] = {1.0, 1.0, 1.0, 1.0};
@@ -697,10 +697,10 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
             const int64_t helpers = std::min<int64_t>(n_own, (ctx->n_cu - base) / 8 * 8);
             if (helpers >= 8 && 4 * helpers >= n_own) {
                 // share of the terms the helpers take: owners keep (1 - x), each helper does x * owners / helpers jobs' worth
-                // per evaluation period, plus its hand-off overhead: x ~ 0.85 r / (1 + r) with r = helpers / owners
+                // per evaluation period, plus its hand-off overhead: x ~ 0.95 r / (1 + r) with r = helpers / owners
                 if (!std::getenv("NYX_HIP_COOP_FRAC")) {
                     const double r = (double)helpers / (double)n_own;
-                    const double x = std::min(0.55, std::max(0.10, 0.85 * r / (1.0 + r)));
+                    const double x = std::min(0.55, std::max(0.10, 0.95 * r / (1.0 + r)));
                     if (std::fabs(x - ctx->host_cfg.coop_frac) > 0.01) {
                         ctx->host_cfg.coop_frac = x;
                         build_schedule(ctx, nw);

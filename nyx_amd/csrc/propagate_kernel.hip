@@ -115,7 +115,9 @@ DEVFN int cheby_eval(const CAS DevSeg &sg, P records, double et_s, double *r3) {
 }
 
 template <typename P>
-DEVFN int epoch_data(CfgPtr cfg, P records, int64_t epoch_ns, double *slot, int lane) {
+// `dcm_flag` (pipelined stage loop): LDS word that is set to `dcm_val` as soon as the DCM is written - the integrator wave
+// needs only that to form the next stage's recursion inputs, the body positions are for the next window.
+DEVFN int epoch_data(CfgPtr cfg, P records, int64_t epoch_ns, double *slot, int lane, volatile int *dcm_flag = nullptr, int dcm_val = 0) {
     const double et = ns_to_seconds(epoch_ns);
     int status = NYX_HIP_OK;
     if (cfg->has_grav || cfg->has_drag || cfg->has_tides) {  // (ctx_create requires these body-fixed frames to coincide)
@@ -125,6 +127,10 @@ DEVFN int epoch_data(CfgPtr cfg, P records, int64_t epoch_ns, double *slot, int 
         else rotation_dcm(cfg->t_rot, et, m);
 #pragma unroll
         for (int q = 0; q < 9; ++q) slot[q * DEV_LANES + lane] = m[q];
+    }
+    if (dcm_flag) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) *dcm_flag = dcm_val;
     }
     const int ns = cfg->n_slots;
 #pragma unroll
@@ -812,17 +818,29 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
                     const unsigned rot = turn++ & 63u;
                     const uint64_t hi = cand >> rot;
                     const int pick = hi ? (int)rot + __builtin_ctzll(hi) : __builtin_ctzll(cand);
+                    // jobs are taken in order, one at a time: an owner may have two outstanding (the pipelined loop posts
+                    // stage i+1 before it has read the answer of stage i).  The five input rows of the job are fetched in the
+                    // shadow of the compare-and-swap (they were complete before `posted` moved): one memory round trip, not two.
+                    const int owner_c = (int)__shfl((int)mine, pick);
+                    const uint32_t seq_c = (uint32_t)__shfl((int)claimed, pick) + 1u;
                     int won = 0;
                     if (lane == pick) {
-                        // jobs are taken in order, one at a time: an owner may have two outstanding (the pipelined loop posts
-                        // stage i+1 before it has read the answer of stage i)
                         uint32_t expect = claimed;
                         won = __hip_atomic_compare_exchange_strong(bt.coop_claimed + widx, &expect, claimed + 1u, __ATOMIC_RELAXED,
                                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
                     }
+                    const CoopBox *b = bt.coop_box + owner_c;
+                    coop_acquire();
+                    const unsigned par = seq_c & 1u;
+                    const double v0 = coop_loadd(&b->in[par][0][lane]), v1 = coop_loadd(&b->in[par][1][lane]),
+                                 v2 = coop_loadd(&b->in[par][2][lane]), v3 = coop_loadd(&b->in[par][3][lane]),
+                                 v4 = coop_loadd(&b->in[par][4][lane]);
                     if (__shfl(won, pick)) {
-                        owner = (int)__shfl((int)mine, pick);
-                        seq = (uint32_t)__shfl((int)claimed, pick) + 1u;
+                        owner = owner_c;
+                        seq = seq_c;
+                        double *il = inl + s * 5 * DEV_LANES;
+                        il[0 * DEV_LANES + lane] = v0; il[1 * DEV_LANES + lane] = v1; il[2 * DEV_LANES + lane] = v2;
+                        il[3 * DEV_LANES + lane] = v3; il[4 * DEV_LANES + lane] = v4;
                         break;
                     }
                     continue;  // another helper was faster: look again
@@ -830,16 +848,6 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
                 const uint32_t fin = has ? coop_load(bt.coop_finished + widx) : 1u;
                 if (__all(fin != 0u)) { owner = -1; break; }
                 __builtin_amdgcn_s_sleep(8);  // ~0.2 us between scans: the set's words are one memory line shared by ~10 helpers
-            }
-            if (owner >= 0) {
-                const CoopBox *b = bt.coop_box + owner;
-                coop_acquire();  // the inputs were posted before `seq`
-                const unsigned par = seq & 1u;
-                const double v0 = coop_loadd(&b->in[par][0][lane]), v1 = coop_loadd(&b->in[par][1][lane]), v2 = coop_loadd(&b->in[par][2][lane]),
-                             v3 = coop_loadd(&b->in[par][3][lane]), v4 = coop_loadd(&b->in[par][4][lane]);
-                double *il = inl + s * 5 * DEV_LANES;
-                il[0 * DEV_LANES + lane] = v0; il[1 * DEV_LANES + lane] = v1; il[2 * DEV_LANES + lane] = v2;
-                il[3 * DEV_LANES + lane] = v3; il[4 * DEV_LANES + lane] = v4;
             }
             if (lane == 0) { jown[s] = owner; jseq[s] = (int)seq; }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1431,6 +1439,8 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         if (lane == 0) ((volatile int *)L.ctl)[4] = i + 1;
                     }
+                    // (the almanac wave finished this stage's data before the barrier this wave has just passed)
+                    if (need_almanac && L.edst[(i & 1) * DEV_LANES + lane]) st_att = L.edst[(i & 1) * DEV_LANES + lane];
                     s_ = nx_s; t_ = nx_t; u_ = nx_u; kfac = nx_kfac;
 #pragma unroll
                     for (int q = 0; q < 9; ++q) m_cur[q] = m_nx[q];
@@ -1516,7 +1526,10 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 if (last_stage) L.spec_ep[lane] = ep;
                 int st = NYX_HIP_OK;
                 if (!dbg_skip_serial || i == 0)  // (timing switch: reuse the data of stages 0/1)
-                    st = rec_in_lds ? epoch_data(cfg, (const double *)L.rec, ep, edn, lane) : epoch_data(cfg, records, ep, edn, lane);
+                {
+                    volatile int *const fl = (pipe && !last_stage) ? (volatile int *)L.ctl + 2 : nullptr;
+                    st = rec_in_lds ? epoch_data(cfg, (const double *)L.rec, ep, edn, lane, fl, i + 1) : epoch_data(cfg, records, ep, edn, lane, fl, i + 1);
+                }
                 L.edst[((i + 1) & 1) * DEV_LANES + lane] = st;
                 if (pipe && !last_stage) {  // tell the integrator wave (which publishes the inputs of stage i+1 inside this window)
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1585,14 +1598,14 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     double *const inbn = ((i + 1) & 1) ? L.inb2 : L.inb;
 #pragma unroll
                     for (int e = 0; e < 3; ++e) ysn[e * DEV_LANES + lane] = nx_pos[e];
-                    if (need_almanac) {  // the almanac wave writes the epoch data of stage i+1 early in this window
+                    if (need_almanac) {  // the almanac wave writes the DCM of stage i+1 first thing in this window
                         // (bounded: a protocol error must end as a failed run, never as a hung GPU)
                         int spin = 0;
                         while (((volatile int *)L.ctl)[2] != i + 1 && ++spin < 4000000) __builtin_amdgcn_s_sleep(4);
                         if (spin >= 4000000) st_att = NYX_HIP_ERR_NAN;
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     }
-                    const double *const edn = L.ed + ((i + 1) & 1) * ED_FIELDS * DEV_LANES;
-                    if (need_almanac && L.edst[((i + 1) & 1) * DEV_LANES + lane]) st_att = L.edst[((i + 1) & 1) * DEV_LANES + lane];
+                    const double *const edn = L.ed + ((i + 1) & 1) * ED_FIELDS * DEV_LANES;  // (its DCM: the flag is raised before the body positions are evaluated)
 #pragma unroll
                     for (int q = 0; q < 9; ++q) m_nx[q] = edn[q * DEV_LANES + lane];
                     const double rb0 = m_nx[0] * nx_pos[0] + m_nx[1] * nx_pos[1] + m_nx[2] * nx_pos[2];
