@@ -696,7 +696,8 @@ static __device__ __attribute__((noinline)) void harmonics_partial_dual(uint64_t
 // the trajectory-owning workgroup posts the five per-lane inputs of the column recursion (2.5 KB) in a mailbox in
 // global memory, keeps the columns of DEV_SCHED_PRIMARY for itself, and its helper evaluates the columns of
 // DEV_SCHED_HELPER for the same 64 lanes and answers with four partial sums per lane (2 KB).  The exchange overlaps
-// the owner's own window; what it costs is two device-scope fences per evaluation on either side.
+// the owner's own window; in the pipelined stage loop the job of stage i+1 is posted inside the window of stage i
+// (mailbox halves by the parity of the sequence number: an owner has up to two jobs outstanding, claimed in order).
 // Deadlock-free without any residency assumption: the owner waits a bounded time for an answer, and if none comes it
 // evaluates the helper's columns itself (walking DEV_SCHED_HELPER) and goes back to DEV_SCHED_SOLO for the rest of the
 // launch; helpers leave when every workgroup they serve has finished.  The owner adds the helper's partial after its
@@ -715,8 +716,8 @@ DEVFN void coop_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"
 #define COOP_TIMEOUT_TICKS 200000LL  /* 2 ms of the 100 MHz realtime counter */
 #define COOP_SET 16                  /* owners per set */
 
-// Posting happens after barrier B1, from the LDS copy of the inputs, when the integrator wave is idle anyway: the
-// owner's critical path never waits for memory.
+// Posting happens from the LDS copy of the inputs, when the integrator wave has nothing else to do (start of the
+// window in the plain loop, right after the next stage's inputs are formed in the pipelined one).
 static __device__ __attribute__((noinline)) void coop_post(CoopBox *box, uint32_t *posted, int lane, uint32_t seq, const double *inb) {
 #pragma unroll
     for (int q = 0; q < 5; ++q) coop_stored(&box->in[seq & 1u][q][lane], inb[q * DEV_LANES + lane]);
