@@ -497,3 +497,34 @@ def test_cooperative_mode_matches_solo_and_oracle(monkeypatch):
     print(f"muted helpers: kernel {ctx.last_kernel_ms():.1f} ms, max dr vs solo {dr.max()*1e3:.2e} m")
     assert dr.max() < 1e-6 and dv.max() < 1e-9 and ctx.last_kernel_ms() < solo_ms + 50.0
     ctx.close()
+
+
+@pytest.mark.parametrize("n,drag", [(256, None), (2048, None), (512, "exp")])
+def test_pipelined_stage_loop_is_bit_identical(monkeypatch, n, drag):
+    """The pipelined stage loop (the next stage's position is published inside the current window), the epoch data carried
+    between attempts and the plain two-barrier loop do the same arithmetic in the same order: bit-identical states and step
+    counts once both walk the same column schedule (by default the two loops use differently calibrated per-wave weights,
+    i.e. a different summation order of the harmonics partial sums).  256 trajectories run alone, 512 (with drag) and
+    2 048 in cooperative mode (one helper per owner: same column split in both loops)."""
+    monkeypatch.setenv("NYX_HIP_WAVE_WEIGHTS", "1,1.3,1.3,1.6,1.6,1.3,1.3,1.3,1.3,0.9,0.9,0.9,0.9,0.5,0.5,0.5")
+    prop, almanac, central = leo_full_setup(degree=70, drag=drag) if drag else leo_full_setup(degree=70)
+    compiled = prop.compile(almanac, central)
+    b = dispersed_leo_batch(n, seed=11)
+    if drag:
+        b.drag_area_m2[:] = 2.0
+        b.cd[:] = 2.2
+    dur = 45 * 60 * nx.NS_PER_S
+    res = {}
+    for pipe, reuse in (("1", "1"), ("0", "0"), ("1", "0"), ("0", "1")):
+        monkeypatch.setenv("NYX_HIP_PIPE", pipe)
+        monkeypatch.setenv("NYX_HIP_ED_REUSE", reuse)
+        ctx = nx.GpuContext(compiled)   # (both switches are read when the context is built)
+        out, st = ctx.propagate(b, dur)
+        assert (st.status == 0).all()
+        assert (ctx.last_coop_helpers() > 0) == (n >= 512)   # cooperative mode needs at least 8 owners
+        res[(pipe, reuse)] = (out.rv().copy(), out.epoch_ns.copy(), st.n_evals.copy(), st.n_rejected.copy())
+        ctx.close()
+    ref = res[("0", "0")]
+    for key, got in res.items():
+        for a, r in zip(got, ref):
+            np.testing.assert_array_equal(a, r, err_msg=f"pipe, reuse = {key}")
