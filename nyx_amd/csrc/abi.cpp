@@ -603,6 +603,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
     dc.rec_doubles = (int32_t)records.size();
     dc.rec_in_lds = (records.size() * sizeof(double) <= 24 * 1024) ? 1 : 0;
     if ((cfg->flags & NYX_HIP_FLAG_STM) && nyx_kernel_lds_bytes(DEV_MAX_WAVES_STM, dc.rec_doubles, 1, 0) > 160 * 1024) dc.rec_in_lds = 0;
+    if (!(cfg->flags & NYX_HIP_FLAG_STM) && nyx_kernel_lds_bytes(DEV_MAX_WAVES, dc.rec_doubles, 0, 0) > 160 * 1024) dc.rec_in_lds = 0;
     // stage-0 epoch data carried between attempts (see role_loop): needs an even stage count (the last stage's window
     // then leaves buffer 0 free) and 9 + 3 * n_slots doubles + 20 bytes of LDS per lane
     dc.ed_reuse = 0;
