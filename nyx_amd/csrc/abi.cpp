@@ -237,7 +237,8 @@ static void build_harmonics(const nyx_hip_gravity_field_t *g, std::vector<HarmEn
 // its columns, in harmonics-term units) and SIMD age weights.  Wave 0 takes what is left.
 // `list`: the columns to distribute, ascending (= longest first).  Returns false if a wave would need more than
 // DEV_MAX_RANGES contiguous ranges.
-static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, const std::vector<int> &list, const double *hc) {
+static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, const std::vector<int> &list, const double *hc,
+                          bool all_columns) {
     for (int w = 0; w < DEV_MAX_WAVES; ++w) sd.n_ranges[w] = 0;
     if (list.empty()) return true;
     double terms = 0.0;
@@ -253,7 +254,11 @@ static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, con
     // pipelined stage loop: the integrator wave now works beside the column waves of SIMD 0 (4, 8, 12), same calibration
     static const double tuned16_pipe[DEV_MAX_WAVES] = {1.0000, 1.1768, 1.3204, 1.8145, 1.7397, 1.3918, 1.4247, 1.3479,
                                                        1.2716, 0.8906, 0.8939, 0.9863, 0.8109, 0.4500, 0.5075, 0.5311};
-    for (int w = 0; w < DEV_MAX_WAVES; ++w) per_wave[w] = n_waves == 16 ? (ctx->host_cfg.pipe ? tuned16_pipe[w] : tuned16[w]) : 1.0;
+    // ... and once more for a workgroup that keeps all its columns (the longest ones included)
+    static const double tuned16_pipe_all[DEV_MAX_WAVES] = {1.0000, 1.3528, 1.5865, 2.0244, 1.9595, 1.5113, 1.4026, 1.4819,
+                                                           1.2655, 0.8341, 0.8420, 0.8337, 0.8163, 0.4153, 0.4511, 0.4752};
+    for (int w = 0; w < DEV_MAX_WAVES; ++w)
+        per_wave[w] = n_waves == 16 ? (ctx->host_cfg.pipe ? (all_columns ? tuned16_pipe_all[w] : tuned16_pipe[w]) : tuned16[w]) : 1.0;
     if (const char *e = std::getenv("NYX_HIP_AGE_WEIGHTS")) {  // coarse knob: one weight per age class
         double aw[4] = {1.0, 1.0, 1.0, 1.0};
         if (std::sscanf(e, "%lf,%lf,%lf,%lf", &aw[0], &aw[1], &aw[2], &aw[3]) == 4 && n_waves == 16)
@@ -332,7 +337,7 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves) {
     if (n_waves >= 8 && !std::getenv("NYX_HIP_ROLE_HANDICAP")) hc[0] = 1e9;
     std::vector<int> all;
     for (int c = 1; c <= nc; ++c) all.push_back(c);
-    (void)fill_schedule(ctx, dc.sched[DEV_SCHED_SOLO], n_waves, all, hc);
+    (void)fill_schedule(ctx, dc.sched[DEV_SCHED_SOLO], n_waves, all, hc, true);
     // Cooperative mode (16-wave workgroups only).  The helper takes the LONGEST columns, at most one per column wave: its job
     // time is then one long column (~18 batches), which is within 17 % of the ideal x * terms / 16 for x <= 0.35, and the
     // owner keeps the many short columns that let it balance its fifteen waves.  (Interleaving the two sets column by
@@ -363,7 +368,7 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves) {
             const int r = hs.n_ranges[w]++;
             hs.range_c0[w][r] = help[k]; hs.range_cnt[w][r] = 1;
         }
-        if (!help.empty() && !own.empty() && fill_schedule(ctx, dc.sched[DEV_SCHED_PRIMARY], n_waves, own, hc)) {
+        if (!help.empty() && !own.empty() && fill_schedule(ctx, dc.sched[DEV_SCHED_PRIMARY], n_waves, own, hc, false)) {
             dc.coop_ok = 1;
         } else {
             dc.coop_ok = 0;
