@@ -500,21 +500,35 @@ static __device__ __attribute__((noinline)) void tides_into_pert(CfgPtr cfg, con
     for (int e = 0; e < 3; ++e) pert[e * DEV_LANES + lane] = pert[e * DEV_LANES + lane] + a[e];
 }
 
+// (zr + i zi)^e by binary exponentiation, e wave-uniform.  Real branches on the bits of e (the optimiser's if-converted
+// form multiplies in every round and selects): the first set bit copies the base instead of multiplying by one, the
+// last round does not square.  Every product that is formed is the one the plain loop forms: same value bit for bit.
 template <typename T>
 DEVFN void cpow_uniform(T zr, T zi, int e, T &pr, T &pi) {
     pr = gone(zr);
     pi = gzero(zr);
     T br = zr, bi = zi;
-    while (e) {  // e is wave-uniform
+    bool first = true;
+    while (e) {
         if (e & 1) {
-            const T t = gmul(pr, br) - gmul(pi, bi);
-            pi = gmul(pr, bi) + gmul(pi, br);
-            pr = t;
+            if (first) {
+                pr = br; pi = bi;
+                first = false;
+                asm volatile("" ::: "memory");
+            } else {
+                const T t = gmul(pr, br) - gmul(pi, bi);
+                pi = gmul(pr, bi) + gmul(pi, br);
+                pr = t;
+            }
+            asm volatile("" ::: "memory");  // keep this a branch
         }
-        const T t = gmul(br, br) - gmul(bi, bi);
-        bi = (gmul(br, bi)) * 2.0;
-        br = t;
         e >>= 1;
+        if (e) {
+            const T t = gmul(br, br) - gmul(bi, bi);
+            bi = (gmul(br, bi)) * 2.0;
+            br = t;
+            asm volatile("" ::: "memory");
+        }
     }
 }
 
