@@ -193,12 +193,12 @@ static void build_harmonics(const nyx_hip_gravity_field_t *g, std::vector<HarmEn
     tab.clear();
     for (int c = 1; c <= n_cols; ++c) {
         const int rows = N + 2 - c;
-        const int nb = (rows + HARM_BATCH - 1) / HARM_BATCH;
+        const int nb = rows / HARM_BATCH, rem = rows % HARM_BATCH;  // full batches, then `rem` rows one at a time
         cols[c].start = (int32_t)tab.size();
-        cols[c].nb = nb;
+        cols[c].nb = nb | (rem << 16);
         cols[c].scale = (double)c * SQ2;
         cols[c].diag = diag[c];
-        col_len[c] = HARM_BATCH * nb;
+        col_len[c] = rows;
         double B = 1.0;  // prod of b[k][c], k = c+1 .. n: the scale of the carried recursion variable (see HarmEntry)
         for (int n = c; n <= N + 1; ++n) {
             HarmEntry e;
@@ -223,9 +223,6 @@ static void build_harmonics(const nyx_hip_gravity_field_t *g, std::vector<HarmEn
             e.t6 = wok ? B * (SQ2 * vr11(n - 1, c - 1) * S(n - 1, c - 1)) : 0.0;
             tab.push_back(e);
         }
-        HarmEntry z;
-        std::memset(&z, 0, sizeof z);
-        for (int k = rows; k < HARM_BATCH * nb; ++k) tab.push_back(z);  // neutral padding rows
     }
 }
 

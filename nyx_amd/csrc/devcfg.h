@@ -94,8 +94,8 @@ struct DevCfg {
     int32_t coop_ok, _pad4; /* PRIMARY / HELPER schedules are valid */
 };
 
-/* Column header (32 B = one s_load_dwordx8): rows of column c start at htab[start] and come in
- * `nb` batches of HARM_BATCH entries (zero-padded); the recursion is seeded with a2 = diag / rho, a1 = 0. */
+/* Column header (32 B = one s_load_dwordx8): rows of column c start at htab[start]: `nb & 0xffff` batches of HARM_BATCH
+ * entries, then `nb >> 16` (< HARM_BATCH) single rows; the recursion is seeded with a2 = diag / rho, a1 = 0. */
 #define HARM_BATCH 5
 struct ColHdr {
     int32_t start, nb;

@@ -589,6 +589,23 @@ DEVFN void touch_batch(HarmPtr e, int &sink) {
         : "memory");
 }
 DEVFN void touch_done(int &sink) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sink) : : "memory"); }
+// One row (the tail of a column, after its full batches).
+typedef int v8i __attribute__((ext_vector_type(8)));
+struct HarmRow {
+    v8i q0;
+    v4i q1;
+    v2i q2;
+};
+DEVFN void load_row(HarmPtr e, HarmRow &r) {
+    asm volatile(
+        "s_load_dwordx8 %0, %3, 0x0\n\t"
+        "s_load_dwordx4 %1, %3, 0x20\n\t"
+        "s_load_dwordx2 %2, %3, 0x30\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(r.q0), "=&s"(r.q1), "=&s"(r.q2)
+        : "s"(e)
+        : "memory");
+}
 #define HB_D(v, i) __builtin_bit_cast(double, (v2i){(v)[(i)], (v)[(i) + 1]})
 #define HB_ENTRY(v0, v1, v2, v3, v4, v5, v6, i0, i1, i2, i3, i4, i5, i6) \
     { HB_D(v0, i0), HB_D(v1, i1), HB_D(v2, i2), HB_D(v3, i3), HB_D(v4, i4), HB_D(v5, i5), HB_D(v6, i6) }
@@ -632,7 +649,7 @@ DEVFN Partial4T<T> harmonics_core(CfgPtr cfg, HarmPtr htab, ColPtr cols, const i
         for (int c = c0; c < c0 + cnt; ++c) {
             const ColHdr hn = load_hdr(cols, c + 1);  // (the header array has a spare tail entry)
             HarmPtr e = htab + hd.start;
-            const int nb = hd.nb;
+            const int nb = hd.nb & 0xffff, rem = hd.nb >> 16;
             T a1 = gzero(zr), a2 = inv_rho * hd.diag;
             T s1 = gzero(zr), s2 = gzero(zr), s3 = gzero(zr), s4 = gzero(zr), s5 = gzero(zr), s6 = gzero(zr);
             int sink = 0;
@@ -652,6 +669,12 @@ DEVFN Partial4T<T> harmonics_core(CfgPtr cfg, HarmPtr htab, ColPtr cols, const i
                 HARM_TERM(h2)
                 HARM_TERM(h3)
                 HARM_TERM(h4)
+            }
+            for (int t = 0; t < rem; ++t, e += 1) {  // (these lines were touched by the last batch)
+                HarmRow hr;
+                load_row(e, hr);
+                const HarmEntry h0 = HB_ENTRY(hr.q0, hr.q0, hr.q0, hr.q0, hr.q1, hr.q1, hr.q2, 0, 2, 4, 6, 0, 2, 0);
+                HARM_TERM(h0)
             }
             if (TOUCH_AHEAD) touch_done(sink);
             const T sc = rho * hd.scale;  // rho * c * sqrt(2)
