@@ -21,7 +21,8 @@ from typing import Callable, List, Optional, Sequence
 import numpy as np
 
 from . import _abi
-from .propagator import Almanac, Frame, Propagator, Spacecraft
+from .params import StateError, StateParameter, state_value
+from .propagator import Almanac, Frame, Propagator, Spacecraft, Traj
 
 # indices into the 9-vector [x, y, z, vx, vy, vz, Cr, Cd, prop mass] (cosmic/spacecraft.rs:451-473)
 STATE_DIM = 9
@@ -57,25 +58,161 @@ class MvnSpacecraft:
     def sample_vector(self, rng: np.random.Generator) -> np.ndarray:
         return self._sqrt_s_v @ rng.standard_normal(STATE_DIM) + self._mean
 
+    def disperses(self, k: int) -> bool:
+        """Is component k of the 9-vector dispersed (non-zero variance or mean)?"""
+        return bool(np.any(self._sqrt_s_v[k] != 0.0) or self._mean[k] != 0.0)
+
+
+# the dispersed components of the 9-vector, as state parameters (multivariate.rs:298-330)
+_VECTOR_PARAMS = [StateParameter.X, StateParameter.Y, StateParameter.Z, StateParameter.VX, StateParameter.VY, StateParameter.VZ,
+                  StateParameter.Cr, StateParameter.Cd, StateParameter.PropMass]
+
+
+class DispersedState(Spacecraft):
+    """generator.rs:59-67: the dispersed state plus `actual_dispersions`, the list of (parameter, delta).  The delta is
+    `template.value(param) - state.value(param)` - template MINUS dispersed, as the reference computes it
+    (multivariate.rs:320-325).  Subclass of Spacecraft so that it packs like one (`.state` returns itself)."""
+
+    actual_dispersions: list = []
+
+    @property
+    def state(self) -> "Spacecraft":
+        return self
+
+
+class PropResult:
+    """results.rs:73-80: the final state of a run and its trajectory.  `traj` is None when the run was made without
+    dense output (`with_traj=False`) or on another rank of a sharded ensemble.  Attribute access falls through to the
+    state, so `run.result.rv` and `run.result.state.rv` are the same thing."""
+
+    def __init__(self, state: Spacecraft, traj_src=None):
+        self.state = state
+        self._traj_src = traj_src   # (context, TrajBatch, row) - the Traj object is built on first use
+        self._traj = None
+
+    @property
+    def traj(self) -> Optional[Traj]:
+        if self._traj is None and self._traj_src is not None:
+            ctx, batch, row = self._traj_src
+            self._traj = Traj(ctx, batch, row)
+        return self._traj
+
+    def __getattr__(self, name):
+        if name.startswith("_") or name in ("state", "traj"):
+            raise AttributeError(name)
+        return getattr(self.state, name)
+
 
 @dataclass
 class Run:
     index: int
-    dispersed_state: Spacecraft
-    result: object  # Spacecraft or PropagationError
+    dispersed_state: DispersedState
+    result: object  # PropResult or PropagationError
 
 
 @dataclass
 class Results:
+    """mc/results.rs:60-245.  Runs are sorted by index.  When the runs of this process carry trajectories they share one
+    dense-output batch, and the `every_value_of*` reports resample ALL of them with one launch of the trajectory kernel
+    (`Traj::every` per run in the reference, results.rs:134-160)."""
+
     runs: List[Run]
     scenario: str
+    mu_km3_s2: float = 0.0
+    _traj_ctx: object = field(default=None, repr=False)
+    _traj_batch: object = field(default=None, repr=False)
+    _traj_rows: dict = field(default_factory=dict, repr=False)   # run index -> row of the dense-output batch
+
+    def ok_runs(self) -> List[Run]:
+        return [r for r in self.runs if isinstance(r.result, PropResult)]
 
     def final_rv(self) -> np.ndarray:
-        return np.array([r.result.rv for r in self.runs if isinstance(r.result, Spacecraft)])
+        return np.array([r.result.state.rv for r in self.ok_runs()])
 
     def mean_and_covariance(self):
         x = self.final_rv()
         return x.mean(axis=0), np.cov(x, rowvar=False)
+
+    # ---- reports (results.rs:86-245): one flat list, run after run, failed runs replaced by `value_if_run_failed`
+    def _value(self, param: StateParameter, run: Run, rv: np.ndarray) -> np.ndarray:
+        s = run.result.state
+        return state_value(param, rv, self.mu_km3_s2, cr=s.cr, cd=s.cd, dry_mass_kg=s.dry_mass_kg, prop_mass_kg=s.prop_mass_kg,
+                           extra_mass_kg=getattr(s, "extra_mass_kg", 0.0))
+
+    def _report(self, param: StateParameter, states_of_run, value_if_run_failed: Optional[float]) -> List[float]:
+        report: List[float] = []
+        for run in self.runs:
+            if not isinstance(run.result, PropResult):
+                if value_if_run_failed is not None:
+                    report.append(float(value_if_run_failed))
+                continue
+            rv = states_of_run(run)
+            try:
+                report.extend(self._value(param, run, rv).ravel().tolist())
+            except StateError:
+                # (the reference pushes the substitute once per state that cannot be evaluated)
+                if value_if_run_failed is not None:
+                    report.extend([float(value_if_run_failed)] * len(rv))
+        return report
+
+    def _need_traj(self):
+        if self._traj_batch is None:
+            raise ValueError("these results carry no trajectories (with_traj=False or a sharded run)")
+
+    def every_value_of(self, param: StateParameter, step_ns: int, value_if_run_failed: Optional[float] = None) -> List[float]:
+        """results.rs:127-160: `param` of every run from the start to the end of its trajectory every `step_ns`."""
+        self._need_traj()
+        tb = self._traj_batch
+        last = np.array([tb.epoch_ns[max(min(int(tb.len[i]), tb.capacity) - 1, 0), i] for i in range(tb.n)])
+        count = int(np.max(np.abs(last - tb.epoch_ns[0]) // abs(int(step_ns)))) + 1 if tb.n else 1
+        res = self._traj_ctx.traj_every(tb, int(step_ns), count)
+        return self._report(param, lambda run: res.trajectory(self._traj_rows[run.index])[1], value_if_run_failed)
+
+    def every_value_of_between(self, param: StateParameter, step_ns: int, start_ns: int, end_ns: int,
+                               value_if_run_failed: Optional[float] = None) -> List[float]:
+        """results.rs:89-125: as above between max(start, first epoch) and min(end, last epoch) of each run
+        (`Traj::every_between`, traj.rs:153-162; the series stops at the first epoch that cannot be interpolated)."""
+        self._need_traj()
+        tb = self._traj_batch
+
+        def states_of_run(run):
+            i = self._traj_rows[run.index]
+            ep, _ = tb.trajectory(i)
+            lo, hi = max(int(start_ns), int(ep.min())), min(int(end_ns), int(ep.max()))
+            if hi < lo:
+                return np.zeros((0, 6))
+            q = lo + int(step_ns) * np.arange((hi - lo) // int(step_ns) + 1, dtype=np.int64)
+            one = _abi.TrajBatch(1, max(len(ep), 1))
+            one.len[0] = len(ep)
+            one.epoch_ns[: len(ep), 0] = tb.epoch_ns[: len(ep), i]
+            one.state[:, : len(ep), 0] = tb.state[:, : len(ep), i]
+            states, status = self._traj_ctx.traj_at(one, q)
+            bad = np.nonzero(status[:, 0] != _abi.INTERP_OK)[0]
+            return states[: (bad[0] if len(bad) else len(q)), 0]
+
+        return self._report(param, states_of_run, value_if_run_failed)
+
+    def first_values_of(self, param: StateParameter, value_if_run_failed: Optional[float] = None) -> List[float]:
+        """results.rs:162-190."""
+        self._need_traj()
+        return self._report(param, lambda run: np.asarray(run.result.traj.first())[None, :], value_if_run_failed)
+
+    def last_values_of(self, param: StateParameter, value_if_run_failed: Optional[float] = None) -> List[float]:
+        """results.rs:192-220."""
+        self._need_traj()
+        return self._report(param, lambda run: np.asarray(run.result.traj.last())[None, :], value_if_run_failed)
+
+    def dispersion_values_of(self, param: StateParameter) -> List[float]:
+        """results.rs:222-239: the applied dispersion of `param` for every run; StateError if it was not dispersed."""
+        report = []
+        for run in self.runs:
+            for dparam, val in run.dispersed_state.actual_dispersions:
+                if dparam == param:
+                    report.append(val)
+                    break
+            else:
+                raise StateError(param)
+        return report
 
 
 def shard_bounds(n: int, rank: int, world: int):
@@ -106,21 +243,36 @@ class MonteCarlo:
             if index < skip:
                 continue
             x = base + v
-            s = Spacecraft(**{**t.__dict__})
+            s = DispersedState(**{**t.__dict__})
             s.rv, s.cr, s.cd, s.prop_mass_kg = x[:6].copy(), float(x[6]), float(x[7]), float(x[8])
+            # template.value(param) - state.value(param) for every dispersed component (multivariate.rs:320-325)
+            s.actual_dispersions = [(p, float(base[k] - x[k])) for k, p in enumerate(_VECTOR_PARAMS) if self.random_state.disperses(k)]
             out.append((index, s))
         return out
 
-    def run_until_epoch(self, prop: Propagator, almanac: Almanac, end_epoch_ns: int, num_runs: int) -> Results:
-        return self.resume_run_until_epoch(prop, almanac, 0, end_epoch_ns, num_runs)
+    def run_until_epoch(self, prop: Propagator, almanac: Almanac, end_epoch_ns: int, num_runs: int, with_traj: bool = True,
+                        capacity: int = 4096) -> Results:
+        return self.resume_run_until_epoch(prop, almanac, 0, end_epoch_ns, num_runs, with_traj=with_traj, capacity=capacity)
 
     def resume_run_until_epoch(self, prop: Propagator, almanac: Almanac, skip: int, end_epoch_ns: int, num_runs: int,
-                               dist=None) -> Results:
-        """montecarlo.rs:208-273.  With `dist` (an initialised torch.distributed module) the runs are sharded by
-        contiguous index range over the ranks and every rank returns the complete, index-sorted Results."""
+                               dist=None, with_traj: bool = True, capacity: int = 4096) -> Results:
+        """montecarlo.rs:208-273: every run is `until_epoch_with_traj` (:236-239), so each PropResult carries its
+        trajectory - recorded on the device by the propagation kernel, `capacity` accepted steps per run (doubled and
+        re-run if a run needs more).  `with_traj=False` skips the dense output.  With `dist` (an initialised
+        torch.distributed module) the runs are sharded by contiguous index range over the ranks and every rank returns the
+        complete, index-sorted Results; trajectories stay on the rank that propagated them."""
+        t_epoch = int(self.random_state.template.epoch_ns)
 
         def run(ctx, batch):
-            return ctx.propagate_until_epoch(batch, int(end_epoch_ns))
+            if not with_traj:
+                return ctx.propagate_until_epoch(batch, int(end_epoch_ns))
+            cap = int(capacity)
+            while True:
+                out, st, traj = ctx.propagate_with_traj(batch, int(end_epoch_ns) - t_epoch, cap)
+                need = int(traj.len.max()) if traj.n else 0
+                if need <= cap:
+                    return out, st, traj, ctx
+                cap = max(2 * cap, need)
 
         return self._run(prop, almanac, skip, num_runs, dist, run, int(end_epoch_ns))
 
@@ -133,8 +285,8 @@ class MonteCarlo:
         """montecarlo.rs:115-186: every run stops at the `trigger`-th occurrence of `event` (or fails with NthEventError)."""
 
         def run(ctx, batch):
-            out, st, _, _ = ctx.propagate_until_event(batch, int(max_duration_ns), event, trigger, capacity)
-            return out, st
+            out, st, traj, _ = ctx.propagate_until_event(batch, int(max_duration_ns), event, trigger, capacity)
+            return out, st, traj, ctx
 
         return self._run(prop, almanac, skip, num_runs, dist, run, ("event", int(max_duration_ns), event, trigger))
 
@@ -146,10 +298,11 @@ class MonteCarlo:
         lo, hi = shard_bounds(len(states), rank, world)
         mine = states[lo:hi]
         batch = pack_spacecraft([s for _, s in mine], False)
-        if self.propagate_fn is not None:
-            out, st = self.propagate_fn(batch, fn_arg)
-        else:
-            out, st = run(prop._context(almanac, self.random_state.template.frame, False), batch)
+        # (out, stats) or (out, stats, TrajBatch, evaluator of trajectories: anything with traj_at / traj_every)
+        got = self.propagate_fn(batch, fn_arg) if self.propagate_fn is not None else \
+            run(prop._context(almanac, self.random_state.template.frame, False), batch)
+        out, st = got[0], got[1]
+        traj_batch, traj_ctx = (got[2], got[3]) if len(got) == 4 else (None, None)
         payload = np.concatenate([out.rv(), out.cr[:, None], out.cd[:, None], out.prop_mass_kg[:, None],
                                   np.ascontiguousarray(out.epoch_ns, dtype=np.int64).view(np.float64)[:, None],  # bit pattern: ns past J2000 exceed 2^53
                                   st.status[:, None].astype(np.float64)], axis=1)
@@ -160,13 +313,18 @@ class MonteCarlo:
             row = payload[k]
             status = int(row[10])
             if status == _abi.OK:
-                r = Spacecraft(**{**s.__dict__})
+                r = Spacecraft(**{f: v for f, v in s.__dict__.items() if f != "actual_dispersions"})
                 r.rv, r.cr, r.cd, r.prop_mass_kg, r.epoch_ns = row[:6].copy(), float(row[6]), float(row[7]), float(row[8]), int(row[9:10].view(np.int64)[0])
-                runs.append(Run(index, s, r))
+                src = (traj_ctx, traj_batch, k - lo) if (traj_batch is not None and lo <= k < hi) else None
+                runs.append(Run(index, s, PropResult(r, src)))
             else:
                 runs.append(Run(index, s, PropagationError(status, index)))
+        rows = {index: k - lo for k, (index, _) in enumerate(states) if lo <= k < hi} if traj_batch is not None else {}
         runs.sort(key=lambda r: r.index)  # par_sort_by_key(index), montecarlo.rs:267
-        return Results(runs, self.scenario)
+        # reports need every run's trajectory: only a process that propagated the whole ensemble can make them
+        whole = traj_batch is not None and lo == 0 and hi == len(states)
+        return Results(runs, self.scenario, float(self.random_state.template.frame.mu_km3_s2),
+                       traj_ctx if whole else None, traj_batch if whole else None, rows if whole else {})
 
 
 def all_gather_rows(dist, local: np.ndarray, bounds) -> np.ndarray:

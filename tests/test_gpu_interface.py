@@ -64,6 +64,32 @@ def test_monte_carlo_run_until_epoch_on_gpu():
     # resume_run_until_epoch(skip) reproduces the tail (montecarlo.rs:208-224)
     tail = mc.resume_run_until_epoch(prop, almanac, 6, end, 4)
     np.testing.assert_array_equal(tail.final_rv(), rslts.final_rv()[6:])
+    # every run is `until_epoch_with_traj` (montecarlo.rs:236-239): PropResult { state, traj }, and the reports of
+    # mc/results.rs resample all trajectories with one launch of the trajectory kernel
+    from nyx_amd.params import StateParameter as P
+    for r in rslts.runs:
+        ep, xs = r.result.traj
+        assert ep[0] == EPOCH0_NS and ep[-1] == end
+        np.testing.assert_array_equal(xs[-1], r.result.state.rv)
+    step = 120 * nx.NS_PER_S
+    sma = np.array(rslts.every_value_of(P.SemiMajorAxis, step)).reshape(10, 31)
+    assert np.isfinite(sma).all() and abs(np.median(sma) - 6680.0) < 15.0              # (single samples inside a step cluster are off: DESIGN 3b)
+    xs = np.array(rslts.every_value_of(P.X, step)).reshape(10, 31)
+    _, _, otraj = oracle_lib.propagate_with_traj(prop.compile(almanac, central), batch, 3600 * nx.NS_PER_S, 256)
+    want = oracle_lib.traj_every(otraj, step, 31)
+    inner = slice(3, 28)                                                             # (edge windows: DESIGN 3b)
+    d = np.abs(xs[:, inner] - want.state[0, :31, :].T[:, inner])
+    print(f"MC every_value_of(X) vs oracle: median {np.median(d)*1e3:.2e} m, max {d.max()*1e3:.2e} m")
+    # mm level (f64 seconds past J2000) except single samples inside a step cluster, where the 13-point window is
+    # ill-conditioned and amplifies the micrometre differences between the two trajectories
+    assert np.median(d) < 1e-6 and (d < 5e-6).mean() > 0.9
+    np.testing.assert_array_equal(rslts.first_values_of(P.VZ), [r.dispersed_state.rv[5] for r in rslts.runs])
+    np.testing.assert_array_equal(rslts.last_values_of(P.Y), rslts.final_rv()[:, 1])
+    assert len(rslts.dispersion_values_of(P.VX)) == 10
+    # without dense output: states only
+    bare = mc.run_until_epoch(prop, almanac, end, 10, with_traj=False)
+    np.testing.assert_array_equal(bare.final_rv(), rslts.final_rv())
+    assert bare.runs[0].result.traj is None
 
 
 def test_monte_carlo_run_until_nth_event_on_gpu():
@@ -73,7 +99,7 @@ def test_monte_carlo_run_until_nth_event_on_gpu():
     template = nx.Spacecraft(EPOCH0_NS, leo_nominal(), central, dry_mass_kg=100.0)
     mc = nx.MonteCarlo(nx.MvnSpacecraft.from_sigmas(template, [1.0, 1.0, 1.0, 1e-3, 1e-3, 1e-3]), seed=3)
     rslts = mc.run_until_nth_event(prop, almanac, 4 * 3600 * nx.NS_PER_S, nx.Event.apoapsis(), 2, 12)
-    assert [r.index for r in rslts.runs] == list(range(12)) and all(isinstance(r.result, nx.Spacecraft) for r in rslts.runs)
+    assert [r.index for r in rslts.runs] == list(range(12)) and all(isinstance(r.result, nx.PropResult) for r in rslts.runs)
     epochs = np.array([r.result.epoch_ns for r in rslts.runs])
     assert len(set(epochs)) == 12 and ((epochs - EPOCH0_NS) > 1.4 * 5400 * nx.NS_PER_S).all()    # per-run event epochs
     short = mc.run_until_nth_event(prop, almanac, 600 * nx.NS_PER_S, nx.Event.apoapsis(), 2, 5)
