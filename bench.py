@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--degree", type=int, default=70)
     ap.add_argument("--waves", type=int, default=0, help="column-split waves per workgroup (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-dense-output", action="store_true", help="skip the extra launch with the trajectories recorded")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -205,6 +206,30 @@ def main():
                          "hbm": {"achieved": hbm_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_gbps / HBM_PEAK_GBPS,
                                  "algorithmic_bytes_per_trajectory": BYTES_PER_TRAJ}},
         }
+        if world == 1 and not args.no_dense_output:
+            # The reference's Monte Carlo runs `until_epoch_with_traj` (mc/montecarlo.rs:236-239): the same launch with the
+            # dense output on (every accepted state of every run appended in HBM), timed once, reported beside the headline.
+            cap = int(tst["n_accepted"].max().item()) + 2
+            t_ep = torch.zeros((cap, args.n), dtype=torch.int64, device=dev)
+            t_st = torch.zeros((6, cap, args.n), dtype=torch.float64, device=dev)
+            t_len = torch.zeros(args.n, dtype=torch.int32, device=dev)
+            tr = _abi.Traj()
+            tr.capacity = cap
+            tr.epoch_ns = C.cast(t_ep.data_ptr(), _abi.c_int64_p)
+            for k, f in enumerate(["x_km", "y_km", "z_km", "vx_km_s", "vy_km_s", "vz_km_s"]):
+                setattr(tr, f, C.cast(t_st[k].data_ptr(), _abi.c_double_p))
+            tr.len = C.cast(t_len.data_ptr(), _abi.c_int32_p)
+            rc = lib.nyx_hip_propagate_batch_with_traj_device(ctx._h, C.byref(sin), dur_ns, C.byref(sout), C.byref(sst), C.byref(tr),
+                                                              C.c_void_p(stream.cuda_stream))
+            if rc != 0:
+                raise RuntimeError(_abi.last_error())
+            torch.cuda.synchronize(dev)
+            d_ms = ctx.last_kernel_ms()
+            n_states = int(t_len.sum().item())
+            line["dense_output"] = {"kernel_ms": d_ms, "value": args.n / (d_ms * 1e-3), "unit": "trajectories/s",
+                                    "states_written": n_states, "bytes_written": n_states * 56,
+                                    "note": "one launch of nyx_hip_propagate_batch_with_traj_device (until_epoch_with_traj of every run)"}
+            del t_ep, t_st, t_len
         if not args.no_cpu_baseline and world == 1:
             cb, sample, ref = cpu_baseline(compiled, args.n, args.hours, seed=0)
             # the sample is the head of this rank's shard: check parity on it while we are here
