@@ -22,7 +22,7 @@ import numpy as np
 
 from . import _abi
 from .params import StateError, StateParameter, state_value
-from .propagator import Almanac, Frame, Propagator, Spacecraft, Traj
+from .propagator import Almanac, Propagator, Spacecraft, Traj
 
 # indices into the 9-vector [x, y, z, vx, vy, vz, Cr, Cd, prop mass] (cosmic/spacecraft.rs:451-473)
 STATE_DIM = 9

@@ -21,7 +21,6 @@ from __future__ import annotations
 
 import ctypes as C
 import enum
-import math
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
