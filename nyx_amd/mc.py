@@ -2,7 +2,7 @@
 
 Mirror of the reference's `MonteCarlo` (nyx-core/src/mc/montecarlo.rs:44-296) at the level this path
 needs it: states are generated on the host, one by one, from a single seeded stream
-(`generate_states`, montecarlo.rs:277-296), run `index` keeps its dispersed state
+(`generate_states`, montecarlo.rs:277-296; the index is the position AFTER the skip, as there), run `index` keeps its dispersed state
 (`Run{index, dispersed_state, result}`, mc/results.rs:48-59), `resume_run_until_epoch(skip, ..)`
 regenerates the stream and skips the first `skip` samples (montecarlo.rs:208-224).  Where the reference
 hands the states to a rayon `par_iter` (montecarlo.rs:233-253), this hands the whole batch to the GPU
@@ -247,7 +247,7 @@ class MonteCarlo:
             s.rv, s.cr, s.cd, s.prop_mass_kg = x[:6].copy(), float(x[6]), float(x[7]), float(x[8])
             # template.value(param) - state.value(param) for every dispersed component (multivariate.rs:320-325)
             s.actual_dispersions = [(p, float(base[k] - x[k])) for k, p in enumerate(_VECTOR_PARAMS) if self.random_state.disperses(k)]
-            out.append((index, s))
+            out.append((index - skip, s))   # `.skip(skip).take(num_runs).enumerate()`: a resumed run counts from 0 again (montecarlo.rs:290-295)
         return out
 
     def run_until_epoch(self, prop: Propagator, almanac: Almanac, end_epoch_ns: int, num_runs: int, with_traj: bool = True,
