@@ -9,18 +9,24 @@ hands the states to a rayon `par_iter` (montecarlo.rs:233-253), this hands the w
 through the C-ABI; with several ranks the ensemble is split into contiguous index shards and the
 final states are collected with one all-gather (RCCL on GPUs, gloo in the CPU tests).
 
-NOT restated: the reference's RNG (`Pcg64Mcg` + ziggurat `Normal`).  Dispersions here come from
-`numpy.random.default_rng(seed)`; the dispersed STATES are the contract of the parity tests, not the
-stream.
+The random stream is the reference's (`rand_pcg::Pcg64Mcg::new(seed)` + ziggurat `Normal(0, 1)`, nine draws per
+state: nyx_amd/rng.py, pinned by the reference's seeded known-answer tests).  What is NOT pinned is the orientation of
+the covariance factor: the reference takes `V sqrt(S)` from nalgebra's `svd_unordered`, whose column order and signs for
+repeated or zero singular values are nalgebra's own; here a diagonal covariance maps component k to draw k (which is what
+the reference's seeded tests show for diagonal cases) and a general one goes through LAPACK's SVD - the same
+distribution, possibly another labelling of the draws.
 """
 from __future__ import annotations
 
 from dataclasses import dataclass, field
 from typing import Callable, List, Optional, Sequence
 
+import os
+
 import numpy as np
 
 from . import _abi
+from .rng import Pcg64Mcg
 from .params import StateError, StateParameter, state_value
 from .propagator import Almanac, Propagator, Spacecraft, Traj
 
@@ -29,25 +35,76 @@ STATE_DIM = 9
 
 
 @dataclass
+class StateDispersion:
+    """mc/dispersion.rs:29-48."""
+
+    param: StateParameter
+    mean: Optional[float] = None
+    std_dev: Optional[float] = None
+
+    @classmethod
+    def zero_mean(cls, param: StateParameter, std_dev: float):
+        return cls(param, 0.0, std_dev)
+
+
+_ORBITAL = {StateParameter.X, StateParameter.Y, StateParameter.Z, StateParameter.VX, StateParameter.VY, StateParameter.VZ,
+            StateParameter.Rmag, StateParameter.Vmag, StateParameter.Hmag, StateParameter.Energy, StateParameter.SemiMajorAxis,
+            StateParameter.Eccentricity, StateParameter.Inclination, StateParameter.RAAN, StateParameter.AoP,
+            StateParameter.TrueAnomaly, StateParameter.Period, StateParameter.ApoapsisRadius, StateParameter.PeriapsisRadius}
+
+
+def _partials(param: StateParameter, rv: np.ndarray, mu: float) -> np.ndarray:
+    """d param / d (x, y, z, vx, vy, vz) at `rv`.  The reference reads them off ANISE's `OrbitGrad` (hyperdual numbers,
+    absent here): exact for the Cartesian components and the magnitudes, central differences for the Keplerian elements."""
+    cart = [StateParameter.X, StateParameter.Y, StateParameter.Z, StateParameter.VX, StateParameter.VY, StateParameter.VZ]
+    g = np.zeros(6)
+    if param in cart:
+        g[cart.index(param)] = 1.0
+    elif param is StateParameter.Rmag:
+        g[:3] = rv[:3] / np.linalg.norm(rv[:3])
+    elif param is StateParameter.Vmag:
+        g[3:] = rv[3:] / np.linalg.norm(rv[3:])
+    else:
+        for k in range(6):
+            h = 1e-6 * (np.linalg.norm(rv[:3]) if k < 3 else np.linalg.norm(rv[3:]))
+            up, dn = rv.copy(), rv.copy()
+            up[k] += h
+            dn[k] -= h
+            d = state_value(param, up, mu) - state_value(param, dn, mu)
+            if param in (StateParameter.RAAN, StateParameter.AoP, StateParameter.TrueAnomaly):
+                d = (d + 180.0) % 360.0 - 180.0
+            g[k] = d / (2.0 * h)
+    return g
+
+
 class MvnSpacecraft:
-    """Multivariate normal over the 9-state: x = L z + mean, z ~ N(0, I) (mc/multivariate.rs:298-330).
-    `cov` is 9x9 (or 6x6 for an orbit-only dispersion); the factor is taken by SVD like the reference
-    (`sqrt_s_v`, multivariate.rs:262-295)."""
+    """Multivariate normal over the 9-state: x = L z + mean, z ~ N(0, I) (mc/multivariate.rs:63-330); L = V sqrt(S) from the
+    SVD of the 9x9 covariance (`sqrt_s_v`, multivariate.rs:203-218, 262-272).  Built from a covariance (`from_spacecraft_cov`,
+    the constructor; `from_sigmas` for a diagonal one) or from dispersions of state parameters (`new` / `zero_mean`)."""
 
-    template: Spacecraft
-    cov: np.ndarray
-    mean: Optional[np.ndarray] = None
-
-    def __post_init__(self):
+    def __init__(self, template: Spacecraft, cov: np.ndarray, mean: Optional[np.ndarray] = None, dispersions=None):
+        self.template = template
         c = np.zeros((STATE_DIM, STATE_DIM))
-        cov = np.asarray(self.cov, dtype=np.float64)
+        cov = np.asarray(cov, dtype=np.float64)
         c[: cov.shape[0], : cov.shape[1]] = cov
-        u, s, _ = np.linalg.svd(c)
-        self._sqrt_s_v = u @ np.diag(np.sqrt(s))
+        if np.any(np.linalg.eigvalsh(0.5 * (c + c.T)) < -1e-12 * max(1.0, float(np.abs(c).max()))):
+            raise ValueError("covariance matrix is not positive semi-definite")   # NyxError::CovarianceMatrixNotPsd
+        self.cov = c
+        if np.count_nonzero(c - np.diag(np.diagonal(c))) == 0:
+            self._sqrt_s_v = np.diag(np.sqrt(np.diagonal(c)))   # V = I: component k takes draw k
+        else:
+            _, sv, vt = np.linalg.svd(c)
+            self._sqrt_s_v = vt.T * np.sqrt(sv)[None, :]
         m = np.zeros(STATE_DIM)
-        if self.mean is not None:
-            m[: len(self.mean)] = self.mean
+        if mean is not None:
+            m[: len(mean)] = mean
         self._mean = m
+        self.mean = m
+        if dispersions is None:   # from_spacecraft_cov lists the nine components (multivariate.rs:274-312: std_dev <- the VARIANCE)
+            dispersions = [StateDispersion(p, None, float(c[k, k])) for k, p in enumerate(_VECTOR_PARAMS)]
+        self.dispersions = list(dispersions)
+
+    from_spacecraft_cov = classmethod(lambda cls, template, cov, mean=None: cls(template, cov, mean))
 
     @classmethod
     def from_sigmas(cls, template: Spacecraft, sigmas: Sequence[float]):
@@ -55,8 +112,46 @@ class MvnSpacecraft:
         s[: len(sigmas)] = sigmas
         return cls(template, np.diag(s ** 2))
 
-    def sample_vector(self, rng: np.random.Generator) -> np.ndarray:
-        return self._sqrt_s_v @ rng.standard_normal(STATE_DIM) + self._mean
+    @classmethod
+    def new(cls, template: Spacecraft, dispersions: Sequence[StateDispersion]):
+        """multivariate.rs:78-226: the dispersions of orbital parameters are independent in THEIR space; the Jacobian J of the
+        parameters w.r.t. the Cartesian state maps them back, C = J+ P J+^T with J+ the pseudo-inverse, mean = J+ means."""
+        dispersions = list(dispersions)
+        cov = np.zeros((STATE_DIM, STATE_DIM))
+        mean = np.zeros(STATE_DIM)
+        orbital = [d for d in dispersions if d.param in _ORBITAL]
+        if orbital:
+            rv = np.asarray(template.rv, dtype=np.float64)
+            jac = np.stack([_partials(d.param, rv, float(template.frame.mu_km3_s2)) for d in orbital])
+            p = np.diag([(d.std_dev or 0.0) ** 2 for d in orbital])
+            means = np.array([d.mean or 0.0 for d in orbital])
+            jac_inv = np.linalg.pinv(jac)
+            cov[:6, :6] = jac_inv @ p @ jac_inv.T
+            mean[:6] = jac_inv @ means
+        for d in dispersions:
+            if d.param in _ORBITAL:
+                continue
+            # as written in the reference (multivariate.rs:183-197): the variance is taken from `mean`, Cr lands in slot 7 and
+            # Cd in slot 8 of [.., Cr, Cd, prop mass]; the mass branch indexes (9, 9) of a 9x9 matrix and panics
+            if d.param is StateParameter.Cr:
+                cov[7, 7] = (d.mean or 0.0) ** 2
+            elif d.param is StateParameter.Cd:
+                cov[8, 8] = (d.mean or 0.0) ** 2
+            elif d.param in (StateParameter.DryMass, StateParameter.PropMass):
+                raise IndexError("Matrix index out of bounds (multivariate.rs:193: cov[(9, 9)] of a 9x9)")
+            else:
+                raise StateError(d.param)   # StateError::ReadOnly
+        return cls(template, cov, mean, dispersions)
+
+    @classmethod
+    def zero_mean(cls, template: Spacecraft, dispersions: Sequence[StateDispersion]):
+        return cls.new(template, [StateDispersion(d.param, 0.0, d.std_dev) for d in dispersions])
+
+    def sample_vector(self, rng) -> np.ndarray:
+        """multivariate.rs:300-303: nine standard normals, in order, from the run's stream (`rng`: nyx_amd.rng.Pcg64Mcg, or a
+        numpy Generator)."""
+        z = np.array(rng.normal_vector(STATE_DIM)) if hasattr(rng, "normal_vector") else rng.standard_normal(STATE_DIM)
+        return self._sqrt_s_v @ z + self._mean
 
     def disperses(self, k: int) -> bool:
         """Is component k of the 9-vector dispersed (non-zero variance or mean)?"""
@@ -234,7 +329,9 @@ class MonteCarlo:
 
     def generate_states(self, skip: int, num_runs: int, seed: Optional[int] = None):
         """montecarlo.rs:277-296: one stream, samples drawn sequentially, first `skip` discarded."""
-        rng = np.random.default_rng(self.seed if seed is None else seed)
+        use = self.seed if seed is None else seed
+        # Pcg64Mcg::new(seed) (montecarlo.rs:284-287); without a seed the reference takes one from the OS
+        rng = Pcg64Mcg(use if use is not None else int.from_bytes(os.urandom(16), "little"))
         t = self.random_state.template
         base = np.concatenate([np.asarray(t.rv, dtype=np.float64), [t.cr, t.cd, t.prop_mass_kg]])
         out = []
@@ -246,7 +343,13 @@ class MonteCarlo:
             s = DispersedState(**{**t.__dict__})
             s.rv, s.cr, s.cd, s.prop_mass_kg = x[:6].copy(), float(x[6]), float(x[7]), float(x[8])
             # template.value(param) - state.value(param) for every dispersed component (multivariate.rs:320-325)
-            s.actual_dispersions = [(p, float(base[k] - x[k])) for k, p in enumerate(_VECTOR_PARAMS) if self.random_state.disperses(k)]
+            mu = float(t.frame.mu_km3_s2)
+
+            def val(sc, p):
+                return float(state_value(p, np.asarray(sc.rv, dtype=np.float64), mu, cr=sc.cr, cd=sc.cd, dry_mass_kg=sc.dry_mass_kg,
+                                         prop_mass_kg=sc.prop_mass_kg, extra_mass_kg=sc.extra_mass_kg))
+
+            s.actual_dispersions = [(d.param, val(t, d.param) - val(s, d.param)) for d in self.random_state.dispersions]
             out.append((index - skip, s))   # `.skip(skip).take(num_runs).enumerate()`: a resumed run counts from 0 again (montecarlo.rs:290-295)
         return out
 

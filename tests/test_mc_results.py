@@ -78,9 +78,11 @@ def test_failed_runs_and_dispersions():
     t = mc.random_state.template
     d = res.dispersion_values_of(P.X)
     np.testing.assert_allclose(d, [t.rv[0] - r.dispersed_state.rv[0] for r in res.runs], rtol=0, atol=0)
-    assert [p for p, _ in res.runs[0].dispersed_state.actual_dispersions] == [P.X, P.Y, P.Z, P.VX, P.VY, P.VZ]
+    # a generator built from a covariance lists all nine components (multivariate.rs:274-312)
+    assert [p for p, _ in res.runs[0].dispersed_state.actual_dispersions] == [P.X, P.Y, P.Z, P.VX, P.VY, P.VZ, P.Cr, P.Cd, P.PropMass]
+    assert res.dispersion_values_of(P.Cr) == [0.0] * 4
     with pytest.raises(nx.StateError):
-        res.dispersion_values_of(P.Cr)
+        res.dispersion_values_of(P.SemiMajorAxis)
 
 
 def test_resume_skips_and_without_traj():
