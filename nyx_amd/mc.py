@@ -324,6 +324,7 @@ class MonteCarlo:
     random_state: MvnSpacecraft
     seed: Optional[int] = None
     scenario: str = "MonteCarlo"
+    nominal_state: Optional[Spacecraft] = None   # (carried for the reports' headers in the reference, montecarlo.rs:49-51)
     # injectable for the CPU tests (gloo): (batch, end_epoch_ns) -> (out batch, stats); default = the GPU context
     propagate_fn: Optional[Callable] = field(default=None, repr=False)
 

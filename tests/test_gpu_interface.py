@@ -92,6 +92,31 @@ def test_monte_carlo_run_until_epoch_on_gpu():
     assert bare.runs[0].result.traj is None
 
 
+def test_monte_carlo_epoch_like_the_reference_test():
+    """tests/monte_carlo/framework.rs:20-95 (`test_monte_carlo_epoch`): SMA and eccentricity dispersed (5 %), point masses,
+    DP78, ten runs of one day from seed 0, then the four reports the reference prints.  (It asserts nothing; here: the report
+    shapes, and that the averages are the physics they should be.)"""
+    from nyx_amd.params import StateParameter as P
+    from scenarios import keplerian_to_cartesian
+    prop, almanac, central = leo_full_setup(degree=0, srp=False, method=nx.IntegratorMethod.DormandPrince78)
+    nominal = nx.Spacecraft(EPOCH0_NS, keplerian_to_cartesian(8_191.93, 1e-6, 12.85, 306.614, 314.19, 99.887_7, central.mu_km3_s2), central)
+    random_state = nx.MvnSpacecraft.new(nominal, [nx.StateDispersion.zero_mean(P.SemiMajorAxis, 0.05),
+                                                   nx.StateDispersion.zero_mean(P.Eccentricity, 0.05)])
+    mc = nx.MonteCarlo(random_state, seed=0, scenario="test_monte_carlo_epoch", nominal_state=nominal)
+    rslts = mc.run_until_epoch(prop, almanac, EPOCH0_NS + 86_400 * nx.NS_PER_S, 10)
+    assert len(rslts.ok_runs()) == 10
+    disp = np.array(rslts.dispersion_values_of(P.SemiMajorAxis))
+    every = np.array(rslts.every_value_of(P.SemiMajorAxis, 300 * nx.NS_PER_S))
+    first = np.array(rslts.first_values_of(P.SemiMajorAxis))
+    last = np.array(rslts.last_values_of(P.SemiMajorAxis))
+    print(f"Average SMA dispersion = {disp.mean()} km; initial {first.mean()} km; final {last.mean()} km; all {np.median(every)} km")
+    assert disp.shape == (10,) and first.shape == (10,) and last.shape == (10,) and every.shape == (10 * 289,)
+    # the dispersion is template minus state; the initial SMA is the template's minus it
+    np.testing.assert_allclose(first, 8_191.93 - disp, rtol=1e-9)
+    # third bodies move the osculating SMA of this orbit by metres over a day: first, last and the resampled values agree
+    assert np.abs(last - first).max() < 0.5 and np.abs(np.median(every.reshape(10, 289), axis=1) - first).max() < 0.5
+
+
 def test_monte_carlo_run_until_nth_event_on_gpu():
     # MonteCarlo::run_until_nth_event (montecarlo.rs:93-186): every run stops at its own 2nd apoapsis; failures keep
     # their index (NthEventError) like `Run.result: Err(..)`
