@@ -775,9 +775,20 @@ class Traj:
     def __init__(self, ctx: "GpuContext", batch: _abi.TrajBatch, index: int = 0):
         self._ctx, self._batch, self._i = ctx, batch, index
         ep, xs = batch.trajectory(index)
+        self._finalize(ep, xs)
+
+    def _finalize(self, ep, xs):
         order = np.argsort(ep, kind="stable")                       # finalize(): sort_by_key(epoch) ...
         keep = np.concatenate([[True], np.diff(ep[order]) != 0]) if len(ep) else np.zeros(0, dtype=bool)
         self.epochs_ns, self.states = ep[order][keep], xs[order][keep]  # ... after dedup_by epoch (traj.rs:76-79)
+
+    @classmethod
+    def from_arrays(cls, ctx, epochs_ns, states) -> "Traj":
+        """A trajectory from stored samples (`Traj::new()` + pushes + `finalize()`); `ctx` evaluates it (traj_at / traj_every)."""
+        t = cls.__new__(cls)
+        t._ctx, t._batch, t._i = ctx, None, 0
+        t._finalize(np.asarray(epochs_ns, dtype=np.int64).reshape(-1), np.asarray(states, dtype=np.float64).reshape(-1, 6))
+        return t
 
     def __iter__(self):
         return iter((self.epochs_ns, self.states))
@@ -812,6 +823,64 @@ class Traj:
         count = int((self.epochs_ns[-1] - self.epochs_ns[0]) // int(step_ns)) + 1
         out = self._ctx.traj_every(self._single(), int(step_ns), count)
         return out.trajectory(0)
+
+    def start_epoch(self) -> int:
+        return int(self.epochs_ns[0])
+
+    def end_epoch(self) -> int:
+        return int(self.epochs_ns[-1])
+
+    def every_between(self, step_ns: int, start_ns: int, end_ns: int):
+        """traj.rs:153-162: the inclusive series from max(start, first epoch) to min(end, last epoch); it stops at the first
+        epoch that cannot be interpolated (traj_it.rs:39-61)."""
+        if len(self) == 0:
+            return np.zeros(0, dtype=np.int64), np.zeros((0, 6))
+        lo, hi = max(int(start_ns), self.start_epoch()), min(int(end_ns), self.end_epoch())
+        if hi < lo:
+            return np.zeros(0, dtype=np.int64), np.zeros((0, 6))
+        q = lo + int(step_ns) * np.arange((hi - lo) // int(step_ns) + 1, dtype=np.int64)
+        states, status = self._ctx.traj_at(self._single(), q)
+        bad = np.nonzero(status[:, 0] != _abi.INTERP_OK)[0]
+        n = int(bad[0]) if len(bad) else len(q)
+        return q[:n], states[:n, 0]
+
+    def filter_by_epoch(self, start_ns: Optional[int] = None, end_ns: Optional[int] = None, end_inclusive: bool = True) -> "Traj":
+        """traj.rs:165-173: the stored states whose epoch lies in the range (a Rust RangeBounds: `a..b`, `a..=b`, `..`)."""
+        keep = np.ones(len(self), dtype=bool)
+        if start_ns is not None:
+            keep &= self.epochs_ns >= int(start_ns)
+        if end_ns is not None:
+            keep &= (self.epochs_ns <= int(end_ns)) if end_inclusive else (self.epochs_ns < int(end_ns))
+        return Traj.from_arrays(self._ctx, self.epochs_ns[keep], self.states[keep])
+
+    def filter_by_offset(self, start_offset_ns: Optional[int] = None, end_offset_ns: Optional[int] = None) -> "Traj":
+        """traj.rs:177-193: offsets from the FIRST epoch; both bounds end up inclusive whatever the range type was
+        (`filter_by_epoch(start..=end)`)."""
+        if len(self) == 0:
+            return self
+        start = self.start_epoch() + (0 if start_offset_ns is None else int(start_offset_ns))
+        end = self.end_epoch() if end_offset_ns is None else self.start_epoch() + int(end_offset_ns)
+        return self.filter_by_epoch(start, end, True)
+
+    def resample(self, step_ns: int) -> "Traj":
+        """traj.rs:367-384: a new trajectory of the states `every(step)`."""
+        if len(self) == 0:
+            raise TrajError(1, 0)   # CreationError: "No trajectory to convert"
+        ep, xs = self.every(step_ns)
+        return Traj.from_arrays(self._ctx, ep, xs)
+
+    def rebuild(self, epochs_ns) -> "Traj":
+        """traj.rs:388-407: a new trajectory of `at(epoch)` for the given epochs; the first failure is the error."""
+        if len(self) == 0:
+            raise TrajError(1, 0)
+        q = np.asarray(epochs_ns, dtype=np.int64).reshape(-1)
+        if len(q) == 0:
+            return Traj.from_arrays(self._ctx, q, np.zeros((0, 6)))
+        states, status = self._ctx.traj_at(self._single(), q)
+        bad = np.nonzero(status[:, 0] != _abi.INTERP_OK)[0]
+        if len(bad):
+            raise TrajError(int(status[bad[0], 0]), int(q[bad[0]]))
+        return Traj.from_arrays(self._ctx, q, states[:, 0])
 
 
 class Propagator:

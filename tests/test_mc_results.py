@@ -119,3 +119,34 @@ def test_state_values_of_a_known_orbit():
         np.testing.assert_allclose(got, val, rtol=2e-12, err_msg=param.name)
     assert nx.state_value(P.VX, rv, mu) == rv[3]
     np.testing.assert_array_equal(nx.state_value(P.Cd, np.zeros((3, 2, 6)), mu, cd=2.2), np.full((3, 2), 2.2))
+
+
+def test_traj_views_follow_the_reference():
+    """Traj::every_between / filter_by_epoch / filter_by_offset / resample / rebuild (md/trajectory/traj.rs:148-193, 367-407)."""
+    prop, almanac, compiled, mc = _mc()
+    end = EPOCH0_NS + 1800 * nx.NS_PER_S
+    traj = mc.run_until_epoch(prop, almanac, end, 1).runs[0].result.traj
+    assert traj.start_epoch() == EPOCH0_NS and traj.end_epoch() == end
+    s = nx.NS_PER_S
+    ep, xs = traj.every_between(300 * s, EPOCH0_NS - 1000 * s, EPOCH0_NS + 700 * s)      # clamped at the start: 0, 300, 600
+    assert list(ep - EPOCH0_NS) == [0, 300 * s, 600 * s] and xs.shape == (3, 6)
+    np.testing.assert_array_equal(xs[0], traj.first())
+    assert traj.every_between(300 * s, end + s, end + 10 * s)[0].size == 0
+    # resample = every(step) as a trajectory; evaluating it at its own nodes gives them back
+    rs = traj.resample(450 * s)
+    assert list(rs.epochs_ns - EPOCH0_NS) == [0, 450 * s, 900 * s, 1350 * s, 1800 * s]
+    np.testing.assert_array_equal(rs.states, traj.every(450 * s)[1])
+    np.testing.assert_allclose(rs.at(EPOCH0_NS + 900 * s), rs.states[2], rtol=0, atol=1e-9)
+    # rebuild: at() for the given epochs, sorted by finalize(); an epoch outside is the error
+    rb = traj.rebuild([EPOCH0_NS + 1000 * s, EPOCH0_NS + 10 * s])
+    assert list(rb.epochs_ns - EPOCH0_NS) == [10 * s, 1000 * s]
+    np.testing.assert_array_equal(rb.states[1], traj.at(EPOCH0_NS + 1000 * s))
+    with pytest.raises(nx.TrajError):
+        traj.rebuild([end + s])
+    # filters keep STORED states
+    mid = traj.filter_by_epoch(EPOCH0_NS + 200 * s, EPOCH0_NS + 1500 * s)
+    assert len(mid) == int(((traj.epochs_ns >= EPOCH0_NS + 200 * s) & (traj.epochs_ns <= EPOCH0_NS + 1500 * s)).sum()) > 0
+    assert len(traj.filter_by_epoch(None, end, end_inclusive=False)) == len(traj) - 1
+    off = traj.filter_by_offset(200 * s, 1500 * s)
+    np.testing.assert_array_equal(off.epochs_ns, mid.epochs_ns)
+    assert len(traj.filter_by_offset()) == len(traj)
