@@ -5,8 +5,54 @@
 #include <vector>
 
 #include "nyx_hip.hpp"
+#include "nyx_hip_mc.hpp"
+
+// The reference's seeded known-answer tests of the dispersions (nyx-core/src/mc/multivariate.rs:420-556), host side only:
+// Pcg64Mcg::new(0), 1 000 samples, exact counts.
+static bool rng_known_answers() {
+    const double mu = 398600.4415;
+    // Orbit::keplerian(8191.93, 1e-6, 12.85, 306.614, 314.19, 99.8877)
+    const double sma = 8191.93, ecc = 1e-6, d2r = 3.14159265358979323846 / 180.0;
+    const double inc = 12.85 * d2r, raan = 306.614 * d2r, aop = 314.19 * d2r, ta = 99.8877 * d2r;
+    const double p = sma * (1 - ecc * ecc), r = p / (1 + ecc * std::cos(ta));
+    const double rp[3] = {r * std::cos(ta), r * std::sin(ta), 0.0};
+    const double vp[3] = {-std::sqrt(mu / p) * std::sin(ta), std::sqrt(mu / p) * (ecc + std::cos(ta)), 0.0};
+    const double cO = std::cos(raan), sO = std::sin(raan), ci = std::cos(inc), si = std::sin(inc), cw = std::cos(aop), sw = std::sin(aop);
+    const double R[3][3] = {{cO * cw - sO * sw * ci, -cO * sw - sO * cw * ci, sO * si},
+                            {sO * cw + cO * sw * ci, -sO * sw + cO * cw * ci, -cO * si},
+                            {sw * si, cw * si, ci}};
+    nyx::Spacecraft t;
+    for (int i = 0; i < 3; ++i) {
+        t.rv[i] = R[i][0] * rp[0] + R[i][1] * rp[1] + R[i][2] * rp[2];
+        t.rv[3 + i] = R[i][0] * vp[0] + R[i][1] * vp[1] + R[i][2] * vp[2];
+    }
+    // disperse_full_cartesian: components beyond one sigma, over 6: exactly 312
+    const std::array<double, 9> sig = {10.0, 10.0, 10.0, 0.2, 0.2, 0.2, 0.0, 0.0, 0.0};
+    nyx::MonteCarlo full(nyx::MvnSpacecraft::from_sigmas(t, sig), 0, "disperse_full_cartesian");
+    int cnt = 0;
+    for (const auto &is : full.generate_states(0, 1000))
+        for (int k = 0; k < 6; ++k) cnt += std::fabs(is.second.rv[k] - t.rv[k]) > sig[k] ? 1 : 0;
+    // disperse_r_mag: covariance sigma^2 r^ r^T (Jacobian pseudo-inverse of |r|, sigma = 1 km): exactly 6 samples beyond 3 sigma
+    const double rm = std::sqrt(t.rv[0] * t.rv[0] + t.rv[1] * t.rv[1] + t.rv[2] * t.rv[2]);
+    std::array<double, 81> cov{};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) cov[i * 9 + j] = (t.rv[i] / rm) * (t.rv[j] / rm);
+    nyx::MonteCarlo rmag(nyx::MvnSpacecraft(t, cov), 0, "disperse_r_mag");
+    int too_far = 0;
+    for (const auto &is : rmag.generate_states(0, 1000)) {
+        const double m = std::sqrt(is.second.rv[0] * is.second.rv[0] + is.second.rv[1] * is.second.rv[1] + is.second.rv[2] * is.second.rv[2]);
+        too_far += std::fabs(rm - m) >= 3.0 ? 1 : 0;
+    }
+    // resume: indices restart after the skip, the states are the tail of the same stream
+    const auto all = full.generate_states(0, 6), tail = full.generate_states(4, 2);
+    const bool resume_ok = tail.size() == 2 && tail[0].first == 0 && tail[1].first == 1 && tail[0].second.rv[0] == all[4].second.rv[0] &&
+                           tail[1].second.rv[5] == all[5].second.rv[5];
+    std::printf("dispersion known answers: %d (want 312), %d (want 6), resume %s\n", cnt / 6, too_far, resume_ok ? "ok" : "FAILED");
+    return cnt / 6 == 312 && too_far == 6 && resume_ok;
+}
 
 int main() {
+    if (!rng_known_answers()) return 2;
     nyx_hip_config_t cfg{};
     cfg.abi_version = NYX_HIP_ABI_VERSION;
     cfg.opts = nyx::default_options(NYX_HIP_RK89);
@@ -50,5 +96,14 @@ int main() {
     prop.many_until_event(in, 3 * 3600LL * 1000000000LL, apo, out, st, etraj, &crossings);
     const bool event_ok = st.status[0] == NYX_HIP_OK && crossings[0] == 1 && out.get(0).epoch_ns > 0 && out.get(0).epoch_ns < 3 * 3600LL * 1000000000LL;
     std::printf("until_event: %s (apoapsis at %.3f s)\n", event_ok ? "ok" : "FAILED", out.get(0).epoch_ns * 1e-9);
-    return resample_ok && event_ok ? 0 : 1;
+
+    // MonteCarlo::run_until_epoch through the mirror: 8 dispersed runs, each PropResult { state, traj }
+    nyx::MonteCarlo mc(nyx::MvnSpacecraft::from_sigmas(sc, {1.0, 1.0, 1.0, 1e-3, 1e-3, 1e-3, 0.0, 0.0, 0.0}), 7, "mirror");
+    nyx::Results res = mc.run_until_epoch(prop, 1800LL * 1000000000LL, 8, 256);
+    bool mc_ok = res.runs.size() == 8;
+    for (const auto &run : res.runs)
+        mc_ok = mc_ok && run.status == NYX_HIP_OK && run.state.epoch_ns == 1800LL * 1000000000LL &&
+                res.traj.state(0, res.traj.len((int64_t)run.index) - 1, (int64_t)run.index) == run.state.rv[0];
+    std::printf("MonteCarlo::run_until_epoch: %s\n", mc_ok ? "ok" : "FAILED");
+    return resample_ok && event_ok && mc_ok ? 0 : 1;
 }

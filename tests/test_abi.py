@@ -91,10 +91,13 @@ def _build_cxx_check(tmp_path):
 
 
 def test_cxx_host_mirror_compiles_and_links(tmp_path):
+    """Also runs the host-only part: the reference's seeded known-answer counts of the dispersions
+    (mc/multivariate.rs:420-556) through include/nyx_hip_mc.hpp."""
     import subprocess
     _abi.load_library()
     r = subprocess.run([_build_cxx_check(tmp_path)], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+    assert "dispersion known answers: 312 (want 312), 6 (want 6), resume ok" in r.stdout
 
 
 @pytest.mark.gpu
