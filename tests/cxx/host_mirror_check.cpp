@@ -103,7 +103,7 @@ int main() {
     bool mc_ok = res.runs.size() == 8;
     for (const auto &run : res.runs)
         mc_ok = mc_ok && run.status == NYX_HIP_OK && run.state.epoch_ns == 1800LL * 1000000000LL &&
-                res.traj.state(0, res.traj.len((int64_t)run.index) - 1, (int64_t)run.index) == run.state.rv[0];
+                res.traj.state(res.traj.len((int64_t)run.index) - 1, (int64_t)run.index, 0) == run.state.rv[0];
     std::printf("MonteCarlo::run_until_epoch: %s\n", mc_ok ? "ok" : "FAILED");
     return resample_ok && event_ok && mc_ok ? 0 : 1;
 }
