@@ -341,7 +341,7 @@ class MonteCarlo:
             if index < skip:
                 continue
             x = base + v
-            s = DispersedState(**{**t.__dict__})
+            s = DispersedState(**{f: v for f, v in t.__dict__.items() if f != "actual_dispersions"})
             s.rv, s.cr, s.cd, s.prop_mass_kg = x[:6].copy(), float(x[6]), float(x[7]), float(x[8])
             # template.value(param) - state.value(param) for every dispersed component (multivariate.rs:320-325)
             mu = float(t.frame.mu_km3_s2)
