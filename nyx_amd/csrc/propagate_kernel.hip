@@ -4,9 +4,9 @@
 //
 //   * lane <-> trajectory.  Every lane of every wave of the workgroup is bound to the same
 //     trajectory slot, so all shared tables (Stokes coefficients and Legendre recursion constants,
-//     column schedule) are WAVE-UNIFORM and are fetched with scalar loads (4 x s_load_dwordx16 = four
-//     64-byte harmonics entries per batch) straight into SGPRs: the f64 VALU ops take them as scalar
-//     operands, no LDS/VGPR traffic for the big table at all.
+//     column schedule) are WAVE-UNIFORM and are fetched with scalar loads (a batch of five 56-byte
+//     harmonics entries = 70 SGPRs behind one wait) straight into SGPRs: the f64 VALU ops take them as
+//     scalar operands, no LDS/VGPR traffic for the big table at all.
 //   * the waves of the workgroup are ROLE-SPECIALISED (all roles also carry harmonics columns):
 //       wave 0  "integrator"    RK state machine of the 64 trajectories: per-lane adaptive step,
 //                               accept/reject, integer-ns epoch bookkeeping (reference instance.rs:87-493),
@@ -15,8 +15,12 @@
 //                               (3 sincos), Sun/Moon Chebyshev chains — one stage AHEAD, into LDS.
 //       wave 2  "perturbations" position-dependent third-body and SRP/eclipse terms of the current stage.
 //       wave 3+ "columns"       spherical-harmonics column workers.
-//     Roles only meet in LDS; two workgroup barriers per force evaluation.  The split keeps every code
-//     path under 128 VGPRs so that 16 waves (4 per SIMD) fit and hide the scalar-load latency.
+//     Roles only meet in LDS: one workgroup barrier per force evaluation in the pipelined stage loop (the
+//     integrator publishes the next stage's position inside the current window; see role_loop), two in the
+//     plain one.  The split keeps every code path under 128 VGPRs so that 16 waves (4 per SIMD) fit and
+//     hide the scalar-load latency.
+//   * when the launch has fewer workgroups than the chip has CUs, HELPER workgroups on the idle CUs take over
+//     a share of the harmonics columns through mailboxes in uncached memory ("cooperative mode" below).
 //   * the spherical-harmonics double sum (reference gravity_field.rs:148-268), ~97 % of the work,
 //     is split BY COLUMN (order m) over the waves.  Columns of the normalised derived-Legendre table
 //     are independent given u = z/r, so each wave runs a rolling 2-term recursion down its columns
