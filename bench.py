@@ -1,15 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py — headline benchmark of the MI355X-native propagation path.
+"""bench.py — benchmark of the MI355X-native propagation path.
 
-Metric (BASELINE.json): propagated trajectories / second, 10 000-trajectory LEO Monte Carlo,
-70x70 gravity (JGM3, the model present in the reference checkout) + Sun/Moon point masses +
-cannonball SRP with Earth shadow, RK89 default options, 1 day  (configs[1]).
+Headline (BASELINE.json `metric`, default, `--config 2`): propagated trajectories / second, 10 000-trajectory LEO Monte
+Carlo, 70x70 gravity (JGM3, the model present in the reference checkout) + Sun/Moon point masses + cannonball SRP with
+Earth shadow, RK89 default options, 1 day (configs[1]).  `--config 3|4|5` run BASELINE.json's other GPU configurations
+with the same JSON shape:
 
-A "step" is one pass of the hot path over one batch: every rank propagates its shard of
-dispersed states (already resident in HBM) for one day through the C-ABI
-(`nyx_hip_propagate_batch_device`), then the ranks exchange the final states with one RCCL
-all-gather (the Monte Carlo result collection of north_star).  Weak scaling: the per-GPU ensemble
-is fixed (--n, default 10 000), `value` = all ranks' trajectories / max-over-ranks time.
+    3  JWST covariance Monte Carlo: 5 000 dispersed halo-orbit states, Sun/Moon/Jupiter point masses + SRP with Earth and
+       Moon shadows, RK89, 30 days
+    4  GEO covariance mapping: 1 000 states, 21x21 + Sun/Moon + SRP (Cr estimated), 9x9 STM, sixty 1-minute time updates
+       (`nyx_hip_predict_until`: segment kernel + time-update kernel on one stream)
+    5  low lunar orbit: 150x150 (synthetic Kaula field, the GRGM file is a missing blob) + Earth/Sun point masses, DP78,
+       3 days; 50 000 trajectories over 8 GPUs = 6 250 per GPU
+
+A "step" is one pass of the hot path over one batch: every rank propagates its shard of dispersed states (already
+resident in HBM; config 4 goes through the host-buffer entry, its only one) through the C-ABI, then the ranks exchange
+the final states with one RCCL all-gather (the Monte Carlo result collection of north_star).  Weak scaling: the per-GPU
+ensemble is fixed (--n), `value` = all ranks' trajectories / max-over-ranks time.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
@@ -17,6 +24,7 @@ is fixed (--n, default 10 000), `value` = all ranks' trajectories / max-over-ran
 """
 import argparse
 import ctypes as C
+import glob
 import json
 import os
 import sys
@@ -30,13 +38,93 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import nyx_amd as nx  # noqa: E402
-from nyx_amd import _abi  # noqa: E402
-from scenarios import dispersed_leo_batch, leo_full_setup  # noqa: E402
+from nyx_amd import _abi, ephem  # noqa: E402
+import scenarios as sc  # noqa: E402
 
-FLOP_PER_EVAL = 7.3e4          # config 2, algorithmic FLOP per force-model evaluation
 FP64_VECTOR_PEAK_TFLOPS = 78.6  # MI355X vector FP64 (= matrix FP64) peak, SURVEY 8(d) / MI355X_MICROARCH.md clocks
 HBM_PEAK_GBPS = 8000.0
 BYTES_PER_TRAJ = 2 * 13 * 8 + 8 * 8  # 13 f64 + epoch in and out, plus status/details/counters
+N_CU = 256
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Algorithmic FLOP per force-model evaluation, SURVEY.md section 8(d) ("Algorithmic work per unit"): the REFERENCE
+# formulation's cost (what `roofline.achieved` is quoted in); the kernel's own instruction count is lower, see
+# `executed_flop_per_eval` below and DESIGN.md section 3.
+# ---------------------------------------------------------------------------------------------------------------------
+def harmonics_flop(n):
+    """4 N(N+1)/2 [interior recursion] + 24 (N(N+1)/2 + N) [(n, m) sum] + 16 N  (SURVEY 8d)."""
+    return 4 * n * (n + 1) / 2 + 24 * (n * (n + 1) / 2 + n) + 16 * n
+
+
+def algorithmic_flop_per_eval(degree, n_pm, srp, n_shadow, stm):
+    f = 20.0 + n_pm * (40.0 + 250.0) + (150.0 + 100.0 * max(n_shadow - 1, 0) if srp else 0.0)
+    if degree > 0:
+        f += 100.0 + harmonics_flop(degree)          # body-fixed rotation in and out + the double sum
+    if stm:
+        # SURVEY 8d: "+ 1 458 (9x9x9 MAC) + partials (analytic: ~3x the non-STM harmonics cost)"; the point-mass and SRP
+        # duals roughly triple their real parts as well
+        f += 1458.0 + 3.0 * (harmonics_flop(degree) if degree > 0 else 0.0) + 2.0 * (n_pm * 40.0 + (150.0 if srp else 0.0))
+    return f
+
+
+def executed_flop_per_eval(degree, stm):
+    """What the kernel issues for the harmonics (disassembly of harmonics_partial: 7 v_fma_f64 + 2 v_mul_f64 = 16 FLOP per
+    table entry, (N+1)(N+4)/2 entries; x4 for the dual variant) — reported beside the algorithmic figure."""
+    if degree <= 0:
+        return None
+    entries = (degree + 1) * (degree + 4) / 2
+    return entries * 16.0 * (4.0 if stm else 1.0)
+
+
+def geo_batch(n, seed):
+    b = sc.dispersed_leo_batch(n, seed=seed)
+    geo = sc.keplerian_to_cartesian(42164.0, 1e-5, 0.0, 163.0, 75.0, 0.0, ephem.MU_EARTH)   # examples/03_geo_analysis/drift.rs:50
+    rv = b.rv()
+    b.set_rv(geo[None, :] + (rv - rv.mean(axis=0)))
+    return b
+
+
+def init_covar(n, seed=0):
+    rng = np.random.default_rng(seed)
+    a = rng.standard_normal((n, 9, 9)) * np.array([1.0, 1.0, 1.0, 1e-3, 1e-3, 1e-3, 1e-2, 0.0, 0.0])[None, :, None]
+    return a @ np.transpose(a, (0, 2, 1))
+
+
+def workload(cfg_id, degree=None):
+    """(propagator, almanac, central frame, batch maker, defaults, description) of one BASELINE configuration."""
+    if cfg_id == 2:
+        deg = 70 if degree is None else degree
+        prop, almanac, central = sc.leo_full_setup(degree=deg)
+        return dict(prop=prop, almanac=almanac, central=central, batch=sc.dispersed_leo_batch, n=10_000, hours=24.0, stm=False,
+                    flop=algorithmic_flop_per_eval(deg, 2, True, 1, False), exec_flop=executed_flop_per_eval(deg, False), degree=deg,
+                    metric="propagated trajectories/sec (10k-ensemble, 1-day RK89)",
+                    label=lambda n, h: f"configs[1]: {n}-trajectory LEO Monte Carlo per GPU, {deg}x{deg} JGM3 gravity + Sun/Moon point masses + "
+                                       f"cannonball SRP (Earth shadow), RK89 default options, {h:g} h")
+    if cfg_id == 3:
+        prop, almanac, central = sc.jwst_setup()
+        return dict(prop=prop, almanac=almanac, central=central, batch=sc.jwst_batch, n=5_000, hours=30 * 24.0, stm=False,
+                    flop=algorithmic_flop_per_eval(0, 3, True, 2, False), exec_flop=None, degree=0,
+                    metric="propagated trajectories/sec (JWST 5k-ensemble, 30-day RK89)",
+                    label=lambda n, h: f"configs[2]: {n} dispersed JWST halo-orbit states per GPU, Sun/Moon/Jupiter point masses + SRP "
+                                       f"(Earth and Moon shadows), RK89 default options, {h / 24:g} days")
+    if cfg_id == 4:
+        deg = 21 if degree is None else degree
+        prop, almanac, central = sc.leo_full_setup(degree=deg)
+        return dict(prop=prop, almanac=almanac, central=central, batch=geo_batch, n=1_000, hours=1.0, stm=True,
+                    flop=algorithmic_flop_per_eval(deg, 2, True, 1, True), exec_flop=executed_flop_per_eval(deg, True), degree=deg,
+                    metric="covariance-mapped trajectories/sec (GEO 1k-ensemble, 9x9 STM, sixty 1-minute EKF time updates)",
+                    label=lambda n, h: f"configs[3]: {n} GEO states per GPU, {deg}x{deg} JGM3 + Sun/Moon + SRP (Cr estimated), 9x9 STM, "
+                                       f"{int(round(h * 60))} one-minute time updates with STM reset (predict_until), RK89")
+    if cfg_id == 5:
+        deg = 150 if degree is None else degree
+        prop, almanac, central = sc.lunar_setup(degree=deg)
+        return dict(prop=prop, almanac=almanac, central=central, batch=sc.lunar_batch, n=6_250, hours=72.0, stm=False,
+                    flop=algorithmic_flop_per_eval(deg, 2, False, 0, False), exec_flop=executed_flop_per_eval(deg, False), degree=deg,
+                    metric="propagated trajectories/sec (LLO 50k-ensemble over 8 GPUs, 3-day DP78)",
+                    label=lambda n, h: f"configs[4]: {n} low-lunar-orbit states per GPU (50 000 over 8), {deg}x{deg} synthetic Kaula field + "
+                                       f"Earth/Sun point masses, DP78 default options, {h / 24:g} days")
+    raise SystemExit(f"unknown --config {cfg_id}")
 
 
 def tensor_states(batch: _abi.StateBatch, dev):
@@ -69,29 +157,68 @@ def tensor_stats(n, dev):
     return t, s
 
 
-def cpu_baseline(compiled, n_per_gpu, hours, seed):
-    """The oracle (CPU restatement of the reference, kind = "port") timed on this box's host cores on a bounded
-    sample of the SAME workload: full-length trajectories, as many as fit in ~20 s."""
+def host_threads():
+    """(hardware threads, physical cores) of this host."""
+    logical = os.cpu_count() or 1
+    try:
+        cores = set()
+        phys = core = None
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("physical id"):
+                phys = ln.split(":")[1].strip()
+            elif ln.startswith("core id"):
+                core = ln.split(":")[1].strip()
+            elif not ln.strip():
+                if phys is not None and core is not None:
+                    cores.add((phys, core))
+                phys = core = None
+        return logical, (len(cores) or logical)
+    except OSError:
+        return logical, logical
+
+
+def cpu_baseline(w, compiled, n_per_gpu, hours, seed):
+    """The oracle (CPU restatement of the reference, kind = "port") timed on this box's host on a bounded sample of the
+    SAME workload: one pthread per hardware thread over trajectories (rayon par_iter analogue), full-length trajectories
+    when a round of them fits the ~25 s budget, otherwise the head of the propagation (stated in `sample`)."""
     import oracle_lib
-    cores = os.cpu_count() or 1
-    probe = dispersed_leo_batch(cores, seed=seed)
+    threads, phys = host_threads()
+    probe = w["batch"](threads, seed=seed)
+    probe_h = min(0.25, hours)
     t0 = time.time()
-    oracle_lib.propagate(compiled, probe, int(0.25 * 3600) * nx.NS_PER_S, n_threads=cores)
-    per_traj_hour = (time.time() - t0) / 0.25  # seconds of wall per (cores trajectories) per hour of propagation
-    # one round = `cores` full-length trajectories, one per thread (~13 s for 24 h on this class of host); the short probe
-    # underestimates it (caches, clocks), so at most two rounds: 10-30 s of CPU work whatever the probe says
+    oracle_lib.propagate(compiled, probe, int(probe_h * 3600) * nx.NS_PER_S, n_threads=threads)
+    per_hour = (time.time() - t0) / probe_h  # wall seconds per hour of propagation of one round (`threads` trajectories)
     budget_s = 25.0
-    rounds = max(1, min(2, int(budget_s / max(per_traj_hour * hours, 1e-3))))
-    n = cores * rounds
-    sample = dispersed_leo_batch(n, seed=seed)
+    samp_h = hours
+    if per_hour * hours > budget_s:      # a full-length round does not fit: time the first `samp_h` hours instead
+        samp_h = max(probe_h, min(hours, float(int(budget_s / per_hour * 4) / 4.0)))
+    rounds = max(1, min(2, int(budget_s / max(per_hour * samp_h, 1e-3))))
+    n = threads * rounds
+    sample = w["batch"](n, seed=seed)
     t0 = time.time()
-    out, st = oracle_lib.propagate(compiled, sample, int(hours * 3600) * nx.NS_PER_S, n_threads=cores)
+    out, st = oracle_lib.propagate(compiled, sample, int(samp_h * 3600) * nx.NS_PER_S, n_threads=threads)
     dt = time.time() - t0
     assert (st.status == 0).all()
-    return {"value": n / dt, "unit": "trajectories/s", "cores": cores, "kind": "port",
-            "sample": f"{n} of the {n_per_gpu} dispersed LEO states, full {hours:g} h propagation each, {cores} pthreads "
+    frac = samp_h / hours
+    what = f"full {hours:g} h propagation each" if frac == 1.0 else \
+        f"the first {samp_h:g} h of the {hours:g} h propagation each (rate scaled by {frac:.4g}: the orbit is periodic, the cost per hour constant)"
+    return {"value": n / dt * frac, "unit": "trajectories/s", "cores": threads, "physical_cores": phys, "kind": "port",
+            "sample": f"{n} of the {n_per_gpu} dispersed states, {what}, {threads} pthreads = hardware threads on {phys} physical cores "
                       f"(rayon par_iter analogue), {dt:.1f} s wall, {int(st.n_evals.sum())} force evaluations",
-            "evals_per_s": float(st.n_evals.sum()) / dt}, sample, out
+            "evals_per_s": float(st.n_evals.sum()) / dt}, sample, out, samp_h
+
+
+def measured_traffic(cfg_id, n, hours, degree):
+    """HBM bytes per launch from the committed rocprofv3 --pmc pass of this command (profiles/*hbm_traffic*.json), if any."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic*.json"))):
+        try:
+            tj = json.load(open(path))
+        except Exception:
+            continue
+        if tj.get("config", 2) == cfg_id and tj.get("n") == n and tj.get("hours") == hours and tj.get("degree") == degree:
+            best = (tj.get("hbm_bytes_per_launch"), os.path.relpath(path, ROOT))
+    return best or (None, None)
 
 
 def main():
@@ -99,12 +226,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=10_000, help="trajectories per GPU")
-    ap.add_argument("--hours", type=float, default=24.0)
-    ap.add_argument("--degree", type=int, default=70)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json configuration (1-based; default 2 = the headline)")
+    ap.add_argument("--n", type=int, default=0, help="trajectories per GPU (0 = the configuration's own size)")
+    ap.add_argument("--hours", type=float, default=0.0, help="propagation length (0 = the configuration's own)")
+    ap.add_argument("--degree", type=int, default=None)
     ap.add_argument("--waves", type=int, default=0, help="column-split waves per workgroup (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-output", action="store_true", help="skip the extra launch with the trajectories recorded")
+    ap.add_argument("--no-host-call", action="store_true", help="skip the PCIe-inclusive host-buffer call")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -121,30 +250,51 @@ def main():
         import torch.distributed as dist  # noqa: F811
         dist.init_process_group("nccl", device_id=dev)
 
-    prop, almanac, central = leo_full_setup(degree=args.degree)
-    compiled = prop.compile(almanac, central)
+    w = workload(args.config, args.degree)
+    n = args.n or w["n"]
+    hours = args.hours or w["hours"]
+    prop, almanac, central = w["prop"], w["almanac"], w["central"]
+    compiled = prop.compile(almanac, central, stm=w["stm"])
     ctx = nx.GpuContext(compiled, device=local_rank)
     if args.waves:
         ctx.set_column_waves(args.waves)
     lib = _abi.load_library()
 
     # contiguous index shards of ONE ensemble: rank r owns trajectories [r*n, (r+1)*n) (seed = global stream)
-    full = dispersed_leo_batch(args.n * world, seed=0)
-    shard = full.slice(rank * args.n, (rank + 1) * args.n)
-    tin, sin = tensor_states(shard, dev)
-    tout, sout = tensor_states(shard, dev)
-    tst, sst = tensor_stats(args.n, dev)
-    dur_ns = int(args.hours * 3600) * nx.NS_PER_S
+    full = w["batch"](n * world, seed=0)
+    shard = full.slice(rank * n, (rank + 1) * n)
+    dur_ns = int(round(hours * 3600)) * nx.NS_PER_S
     stream = torch.cuda.current_stream(dev)
-    gathered = [torch.empty((args.n, 7), dtype=torch.float64, device=dev) for _ in range(world)] if world > 1 else None
+    gathered = [torch.empty((n, 7), dtype=torch.float64, device=dev) for _ in range(world)] if world > 1 else None
+    host_call = None
 
-    def step():
-        rc = lib.nyx_hip_propagate_batch_device(ctx._h, C.byref(sin), dur_ns, C.byref(sout), C.byref(sst), C.c_void_p(stream.cuda_stream))
-        if rc != 0:
-            raise RuntimeError(_abi.last_error())
-        if world > 1:  # final-state collection over RCCL/xGMI (one all-gather, latency-bound: n x 7 f64)
-            final = torch.stack([tout[f] for f in _abi.F64_FIELDS[:6]] + [tout["epoch_ns"].to(torch.float64)], dim=1)
-            dist.all_gather(gathered, final)
+    if not w["stm"]:
+        tin, sin = tensor_states(shard, dev)
+        tout, sout = tensor_states(shard, dev)
+        tst, sst = tensor_stats(n, dev)
+
+        def step():
+            rc = lib.nyx_hip_propagate_batch_device(ctx._h, C.byref(sin), dur_ns, C.byref(sout), C.byref(sst), C.c_void_p(stream.cuda_stream))
+            if rc != 0:
+                raise RuntimeError(_abi.last_error())
+            if world > 1:  # final-state collection over RCCL/xGMI (one all-gather, latency-bound: n x 7 f64)
+                final = torch.stack([tout[f] for f in _abi.F64_FIELDS[:6]] + [tout["epoch_ns"].to(torch.float64)], dim=1)
+                dist.all_gather(gathered, final)
+    else:
+        # covariance mapping: the C-ABI entry takes host buffers (states, covariances) and keeps the whole segment /
+        # time-update loop on one stream; the timed region therefore includes the one H2D and the one D2H of the call
+        shard.stm = np.zeros((n, 81))
+        shard.reset_stm()
+        p0 = init_covar(n)
+        end_ns = int(shard.epoch_ns[0]) + dur_ns
+        last = {}
+
+        def step():
+            last["res"] = nx.predict_until(ctx, shard, p0, end_ns, 60 * nx.NS_PER_S)
+            if world > 1:
+                r = last["res"].states
+                final = torch.from_numpy(np.concatenate([r.rv(), r.epoch_ns[:, None].astype(np.float64)], axis=1)).to(dev)
+                dist.all_gather(gathered, final)
 
     def barrier():
         if world > 1:
@@ -158,7 +308,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        kernel_ms.append(ctx.last_kernel_ms())  # HIP events recorded on the launch stream around the kernel
+        kernel_ms.append(ctx.last_kernel_ms() if not w["stm"] else last["res"].kernel_ms)  # HIP events on the launch stream
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -166,53 +316,75 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    n_evals = int(tst["n_evals"].sum().item())
-    n_bad = int((tst["status"] != 0).sum().item())
-    n_acc, n_rej = int(tst["n_accepted"].sum().item()), int(tst["n_rejected"].sum().item())
+    if not w["stm"]:
+        n_evals = int(tst["n_evals"].sum().item())
+        n_bad = int((tst["status"] != 0).sum().item())
+        n_acc, n_rej = int(tst["n_accepted"].sum().item()), int(tst["n_rejected"].sum().item())
+    else:
+        st = last["res"].stats
+        n_evals, n_bad = int(st.n_evals.sum()), int((st.status != 0).sum())
+        n_acc, n_rej = int(st.n_accepted.sum()), int(st.n_rejected.sum())
     if n_bad:
         raise SystemExit(f"{n_bad} trajectories failed")
     k_ms = float(np.mean(kernel_ms))
-    total_traj = args.n * world
+    total_traj = n * world
     value = total_traj * args.steps / elapsed
 
     if rank == 0:
-        flops = n_evals * FLOP_PER_EVAL
+        flops = n_evals * w["flop"]
         achieved_tf = flops / (k_ms * 1e-3) / 1e12
-        hbm_gbps = args.n * BYTES_PER_TRAJ / (k_ms * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "round01_hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("n") == args.n and tj.get("hours") == args.hours and tj.get("degree") == args.degree:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        alg_gbps = n * BYTES_PER_TRAJ / (k_ms * 1e-3) / 1e9
+        traffic, traffic_src = measured_traffic(args.config, n, hours, w["degree"])
+        # CU occupancy of the launch: trajectory-owning workgroups (64 trajectories each) + cooperative-mode helpers
+        owners = (n + 63) // 64
+        helpers = ctx.last_coop_helpers() if not w["stm"] else 0
         line = {
-            "metric": "propagated trajectories/sec (10k-ensemble, 1-day RK89)",
+            "metric": w["metric"],
             "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"configs[1]: {args.n}-trajectory LEO Monte Carlo per GPU, {args.degree}x{args.degree} JGM3 gravity + "
-                                   f"Sun/Moon point masses + cannonball SRP (Earth shadow), RK89 default options, {args.hours:g} h",
-                       "trajectories_per_gpu": args.n, "column_waves": args.waves or "auto",
+            "config": {"workload": w["label"](n, hours), "baseline_config": args.config,
+                       "trajectories_per_gpu": n, "column_waves": args.waves or "auto",
                        "sharding": "contiguous index shards, no data-path collective; one RCCL all-gather of final states per step"},
             "force_evals_per_s": n_evals * world / (elapsed / args.steps),
             "force_evals_per_launch": n_evals, "accepted_steps": n_acc, "rejected_attempts": n_rej,
             "kernel_ms": k_ms,
+            "occupancy": {"workgroups": owners + helpers, "owner_workgroups": owners, "helper_workgroups": helpers, "cus": N_CU,
+                          "cu_fraction": min(1.0, (owners + helpers) / N_CU)},
             "roofline": {"bound": "valu_fp64", "achieved": achieved_tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved_tf / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic,
-                         "algorithmic_flop_per_eval": FLOP_PER_EVAL,
-                         "hbm": {"achieved": hbm_gbps, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": hbm_gbps / HBM_PEAK_GBPS,
+                         "frac": achieved_tf / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_flop_per_eval": w["flop"],
+                         "hbm": {"algorithmic": alg_gbps, "achieved": (traffic / (k_ms * 1e-3) / 1e9) if traffic else None,
+                                 "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "frac": ((traffic / (k_ms * 1e-3) / 1e9) if traffic else alg_gbps) / HBM_PEAK_GBPS,
                                  "algorithmic_bytes_per_trajectory": BYTES_PER_TRAJ}},
         }
-        if world == 1 and not args.no_dense_output:
+        if w["exec_flop"]:
+            # what the kernel itself issues for the harmonics (lower than the reference formulation's count): the f64-pipe view
+            ex_tf = n_evals * w["exec_flop"] / (k_ms * 1e-3) / 1e12
+            line["roofline"]["executed_harmonics_flop_per_eval"] = w["exec_flop"]
+            line["roofline"]["executed_frac"] = ex_tf / FP64_VECTOR_PEAK_TFLOPS
+        if world == 1 and not args.no_host_call:
+            # SURVEY 8d "report both": the same batch through the HOST-buffer entry (H2D of the states, kernel, D2H of the
+            # results inside the call; ctx_create excluded), timed once with the wall clock
+            if not w["stm"]:
+                t1 = time.perf_counter()
+                out_h, st_h = ctx.propagate(shard, dur_ns)
+                wall = time.perf_counter() - t1
+                host_call = {"ms": wall * 1e3, "value": n / wall, "unit": "trajectories/s", "kernel_ms": ctx.last_kernel_ms(),
+                             "note": "nyx_hip_propagate_batch on host buffers: PCIe-inclusive wall time of one call"}
+            else:
+                host_call = {"ms": elapsed / args.steps * 1e3, "value": value, "unit": "trajectories/s", "kernel_ms": k_ms,
+                             "note": "nyx_hip_predict_until takes host buffers: the timed steps ARE PCIe-inclusive; kernel_ms = the "
+                                     "device time of the segment + time-update launches"}
+            line["host_call"] = host_call
+        if world == 1 and not args.no_dense_output and not w["stm"] and args.config == 2:
             # The reference's Monte Carlo runs `until_epoch_with_traj` (mc/montecarlo.rs:236-239): the same launch with the
             # dense output on (every accepted state of every run appended in HBM), timed once, reported beside the headline.
             cap = int(tst["n_accepted"].max().item()) + 2
-            t_ep = torch.zeros((cap, args.n), dtype=torch.int64, device=dev)
-            t_st = torch.zeros((6, cap, args.n), dtype=torch.float64, device=dev)
-            t_len = torch.zeros(args.n, dtype=torch.int32, device=dev)
+            t_ep = torch.zeros((cap, n), dtype=torch.int64, device=dev)
+            t_st = torch.zeros((6, cap, n), dtype=torch.float64, device=dev)
+            t_len = torch.zeros(n, dtype=torch.int32, device=dev)
             tr = _abi.Traj()
             tr.capacity = cap
             tr.epoch_ns = C.cast(t_ep.data_ptr(), _abi.c_int64_p)
@@ -226,17 +398,41 @@ def main():
             torch.cuda.synchronize(dev)
             d_ms = ctx.last_kernel_ms()
             n_states = int(t_len.sum().item())
-            line["dense_output"] = {"kernel_ms": d_ms, "value": args.n / (d_ms * 1e-3), "unit": "trajectories/s",
+            line["dense_output"] = {"kernel_ms": d_ms, "value": n / (d_ms * 1e-3), "unit": "trajectories/s",
                                     "states_written": n_states, "bytes_written": n_states * 56,
                                     "note": "one launch of nyx_hip_propagate_batch_with_traj_device (until_epoch_with_traj of every run)"}
             del t_ep, t_st, t_len
         if not args.no_cpu_baseline and world == 1:
-            cb, sample, ref = cpu_baseline(compiled, args.n, args.hours, seed=0)
-            # the sample is the head of this rank's shard: check parity on it while we are here
-            got = np.stack([tout[f][: sample.n].cpu().numpy() for f in _abi.F64_FIELDS[:6]], axis=1)
-            d = got - ref.rv()
-            cb["parity_on_sample"] = {"max_dr_m": float(np.linalg.norm(d[:, :3], axis=1).max() * 1e3),
-                                      "max_dv_mm_s": float(np.linalg.norm(d[:, 3:], axis=1).max() * 1e6)}
+            if not w["stm"]:
+                cb, sample, ref, samp_h = cpu_baseline(w, compiled, n, hours, seed=0)
+                if samp_h == hours:
+                    # the sample is the head of this rank's shard: check parity on it while we are here
+                    got = np.stack([tout[f][: sample.n].cpu().numpy() for f in _abi.F64_FIELDS[:6]], axis=1)
+                else:
+                    # the CPU sample stops early: propagate the same head for the same span on the device for the comparison
+                    o2, s2 = ctx.propagate(sample, int(samp_h * 3600) * nx.NS_PER_S)
+                    assert (s2.status == 0).all()
+                    got = o2.rv()
+                d = got - ref.rv()
+                cb["parity_on_sample"] = {"max_dr_m": float(np.linalg.norm(d[:, :3], axis=1).max() * 1e3),
+                                          "max_dv_mm_s": float(np.linalg.norm(d[:, 3:], axis=1).max() * 1e6)}
+            else:
+                import oracle_lib
+                threads, phys = host_threads()
+                ns = min(n, 256)
+                sb = shard.slice(0, ns)
+                t1 = time.time()
+                ref = oracle_lib.predict_until(compiled, sb, p0[:ns], end_ns, 60 * nx.NS_PER_S)
+                dt = time.time() - t1
+                got = last["res"]
+                scale = np.maximum(np.abs(ref.covar), 1e-6 * np.abs(ref.covar).max(axis=(-2, -1), keepdims=True))
+                d = got.states.rv()[:ns] - ref.states.rv()
+                cb = {"value": ns / dt, "unit": "trajectories/s", "cores": 1, "physical_cores": phys, "kind": "port",
+                      "sample": f"{ns} of the {n} GEO states, all {int(round(hours * 60))} one-minute time updates each, the oracle's predict_until "
+                                f"twin on ONE thread (the reference's OD process is sequential per estimate), {dt:.1f} s wall",
+                      "parity_on_sample": {"max_dr_m": float(np.linalg.norm(d[:, :3], axis=1).max() * 1e3),
+                                           "max_dv_mm_s": float(np.linalg.norm(d[:, 3:], axis=1).max() * 1e6),
+                                           "max_rel_covar": float((np.abs(got.covar[:ns] - ref.covar) / scale).max())}}
             line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -102,6 +102,9 @@ typedef struct nyx_hip_cheby_segment {
     int32_t n_coeffs;
     const double *records; /* n_records * (2 + 3*n_coeffs) doubles */
 } nyx_hip_cheby_segment_t;
+/* The device Clenshaw loop walks a fixed window: segments with more coefficients per component are refused by
+ * nyx_hip_ctx_create (NYX_HIP_RC_UNSUPPORTED), never truncated.  DE440s uses 11-13. */
+#define NYX_HIP_MAX_CHEBY_COEFFS 16
 
 #define NYX_HIP_MAX_CHAIN 4
 #define NYX_HIP_MAX_BODIES 8
@@ -257,9 +260,13 @@ typedef struct nyx_hip_ctx nyx_hip_ctx;
 /* Number of visible HIP devices (0 if none / no runtime). */
 int32_t nyx_hip_device_count(void);
 
-/* Builds an immutable propagation context on `device`: validates the config,
- * precomputes the recursion tables (GravityField::new, gravity_field.rs:52-132)
- * and uploads every shared table once.  `Propagator::new` + `Arc<Almanac>` analogue. */
+/* Builds a propagation context on `device`: validates the config (counts, chain lengths, segment shapes: bad input is
+ * NYX_HIP_RC_BAD_ARG / _UNSUPPORTED, never silently clipped), precomputes the recursion tables (GravityField::new,
+ * gravity_field.rs:52-132) and uploads every shared table once.  `Propagator::new` + `Arc<Almanac>` analogue.
+ * Concurrency: the physical model is immutable, and every entry point takes the context's lock, so host threads may
+ * share a context (`Send + Sync`).  On the device the launches of ONE context run one after the other whatever their
+ * streams (they share the launch descriptor, the cooperative-mode mailboxes and the staging blocks; each launch waits
+ * on the previous one's completion event).  For kernels that overlap, create one context per stream. */
 int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t device, nyx_hip_ctx **out);
 void nyx_hip_ctx_destroy(nyx_hip_ctx *ctx);
 

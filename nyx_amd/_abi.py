@@ -21,6 +21,8 @@ RK89, DP78, DP45, RK4, CASHKARP45, VERNER56 = range(6)
 RSS_CARTESIAN_STATE, RSS_CARTESIAN_STEP, RSS_STATE, RSS_STEP, LARGEST_ERROR, LARGEST_STATE, LARGEST_STEP = range(7)
 # enum nyx_hip_status
 OK, ERR_NAN, ERR_MASSLESS, ERR_FUEL_EXHAUSTED, ERR_EPHEM_RANGE, ERR_UNSUPPORTED, ERR_EVENT_NOT_FOUND, ERR_EVENT_SEARCH = range(8)
+# return codes of the entry points (enum nyx_hip_rc)
+RC_OK, RC_BAD_ARG, RC_NO_DEVICE, RC_HIP_ERROR, RC_UNSUPPORTED = range(5)
 STATUS_NAMES = ["Ok", "PropMathError(NaN)", "MasslessSpacecraft", "FuelExhausted", "EphemerisOutOfRange", "Unsupported",
                 "NthEventError", "EventSearchFailed"]
 # enum nyx_hip_interp_status

@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/nyx_hip.h"
@@ -87,7 +88,14 @@ struct nyx_hip_ctx {
     int last_coop_helpers = 0;  // helpers of the last launch (0 = solo)
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double last_ms = -1.0;
+    // Concurrency contract (nyx_hip.h): every entry point locks `mu`, so host threads may share a context; on the DEVICE the
+    // launches of one context are chained through `ev_done` (each launch waits for the previous one, whatever its stream),
+    // because they share d_cfg, the cooperative-mode mailboxes and the staging blocks.  Concurrent kernels => one ctx each.
+    std::recursive_mutex mu;
+    hipEvent_t ev_done = nullptr;
+    bool launched = false;
 };
+#define CTX_LOCK(ctx) std::lock_guard<std::recursive_mutex> lock_((ctx)->mu)
 
 static void free_arrays(DevArrays &a) {
     (void)hipFree(a.dblock);
@@ -399,6 +407,7 @@ static int pick_waves(const nyx_hip_ctx *ctx, int64_t n) {
 
 extern "C" int32_t nyx_hip_ctx_set_column_waves(nyx_hip_ctx *ctx, int32_t waves) {
     if (!ctx || waves < 0 || waves > DEV_MAX_WAVES) return NYX_HIP_RC_BAD_ARG;
+    CTX_LOCK(ctx);
     ctx->forced_waves = waves;
     return NYX_HIP_RC_OK;
 }
@@ -407,6 +416,7 @@ extern "C" int32_t nyx_hip_last_coop_helpers(nyx_hip_ctx *ctx) { return ctx ? ct
 
 extern "C" double nyx_hip_last_kernel_ms(nyx_hip_ctx *ctx) {
     if (!ctx || !ctx->ev1) return -1.0;
+    CTX_LOCK(ctx);
     if (hipEventSynchronize(ctx->ev1) != hipSuccess) return -1.0;
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) != hipSuccess) return -1.0;
@@ -430,6 +440,7 @@ extern "C" void nyx_hip_ctx_destroy(nyx_hip_ctx *ctx) {
     (void)hipFree(ctx->d_coop);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    if (ctx->ev_done) hipEventDestroy(ctx->ev_done);
     delete ctx;
 }
 
@@ -462,6 +473,25 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
             !(cfg->tides->eq_radius_km > 0.0)) {
             nyx_set_error("bad solid-tides model");
             return NYX_HIP_RC_BAD_ARG;
+        }
+    }
+    // ---- plain-data validation: nothing below may index past what the device code assumes
+    if (cfg->n_bodies < 0 || cfg->n_bodies > NYX_HIP_MAX_BODIES || (cfg->n_bodies > 0 && !cfg->bodies) || cfg->n_segments < 0 ||
+        (cfg->n_segments > 0 && !cfg->segments) || cfg->n_point_masses < 0 || cfg->n_point_masses > NYX_HIP_MAX_BODIES) {
+        nyx_set_error("bad body / segment / point-mass counts"); return NYX_HIP_RC_BAD_ARG;
+    }
+    for (int b = 0; b < cfg->n_bodies; ++b)
+        if (cfg->bodies[b].n_chain < 0 || cfg->bodies[b].n_chain > NYX_HIP_MAX_CHAIN) {
+            nyx_set_error("body %d: n_chain %d outside 0..%d", b, cfg->bodies[b].n_chain, NYX_HIP_MAX_CHAIN); return NYX_HIP_RC_BAD_ARG;
+        }
+    for (int i = 0; i < cfg->n_segments; ++i) {
+        const nyx_hip_cheby_segment_t &sg = cfg->segments[i];
+        if (sg.n_coeffs < 1 || sg.n_records < 1 || !(sg.interval_s > 0.0) || !sg.records) {
+            nyx_set_error("segment %d: n_coeffs >= 1, n_records >= 1, interval_s > 0 and records are required", i); return NYX_HIP_RC_BAD_ARG;
+        }
+        if (sg.n_coeffs > NYX_HIP_MAX_CHEBY_COEFFS) {  // the device Clenshaw loop walks a fixed 16-wide window (cheby_eval)
+            nyx_set_error("segment %d: %d Chebyshev coefficients per component, the device path evaluates at most %d", i, sg.n_coeffs, NYX_HIP_MAX_CHEBY_COEFFS);
+            return NYX_HIP_RC_UNSUPPORTED;
         }
     }
     if (nyx_hip_device_count() <= device || device < 0) { nyx_set_error("no HIP device %d", device); return NYX_HIP_RC_NO_DEVICE; }
@@ -635,6 +665,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
     HIP_TRY(hipMemcpy(ctx->d_records, records.data(), records.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(hipEventCreate(&ctx->ev0));
     HIP_TRY(hipEventCreate(&ctx->ev1));
+    HIP_TRY(hipEventCreateWithFlags(&ctx->ev_done, hipEventDisableTiming));
     *out = ctx;
     return NYX_HIP_RC_OK;
 }
@@ -646,6 +677,8 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
 static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t *out, nyx_hip_step_stats_t *st,
                   int64_t duration_ns, int64_t end_epoch_ns, int use_end, hipStream_t stream, bool time_it,
                   const nyx_hip_traj_t *traj = nullptr, const int64_t *dur_ns = nullptr, const DevBatch *ev = nullptr) {
+    CTX_LOCK(ctx);
+    if (ctx->launched) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_done, 0));  // one launch of a context at a time on the device
     const int nw = pick_waves(ctx, in->n);
     if (nw != ctx->host_cfg.n_waves) {
         build_schedule(ctx, nw);
@@ -748,6 +781,8 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
     HIP_TRY(nyx_launch_propagate(bt, ctx->d_cfg, ctx->d_htab, ctx->d_cols, ctx->d_records, nw,
                                  ctx->host_cfg.rec_in_lds ? ctx->host_cfg.rec_doubles : 0, ctx->host_cfg.ed_reuse, stream));
     if (time_it) HIP_TRY(hipEventRecord(ctx->ev1, stream));
+    HIP_TRY(hipEventRecord(ctx->ev_done, stream));
+    ctx->launched = true;
     return NYX_HIP_RC_OK;
 }
 
@@ -765,6 +800,7 @@ extern "C" int32_t nyx_hip_propagate_batch_device(nyx_hip_ctx *ctx, const nyx_hi
     if (int rc = check_states(in, "in")) return rc;
     if (int rc = check_states(out, "out")) return rc;
     if (in->n == 0) return NYX_HIP_RC_OK;
+    CTX_LOCK(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
     int rc = launch(ctx, in, out, stats, duration_ns, 0, 0, (hipStream_t)hip_stream, true);
     return rc;
@@ -777,6 +813,7 @@ extern "C" int32_t nyx_hip_propagate_batch_with_traj_device(nyx_hip_ctx *ctx, co
     if (int rc = check_states(in, "in")) return rc;
     if (int rc = check_states(out, "out")) return rc;
     if (in->n == 0) return NYX_HIP_RC_OK;
+    CTX_LOCK(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
     return launch(ctx, in, out, stats, duration_ns, 0, 0, (hipStream_t)hip_stream, true, traj);
 }
@@ -866,6 +903,7 @@ static int host_propagate(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t 
     const int64_t n = in->n;
     if (n == 0) return NYX_HIP_RC_OK;
     if (out->n < n) { nyx_set_error("out batch smaller than in batch"); return NYX_HIP_RC_BAD_ARG; }
+    CTX_LOCK(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
     Staged sg;
     if (int rc = stage_batch(ctx, in, out, sg)) return rc;
@@ -946,13 +984,17 @@ static int traj_eval_device(nyx_hip_ctx *ctx, const nyx_hip_traj_t *traj, int64_
         return NYX_HIP_RC_BAD_ARG;
     }
     if (n == 0) return NYX_HIP_RC_OK;
+    CTX_LOCK(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
     TrajEvalArgs a;
     std::memset(&a, 0, sizeof a);
     a.src = *traj; a.dst = *out; a.n = n; a.query = query; a.m = m; a.step_ns = step_ns; a.status = status; a.mode = mode;
+    if (ctx->launched) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_done, 0));
     HIP_TRY(hipEventRecord(ctx->ev0, stream));
     HIP_TRY(nyx_launch_traj_eval(&a, stream));
     HIP_TRY(hipEventRecord(ctx->ev1, stream));
+    HIP_TRY(hipEventRecord(ctx->ev_done, stream));
+    ctx->launched = true;
     return NYX_HIP_RC_OK;
 }
 
@@ -1016,6 +1058,7 @@ static int traj_eval_host(nyx_hip_ctx *ctx, const nyx_hip_traj_t *traj, int64_t 
     if (int rc = check_traj(traj, "traj", true)) return rc;
     if (int rc = check_traj(out, "out", true)) return rc;
     if (n <= 0) return n == 0 ? NYX_HIP_RC_OK : NYX_HIP_RC_BAD_ARG;
+    CTX_LOCK(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
     DevTraj src, dst;
     if (int rc = src.alloc(traj->capacity, n)) return rc;
@@ -1091,6 +1134,7 @@ extern "C" int32_t nyx_hip_propagate_until_event(nyx_hip_ctx *ctx, const nyx_hip
     const int64_t n = in->n;
     if (n == 0) return NYX_HIP_RC_OK;
     if (out->n < n) { nyx_set_error("out batch smaller than in batch"); return NYX_HIP_RC_BAD_ARG; }
+    CTX_LOCK(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
     Staged sg;
     if (int rc = stage_batch(ctx, in, out, sg)) return rc;
@@ -1142,6 +1186,7 @@ extern "C" int32_t nyx_hip_predict_until(nyx_hip_ctx *ctx, const nyx_hip_states_
     const int64_t n = in->n;
     if (n == 0) return NYX_HIP_RC_OK;
     if (out->n < n) { nyx_set_error("out batch smaller than in batch"); return NYX_HIP_RC_BAD_ARG; }
+    CTX_LOCK(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
     Staged sg;
     if (int rc = stage_batch(ctx, in, out, sg, /*upload_stm=*/false)) return rc;
@@ -1221,6 +1266,7 @@ extern "C" int32_t nyx_hip_predict_until(nyx_hip_ctx *ctx, const nyx_hip_states_
 // Introspection for tests / DESIGN.md: column schedule of the current context.
 extern "C" int32_t nyx_hip_debug_schedule(nyx_hip_ctx *ctx, int32_t n_waves, int32_t *loads /* [8] */) {
     if (!ctx || n_waves < 1 || n_waves > DEV_MAX_WAVES) return NYX_HIP_RC_BAD_ARG;
+    CTX_LOCK(ctx);
     const int keep = ctx->host_cfg.n_waves;
     build_schedule(ctx, n_waves);
     for (int w = 0; w < DEV_MAX_WAVES; ++w) {

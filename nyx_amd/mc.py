@@ -217,6 +217,9 @@ class Results:
     _traj_ctx: object = field(default=None, repr=False)
     _traj_batch: object = field(default=None, repr=False)
     _traj_rows: dict = field(default_factory=dict, repr=False)   # run index -> row of the dense-output batch
+    # sharded ensemble: the process group and the positions [lo, hi) of `runs` this rank propagated (and holds trajectories of)
+    _dist: object = field(default=None, repr=False)
+    _local: Optional[tuple] = field(default=None, repr=False)
 
     def ok_runs(self) -> List[Run]:
         return [r for r in self.runs if isinstance(r.result, PropResult)]
@@ -224,9 +227,30 @@ class Results:
     def final_rv(self) -> np.ndarray:
         return np.array([r.result.state.rv for r in self.ok_runs()])
 
+    def _local_runs(self) -> List[Run]:
+        return self.runs if self._local is None else self.runs[self._local[0]:self._local[1]]
+
     def mean_and_covariance(self):
-        x = self.final_rv()
-        return x.mean(axis=0), np.cov(x, rowvar=False)
+        """Ensemble mean and (unbiased) covariance of the final 9-vectors [r, v, Cr, Cd, prop mass] of the successful runs.
+        On a sharded ensemble each rank sums ITS runs only and one all-reduce (RCCL / gloo) of the 1 + 9 + 45 moments
+        [count, sum(x - x0), upper triangle of sum((x - x0)(x - x0)^T)] completes them; x0 = the final state of the
+        first successful run (every rank holds the gathered final states), which keeps the sums well conditioned.
+        Returns (mean[9], cov[9, 9])."""
+        d = STATE_DIM
+        ok = self.ok_runs()
+        x0 = _vec9(ok[0].result.state) if ok else np.zeros(d)
+        xs = np.array([_vec9(r.result.state) for r in self._local_runs() if isinstance(r.result, PropResult)]).reshape(-1, d) - x0
+        iu = np.triu_indices(d)
+        mom = np.concatenate([[float(len(xs))], xs.sum(axis=0), (xs.T @ xs)[iu]])
+        if self._dist is not None and self._dist.get_world_size() > 1:
+            mom = all_reduce_sum(self._dist, mom)
+        n, sx = mom[0], mom[1:1 + d]
+        sxx = np.zeros((d, d))
+        sxx[iu] = mom[1 + d:]
+        sxx = sxx + np.triu(sxx, 1).T
+        mean = sx / n
+        cov = (sxx - n * np.outer(mean, mean)) / (n - 1.0) if n > 1 else np.full((d, d), np.nan)
+        return mean + x0, cov
 
     # ---- reports (results.rs:86-245): one flat list, run after run, failed runs replaced by `value_if_run_failed`
     def _value(self, param: StateParameter, run: Run, rv: np.ndarray) -> np.ndarray:
@@ -235,8 +259,10 @@ class Results:
                            extra_mass_kg=getattr(s, "extra_mass_kg", 0.0))
 
     def _report(self, param: StateParameter, states_of_run, value_if_run_failed: Optional[float]) -> List[float]:
+        """One flat list, run after run.  Sharded ensemble: every rank reports the runs it propagated (it holds their
+        trajectories) and the pieces are gathered in rank order = index order (contiguous shards): a collective call."""
         report: List[float] = []
-        for run in self.runs:
+        for run in self._local_runs():
             if not isinstance(run.result, PropResult):
                 if value_if_run_failed is not None:
                     report.append(float(value_if_run_failed))
@@ -248,11 +274,13 @@ class Results:
                 # (the reference pushes the substitute once per state that cannot be evaluated)
                 if value_if_run_failed is not None:
                     report.extend([float(value_if_run_failed)] * len(rv))
+        if self._dist is not None and self._dist.get_world_size() > 1:
+            report = all_gather_lists(self._dist, report)
         return report
 
     def _need_traj(self):
         if self._traj_batch is None:
-            raise ValueError("these results carry no trajectories (with_traj=False or a sharded run)")
+            raise ValueError("these results carry no trajectories (with_traj=False)")
 
     def every_value_of(self, param: StateParameter, step_ns: int, value_if_run_failed: Optional[float] = None) -> List[float]:
         """results.rs:127-160: `param` of every run from the start to the end of its trajectory every `step_ns`."""
@@ -260,7 +288,7 @@ class Results:
         tb = self._traj_batch
         last = np.array([tb.epoch_ns[max(min(int(tb.len[i]), tb.capacity) - 1, 0), i] for i in range(tb.n)])
         count = int(np.max(np.abs(last - tb.epoch_ns[0]) // abs(int(step_ns)))) + 1 if tb.n else 1
-        res = self._traj_ctx.traj_every(tb, int(step_ns), count)
+        res = self._traj_ctx.traj_every(tb, int(step_ns), count) if tb.n else None   # (each rank resamples ITS shard on its device)
         return self._report(param, lambda run: res.trajectory(self._traj_rows[run.index])[1], value_if_run_failed)
 
     def every_value_of_between(self, param: StateParameter, step_ns: int, start_ns: int, end_ns: int,
@@ -308,6 +336,10 @@ class Results:
             else:
                 raise StateError(param)
         return report
+
+
+def _vec9(sc) -> np.ndarray:
+    return np.concatenate([np.asarray(sc.rv, dtype=np.float64), [float(sc.cr), float(sc.cd), float(sc.prop_mass_kg)]])
 
 
 def shard_bounds(n: int, rank: int, world: int):
@@ -397,8 +429,12 @@ class MonteCarlo:
     def _run(self, prop, almanac, skip, num_runs, dist, run, fn_arg) -> Results:
         from .propagator import PropagationError, pack_spacecraft
 
-        states = self.generate_states(skip, num_runs, self.seed)
         rank, world = (dist.get_rank(), dist.get_world_size()) if dist is not None else (0, 1)
+        seed = self.seed
+        if world > 1 and seed is None:
+            # every rank regenerates the whole stream and keeps its shard: without a seed they must still draw the SAME one
+            seed = broadcast_seed(dist, None)
+        states = self.generate_states(skip, num_runs, seed if seed is not None else None)
         lo, hi = shard_bounds(len(states), rank, world)
         mine = states[lo:hi]
         batch = pack_spacecraft([s for _, s in mine], False)
@@ -425,10 +461,61 @@ class MonteCarlo:
                 runs.append(Run(index, s, PropagationError(status, index)))
         rows = {index: k - lo for k, (index, _) in enumerate(states) if lo <= k < hi} if traj_batch is not None else {}
         runs.sort(key=lambda r: r.index)  # par_sort_by_key(index), montecarlo.rs:267
-        # reports need every run's trajectory: only a process that propagated the whole ensemble can make them
-        whole = traj_batch is not None and lo == 0 and hi == len(states)
-        return Results(runs, self.scenario, float(self.random_state.template.frame.mu_km3_s2),
-                       traj_ctx if whole else None, traj_batch if whole else None, rows if whole else {})
+        # every rank holds every final state; trajectories (and hence the reports' raw material) stay on the rank that
+        # propagated them: Results gathers the report pieces / reduces the moments over `dist` (index order = rank order,
+        # runs being sorted by index and the shards contiguous)
+        sharded = dist is not None and world > 1
+        return Results(runs, self.scenario, float(self.random_state.template.frame.mu_km3_s2), traj_ctx, traj_batch, rows,
+                       dist if sharded else None, (lo, hi) if sharded else None)
+
+
+def _coll_device(dist):
+    import torch
+
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def all_reduce_sum(dist, v: np.ndarray) -> np.ndarray:
+    """One all-reduce (sum) of a small f64 vector: the ensemble moments (RCCL over xGMI on GPUs; latency-bound at 55 doubles)."""
+    import torch
+
+    t = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64)).to(_coll_device(dist))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
+
+
+def broadcast_seed(dist, seed: Optional[int]) -> int:
+    """A 128-bit seed agreed by all ranks: rank 0's (drawn from the OS when None, as the reference does), as four int32-safe
+    limbs in one int64 tensor."""
+    import torch
+
+    if dist.get_rank() == 0:
+        seed = int.from_bytes(os.urandom(16), "little") if seed is None else int(seed)
+    limbs = [((seed or 0) >> (32 * k)) & 0xFFFFFFFF for k in range(4)]
+    t = torch.tensor(limbs, dtype=torch.int64, device=_coll_device(dist))
+    dist.broadcast(t, src=0)
+    return sum(int(x) << (32 * k) for k, x in enumerate(t.cpu().tolist()))
+
+
+def all_gather_lists(dist, local: List[float]) -> List[float]:
+    """Ragged all-gather of per-rank report pieces, concatenated in rank order: lengths first, then one padded all-gather."""
+    import torch
+
+    dev = _coll_device(dist)
+    world = dist.get_world_size()
+    n = torch.tensor([len(local)], dtype=torch.int64, device=dev)
+    lens = [torch.zeros_like(n) for _ in range(world)]
+    dist.all_gather(lens, n)
+    lens = [int(x.item()) for x in lens]
+    buf = torch.zeros(max(max(lens), 1), dtype=torch.float64, device=dev)
+    if local:
+        buf[: len(local)] = torch.tensor(local, dtype=torch.float64).to(dev)
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    out: List[float] = []
+    for r in range(world):
+        out.extend(parts[r][: lens[r]].cpu().tolist())
+    return out
 
 
 def all_gather_rows(dist, local: np.ndarray, bounds) -> np.ndarray:

@@ -20,7 +20,9 @@ fallback in this module.
 from __future__ import annotations
 
 import ctypes as C
+import dataclasses
 import enum
+import hashlib
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
@@ -624,30 +626,46 @@ class GpuContext:
             raise RuntimeError(f"nyx_hip_propagate_batch failed (rc={rc}): {_abi.last_error()}")
         return out, stats
 
-    def propagate_with_traj(self, batch: _abi.StateBatch, duration_ns: int, capacity: int):
-        """Batch form of `for_duration_with_traj` (instance.rs:297-326): final states, stats and the accepted states."""
-        out = batch.copy()
-        stats = _abi.StatsBatch(batch.n)
-        traj = _abi.TrajBatch(batch.n, int(capacity))
-        cin, cout, cst, ctr = batch.as_c(), out.as_c(), stats.as_c(), traj.as_c()
-        rc = self._lib.nyx_hip_propagate_batch_with_traj(self._h, C.byref(cin), int(duration_ns), C.byref(cout), C.byref(cst), C.byref(ctr))
-        if rc != 0:
-            raise RuntimeError(f"nyx_hip_propagate_batch_with_traj failed (rc={rc}): {_abi.last_error()}")
-        return out, stats, traj
+    def propagate_with_traj(self, batch: _abi.StateBatch, duration_ns: int, capacity: int, grow: bool = True):
+        """Batch form of `for_duration_with_traj` (instance.rs:297-326): final states, stats and the accepted states.
+        The kernel stops STORING at `capacity` accepted states per run but keeps counting (`traj.len`): with `grow` (default)
+        the launch is repeated with the needed capacity, so no caller ever sees a clipped trajectory; `grow=False` raises."""
+        cap = max(int(capacity), 1)
+        while True:
+            out = batch.copy()
+            stats = _abi.StatsBatch(batch.n)
+            traj = _abi.TrajBatch(batch.n, cap)
+            cin, cout, cst, ctr = batch.as_c(), out.as_c(), stats.as_c(), traj.as_c()
+            rc = self._lib.nyx_hip_propagate_batch_with_traj(self._h, C.byref(cin), int(duration_ns), C.byref(cout), C.byref(cst), C.byref(ctr))
+            if rc != 0:
+                raise RuntimeError(f"nyx_hip_propagate_batch_with_traj failed (rc={rc}): {_abi.last_error()}")
+            need = int(traj.len.max()) if batch.n else 0
+            if need <= cap:
+                return out, stats, traj
+            if not grow:
+                raise OverflowError(f"dense output needs {need} states per run, capacity is {cap}")
+            cap = max(2 * cap, need)
 
     def propagate_until_event(self, batch: _abi.StateBatch, max_duration_ns: int, event: "Event", trigger: int = 1, capacity: int = 4096):
         """Batch form of `until_nth_event` (propagators/event.rs:88-211): (states at the event, stats, TrajBatch, crossings).
         stats.status is ERR_EVENT_NOT_FOUND where `max_duration_ns` elapsed first (the reference's NthEventError)."""
-        out = batch.copy()
-        stats = _abi.StatsBatch(batch.n)
-        traj = _abi.TrajBatch(batch.n, int(capacity))
-        crossings = np.zeros(batch.n, dtype=np.int32)
-        cin, cout, cst, ctr, cev = batch.as_c(), out.as_c(), stats.as_c(), traj.as_c(), event.as_c(trigger)
-        rc = self._lib.nyx_hip_propagate_until_event(self._h, C.byref(cin), int(max_duration_ns), C.byref(cev), C.byref(cout), C.byref(cst),
-                                                     C.byref(ctr), crossings.ctypes.data_as(_abi.c_int32_p))
-        if rc != 0:
-            raise RuntimeError(f"nyx_hip_propagate_until_event failed (rc={rc}): {_abi.last_error()}")
-        return out, stats, traj, crossings
+        cap = max(int(capacity), 2)
+        while True:
+            out = batch.copy()
+            stats = _abi.StatsBatch(batch.n)
+            traj = _abi.TrajBatch(batch.n, cap)
+            crossings = np.zeros(batch.n, dtype=np.int32)
+            cin, cout, cst, ctr, cev = batch.as_c(), out.as_c(), stats.as_c(), traj.as_c(), event.as_c(trigger)
+            rc = self._lib.nyx_hip_propagate_until_event(self._h, C.byref(cin), int(max_duration_ns), C.byref(cev), C.byref(cout), C.byref(cst),
+                                                         C.byref(ctr), crossings.ctypes.data_as(_abi.c_int32_p))
+            if rc != 0:
+                raise RuntimeError(f"nyx_hip_propagate_until_event failed (rc={rc}): {_abi.last_error()}")
+            need = int(traj.len.max()) if batch.n else 0
+            # the search appends the end state to the run's trajectory (event.rs:179): it needs len < capacity; a buffer
+            # that is too small would have turned the root search into ERR_EVENT_SEARCH: grow and repeat instead
+            if need < cap:
+                return out, stats, traj, crossings
+            cap = max(2 * cap, need + 1)
 
     def traj_at(self, traj: _abi.TrajBatch, epochs_ns):
         """`Traj::at(epoch)` (traj.rs:82-127) of every trajectory of the batch at the shared epochs:
@@ -883,6 +901,34 @@ class Traj:
         return Traj.from_arrays(self._ctx, q, states[:, 0])
 
 
+def _feed(h, obj) -> None:
+    """Content fingerprint of a model tree (dataclasses, containers, numpy arrays, scalars): what the context cache is
+    keyed on, so that ANY change of the dynamics, the options, the frame or the almanac's tables builds a new context."""
+    if isinstance(obj, np.ndarray):
+        h.update(str((obj.dtype.str, obj.shape)).encode())
+        h.update(np.ascontiguousarray(obj).tobytes())
+    elif dataclasses.is_dataclass(obj) and not isinstance(obj, type):
+        h.update(type(obj).__name__.encode())
+        for f in dataclasses.fields(obj):
+            h.update(f.name.encode())
+            _feed(h, getattr(obj, f.name))
+    elif isinstance(obj, Almanac):
+        _feed(h, obj.segments)
+        _feed(h, sorted(obj.bodies.items()))
+    elif isinstance(obj, dict):
+        _feed(h, sorted(obj.items()))
+    elif isinstance(obj, (list, tuple)):
+        h.update(b"[")
+        for x in obj:
+            _feed(h, x)
+        h.update(b"]")
+    elif isinstance(obj, float):
+        h.update(np.float64(obj).tobytes())
+    else:
+        h.update(repr(obj).encode())
+    h.update(b";")
+
+
 class Propagator:
     """propagator.rs:34-121."""
 
@@ -924,8 +970,16 @@ class Propagator:
         return compile_config(self.dynamics, self.method, self.opts, almanac, central, stm=stm)
 
     def _context(self, almanac: Almanac, central: Frame, stm: bool) -> GpuContext:
-        key = (id(almanac), central.naif_id, central.mu_km3_s2, stm)
+        """Cached device context.  The key is a CONTENT fingerprint (dynamics, method, options, the full central frame, the
+        almanac's bodies and segment tables): `prop.opts.tolerance = ...`, a mutated almanac or a new one at a recycled
+        address all miss the cache instead of silently reusing a stale compiled configuration."""
+        h = hashlib.blake2b(digest_size=16)
+        _feed(h, (self.dynamics, int(self.method), self.opts, central, bool(stm), int(self.device)))
+        _feed(h, almanac)
+        key = h.digest()
         if key not in self._ctx_cache:
+            if len(self._ctx_cache) >= 8:   # bounded: drop the oldest context (device tables are a few MB each)
+                self._ctx_cache.pop(next(iter(self._ctx_cache))).close()
             self._ctx_cache[key] = GpuContext(self.compile(almanac, central, stm), self.device)
         return self._ctx_cache[key]
 

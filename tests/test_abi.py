@@ -105,3 +105,73 @@ def test_cxx_host_mirror_golden_on_gpu(tmp_path):
     import subprocess
     r = subprocess.run([_build_cxx_check(tmp_path)], capture_output=True, text=True)
     assert r.returncode == 0 and "max |delta|" in r.stdout, r.stdout + r.stderr
+
+
+def _create_rc(cc):
+    lib = _abi.load_library()
+    h = C.c_void_p()
+    rc = lib.nyx_hip_ctx_create(C.byref(cc.cfg), 0, C.byref(h))
+    if rc == 0:
+        lib.nyx_hip_ctx_destroy(h)
+    return rc, _abi.last_error()
+
+
+def test_ctx_create_refuses_what_the_device_code_cannot_represent():
+    """Plain-data validation happens before any device is touched: a segment the 16-wide Clenshaw window would truncate,
+    degenerate segments and over-long body chains are errors, never silently clipped."""
+    from nyx_amd import ephem
+    day = 86400.0
+    prop, _, central = leo_full_setup(degree=4)
+
+    def almanac_with(n_coeffs, interval=16 * day, n_chain=1):
+        al = nx.Almanac()
+        s = al.add_segment(ephem.fit_segment(ephem.sun_geocentric, 7.6e8, interval, 3, n_coeffs))
+        al.add_body(nx.EARTH, ephem.MU_EARTH, ephem.R_EARTH, [])
+        al.add_body(nx.SUN, ephem.MU_SUN, ephem.R_SUN, [(s, +1)] * n_chain)
+        al.add_body(nx.MOON, ephem.MU_MOON, ephem.R_MOON, [(s, +1)])
+        return al
+
+    rc, msg = _create_rc(prop.compile(almanac_with(17), central))
+    assert rc == _abi.RC_UNSUPPORTED and "17 Chebyshev coefficients" in msg
+    cc = prop.compile(almanac_with(13), central)
+    cc.cfg.segments[0].interval_s = 0.0
+    assert _create_rc(cc)[0] == _abi.RC_BAD_ARG
+    cc = prop.compile(almanac_with(13), central)
+    cc.cfg.segments[0].n_records = 0
+    assert _create_rc(cc)[0] == _abi.RC_BAD_ARG
+    cc = prop.compile(almanac_with(13), central)
+    cc.cfg.bodies[1].n_chain = 5
+    rc, msg = _create_rc(cc)
+    assert rc == _abi.RC_BAD_ARG and "n_chain" in msg
+    # a valid 16-coefficient segment gets past validation (and then stops at "no device" on this box)
+    rc, msg = _create_rc(prop.compile(almanac_with(16), central))
+    assert rc in (0, _abi.RC_NO_DEVICE), msg
+
+
+@pytest.mark.gpu
+def test_sixteen_coefficient_segments_device_vs_oracle():
+    """The widest segment the device evaluates (NYX_HIP_MAX_CHEBY_COEFFS): every coefficient must enter the Clenshaw sum."""
+    import oracle_lib
+    from nyx_amd import ephem
+    from scenarios import EPOCH0_NS, dispersed_leo_batch, pos_vel_errors
+    day = 86400.0
+    et0 = nx.to_seconds(EPOCH0_NS)
+    al = nx.Almanac()
+    s_sun = al.add_segment(ephem.fit_segment(ephem.sun_geocentric, et0 - 2 * day, 16 * day, 2, 16))
+    s_moon = al.add_segment(ephem.fit_segment(ephem.moon_geocentric, et0 - 2 * day, 8 * day, 3, 16))   # 8-day Moon records NEED the high orders
+    al.add_body(nx.EARTH, ephem.MU_EARTH, ephem.R_EARTH, [])
+    al.add_body(nx.SUN, ephem.MU_SUN, ephem.R_SUN, [(s_sun, +1)])
+    al.add_body(nx.MOON, ephem.MU_MOON, ephem.R_MOON, [(s_moon, +1)])
+    prop, _, central = leo_full_setup(degree=4)
+    compiled = prop.compile(al, central)
+    b = dispersed_leo_batch(70, seed=16)
+    ctx = nx.GpuContext(compiled)
+    dur = 2 * 3600 * nx.NS_PER_S
+    out, st = ctx.propagate(b, dur)
+    ref, rst = oracle_lib.propagate(compiled, b, dur, n_threads=os.cpu_count() or 1)
+    assert (st.status == 0).all() and (rst.status == 0).all()
+    dr, dv = pos_vel_errors(out, ref)
+    assert dr.max() < 1e-6 and dv.max() < 1e-9, (dr.max(), dv.max())
+    # the 16th coefficient matters: dropping it moves the Moon by more than the parity bar allows to hide
+    rec = al.segments[s_moon].records
+    assert np.abs(rec[:, 2 + 15]).max() > 1e-3

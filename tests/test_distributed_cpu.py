@@ -1,6 +1,6 @@
-"""N > 1 path on CPU: world_size-2 gloo run of the sharded Monte Carlo front end.  The propagation itself is
-injected (the oracle) because there is no GPU here; what is under test is the sharding, the all-gather and the
-index-stable ordering (reference mc/montecarlo.rs:208-273)."""
+"""N > 1 path on CPU: world_size-2 and -3 gloo runs of the sharded Monte Carlo front end.  The propagation itself is
+injected (the oracle) because there is no GPU here; what is under test is the sharding, the all-gather, the index-stable
+ordering (reference mc/montecarlo.rs:208-273), the all-reduce of the ensemble moments and the gathered reports."""
 import os
 import socket
 import sys
@@ -38,6 +38,51 @@ def _build():
         return oracle_lib.propagate(compiled, batch, arg - int(batch.epoch_ns[0]))
 
     return prop, almanac, nx.MonteCarlo(mvn, seed=7, propagate_fn=fn)
+
+
+class _OracleTrajEval:
+    """Stands in for the GpuContext as the evaluator of dense output (anything with traj_at / traj_every)."""
+
+    def traj_every(self, tb, step_ns, capacity):
+        import oracle_lib
+        return oracle_lib.traj_every(tb, step_ns, capacity)
+
+    def traj_at(self, tb, epochs_ns):
+        import oracle_lib
+        return oracle_lib.traj_at(tb, epochs_ns)
+
+
+def _build_with_traj(seed):
+    import oracle_lib
+    prop, almanac, mc = _build()
+    compiled = prop.compile(almanac, earth_frame(ephem.MU_EARTH))
+
+    def fn(batch, arg):
+        out, st, traj = oracle_lib.propagate_with_traj(compiled, batch, arg - int(batch.epoch_ns[0]), 64)
+        return out, st, traj, _OracleTrajEval()
+
+    mc.propagate_fn = fn
+    mc.seed = seed
+    return prop, almanac, mc
+
+
+def _worker3(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    end = EPOCH0_NS + 900 * nx.NS_PER_S
+    # seed=None (the reference's OS entropy): the ranks must still agree on ONE stream
+    prop, almanac, mc = _build_with_traj(None)
+    res = mc.resume_run_until_epoch(prop, almanac, 0, end, 11, dist=dist)
+    disp = np.array([r.dispersed_state.rv for r in res.runs])
+    fin = np.array([r.result.rv for r in res.runs])
+    mean, cov = res.mean_and_covariance()                       # all-reduce of the moments of the local shards
+    rep = np.array(res.every_value_of(nx.StateParameter.X, 300 * nx.NS_PER_S))    # gathered report
+    last = np.array(res.last_values_of(nx.StateParameter.Rmag))
+    dv = np.array(res.dispersion_values_of(nx.StateParameter.VZ))
+    np.savez(os.path.join(out_dir, f"w{rank}.npz"), disp=disp, fin=fin, mean=mean, cov=cov, rep=rep, last=last, dv=dv,
+             n_local=len(res._local_runs()))
+    dist.destroy_process_group()
 
 
 def _worker(rank, world, port, out_dir):
@@ -80,3 +125,37 @@ def test_two_rank_gloo_monte_carlo(tmp_path):
     tail = mc.resume_run_until_epoch(prop, almanac, 5, EPOCH0_NS + 600 * nx.NS_PER_S, 6)
     assert [r.index for r in tail.runs] == list(range(6))      # (enumerate() after skip(): indices restart, montecarlo.rs:290-295)
     np.testing.assert_array_equal(tail.final_rv(), single.final_rv()[5:])
+
+
+def test_three_rank_ragged_shards_moments_and_reports(tmp_path):
+    port = _free_port()
+    mp.spawn(_worker3, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    w = [np.load(tmp_path / f"w{r}.npz") for r in range(3)]
+    assert [int(x["n_local"]) for x in w] == [4, 4, 3]                       # ragged last shard
+    for k in ("disp", "fin", "mean", "cov", "rep", "last", "dv"):
+        np.testing.assert_array_equal(w[0][k], w[1][k])
+        np.testing.assert_array_equal(w[0][k], w[2][k])
+    # unseeded: one stream for all ranks, and results paired with the states they were propagated from
+    fin, disp = w[0]["fin"], w[0]["disp"]
+    assert np.linalg.norm(fin[:, :3] - disp[:, :3], axis=1).min() > 1000.0 and len(np.unique(disp[:, 0])) == 11
+    # moments from the all-reduce == numpy on the gathered final states (Cr, Cd, prop mass are constant: zero variance)
+    np.testing.assert_allclose(w[0]["mean"][:6], fin.mean(axis=0), rtol=1e-13)
+    np.testing.assert_allclose(w[0]["cov"][:6, :6], np.cov(fin, rowvar=False), rtol=1e-9, atol=1e-12)
+    assert np.all(w[0]["cov"][6:, :] == 0.0)
+    # the gathered report == the single-process report of the same (seeded) ensemble: every run contributes 4 samples
+    # (0, 300, 600, 900 s), in index order
+    rep = w[0]["rep"]
+    assert rep.shape == (44,)
+    np.testing.assert_allclose(rep[0::4], disp[:, 0], rtol=0, atol=0)        # first sample = the dispersed X of each run
+    np.testing.assert_allclose(rep[3::4], fin[:, 0], rtol=0, atol=1e-9)      # last sample = the final X
+    np.testing.assert_allclose(w[0]["last"], np.linalg.norm(fin[:, :3], axis=1), rtol=1e-15)
+    assert w[0]["dv"].shape == (11,)
+
+
+def test_single_process_moments_match_numpy():
+    prop, almanac, mc = _build()
+    res = mc.run_until_epoch(prop, almanac, EPOCH0_NS + 600 * nx.NS_PER_S, 9, with_traj=False)
+    mean, cov = res.mean_and_covariance()
+    x = res.final_rv()
+    np.testing.assert_allclose(mean[:6], x.mean(axis=0), rtol=1e-13)
+    np.testing.assert_allclose(cov[:6, :6], np.cov(x, rowvar=False), rtol=1e-9, atol=1e-12)
