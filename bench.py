@@ -177,13 +177,13 @@ def host_threads():
         return logical, logical
 
 
-def cpu_baseline(w, compiled, n_per_gpu, hours, seed):
+def cpu_baseline(shard, compiled, n_per_gpu, hours):
     """The oracle (CPU restatement of the reference, kind = "port") timed on this box's host on a bounded sample of the
     SAME workload: one pthread per hardware thread over trajectories (rayon par_iter analogue), full-length trajectories
     when a round of them fits the ~25 s budget, otherwise the head of the propagation (stated in `sample`)."""
     import oracle_lib
     threads, phys = host_threads()
-    probe = w["batch"](threads, seed=seed)
+    probe = shard.slice(0, min(threads, shard.n))
     probe_h = min(0.25, hours)
     t0 = time.time()
     oracle_lib.propagate(compiled, probe, int(probe_h * 3600) * nx.NS_PER_S, n_threads=threads)
@@ -192,9 +192,12 @@ def cpu_baseline(w, compiled, n_per_gpu, hours, seed):
     samp_h = hours
     if per_hour * hours > budget_s:      # a full-length round does not fit: time the first `samp_h` hours instead
         samp_h = max(probe_h, min(hours, float(int(budget_s / per_hour * 4) / 4.0)))
-    rounds = max(1, min(2, int(budget_s / max(per_hour * samp_h, 1e-3))))
-    n = threads * rounds
-    sample = w["batch"](n, seed=seed)
+    # as many rounds of `threads` trajectories as fit the budget (the short probe underestimates a long round: at most two
+    # of those), never more than the shard holds
+    per_round = max(per_hour * samp_h, 1e-3)
+    rounds = max(1, min(int(budget_s / per_round), 2 if per_round > 4.0 else 1 << 30, max(1, shard.n // threads)))
+    n = min(threads * rounds, shard.n)
+    sample = shard.slice(0, n)   # the HEAD of this rank's shard: the states the device propagated, not a re-draw
     t0 = time.time()
     out, st = oracle_lib.propagate(compiled, sample, int(samp_h * 3600) * nx.NS_PER_S, n_threads=threads)
     dt = time.time() - t0
@@ -404,7 +407,7 @@ def main():
             del t_ep, t_st, t_len
         if not args.no_cpu_baseline and world == 1:
             if not w["stm"]:
-                cb, sample, ref, samp_h = cpu_baseline(w, compiled, n, hours, seed=0)
+                cb, sample, ref, samp_h = cpu_baseline(shard, compiled, n, hours)
                 if samp_h == hours:
                     # the sample is the head of this rank's shard: check parity on it while we are here
                     got = np.stack([tout[f][: sample.n].cpu().numpy() for f in _abi.F64_FIELDS[:6]], axis=1)
