@@ -25,7 +25,7 @@ extern "C" hipError_t nyx_launch_event_search(const EventSearchArgs *args, hipSt
 extern "C" hipError_t nyx_launch_traj_eval(const TrajEvalArgs *args, hipStream_t stream);
 extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg, const HarmEntry *htab,
                                            const ColHdr *cols, const double *records, int n_waves, int rec_lds_doubles,
-                                           int reuse_fields, hipStream_t stream);
+                                           int reuse_fields, hipStream_t stream, int quad);
 
 // ---------------------------------------------------------------------------------------------
 // error reporting
@@ -79,6 +79,7 @@ struct nyx_hip_ctx {
     std::vector<int32_t> col_len;  // rows per column (index = c)
     int n_waves = 1;
     int forced_waves = 0;
+    int forced_quad = -1;  // STM layout: -1 = by ensemble size, 0 = 64 trajectories x D3 per workgroup, 1 = quad layout (16 x 4 lanes, D1)
     double role_handicap[3] = {0.0, 0.0, 0.0};  // integrator, almanac, perturbations (harmonics-term units)
     DevArrays in, out;
     int64_t *d_prof = nullptr;
@@ -384,8 +385,24 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves) {
     }
 }
 
+// STM layout by ensemble size.  The quad layout spends 4 lanes per trajectory (1.6x the f64 issue slots of the D3 layout
+// per trajectory) to get 4x the workgroups and 4x the waves per workgroup: it wins while the D3 layout would leave most of
+// the chip without a workgroup, i.e. up to ~2 quad workgroups per CU.
+static bool pick_quad(const nyx_hip_ctx *ctx, int64_t n) {
+    if (!(ctx->host_cfg.flags & NYX_HIP_FLAG_STM)) return false;
+    if (ctx->forced_quad >= 0) return ctx->forced_quad != 0;
+    if (const char *e = std::getenv("NYX_HIP_STM_QUAD")) return std::atoi(e) != 0;
+    const int64_t cus = ctx->n_cu > 0 ? ctx->n_cu : 256;
+    return (n + 15) / 16 <= 2 * cus;
+}
+
 static int pick_waves(const nyx_hip_ctx *ctx, int64_t n) {
     const bool stm = (ctx->host_cfg.flags & NYX_HIP_FLAG_STM) != 0;
+    if (stm && pick_quad(ctx, n)) {  // quad layout: 128 VGPRs per wave like the plain kernel
+        if (ctx->forced_waves > 0) return std::min(ctx->forced_waves, DEV_MAX_WAVES);
+        if (!ctx->host_cfg.has_grav) return 3;
+        return ctx->host_cfg.deg < 8 ? 4 : (ctx->host_cfg.deg < 16 ? 8 : 16);
+    }
     if (stm) {  // dual-number variant: 256 VGPRs per wave, at most DEV_MAX_WAVES_STM waves
         if (ctx->forced_waves > 0) return std::min(ctx->forced_waves, DEV_MAX_WAVES_STM);
         return ctx->host_cfg.has_grav ? DEV_MAX_WAVES_STM : 3;
@@ -413,6 +430,14 @@ extern "C" int32_t nyx_hip_ctx_set_column_waves(nyx_hip_ctx *ctx, int32_t waves)
 }
 
 extern "C" int32_t nyx_hip_last_coop_helpers(nyx_hip_ctx *ctx) { return ctx ? ctx->last_coop_helpers : 0; }
+
+// Test / tuning hook: STM layout of the following launches (-1 = by ensemble size, 0 = D3 64-lane, 1 = quad).
+extern "C" int32_t nyx_hip_debug_set_stm_layout(nyx_hip_ctx *ctx, int32_t quad) {
+    if (!ctx || quad < -1 || quad > 1) return NYX_HIP_RC_BAD_ARG;
+    CTX_LOCK(ctx);
+    ctx->forced_quad = quad;
+    return NYX_HIP_RC_OK;
+}
 
 extern "C" double nyx_hip_last_kernel_ms(nyx_hip_ctx *ctx) {
     if (!ctx || !ctx->ev1) return -1.0;
@@ -680,9 +705,18 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
     CTX_LOCK(ctx);
     if (ctx->launched) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_done, 0));  // one launch of a context at a time on the device
     const int nw = pick_waves(ctx, in->n);
-    if (nw != ctx->host_cfg.n_waves) {
-        build_schedule(ctx, nw);
-        HIP_TRY(hipMemcpyAsync(ctx->d_cfg, &ctx->host_cfg, sizeof(DevCfg), hipMemcpyHostToDevice, stream));
+    {
+        // launch-shape dependent parts of the descriptor: column schedule (waves per workgroup) and whether the ephemeris
+        // records fit in LDS next to this layout's buffers (the quad layout is smaller than the D3 one)
+        const bool stm_l = (ctx->host_cfg.flags & NYX_HIP_FLAG_STM) != 0;
+        const int kind = stm_l ? (pick_quad(ctx, in->n) ? 2 : 1) : 0;
+        const int rd = ctx->host_cfg.rec_doubles;
+        const int want_rec = ((size_t)rd * sizeof(double) <= 24 * 1024 &&
+                              nyx_kernel_lds_bytes(DEV_MAX_WAVES, rd, kind, kind == 0 ? ctx->host_cfg.ed_reuse : 0) <= 160 * 1024) ? 1 : 0;
+        bool dirty = want_rec != ctx->host_cfg.rec_in_lds;
+        ctx->host_cfg.rec_in_lds = want_rec;
+        if (nw != ctx->host_cfg.n_waves) { build_schedule(ctx, nw); dirty = true; }
+        if (dirty) HIP_TRY(hipMemcpyAsync(ctx->d_cfg, &ctx->host_cfg, sizeof(DevCfg), hipMemcpyHostToDevice, stream));
     }
     DevBatch bt;
     std::memset(&bt, 0, sizeof bt);
@@ -778,8 +812,10 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
         bt.prof = ctx->d_prof;
     }
     if (time_it) HIP_TRY(hipEventRecord(ctx->ev0, stream));
+    const bool quad = pick_quad(ctx, in->n);
+    // (the LDS staging of the ephemeris records was decided at ctx_create for the D3 layout; the quad layout is smaller)
     HIP_TRY(nyx_launch_propagate(bt, ctx->d_cfg, ctx->d_htab, ctx->d_cols, ctx->d_records, nw,
-                                 ctx->host_cfg.rec_in_lds ? ctx->host_cfg.rec_doubles : 0, ctx->host_cfg.ed_reuse, stream));
+                                 ctx->host_cfg.rec_in_lds ? ctx->host_cfg.rec_doubles : 0, ctx->host_cfg.ed_reuse, stream, quad ? 1 : 0));
     if (time_it) HIP_TRY(hipEventRecord(ctx->ev1, stream));
     HIP_TRY(hipEventRecord(ctx->ev_done, stream));
     ctx->launched = true;

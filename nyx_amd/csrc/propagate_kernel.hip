@@ -353,14 +353,59 @@ DEVFN D3 d3cube(D3 a) {  // powi(3): real = (a*a)*a, dual = 3 a^2 da
     return r;
 }
 
+// One-partial dual: value + ONE position partial.  QUAD LAYOUT of the STM kernel (small ensembles): the four lanes of a
+// quad belong to ONE trajectory; each runs the same dual program as D3 but carries a single partial - lane 1: d/dx,
+// lane 2: d/dy, lane 3: d/dz (lane 0: the value only, d = 0).  Every operation below is D3's own expression for `v` and
+// for one of its three partial slots, so value and partials are bit-identical to the 64-lane D3 layout; what changes is
+// 3 f64 operations per product instead of 7 and a quarter of the registers, i.e. a kernel that fits 16 waves per
+// workgroup where the D3 variant fits 4.
+struct D1 {
+    double v, d;
+};
+DEVFN D1 d1c(double v) { D1 r = {v, 0.0}; return r; }
+DEVFN D1 operator+(D1 a, D1 b) { D1 r = {a.v + b.v, a.d + b.d}; return r; }
+DEVFN D1 operator-(D1 a, D1 b) { D1 r = {a.v - b.v, a.d - b.d}; return r; }
+DEVFN D1 operator-(D1 a) { D1 r = {-a.v, -a.d}; return r; }
+DEVFN D1 operator*(D1 a, D1 b) { D1 r = {a.v * b.v, __builtin_fma(a.v, b.d, a.d * b.v)}; return r; }
+DEVFN D1 operator*(D1 a, double s) { D1 r = {a.v * s, a.d * s}; return r; }
+DEVFN D1 operator*(double s, D1 a) { return a * s; }
+DEVFN D1 d1div(D1 a, D1 b) {
+    const double dd = b.v * b.v;
+    D1 r = {a.v / b.v, (a.d * b.v - a.v * b.d) / dd};
+    return r;
+}
+DEVFN D1 d1sqrt(D1 a) {
+    const double s = sqrt(a.v);
+    const double hh = 0.5 / s;
+    D1 r = {s, a.d * hh};
+    return r;
+}
+DEVFN D1 d1norm(D1 a, D1 b, D1 c) { return d1sqrt(a * a + b * b + c * c); }
+DEVFN D1 d1cube(D1 a) {
+    const double p = a.v * a.v;
+    const double f = 3.0 * p;
+    D1 r = {p * a.v, a.d * f};
+    return r;
+}
+// the seed of position component `comp` (0..2) in quad lane `ql`: d(r_comp)/d(r_{ql-1})
+DEVFN D1 d1seed(double v, int comp, int ql) { D1 r = {v, (ql == comp + 1) ? 1.0 : 0.0}; return r; }
+
 // scalar-generic helpers so that the column recursion is written once for double and D3
 DEVFN double sfma(double a, double s, double c) { return __builtin_fma(a, s, c); }              // a * s + c, s uniform
 DEVFN D3 sfma(D3 a, double s, D3 c) {
     D3 r = {__builtin_fma(a.v, s, c.v), __builtin_fma(a.x, s, c.x), __builtin_fma(a.y, s, c.y), __builtin_fma(a.z, s, c.z)};
     return r;
 }
+DEVFN D1 sfma(D1 a, double s, D1 c) { D1 r = {__builtin_fma(a.v, s, c.v), __builtin_fma(a.d, s, c.d)}; return r; }
 DEVFN double gmul(double a, double b) { return a * b; }
 DEVFN D3 gmul(D3 a, D3 b) { return a * b; }
+DEVFN D1 gmul(D1 a, D1 b) { return a * b; }
+DEVFN D1 gfma(D1 a, D1 b, D1 c) { return a * b + c; }
+DEVFN D1 gzero(D1) { return d1c(0.0); }
+DEVFN D1 gone(D1) { return d1c(1.0); }
+DEVFN D1 gdiv(D1 a, D1 b) { return d1div(a, b); }
+DEVFN D1 gnorm3(D1 a, D1 b, D1 c) { return d1norm(a, b, c); }
+DEVFN D1 glift(double v, D1) { return d1c(v); }
 DEVFN double gfma(double a, double b, double c) { return __builtin_fma(a, b, c); }               // a * b + c
 DEVFN D3 gfma(D3 a, D3 b, D3 c) { return a * b + c; }
 DEVFN double gzero(double) { return 0.0; }
@@ -727,6 +772,36 @@ static __device__ __attribute__((noinline)) void harmonics_partial_dual(uint64_t
         outD[(4 * q + 0) * DEV_LANES + lane] = o4[q].v; outD[(4 * q + 1) * DEV_LANES + lane] = o4[q].x;
         outD[(4 * q + 2) * DEV_LANES + lane] = o4[q].y; outD[(4 * q + 3) * DEV_LANES + lane] = o4[q].z;
     }
+}
+
+// Quad layout (D1): 5 inputs and 4 partial sums of (value, this lane's partial) through LDS: 10 + 8 doubles per lane.
+static __device__ __attribute__((noinline)) void harmonics_partial_d1(uint64_t cfg_u, uint64_t htab_u, uint64_t cols_u, int wave_v,
+                                                                    const double *inbQ, double *outQ, int lane) {
+    CfgPtr cfg = (CfgPtr)uniform_u64(cfg_u);
+    HarmPtr htab = (HarmPtr)uniform_u64(htab_u);
+    ColPtr cols = (ColPtr)uniform_u64(cols_u);
+    const int wave = __builtin_amdgcn_readfirstlane(wave_v);
+    D1 in[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { in[q].v = inbQ[(2 * q + 0) * DEV_LANES + lane]; in[q].d = inbQ[(2 * q + 1) * DEV_LANES + lane]; }
+    const Partial4T<D1> pd = harmonics_core<D1>(cfg, htab, cols, wave, DEV_SCHED_SOLO, in[0], in[1], in[2], in[3], in[4]);
+    const D1 o4[4] = {pd.x, pd.y, pd.z, pd.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { outQ[(2 * q + 0) * DEV_LANES + lane] = o4[q].v; outQ[(2 * q + 1) * DEV_LANES + lane] = o4[q].d; }
+}
+
+// Quad-lane exchange (DPP quad_perm broadcast of lane SEL of every quad; two 32-bit moves per double).
+template <int SEL>
+DEVFN double quad_bcast(double x) {
+    constexpr int ctrl = SEL | (SEL << 2) | (SEL << 4) | (SEL << 6);
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), ctrl, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), ctrl, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+DEVFN int quad_or(int x) {
+    x |= __builtin_amdgcn_mov_dpp(x, 0xb1, 0xf, 0xf, true);  // quad_perm [1, 0, 3, 2]
+    x |= __builtin_amdgcn_mov_dpp(x, 0x4e, 0xf, 0xf, true);  // quad_perm [2, 3, 0, 1]
+    return x;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1130,6 +1205,97 @@ DEVFN bool stm_update(double *phi, double h, const double *sacc, int lane, doubl
     return nan;
 }
 
+// Quad layout of the two functions above.  out[15][64]: a_pm(3), column (ql - 1) of G_pm (3), f_srp/m(3), column of
+// G_srp/m (3), c(3); every expression is pert_gradients' own for the value and for ONE partial slot.
+DEVFN void pert_gradients_q(CfgPtr cfg, const double *ed, int lane, int ql, const double *r, double cr, double area, double mass,
+                            bool has_pm, bool has_srp, bool has_tides, double *out) {
+    double o[15];
+#pragma unroll
+    for (int q = 0; q < 15; ++q) o[q] = 0.0;
+    if (has_pm) {
+        const int npm = cfg->n_pm;
+#pragma unroll
+        for (int k = 0; k < DEV_MAX_SLOTS; ++k) {
+            if (k < npm) {
+                const int s = cfg->pm_slot[k];
+                const D1 rij[3] = {d1c(ED_BP(ed, s, 0)), d1c(ED_BP(ed, s, 1)), d1c(ED_BP(ed, s, 2))};
+                const D1 rij3 = d1cube(d1norm(rij[0], rij[1], rij[2]));
+                const D1 rj[3] = {d1seed(r[0] - rij[0].v, 0, ql), d1seed(r[1] - rij[1].v, 1, ql), d1seed(r[2] - rij[2].v, 2, ql)};
+                const D1 rj3 = d1cube(d1norm(rj[0], rj[1], rj[2]));
+                const D1 gm = d1c(-cfg->slot[s].mu);
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const D1 t = (d1div(rj[i], rj3) + d1div(rij[i], rij3)) * gm;
+                    o[i] += t.v;
+                    o[3 + i] += t.d;
+                }
+            }
+        }
+    }
+    if (has_tides) {
+        const D1 rd[3] = {d1seed(r[0], 0, ql), d1seed(r[1], 1, ql), d1seed(r[2], 2, ql)};
+        D1 at[3];
+        tides_accel<D1>(cfg, ed, lane, rd, at);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { o[i] += at[i].v; o[3 + i] += at[i].d; }
+    }
+    if (has_srp) {
+        const int ss = cfg->sun_slot;
+        const double ps[3] = {ED_BP(ed, ss, 0), ED_BP(ed, ss, 1), ED_BP(ed, ss, 2)};
+        const D1 rs[3] = {d1seed(r[0] - ps[0], 0, ql), d1seed(r[1] - ps[1], 1, ql), d1seed(r[2] - ps[2], 2, ql)};
+        const D1 n = d1norm(rs[0], rs[1], rs[2]);
+        double f3[3];
+        const double kfro = srp_force(cfg, ed, lane, r, cr, area, f3);
+        const D1 r_au = n * (1.0 / 149597870.700);
+        const D1 inv = d1div(d1c(1.0), r_au);
+        const D1 flux = (inv * inv) * (kfro * cfg->phi / cfg->c_m_s);
+        const double scal = 1e-3 * cr * area;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const D1 f = (flux * scal) * d1div(rs[i], n);
+            o[6 + i] = f3[i] / mass;
+            o[9 + i] = f.d / mass;
+            if (cfg->srp_estimate) o[12 + i] = (f3[i] / cr) / mass;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 15; ++q) out[q * DEV_LANES + lane] = o[q];
+}
+
+// stm_update for the quad layout: sacc rows 0..2 hold, per lane, column (ql - 1) of sum b_i G_i and rows 3..5 sum b_i c_i
+// (the same in the four lanes); the nine rows of Phi are dealt over the quad's lanes.
+DEVFN bool stm_update_q(double *phi, double h, const double *sacc, int lane, int ql, double sumb) {
+    double gs[12];
+    const int base = lane & ~3;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) gs[3 * i + j] = sacc[i * DEV_LANES + base + 1 + j];
+        gs[9 + i] = sacc[(3 + i) * DEV_LANES + lane];
+    }
+    bool nan = false;
+    for (int r = ql; r < 9; r += 4) {
+        double row[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) row[c] = phi[r + 9 * c];
+        double nw[9];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            nw[j] = row[j] + h * (row[3] * gs[0 * 3 + j] + row[4] * gs[1 * 3 + j] + row[5] * gs[2 * 3 + j]);
+            nw[3 + j] = row[3 + j] + h * (sumb * row[j]);
+        }
+        nw[6] = row[6] + h * (row[3] * gs[9] + row[4] * gs[10] + row[5] * gs[11]);
+        nw[7] = row[7];
+        nw[8] = row[8];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            nan = nan || (nw[c] != nw[c]);
+            phi[r + 9 * c] = nw[c];
+        }
+    }
+    return quad_or(nan ? 1 : 0) != 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // The kernel
 // ---------------------------------------------------------------------------------------------
@@ -1138,7 +1304,8 @@ DEVFN bool stm_update(double *phi, double h, const double *sacc, int lane, doubl
 // timing-only debug switches (NYX_HIP_DEBUG env, never set in production): results are physically wrong
 #define DBG_SKIP_SERIAL 0x100
 #define DBG_SKIP_HARMONICS 0x200
-#define KB(stage, comp) kbuf[((stage)*6 + (comp)) * DEV_LANES + lane]
+// (quad layout: the four lanes of a quad share ONE k-buffer column, KB_STR = 16 trajectories per workgroup)
+#define KB(stage, comp) kbuf[((stage)*6 + (comp)) * KB_STR + kb_li]
 
 // Integrator state that is only touched between attempts lives in LDS (per lane, field-major), not in
 // registers: the stage loop then keeps ~30 VGPRs of integrator state live instead of ~90 (no scratch spills).
@@ -1220,25 +1387,25 @@ struct LdsMap {
     double *partD;  // [P][16][64]    dual harmonics partials
 };
 
-DEVFN LdsMap carve_lds(char *smem, int n_waves, bool stm, int rec_lds_doubles, int reuse_fields) {
+DEVFN LdsMap carve_lds(char *smem, int n_waves, bool stm, int rec_lds_doubles, int reuse_fields, bool quad = false) {
     LdsMap m;
     double *p = (double *)smem;
-    m.kbuf = p; p += DEV_MAX_STAGES * 6 * DEV_LANES;
+    m.kbuf = p; p += DEV_MAX_STAGES * 6 * (quad ? DEV_LANES / 4 : DEV_LANES);
     m.tabl = p; p += DEV_MAX_STAGES * DEV_MAX_STAGES + 3 * DEV_MAX_STAGES;
     m.ys = p; p += 6 * DEV_LANES;
     m.ed = p; p += 2 * ED_FIELDS * DEV_LANES;
     m.step = p; p += 2 * DEV_LANES;
     m.cs = p; p += CS_FIELDS * DEV_LANES;
-    m.part = p; p += DEV_MAX_WAVES * 4 * DEV_LANES;  // = DEV_MAX_WAVES_STM * 16 * DEV_LANES: reused for the dual partials
+    m.part = p; p += DEV_MAX_WAVES * (quad ? 8 : 4) * DEV_LANES;  // = DEV_MAX_WAVES_STM * 16 * DEV_LANES: reused for the dual partials (quad: 16 waves x 8)
     m.edst = (int *)p; p += DEV_LANES;       // 2*64 ints
     m.pertst = (int *)p; p += DEV_LANES / 2; // 64 ints
     m.ctl = (int *)p; p += 8;
     m.inbD = m.pertD = m.sacc = m.partD = nullptr;
     if (stm) {
         // the plain inb / pert slots alias the head of their dual counterparts (written first, overwritten after)
-        m.inbD = p; m.inb = p; p += 20 * DEV_LANES;
-        m.pertD = p; m.pert = p; p += 27 * DEV_LANES;
-        m.sacc = p; p += 12 * DEV_LANES;
+        m.inbD = p; m.inb = p; p += (quad ? 10 : 20) * DEV_LANES;
+        m.pertD = p; m.pert = p; p += (quad ? 15 : 27) * DEV_LANES;
+        m.sacc = p; p += (quad ? 6 : 12) * DEV_LANES;
         m.partD = m.part;
     } else {
         m.inb = p; p += NIN * DEV_LANES;
@@ -1258,11 +1425,12 @@ DEVFN LdsMap carve_lds(char *smem, int n_waves, bool stm, int rec_lds_doubles, i
     return m;
 }
 
-extern "C" size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles, int stm, int reuse_fields) {
-    size_t d = (size_t)DEV_MAX_STAGES * 6 * DEV_LANES + DEV_MAX_STAGES * DEV_MAX_STAGES + 3 * DEV_MAX_STAGES + 6 * DEV_LANES +
-               2 * ED_FIELDS * DEV_LANES + 2 * DEV_LANES + CS_FIELDS * DEV_LANES + (size_t)DEV_MAX_WAVES * 4 * DEV_LANES + DEV_LANES +
+extern "C" size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles, int stm, int reuse_fields) {  // stm: 0 = plain, 1 = D3, 2 = quad layout
+    const bool quad = stm == 2;
+    size_t d = (size_t)DEV_MAX_STAGES * 6 * (quad ? DEV_LANES / 4 : DEV_LANES) + DEV_MAX_STAGES * DEV_MAX_STAGES + 3 * DEV_MAX_STAGES + 6 * DEV_LANES +
+               2 * ED_FIELDS * DEV_LANES + 2 * DEV_LANES + CS_FIELDS * DEV_LANES + (size_t)DEV_MAX_WAVES * (quad ? 8 : 4) * DEV_LANES + DEV_LANES +
                DEV_LANES / 2 + 8 + (size_t)rec_doubles;
-    d += stm ? (size_t)(20 + 27 + 12) * DEV_LANES : (size_t)(NIN + 9 + 6 + NIN + 9) * DEV_LANES;
+    d += quad ? (size_t)(10 + 15 + 6) * DEV_LANES : (stm ? (size_t)(20 + 27 + 12) * DEV_LANES : (size_t)(NIN + 9 + 6 + NIN + 9) * DEV_LANES);
     (void)n_waves;
     if (reuse_fields > 0) d += (size_t)reuse_fields * DEV_LANES + 2 * DEV_LANES + DEV_LANES / 2;
     return d * sizeof(double) + 64;
@@ -1277,7 +1445,7 @@ extern "C" size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles, int stm, in
 
 // One role (or a merged set of roles) of the workgroup.  Every instantiation executes the SAME sequence of
 // workgroup barriers; only the work between them differs, so that each role keeps just its own state live.
-template <bool INTEG, bool ALMANAC, bool PERT, bool STM>
+template <bool INTEG, bool ALMANAC, bool PERT, bool STM, bool QUAD = false>
 DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPtr htab, ColPtr cols,
                      const double *__restrict__ records, const LdsMap &L, const int lane, const int wave, const int nw) {
     double *const kbuf = L.kbuf;
@@ -1303,9 +1471,16 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     const int64_t prof_start = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;
     const int64_t prof_rt0 = prof_on ? (int64_t)__builtin_amdgcn_s_memrealtime() : 0;
 
-    // ---- per-lane trajectory binding (every wave maps lane -> the same trajectory)
-    const int64_t gid = (int64_t)blockIdx.x * DEV_LANES + lane;
+    // ---- per-lane trajectory binding (every wave maps lane -> the same trajectory).  Quad layout: 16 trajectories per
+    // workgroup, the four lanes of a quad are bound to the same one (everything that is per trajectory is computed four
+    // times over, identically; `wr` picks the lane that writes it out) and differ in the partial their duals carry.
+    static_assert(!QUAD || STM, "the quad layout is the STM kernel's");
+    const int ql = QUAD ? (lane & 3) : 0;
+    constexpr int KB_STR = QUAD ? DEV_LANES / 4 : DEV_LANES;
+    const int kb_li = QUAD ? (lane >> 2) : lane;
+    const int64_t gid = QUAD ? (int64_t)blockIdx.x * (DEV_LANES / 4) + (lane >> 2) : (int64_t)blockIdx.x * DEV_LANES + lane;
     const bool valid = gid < bt.n;
+    const bool wr = valid && ql == 0;
     const int64_t idx = valid ? gid : bt.n - 1;
 
     // perturbation-wave constants
@@ -1334,20 +1509,20 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
         const double mass = (bt.mdry ? bt.mdry[idx] : 0.0) + c.y[8] + (bt.mextra ? bt.mextra[idx] : 0.0);
         c.massless = (has_srp || has_drag) && !(mass > 0.0);  // MasslessSpacecraft (spacecraft.rs:201-203)
         cold_store(L.cs, lane, c);
-        if (bt.ev_on && valid) {  // y_prev of the start state (event.rs:104-106)
+        if (bt.ev_on && wr) {  // y_prev of the start state (event.rs:104-106)
             const double y0[6] = {c.y[0], c.y[1], c.y[2], c.y[3], c.y[4], c.y[5]};
             bt.ev_prev[gid] = ev_eval(bt.ev_scalar, bt.ev_desired, bt.ev_mu, y0);
             bt.ev_count[gid] = 0;
             bt.ev_found[gid] = 0;
         }
-        if (bt.traj_cap > 0 && valid) {  // dense output: the start state is entry 0 (instance.rs:319-321)
+        if (bt.traj_cap > 0 && wr) {  // dense output: the start state is entry 0 (instance.rs:319-321)
             bt.t_epoch[gid] = c.epoch;
 #pragma unroll
             for (int e = 0; e < 6; ++e) bt.t_state[e][gid] = c.y[e];
             bt.t_len[gid] = (duration == 0 || c.done) ? 1 : 1;
         }
         if (STM && valid && bt.o_stm != bt.stm) {
-            for (int q = 0; q < 81; ++q) bt.o_stm[gid * 81 + q] = bt.stm[gid * 81 + q];
+            for (int q = ql; q < 81; q += (QUAD ? 4 : 1)) bt.o_stm[gid * 81 + q] = bt.stm[gid * 81 + q];
         }
     }
     if (PERT) {
@@ -1418,7 +1593,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             h = c.h;
             if (STM) {
 #pragma unroll
-                for (int q = 0; q < 12; ++q) L.sacc[q * DEV_LANES + lane] = 0.0;
+                for (int q = 0; q < (QUAD ? 6 : 12); ++q) L.sacc[q * DEV_LANES + lane] = 0.0;
             }
             L.step[lane] = __longlong_as_double(c.epoch);
             L.step[DEV_LANES + lane] = h;
@@ -1522,7 +1697,18 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     inbb[2 * DEV_LANES + lane] = rho * u_;
                     inbb[3 * DEV_LANES + lane] = rho;
                     inbb[4 * DEV_LANES + lane] = r_ * cfg->g_inv_re;
-                    if (STM) {
+                    if (STM && QUAD) {
+                        const D1 x0 = d1seed(rb0, 0, ql), x1 = d1seed(rb1, 1, ql), x2 = d1seed(rb2, 2, ql);
+                        const D1 rD = d1norm(x0, x1, x2);
+                        const D1 sD = d1div(x0, rD), tD = d1div(x1, rD), uD = d1div(x2, rD);
+                        const D1 rhoD = d1div(d1c(cfg->g_re), rD);
+                        const D1 invD = rD * cfg->g_inv_re;
+                        const D1 pub[5] = {rhoD * sD, rhoD * tD, rhoD * uD, rhoD, invD};
+#pragma unroll
+                        for (int q = 0; q < 5; ++q) {
+                            L.inbD[(2 * q + 0) * DEV_LANES + lane] = pub[q].v; L.inbD[(2 * q + 1) * DEV_LANES + lane] = pub[q].d;
+                        }
+                    } else if (STM) {
                         // the same quantities as duals seeded in the BODY-FIXED frame (gravity_field.rs:285-291)
                         const D3 x0 = {rb0, 1.0, 0.0, 0.0}, x1 = {rb1, 0.0, 1.0, 0.0}, x2 = {rb2, 0.0, 0.0, 1.0};
                         const D3 rD = d3norm(x0, x1, x2);
@@ -1604,7 +1790,8 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
 #pragma unroll
                     for (int e = 0; e < 3; ++e) pertp[(6 + e) * DEV_LANES + lane] = d3f[e] / p_mass;
                 }
-                if (STM) pert_gradients(cfg, edc, lane, r, p_cr, p_area, p_mass, has_pm, has_srp, has_tides, L.pertD);
+                if (STM && QUAD) pert_gradients_q(cfg, edc, lane, ql, r, p_cr, p_area, p_mass, has_pm, has_srp, has_tides, L.pertD);
+                else if (STM) pert_gradients(cfg, edc, lane, r, p_cr, p_area, p_mass, has_pm, has_srp, has_tides, L.pertD);
                 // third accel model (dynamics/sequence/config.rs:116-118): added to the point-mass slot, last, so that no
                 // live value of this role crosses the call
                 if (has_tides && !STM) tides_into_pert(cfg, edc, lane, ysp, pertp);
@@ -1680,7 +1867,9 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 pp[0 * DEV_LANES + lane] = 0.0; pp[1 * DEV_LANES + lane] = 0.0;
                 pp[2 * DEV_LANES + lane] = 0.0; pp[3 * DEV_LANES + lane] = 0.0;
             }
-            if (STM && has_grav)
+            if (STM && QUAD && has_grav)
+                harmonics_partial_d1((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, L.inbD, L.partD + wave * 8 * DEV_LANES, lane);
+            else if (STM && has_grav)
                 harmonics_partial_dual((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, L.inbD, L.partD + wave * 16 * DEV_LANES, lane);
             if (!STM && has_grav && !dbg_skip_harm) {
                 // (ctl[1] is written before the barrier that precedes this read: B1 for stage 0, B2 of the previous stage otherwise;
@@ -1761,7 +1950,68 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 if (!STM && has_drag) {
                     acc[0] += pertc[6 * DEV_LANES + lane]; acc[1] += pertc[7 * DEV_LANES + lane]; acc[2] += pertc[8 * DEV_LANES + lane];
                 }
-                if (STM) {
+                if (STM && QUAD) {
+                    // the D3 block below, one partial per lane: Gc[i] = G[3 i + (ql - 1)]
+                    double Gc[3], cv[3] = {0.0, 0.0, 0.0};
+                    const D1 rad[3] = {d1seed(ys[0], 0, ql), d1seed(ys[1], 1, ql), d1seed(ys[2], 2, ql)};
+                    const D1 fac = d1div(d1c(-cfg->mu_central), d1cube(d1norm(rad[0], rad[1], rad[2])));
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const D1 a = rad[q] * fac;
+                        acc[q] = a.v; Gc[q] = a.d;
+                    }
+                    if (has_pm || has_tides) {
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) { acc[q] += L.pertD[q * DEV_LANES + lane]; Gc[q] += L.pertD[(3 + q) * DEV_LANES + lane]; }
+                    }
+                    if (has_grav) {
+                        D1 pD[4] = {d1c(0.0), d1c(0.0), d1c(0.0), d1c(0.0)};
+                        for (int w = 0; w < nw; ++w) {  // fixed wave order
+                            const double *pp = L.partD + w * 8 * DEV_LANES;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { pD[q].v += pp[(2 * q + 0) * DEV_LANES + lane]; pD[q].d += pp[(2 * q + 1) * DEV_LANES + lane]; }
+                        }
+                        double m[9];
+#pragma unroll
+                        for (int q = 0; q < 9; ++q) m[q] = edc[q * DEV_LANES + lane];
+                        const D1 x0 = d1seed(m[0] * ys[0] + m[1] * ys[1] + m[2] * ys[2], 0, ql);
+                        const D1 x1 = d1seed(m[3] * ys[0] + m[4] * ys[1] + m[5] * ys[2], 1, ql);
+                        const D1 x2 = d1seed(m[6] * ys[0] + m[7] * ys[1] + m[8] * ys[2], 2, ql);
+                        const D1 rD = d1norm(x0, x1, x2);
+                        const D1 aux[4] = {d1div(x0, rD), d1div(x1, rD), d1div(x2, rD), d1div(d1div(d1c(cfg->g_mu), rD), d1c(cfg->g_re))};
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) pD[q] = pD[q] * aux[3];
+                        const D1 al[3] = {pD[0] + pD[3] * aux[0], pD[1] + pD[3] * aux[1], pD[2] + pD[3] * aux[2]};
+                        // a = R^T a_bf ; G_h = R^T G_bf R: the first product is linear in the partial slot (this lane's), the second
+                        // mixes the three slots: fetched from the quad's lanes 1..3; this lane forms column b = ql - 1
+                        double tmpc[3];
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) {
+                            acc[a] += m[0 + a] * al[0].v + m[3 + a] * al[1].v + m[6 + a] * al[2].v;
+                            tmpc[a] = m[0 + a] * al[0].d + m[3 + a] * al[1].d + m[6 + a] * al[2].d;
+                        }
+                        const int b = ql > 0 ? ql - 1 : 0;
+                        const double mb0 = edc[(0 + b) * DEV_LANES + lane], mb1 = edc[(3 + b) * DEV_LANES + lane], mb2 = edc[(6 + b) * DEV_LANES + lane];
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) {
+                            const double t0 = quad_bcast<1>(tmpc[a]), t1 = quad_bcast<2>(tmpc[a]), t2 = quad_bcast<3>(tmpc[a]);
+                            Gc[a] += t0 * mb0 + t1 * mb1 + t2 * mb2;
+                        }
+                    }
+                    if (has_srp) {
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) {
+                            acc[q] += L.pertD[(6 + q) * DEV_LANES + lane]; cv[q] = L.pertD[(12 + q) * DEV_LANES + lane];
+                            Gc[q] += L.pertD[(9 + q) * DEV_LANES + lane];
+                        }
+                    }
+                    const double b_i = B_COEF(i);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        L.sacc[q * DEV_LANES + lane] += b_i * Gc[q];
+                        L.sacc[(3 + q) * DEV_LANES + lane] += b_i * cv[q];
+                    }
+                } else if (STM) {
                     // dual path (dual_eom, spacecraft.rs:312-363): f(x) and A = df/dx; the derivative written to k_i is
                     // the dual path's real part, as in the reference's STM branch (spacecraft.rs:208-224)
                     double G[9], cv[3] = {0.0, 0.0, 0.0};
@@ -1900,14 +2150,14 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     // stop condition: checked after every step but the final fixed one; the triggering state is returned,
                     // not published (instance.rs:243-252)
                     bool ev_hit = false;
-                    if (bt.ev_on && valid && !c.is_final)
+                    if (bt.ev_on && valid && !c.is_final)  // (quad layout: the four lanes read and write the same words with the same values)
                         ev_hit = event_step(bt.ev_scalar, bt.ev_trigger, bt.ev_desired, bt.ev_mu, bt.ev_prev + gid, bt.ev_count + gid, y[0], y[1],
                                             y[2], y[3], y[4], y[5]);
                     if (ev_hit) {
-                        bt.ev_found[gid] = 1;
+                        if (wr) bt.ev_found[gid] = 1;
                         c.done = true;
                     }
-                    if (bt.traj_cap > 0 && valid && !ev_hit) {  // chan.send(self.state) after every accepted step, final one included
+                    if (bt.traj_cap > 0 && wr && !ev_hit) {  // chan.send(self.state) after every accepted step, final one included
                         if (c.n_acc < bt.traj_cap) {
                             const int64_t at = c.n_acc * bt.n + gid;
                             bt.t_epoch[at] = c.epoch;
@@ -1919,7 +2169,9 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     if (STM && valid) {
                         double sumb = 0.0;
                         for (int q = 0; q < stages; ++q) sumb += B_COEF(q);
-                        if (stm_update(bt.o_stm + gid * 81, h_used, L.sacc, lane, sumb)) { c.status = NYX_HIP_ERR_NAN; c.done = true; }
+                        const bool bad = QUAD ? stm_update_q(bt.o_stm + gid * 81, h_used, L.sacc, lane, ql, sumb)
+                                              : stm_update(bt.o_stm + gid * 81, h_used, L.sacc, lane, sumb);
+                        if (bad) { c.status = NYX_HIP_ERR_NAN; c.done = true; }
                     }
                     if (y[8] < 0.0) { c.status = NYX_HIP_ERR_FUEL_EXHAUSTED; c.done = true; }
                     if (c.is_final) {
@@ -1950,7 +2202,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
         atomicAdd((unsigned long long *)bt.prof + 16 * 8 + 2, dbg_fb_seq);
         atomicAdd((unsigned long long *)bt.prof + 16 * 8 + 3, (unsigned long long)coop_seq);
     }
-    if (INTEG && valid) {
+    if (INTEG && wr) {
         ColdState c;
         cold_load(L.cs, lane, c);
         bt.o_epoch_ns[gid] = c.epoch;
@@ -1974,13 +2226,13 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     }
 }
 
-template <bool STM>
+template <bool STM, bool QUAD = false>
 DEVFN void propagate_body(const DevBatch &bt, const DevCfg *cfg_g, const HarmEntry *htab_g, const ColHdr *cols_g,
                           const double *__restrict__ records, char *smem) {
     const int lane = threadIdx.x & (DEV_LANES - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nw = (int)(blockDim.x >> 6);
-    const LdsMap L = carve_lds(smem, nw, STM, cfg_g->rec_in_lds ? cfg_g->rec_doubles : 0, STM ? 0 : cfg_g->ed_reuse);
+    const LdsMap L = carve_lds(smem, nw, STM, cfg_g->rec_in_lds ? cfg_g->rec_doubles : 0, STM ? 0 : cfg_g->ed_reuse, QUAD);
     double *const kbuf = L.kbuf;
     double *const tabl = L.tabl;
     CfgPtr cfg = (CfgPtr)cfg_g;
@@ -2021,24 +2273,24 @@ DEVFN void propagate_body(const DevBatch &bt, const DevCfg *cfg_g, const HarmEnt
         // ctl[1]: 1 while this workgroup shares its columns with the helpers
         L.ctl[1] = (!STM && bt.coop_helpers > 0 && cfg->has_grav) ? 1 : 0;
     }
-    for (int q = (int)threadIdx.x; q < DEV_MAX_WAVES * 4 * DEV_LANES; q += (int)blockDim.x) L.part[q] = 0.0;
+    for (int q = (int)threadIdx.x; q < DEV_MAX_WAVES * (QUAD ? 8 : 4) * DEV_LANES; q += (int)blockDim.x) L.part[q] = 0.0;
 
     // ---- role dispatch (wave-uniform): merged roles when the workgroup has fewer than three waves
     if (nw == 1) {
-        role_loop<true, true, true, STM>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
+        role_loop<true, true, true, STM, QUAD>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
     } else if (nw == 2) {
-        if (wave == 0) role_loop<true, false, false, STM>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
-        else role_loop<false, true, true, STM>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
+        if (wave == 0) role_loop<true, false, false, STM, QUAD>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
+        else role_loop<false, true, true, STM, QUAD>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
     } else if (cfg->merge_roles) {
         // almanac + perturbations share wave 1 (their duties fit in one harmonics window), one more column worker
-        if (wave == 0) role_loop<true, false, false, STM>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
-        else if (wave == 1) role_loop<false, true, true, STM>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
-        else role_loop<false, false, false, STM>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
+        if (wave == 0) role_loop<true, false, false, STM, QUAD>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
+        else if (wave == 1) role_loop<false, true, true, STM, QUAD>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
+        else role_loop<false, false, false, STM, QUAD>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
     } else {
-        if (wave == 0) role_loop<true, false, false, STM>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
-        else if (wave == 1) role_loop<false, true, false, STM>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
-        else if (wave == 2) role_loop<false, false, true, STM>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
-        else role_loop<false, false, false, STM>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
+        if (wave == 0) role_loop<true, false, false, STM, QUAD>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
+        else if (wave == 1) role_loop<false, true, false, STM, QUAD>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
+        else if (wave == 2) role_loop<false, false, true, STM, QUAD>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
+        else role_loop<false, false, false, STM, QUAD>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
     }
 }
 
@@ -2058,21 +2310,36 @@ extern "C" __global__ void __launch_bounds__(DEV_MAX_WAVES_STM *DEV_LANES)
     propagate_body<true>(bt, cfg_g, htab_g, cols_g, records, smem);
 }
 
+// STM variant, QUAD LAYOUT (small ensembles): 16 trajectories per workgroup, four lanes per trajectory, each carrying the
+// value and ONE position partial of every dual (D1).  A quarter of the dual registers => the role code fits the
+// 128-VGPR budget of a 16-wave workgroup: column waves to hide the scalar-load latency, and 4x the workgroups.
+extern "C" __global__ void __launch_bounds__(DEV_MAX_WAVES *DEV_LANES)
+    nyx_propagate_kernel_stmq(DevBatch bt, const DevCfg *cfg_g, const HarmEntry *htab_g, const ColHdr *cols_g,
+                              const double *__restrict__ records) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    propagate_body<true, true>(bt, cfg_g, htab_g, cols_g, records, smem);
+}
+
 extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg, const HarmEntry *htab,
                                            const ColHdr *cols, const double *records, int n_waves, int rec_lds_doubles,
-                                           int reuse_fields, hipStream_t stream) {
-    const int64_t blocks = (bt.n + DEV_LANES - 1) / DEV_LANES;
+                                           int reuse_fields, hipStream_t stream, int quad) {
+    const int64_t per_wg = quad ? DEV_LANES / 4 : DEV_LANES;
+    const int64_t blocks = (bt.n + per_wg - 1) / per_wg;
     if (blocks == 0) return hipSuccess;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_stm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_stmq, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const bool stm = bt.o_stm != nullptr;
-    size_t lds = nyx_kernel_lds_bytes(n_waves, rec_lds_doubles, stm ? 1 : 0, stm ? 0 : reuse_fields);
+    size_t lds = nyx_kernel_lds_bytes(n_waves, rec_lds_doubles, stm ? (quad ? 2 : 1) : 0, stm ? 0 : reuse_fields);
     if (!stm && bt.coop_helpers > 0 && lds < (size_t)HELPER_LDS_BYTES) lds = HELPER_LDS_BYTES;
-    if (stm)
+    if (stm && quad)
+        hipLaunchKernelGGL(nyx_propagate_kernel_stmq, dim3((unsigned)blocks), dim3((unsigned)(n_waves * DEV_LANES)), lds, stream, bt, cfg,
+                           htab, cols, records);
+    else if (stm)
         hipLaunchKernelGGL(nyx_propagate_kernel_stm, dim3((unsigned)blocks), dim3((unsigned)(n_waves * DEV_LANES)), lds, stream, bt, cfg,
                            htab, cols, records);
     else {

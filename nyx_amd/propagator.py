@@ -610,6 +610,11 @@ class GpuContext:
     def set_column_waves(self, waves: int):
         self._lib.nyx_hip_ctx_set_column_waves(self._h, int(waves))
 
+    def set_stm_layout(self, quad: int):
+        """STM kernel layout of the following launches: -1 = by ensemble size (default), 0 = 64 trajectories per workgroup
+        with three-partial duals (D3), 1 = quad layout (16 trajectories x 4 lanes, one partial per lane)."""
+        self._lib.nyx_hip_debug_set_stm_layout(self._h, int(quad))
+
     def last_coop_helpers(self) -> int:
         """Helper workgroups of the last launch (0 = no cooperative mode)."""
         return int(self._lib.nyx_hip_last_coop_helpers(self._h))

@@ -70,9 +70,12 @@ def test_full_model_events_not_found_and_mixed_outcomes():
     plain, _ = ctx.propagate(b, 20 * 60 * S)
     assert (st2.status == _abi.ERR_EVENT_NOT_FOUND).all() and (cr2 < 2).all()
     np.testing.assert_array_equal(out2.rv(), plain.rv())
-    # a dense-output buffer too small for the bracket is reported, not overrun
-    out3, st3, small, _ = ctx.propagate_until_event(b, dur, ev, trigger=2, capacity=8)
-    assert (st3.status == _abi.ERR_EVENT_SEARCH).all() and (small.len > 8).all()
+    # a dense-output buffer too small for the bracket is neither overrun nor turned into a failed search: the front end
+    # grows it and repeats the launch (the C entry itself reports ERR_EVENT_SEARCH for a buffer it cannot use)
+    out3, st3, grown, _ = ctx.propagate_until_event(b, dur, ev, trigger=2, capacity=8)
+    assert (st3.status == 0).all() and grown.capacity > int(grown.len.max()) > 8
+    np.testing.assert_array_equal(out3.epoch_ns, out.epoch_ns)
+    np.testing.assert_array_equal(out3.rv(), out.rv())
     ctx.close()
 
 
