@@ -8,8 +8,11 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <array>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <tuple>
 #include <vector>
 
 #include "../../include/nyx_hip.h"
@@ -79,6 +82,16 @@ struct nyx_hip_ctx {
     std::vector<int32_t> col_len;  // rows per column (index = c)
     int n_waves = 1;
     int forced_waves = 0;
+    bool sched_quad = false;  // the schedule / roles in host_cfg were built for the quad layout
+    bool sched_dirty = false; // weights changed: rebuild the schedule at the next launch
+    // Per-wave column weights, calibrated on this device for every workgroup shape this context has launched (see calibrate()):
+    // key = (waves per workgroup, pipelined loop, quad layout, cooperative share in tenths or -1 when working alone)
+    typedef std::tuple<int, int, int, int> WKey;
+    std::map<WKey, std::array<double, 2 * DEV_MAX_WAVES>> weights;  // [0..16): speed weights, [16..32): measured duties (harmonics-term units)
+    std::map<WKey, double> weight_spread;  // (max - min) / mean of the per-wave windows after calibration
+    int calibrate_mode = 1;                // 0 = structural default weights only (deterministic across processes), 1 = calibrate
+    WKey last_key = WKey(0, 0, 0, 0);      // shape of the last launch
+    DevArrays cal;                         // scratch outputs of the calibration launches
     int forced_quad = -1;  // STM layout: -1 = by ensemble size, 0 = 64 trajectories x D3 per workgroup, 1 = quad layout (16 x 4 lanes, D1)
     double role_handicap[3] = {0.0, 0.0, 0.0};  // integrator, almanac, perturbations (harmonics-term units)
     DevArrays in, out;
@@ -243,28 +256,31 @@ static void build_harmonics(const nyx_hip_gravity_field_t *g, std::vector<HarmEn
 // its columns, in harmonics-term units) and SIMD age weights.  Wave 0 takes what is left.
 // `list`: the columns to distribute, ascending (= longest first).  Returns false if a wave would need more than
 // DEV_MAX_RANGES contiguous ranges.
-static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, const std::vector<int> &list, const double *hc,
+static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, const std::vector<int> &list, const double *hc_model,
                           bool all_columns) {
+    double hc[DEV_MAX_WAVES];
+    for (int w = 0; w < DEV_MAX_WAVES; ++w) hc[w] = hc_model[w];
     for (int w = 0; w < DEV_MAX_WAVES; ++w) sd.n_ranges[w] = 0;
     if (list.empty()) return true;
     double terms = 0.0;
     for (int c : list) terms += ctx->col_len[c];
-    // Per-wave weights of a 16-wave workgroup.  The four waves that share a SIMD (w, w+4, w+8, w+12) are arbitrated
-    // oldest-first, so with equal shares the oldest finishes early and the youngest runs the tail alone, with nothing to
-    // hide its scalar-load latency; SIMD 0 also hosts the integrator wave, which carries no columns, so its column waves
-    // (4, 8, 12) can take more.  Calibrated on the device with tools/tune_wave_weights.py (in-kernel cycle accounting of the
-    // north-star force model): the waves of a workgroup then finish their window within ~10 % of each other.
-    static const double tuned16[DEV_MAX_WAVES] = {1.0000, 1.3959, 1.3248, 1.5513, 1.5890, 1.1944, 1.1728, 1.3383,
-                                                  1.3085, 0.8969, 0.9070, 0.9179, 0.8464, 0.5319, 0.5459, 0.5545};
+    // Per-wave weights.  The four waves that share a SIMD (w, w+4, w+8, w+12) are arbitrated oldest-first, so with equal
+    // shares the oldest finishes early and the youngest runs the tail alone, with nothing to hide its scalar-load latency;
+    // role waves carry their duty besides.  The weights are MEASURED: calibrate() runs the workload's own first steps with
+    // the in-kernel cycle accounting and moves columns from the late waves to the early ones until the windows agree;
+    // before that (and with calibration off) a structural guess by age class is used.
     double per_wave[DEV_MAX_WAVES];
-    // pipelined stage loop: the integrator wave now works beside the column waves of SIMD 0 (4, 8, 12), same calibration
-    static const double tuned16_pipe[DEV_MAX_WAVES] = {1.0000, 1.1768, 1.3204, 1.8145, 1.7397, 1.3918, 1.4247, 1.3479,
-                                                       1.2716, 0.8906, 0.8939, 0.9863, 0.8109, 0.4500, 0.5075, 0.5311};
-    // ... and once more for a workgroup that keeps all its columns (the longest ones included)
-    static const double tuned16_pipe_all[DEV_MAX_WAVES] = {1.0000, 1.3528, 1.5865, 2.0244, 1.9595, 1.5113, 1.4026, 1.4819,
-                                                           1.2655, 0.8341, 0.8420, 0.8337, 0.8163, 0.4153, 0.4511, 0.4752};
-    for (int w = 0; w < DEV_MAX_WAVES; ++w)
-        per_wave[w] = n_waves == 16 ? (ctx->host_cfg.pipe ? (all_columns ? tuned16_pipe_all[w] : tuned16_pipe[w]) : tuned16[w]) : 1.0;
+    {
+        const nyx_hip_ctx::WKey key(n_waves, (ctx->host_cfg.pipe && !(ctx->host_cfg.flags & NYX_HIP_FLAG_STM)) ? 1 : 0, ctx->sched_quad ? 1 : 0,
+                                    all_columns ? -1 : (int)(ctx->host_cfg.coop_frac * 10.0 + 0.5));
+        const auto it = ctx->weights.find(key);
+        static const double age[4] = {1.3, 1.2, 0.9, 0.6};
+        for (int w = 0; w < DEV_MAX_WAVES; ++w)
+            per_wave[w] = it != ctx->weights.end() ? it->second[w] : (n_waves == 16 ? age[w / 4] : 1.0);
+        if (it != ctx->weights.end())  // measured duties replace the model's (the integrator keeps its window free: hc_model[0])
+            for (int w = 0; w < n_waves; ++w)
+                if (hc_model[w] < 1e8) hc[w] = it->second[DEV_MAX_WAVES + w];
+    }
     if (const char *e = std::getenv("NYX_HIP_AGE_WEIGHTS")) {  // coarse knob: one weight per age class
         double aw[4] = {1.0, 1.0, 1.0, 1.0};
         if (std::sscanf(e, "%lf,%lf,%lf,%lf", &aw[0], &aw[1], &aw[2], &aw[3]) == 4 && n_waves == 16)
@@ -321,7 +337,78 @@ static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, con
     return true;
 }
 
-static void build_schedule(nyx_hip_ctx *ctx, int n_waves) {
+// Role fan-out (small ensembles: the STM quad layout, and dynamics without a gravity field): with few workgroups on the
+// chip what counts is the latency of ONE force evaluation, and the almanac and perturbation duties are its longest serial
+// pieces.  They are dealt over several waves - the DCM and the body slots over up to DEV_MAX_ALM almanac waves (longest
+// first), point masses (+ tides) and SRP (+ drag) over two perturbation waves - each writing its own LDS rows, so the
+// arithmetic and its order do not change.  Costs in harmonics-term units, as `role_handicap`.
+static int fanout_almanac_units(const DevCfg &dc, int *unit_mask, double *unit_cost) {
+    int n = 0;
+    if (dc.has_grav || dc.has_drag || dc.has_tides) { unit_mask[n] = DEV_ROLE_DCM; unit_cost[n] = 18.0; ++n; }
+    for (int s = 0; s < dc.n_slots; ++s) { unit_mask[n] = 1 << s; unit_cost[n] = 12.0 * dc.slot[s].n_chain; ++n; }
+    return n;
+}
+static bool want_fanout(const nyx_hip_ctx *ctx, bool quad) {
+    if (const char *e = std::getenv("NYX_HIP_FANOUT")) return std::atoi(e) != 0;
+    return quad || !ctx->host_cfg.has_grav;
+}
+static int fanout_role_waves(const nyx_hip_ctx *ctx, int *n_alm_out = nullptr, int *n_pert_out = nullptr) {
+    const DevCfg &dc = ctx->host_cfg;
+    int um[8]; double uc[8];
+    const int units = fanout_almanac_units(dc, um, uc);
+    const int n_alm = std::min(DEV_MAX_ALM, std::max(units, 0));
+    const int n_pert = ((dc.n_pm > 0 || dc.has_tides) ? 1 : 0) + ((dc.has_srp || dc.has_drag) ? 1 : 0);
+    if (n_alm_out) *n_alm_out = n_alm;
+    if (n_pert_out) *n_pert_out = n_pert;
+    return 1 + n_alm + n_pert;
+}
+
+// Deals the roles of an n_waves workgroup (DevCfg.role_*) and returns the serial duty of every wave in `hc`.
+static void assign_roles(nyx_hip_ctx *ctx, int n_waves, bool fanout, double *hc) {
+    DevCfg &dc = ctx->host_cfg;
+    const int all_alm = DEV_ROLE_DCM | ((1 << dc.n_slots) - 1);
+    const int all_pert = (DEV_PERT_PM | DEV_PERT_SRP) << 16;
+    for (int w = 0; w < DEV_MAX_WAVES; ++w) { dc.role_kind[w] = DEV_ROLE_COLUMNS; dc.role_mask[w] = 0; dc.role_slot[w] = 0; hc[w] = 0.0; }
+    dc.n_alm = 1;
+    const double *rh = ctx->role_handicap;
+    if (n_waves == 1) { dc.role_kind[0] = DEV_ROLE_ALL; dc.role_mask[0] = all_alm | all_pert; hc[0] = rh[0] + rh[1] + rh[2]; return; }
+    dc.role_kind[0] = DEV_ROLE_INTEG; hc[0] = rh[0];
+    if (n_waves == 2 || dc.merge_roles) { dc.role_kind[1] = DEV_ROLE_ALMANAC_PERT; dc.role_mask[1] = all_alm | all_pert; hc[1] = rh[1] + rh[2]; return; }
+    int n_alm = 1, n_pert = 1;
+    if (fanout && fanout_role_waves(ctx, &n_alm, &n_pert) <= n_waves && n_alm >= 1 && n_pert >= 1) {
+        int um[8]; double uc[8];
+        const int units = fanout_almanac_units(dc, um, uc);
+        int order[8];
+        for (int k = 0; k < units; ++k) order[k] = k;
+        std::sort(order, order + units, [&](int a, int b) { return uc[a] > uc[b]; });
+        double load[DEV_MAX_ALM] = {0.0, 0.0, 0.0};
+        for (int a = 0; a < n_alm; ++a) { dc.role_kind[1 + a] = DEV_ROLE_ALMANAC; dc.role_slot[1 + a] = a; }
+        for (int k = 0; k < units; ++k) {  // longest unit first onto the least loaded wave
+            int best = 0;
+            for (int a = 1; a < n_alm; ++a) if (load[a] < load[best]) best = a;
+            dc.role_mask[1 + best] |= um[order[k]];
+            load[best] += uc[order[k]];
+        }
+        for (int a = 0; a < n_alm; ++a) hc[1 + a] = load[a];
+        dc.n_alm = n_alm;
+        int w = 1 + n_alm;
+        const double pm_cost = 6.0 * dc.n_pm + (dc.has_tides ? 14.0 + 8.0 * dc.t_n : 0.0);
+        const double srp_cost = (dc.has_srp ? 6.0 + 6.0 * dc.n_shadow : 0.0) + (dc.has_drag ? 10.0 : 0.0);
+        if (n_pert == 2) {
+            dc.role_kind[w] = DEV_ROLE_PERT; dc.role_mask[w] = DEV_PERT_PM << 16; hc[w] = pm_cost; ++w;
+            dc.role_kind[w] = DEV_ROLE_PERT; dc.role_mask[w] = DEV_PERT_SRP << 16; hc[w] = srp_cost; ++w;
+        } else {
+            dc.role_kind[w] = DEV_ROLE_PERT; dc.role_mask[w] = all_pert; hc[w] = pm_cost + srp_cost; ++w;
+        }
+        const bool stm = (dc.flags & NYX_HIP_FLAG_STM) != 0;
+        if (stm) for (int k = 1 + n_alm; k < w; ++k) hc[k] *= 3.0;  // (dual perturbations: ~3x the real ones)
+        return;
+    }
+    dc.role_kind[1] = DEV_ROLE_ALMANAC; dc.role_mask[1] = all_alm; hc[1] = rh[1];
+    dc.role_kind[2] = DEV_ROLE_PERT; dc.role_mask[2] = all_pert; hc[2] = rh[2];
+}
+
+static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
     DevCfg &dc = ctx->host_cfg;
     const int nc = dc.n_cols;
     for (int k = 0; k < DEV_N_SCHED; ++k)
@@ -332,13 +419,10 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves) {
         const char *e = std::getenv("NYX_HIP_PIPE");
         dc.pipe = (n_waves == DEV_MAX_WAVES && !dc.merge_roles && (e ? std::atoi(e) != 0 : true)) ? 1 : 0;
     }
-    if (!dc.has_grav || nc == 0) return;
-    // role handicaps of this workgroup shape (merged roles when there are fewer than three waves)
+    // roles of this workgroup shape and their serial duties (merged roles when there are fewer than three waves)
     double hc[DEV_MAX_WAVES] = {0};
-    if (n_waves == 1) hc[0] = ctx->role_handicap[0] + ctx->role_handicap[1] + ctx->role_handicap[2];
-    else if (n_waves == 2) { hc[0] = ctx->role_handicap[0]; hc[1] = ctx->role_handicap[1] + ctx->role_handicap[2]; }
-    else if (dc.merge_roles) { hc[0] = ctx->role_handicap[0]; hc[1] = ctx->role_handicap[1] + ctx->role_handicap[2]; }
-    else { hc[0] = ctx->role_handicap[0]; hc[1] = ctx->role_handicap[1]; hc[2] = ctx->role_handicap[2]; }
+    assign_roles(ctx, n_waves, want_fanout(ctx, quad), hc);
+    if (!dc.has_grav || nc == 0) return;
     // with enough column workers the integrator keeps its window free: its serial phases A / C gate every other wave
     if (n_waves >= 8 && !std::getenv("NYX_HIP_ROLE_HANDICAP")) hc[0] = 1e9;
     std::vector<int> all;
@@ -400,8 +484,8 @@ static int pick_waves(const nyx_hip_ctx *ctx, int64_t n) {
     const bool stm = (ctx->host_cfg.flags & NYX_HIP_FLAG_STM) != 0;
     if (stm && pick_quad(ctx, n)) {  // quad layout: 128 VGPRs per wave like the plain kernel
         if (ctx->forced_waves > 0) return std::min(ctx->forced_waves, DEV_MAX_WAVES);
-        if (!ctx->host_cfg.has_grav) return 3;
-        return ctx->host_cfg.deg < 8 ? 4 : (ctx->host_cfg.deg < 16 ? 8 : 16);
+        if (!ctx->host_cfg.has_grav) return want_fanout(ctx, true) ? std::max(3, fanout_role_waves(ctx)) : 3;
+        return ctx->host_cfg.deg < 8 ? 8 : 16;
     }
     if (stm) {  // dual-number variant: 256 VGPRs per wave, at most DEV_MAX_WAVES_STM waves
         if (ctx->forced_waves > 0) return std::min(ctx->forced_waves, DEV_MAX_WAVES_STM);
@@ -409,7 +493,10 @@ static int pick_waves(const nyx_hip_ctx *ctx, int64_t n) {
     }
     if (ctx->forced_waves > 0) return std::min(ctx->forced_waves, DEV_MAX_WAVES);
     // no harmonics: integrator + almanac + perturbation waves form a 3-stage pipeline
-    if (!ctx->host_cfg.has_grav) return (ctx->host_cfg.n_slots > 0 || ctx->host_cfg.has_drag || ctx->host_cfg.has_tides) ? 3 : 1;
+    if (!ctx->host_cfg.has_grav) {
+        if (!(ctx->host_cfg.n_slots > 0 || ctx->host_cfg.has_drag || ctx->host_cfg.has_tides)) return 1;
+        return want_fanout(ctx, false) ? std::max(3, fanout_role_waves(ctx)) : 3;
+    }
     // Fill the 256 CUs: workgroups = ceil(n/64); with fewer than ~2 workgroups per CU the column
     // split is what creates the waves that keep the SIMDs busy.
     const int64_t wgs = (n + DEV_LANES - 1) / DEV_LANES;
@@ -430,6 +517,26 @@ extern "C" int32_t nyx_hip_ctx_set_column_waves(nyx_hip_ctx *ctx, int32_t waves)
 }
 
 extern "C" int32_t nyx_hip_last_coop_helpers(nyx_hip_ctx *ctx) { return ctx ? ctx->last_coop_helpers : 0; }
+
+// Introspection: the per-wave column weights of the last launch's workgroup shape and the spread (max - min) / mean of the
+// per-wave windows measured when they were calibrated (-1 = structural default weights, never calibrated).  out[17].
+extern "C" int32_t nyx_hip_debug_weights(nyx_hip_ctx *ctx, double *out) {
+    if (!ctx || !out) return NYX_HIP_RC_BAD_ARG;
+    CTX_LOCK(ctx);
+    const auto it = ctx->weights.find(ctx->last_key);
+    for (int w = 0; w < DEV_MAX_WAVES; ++w) out[w] = it != ctx->weights.end() ? it->second[w] : 0.0;  // (speed weights; the duties follow in the table)
+    const auto sp = ctx->weight_spread.find(ctx->last_key);
+    out[DEV_MAX_WAVES] = sp != ctx->weight_spread.end() ? sp->second : -1.0;
+    return NYX_HIP_RC_OK;
+}
+
+// Calibration of the column weights: 1 = on the device, once per workgroup shape (default), 0 = structural weights only.
+extern "C" int32_t nyx_hip_debug_set_calibration(nyx_hip_ctx *ctx, int32_t mode) {
+    if (!ctx || mode < 0 || mode > 1) return NYX_HIP_RC_BAD_ARG;
+    CTX_LOCK(ctx);
+    ctx->calibrate_mode = mode;
+    return NYX_HIP_RC_OK;
+}
 
 // Test / tuning hook: STM layout of the following launches (-1 = by ensemble size, 0 = D3 64-lane, 1 = quad).
 extern "C" int32_t nyx_hip_debug_set_stm_layout(nyx_hip_ctx *ctx, int32_t quad) {
@@ -462,6 +569,7 @@ extern "C" void nyx_hip_ctx_destroy(nyx_hip_ctx *ctx) {
     hipFree(ctx->d_cfg); hipFree(ctx->d_htab); hipFree(ctx->d_cols); hipFree(ctx->d_records);
     free_arrays(ctx->in);
     free_arrays(ctx->out);
+    free_arrays(ctx->cal);
     (void)hipFree(ctx->d_coop);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -699,9 +807,114 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
 // propagate
 // ---------------------------------------------------------------------------------------------
 
+static bool calibration_on(const nyx_hip_ctx *ctx) {
+    if (std::getenv("NYX_HIP_WAVE_WEIGHTS") || std::getenv("NYX_HIP_AGE_WEIGHTS")) return false;  // explicit weights win
+
+    if (const char *e = std::getenv("NYX_HIP_CALIBRATE")) return std::atoi(e) != 0;
+    return ctx->calibrate_mode != 0;
+}
+
 static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t *out, nyx_hip_step_stats_t *st,
                   int64_t duration_ns, int64_t end_epoch_ns, int use_end, hipStream_t stream, bool time_it,
-                  const nyx_hip_traj_t *traj = nullptr, const int64_t *dur_ns = nullptr, const DevBatch *ev = nullptr) {
+                  const nyx_hip_traj_t *traj, const int64_t *dur_ns, const DevBatch *ev, bool calibrating);
+
+// Device views of a DevArrays block (outputs + stats).
+static void views_of(DevArrays &d, int64_t n, bool stm, nyx_hip_states_t &so, nyx_hip_step_stats_t &ss) {
+    std::memset(&so, 0, sizeof so);
+    so.n = n; so.epoch_ns = d.epoch;
+    double **f[13] = {&so.x_km, &so.y_km, &so.z_km, &so.vx_km_s, &so.vy_km_s, &so.vz_km_s, &so.cr, &so.cd,
+                      &so.prop_mass_kg, &so.dry_mass_kg, &so.extra_mass_kg, &so.srp_area_m2, &so.drag_area_m2};
+    for (int k = 0; k < 13; ++k) *f[k] = d.f[k];
+    so.step_ns = d.step;
+    so.stm = stm ? d.stm : nullptr;
+    ss = {d.status, d.last_step, d.last_error, d.last_attempts, d.n_acc, d.n_rej, d.n_evals};
+}
+
+// On-device calibration of the column schedule of the shape the NEXT launch of `in` will have (replaces tables fitted
+// offline to one force model, and the guessed role handicaps).  Up to four short launches of the workload's own first
+// steps (30 steps; 4 with the STM) into scratch outputs, with the in-kernel cycle accounting on.  Per wave of workgroup 0:
+// duty[w] = cycles of role work inside the window, harm[w] = cycles in its columns, hence c[w] = harm / table entries = what
+// a table entry costs THIS wave (the four waves of a SIMD are arbitrated oldest first: the young ones are slower).  The
+// water-filling then gets the speed weight cbar / c[w] and the handicap duty[w] / c[w] (in entries), which makes
+// duty + columns equal across the waves; iterated with damping because the shares interact through the shared SIMDs.
+// Rounded to 1/64 and kept for the life of the context: launches of one context are deterministic.
+static int calibrate(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, hipStream_t stream) {
+    const bool stm = (ctx->host_cfg.flags & NYX_HIP_FLAG_STM) != 0;
+    const int64_t n = in->n;
+    if (int rc = ensure_arrays(ctx->cal, n, true)) return rc;
+    if (stm && ctx->cal.stm_cap < n) {
+        (void)hipFree(ctx->cal.stm);
+        ctx->cal.stm = nullptr;
+        HIP_TRY(hipMalloc(&ctx->cal.stm, (size_t)std::max<int64_t>(n, 1024) * 81 * sizeof(double)));
+        ctx->cal.stm_cap = std::max<int64_t>(n, 1024);
+    }
+    nyx_hip_states_t so;
+    nyx_hip_step_stats_t ss;
+    views_of(ctx->cal, n, stm, so, ss);
+    const int64_t dur = (stm ? 4 : 30) * ctx->host_cfg.init_step_ns;
+    std::array<double, 2 * DEV_MAX_WAVES> w;
+    bool have = false;
+    nyx_hip_ctx::WKey key(0, 0, 0, 0);
+    double spread = 0.0;
+    std::vector<int64_t> prof(17 * 8);
+    for (int it = 0; it < 4; ++it) {
+        if (have) { ctx->weights[key] = w; ctx->sched_dirty = true; }
+        if (int rc = launch(ctx, in, &so, &ss, dur, 0, 0, stream, false, nullptr, nullptr, nullptr, true)) return rc;
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(hipMemcpy(prof.data(), ctx->d_prof, prof.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+        key = ctx->last_key;
+        const int nw = std::get<0>(key);
+        const DevSched &sd = ctx->host_cfg.sched[std::get<3>(key) >= 0 ? DEV_SCHED_PRIMARY : DEV_SCHED_SOLO];
+        // what the launch measured, per wave of workgroup 0: duty = role work inside the window, harm = its columns
+        double duty[DEV_MAX_WAVES], harm[DEV_MAX_WAVES], ent[DEV_MAX_WAVES], cpe[DEV_MAX_WAVES];
+        double csum = 0.0, lo = 1e300, hi = 0.0, tmean = 0.0;
+        int ccnt = 0, tcnt = 0;
+        for (int q = 0; q < nw; ++q) {
+            duty[q] = (double)prof[q * 8 + 1];
+            harm[q] = (double)prof[q * 8 + 2];
+            ent[q] = 0.0;
+            for (int r = 0; r < sd.n_ranges[q]; ++r)
+                for (int c = sd.range_c0[q][r]; c < sd.range_c0[q][r] + sd.range_cnt[q][r]; ++c) ent[q] += ctx->col_len[c];
+            cpe[q] = (ent[q] > 0.0 && harm[q] > 0.0) ? harm[q] / ent[q] : 0.0;   // cycles per table entry, as this wave sees them
+            if (cpe[q] > 0.0) { csum += cpe[q]; ++ccnt; }
+            if (q > 0 || nw < 8) {
+                const double t = duty[q] + (ent[q] > 0.0 ? harm[q] : 0.0);
+                if (t > 0.0) { lo = std::min(lo, t); hi = std::max(hi, t); tmean += t; ++tcnt; }
+            }
+        }
+        if (ccnt < 2 || tcnt < 2) break;
+        const double cbar = csum / ccnt;
+        spread = (hi - lo) / (tmean / tcnt);
+        std::array<double, 2 * DEV_MAX_WAVES> nwgt;
+        for (int q = 0; q < DEV_MAX_WAVES; ++q) {
+            // a wave that carried no columns this time is given the speed of its SIMD age class (waves q, q+4, q+8, q+12 share a SIMD)
+            double c = q < nw ? cpe[q] : 0.0;
+            if (!(c > 0.0)) {
+                double a = 0.0; int an = 0;
+                for (int k = (q / 4) * 4; k < (q / 4) * 4 + 4 && k < nw; ++k) if (cpe[k] > 0.0) { a += cpe[k]; ++an; }
+                c = an ? a / an : cbar;
+            }
+            nwgt[q] = cbar / c;
+            nwgt[DEV_MAX_WAVES + q] = q < nw ? duty[q] / c : 0.0;
+        }
+        for (int q = 0; q < 2 * DEV_MAX_WAVES; ++q) {
+            const double v = have ? 0.5 * (w[q] + nwgt[q]) : nwgt[q];  // damped: the shares interact through the shared SIMDs
+            w[q] = std::round(v * 64.0) / 64.0;
+        }
+        have = true;
+        if (it > 0 && spread < 0.08) break;
+    }
+    if (have) {
+        ctx->weights[key] = w;
+        ctx->weight_spread[key] = spread;
+        ctx->sched_dirty = true;
+    }
+    return NYX_HIP_RC_OK;
+}
+
+static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t *out, nyx_hip_step_stats_t *st,
+                  int64_t duration_ns, int64_t end_epoch_ns, int use_end, hipStream_t stream, bool time_it,
+                  const nyx_hip_traj_t *traj = nullptr, const int64_t *dur_ns = nullptr, const DevBatch *ev = nullptr, bool calibrating = false) {
     CTX_LOCK(ctx);
     if (ctx->launched) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_done, 0));  // one launch of a context at a time on the device
     const int nw = pick_waves(ctx, in->n);
@@ -715,7 +928,12 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
                               nyx_kernel_lds_bytes(DEV_MAX_WAVES, rd, kind, kind == 0 ? ctx->host_cfg.ed_reuse : 0) <= 160 * 1024) ? 1 : 0;
         bool dirty = want_rec != ctx->host_cfg.rec_in_lds;
         ctx->host_cfg.rec_in_lds = want_rec;
-        if (nw != ctx->host_cfg.n_waves) { build_schedule(ctx, nw); dirty = true; }
+        if (nw != ctx->host_cfg.n_waves || (kind == 2) != ctx->sched_quad || ctx->sched_dirty) {
+            ctx->sched_quad = kind == 2;
+            build_schedule(ctx, nw, kind == 2);
+            ctx->sched_dirty = false;
+            dirty = true;
+        }
         if (dirty) HIP_TRY(hipMemcpyAsync(ctx->d_cfg, &ctx->host_cfg, sizeof(DevCfg), hipMemcpyHostToDevice, stream));
     }
     DevBatch bt;
@@ -773,7 +991,7 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
                     const double x = std::min(0.55, std::max(0.10, 0.95 * r / (1.0 + r)));
                     if (std::fabs(x - ctx->host_cfg.coop_frac) > 0.01) {
                         ctx->host_cfg.coop_frac = x;
-                        build_schedule(ctx, nw);
+                        build_schedule(ctx, nw, false);
                         HIP_TRY(hipMemcpyAsync(ctx->d_cfg, &ctx->host_cfg, sizeof(DevCfg), hipMemcpyHostToDevice, stream));
                     }
                 }
@@ -806,7 +1024,20 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
             }
         }
     }
-    if (std::getenv("NYX_HIP_PROFILE")) {
+    {
+        // the column weights of this launch's workgroup shape: measured once per context (see calibrate())
+        const bool stm_k = (ctx->host_cfg.flags & NYX_HIP_FLAG_STM) != 0;
+        const nyx_hip_ctx::WKey key(nw, (ctx->host_cfg.pipe && !stm_k) ? 1 : 0, ctx->sched_quad ? 1 : 0,
+                                    bt.coop_helpers > 0 ? (int)(ctx->host_cfg.coop_frac * 10.0 + 0.5) : -1);
+        ctx->last_key = key;
+        const int64_t span = use_end ? INT64_MAX : (duration_ns < 0 ? -duration_ns : duration_ns);
+        if (!calibrating && calibration_on(ctx) && ctx->host_cfg.has_grav && nw >= 8 && in->n >= 64 && !traj && !dur_ns && !ev &&
+            span >= 100 * ctx->host_cfg.init_step_ns && !ctx->weights.count(key)) {
+            if (int rc = calibrate(ctx, in, stream)) return rc;
+            return launch(ctx, in, out, st, duration_ns, end_epoch_ns, use_end, stream, time_it, traj, dur_ns, ev, false);
+        }
+    }
+    if (std::getenv("NYX_HIP_PROFILE") || calibrating) {
         if (!ctx->d_prof) HIP_TRY(hipMalloc(&ctx->d_prof, 17 * 8 * sizeof(int64_t)));
         HIP_TRY(hipMemsetAsync(ctx->d_prof, 0, 17 * 8 * sizeof(int64_t), stream));
         bt.prof = ctx->d_prof;
@@ -1267,6 +1498,16 @@ extern "C" int32_t nyx_hip_predict_until(nyx_hip_ctx *ctx, const nyx_hip_states_
     // segment 0 reads the caller's states (ctx->in) with an identity STM and writes ctx->out; later segments run in place
     a.stm = sg.din.stm;
     HIP_TRY(nyx_launch_predict_init(&a, sg.din.epoch_ns, stream));
+    {
+        // the segment launches carry a per-trajectory duration array and are too short to calibrate on themselves: measure
+        // the column weights of their workgroup shape once per context, on the staged states (identity STM set above)
+        const int nw_c = pick_waves(ctx, n);
+        const nyx_hip_ctx::WKey key(nw_c, 0, pick_quad(ctx, n) ? 1 : 0, -1);
+        if (calibration_on(ctx) && ctx->host_cfg.has_grav && nw_c >= 8 && n >= 16 && !ctx->weights.count(key)) {
+            if (int rc = calibrate(ctx, &sg.din, stream)) return rc;
+            HIP_TRY(hipEventRecord(ctx->ev0, stream));  // (the timed region is the segment loop, not the one-off calibration)
+        }
+    }
     a.stm = sg.dout.stm;
     for (int64_t s = 0; s < n_seg; ++s) {
         const nyx_hip_states_t *src = s == 0 ? &sg.din : &sg.dout;

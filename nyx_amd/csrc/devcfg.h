@@ -13,6 +13,13 @@
 #define DEV_MAX_WAVES_STM 4 /* STM variant: dual numbers need 256 VGPRs per wave and 16 partial slots per wave */
 #define DEV_MAX_RANGES 6  /* contiguous column ranges per wave */
 #define DEV_LANES 64
+#define DEV_MAX_ALM 3     /* almanac waves of a workgroup (role fan-out) */
+/* Roles of the waves of a workgroup, dealt by the host (DevCfg.role_kind / role_mask / role_slot).  role_mask: low 16 bits =
+ * almanac share (bit s = body slot s, DEV_ROLE_DCM = the body-fixed DCM), high 16 bits = perturbation share. */
+enum { DEV_ROLE_COLUMNS = 0, DEV_ROLE_ALL = 1, DEV_ROLE_INTEG = 2, DEV_ROLE_ALMANAC = 3, DEV_ROLE_PERT = 4, DEV_ROLE_ALMANAC_PERT = 5 };
+#define DEV_ROLE_DCM 0x100
+#define DEV_PERT_PM 1  /* point masses + solid tides */
+#define DEV_PERT_SRP 2 /* solar radiation pressure + drag */
 
 struct DevSeg {
     double init_et, interval, end_et;
@@ -83,6 +90,10 @@ struct DevCfg {
     double t_k2_5, t_k3_7; /* k2 / 5, k3 / 7 */
     double t_mu, t_re;
     DevRot t_rot;
+
+    /* --- roles of the waves (see DEV_ROLE_*) --- */
+    int32_t role_kind[DEV_MAX_WAVES], role_mask[DEV_MAX_WAVES], role_slot[DEV_MAX_WAVES]; /* role_slot: index of an almanac wave's status rows */
+    int32_t n_alm, _pad5;
 
     /* --- column schedules: wave w walks n_ranges[w] contiguous column ranges --- */
     int32_t n_waves;

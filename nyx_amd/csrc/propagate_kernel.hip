@@ -121,10 +121,12 @@ DEVFN int cheby_eval(const CAS DevSeg &sg, P records, double et_s, double *r3) {
 template <typename P>
 // `dcm_flag` (pipelined stage loop): LDS word that is set to `dcm_val` as soon as the DCM is written - the integrator wave
 // needs only that to form the next stage's recursion inputs, the body positions are for the next window.
-DEVFN int epoch_data(CfgPtr cfg, P records, int64_t epoch_ns, double *slot, int lane, volatile int *dcm_flag = nullptr, int dcm_val = 0) {
+// `amask`: the share of this almanac wave when the duty is dealt over several (role fan-out, DEV_ROLE_DCM = the DCM, bit s =
+// body slot s); every wave writes only its own rows of `slot`.
+DEVFN int epoch_data(CfgPtr cfg, P records, int64_t epoch_ns, double *slot, int lane, int amask, volatile int *dcm_flag = nullptr, int dcm_val = 0) {
     const double et = ns_to_seconds(epoch_ns);
     int status = NYX_HIP_OK;
-    if (cfg->has_grav || cfg->has_drag || cfg->has_tides) {  // (ctx_create requires these body-fixed frames to coincide)
+    if ((amask & DEV_ROLE_DCM) && (cfg->has_grav || cfg->has_drag || cfg->has_tides)) {  // (ctx_create requires these body-fixed frames to coincide)
         double m[9];
         if (cfg->has_grav) rotation_dcm(cfg->g_rot, et, m);
         else if (cfg->has_drag) rotation_dcm(cfg->d_rot, et, m);
@@ -139,7 +141,7 @@ DEVFN int epoch_data(CfgPtr cfg, P records, int64_t epoch_ns, double *slot, int 
     const int ns = cfg->n_slots;
 #pragma unroll
     for (int s = 0; s < DEV_MAX_SLOTS; ++s) {
-        if (s < ns) {
+        if (s < ns && ((amask >> s) & 1)) {
             double b0 = 0.0, b1 = 0.0, b2 = 0.0;
             const int nch = cfg->slot[s].n_chain;
             for (int k = 0; k < nch; ++k) {
@@ -638,23 +640,6 @@ DEVFN void touch_batch(HarmPtr e, int &sink) {
         : "memory");
 }
 DEVFN void touch_done(int &sink) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(sink) : : "memory"); }
-// One row (the tail of a column, after its full batches).
-typedef int v8i __attribute__((ext_vector_type(8)));
-struct HarmRow {
-    v8i q0;
-    v4i q1;
-    v2i q2;
-};
-DEVFN void load_row(HarmPtr e, HarmRow &r) {
-    asm volatile(
-        "s_load_dwordx8 %0, %3, 0x0\n\t"
-        "s_load_dwordx4 %1, %3, 0x20\n\t"
-        "s_load_dwordx2 %2, %3, 0x30\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&s"(r.q0), "=&s"(r.q1), "=&s"(r.q2)
-        : "s"(e)
-        : "memory");
-}
 #define HB_D(v, i) __builtin_bit_cast(double, (v2i){(v)[(i)], (v)[(i) + 1]})
 #define HB_ENTRY(v0, v1, v2, v3, v4, v5, v6, i0, i1, i2, i3, i4, i5, i6) \
     { HB_D(v0, i0), HB_D(v1, i1), HB_D(v2, i2), HB_D(v3, i3), HB_D(v4, i4), HB_D(v5, i5), HB_D(v6, i6) }
@@ -719,11 +704,23 @@ DEVFN Partial4T<T> harmonics_core(CfgPtr cfg, HarmPtr htab, ColPtr cols, const i
                 HARM_TERM(h3)
                 HARM_TERM(h4)
             }
-            for (int t = 0; t < rem; ++t, e += 1) {  // (these lines were touched by the last batch)
-                HarmRow hr;
-                load_row(e, hr);
-                const HarmEntry h0 = HB_ENTRY(hr.q0, hr.q0, hr.q0, hr.q0, hr.q1, hr.q1, hr.q2, 0, 2, 4, 6, 0, 2, 0);
+            if (rem) {
+                // the last 1..4 rows of the column: ONE more batch load (it runs into the next column's rows, or into the
+                // table's padding) and only the first `rem` terms - one scalar-load latency instead of `rem` of them
+                HarmBatch hb;
+                load_batch(e, hb);
+                const HarmEntry h0 = HB_ENTRY(hb.q0, hb.q0, hb.q0, hb.q0, hb.q0, hb.q0, hb.q0, 0, 2, 4, 6, 8, 10, 12);
+                const HarmEntry h1 = HB_ENTRY(hb.q0, hb.q1, hb.q1, hb.q1, hb.q1, hb.q1, hb.q1, 14, 0, 2, 4, 6, 8, 10);
+                const HarmEntry h2 = HB_ENTRY(hb.q1, hb.q1, hb.q2, hb.q2, hb.q2, hb.q2, hb.q2, 12, 14, 0, 2, 4, 6, 8);
+                const HarmEntry h3 = HB_ENTRY(hb.q2, hb.q2, hb.q2, hb.q3, hb.q3, hb.q3, hb.q3, 10, 12, 14, 0, 2, 4, 6);
                 HARM_TERM(h0)
+                if (rem > 1) {
+                    HARM_TERM(h1)
+                    if (rem > 2) {
+                        HARM_TERM(h2)
+                        if (rem > 3) HARM_TERM(h3)
+                    }
+                }
             }
             if (TOUCH_AHEAD) touch_done(sink);
             const T sc = rho * hd.scale;  // rho * c * sqrt(2)
@@ -1208,7 +1205,7 @@ DEVFN bool stm_update(double *phi, double h, const double *sacc, int lane, doubl
 // Quad layout of the two functions above.  out[15][64]: a_pm(3), column (ql - 1) of G_pm (3), f_srp/m(3), column of
 // G_srp/m (3), c(3); every expression is pert_gradients' own for the value and for ONE partial slot.
 DEVFN void pert_gradients_q(CfgPtr cfg, const double *ed, int lane, int ql, const double *r, double cr, double area, double mass,
-                            bool has_pm, bool has_srp, bool has_tides, double *out) {
+                            bool has_pm, bool has_srp, bool has_tides, int pmask, double *out) {
     double o[15];
 #pragma unroll
     for (int q = 0; q < 15; ++q) o[q] = 0.0;
@@ -1258,8 +1255,10 @@ DEVFN void pert_gradients_q(CfgPtr cfg, const double *ed, int lane, int ql, cons
             if (cfg->srp_estimate) o[12 + i] = (f3[i] / cr) / mass;
         }
     }
+    // (role fan-out: rows 0..5 belong to the point-mass share, 6..14 to the SRP share)
 #pragma unroll
-    for (int q = 0; q < 15; ++q) out[q * DEV_LANES + lane] = o[q];
+    for (int q = 0; q < 15; ++q)
+        if (pmask & (q < 6 ? DEV_PERT_PM : DEV_PERT_SRP)) out[q * DEV_LANES + lane] = o[q];
 }
 
 // stm_update for the quad layout: sacc rows 0..2 hold, per lane, column (ql - 1) of sum b_i G_i and rows 3..5 sum b_i c_i
@@ -1369,7 +1368,7 @@ struct LdsMap {
     double *step;   // [2][64]        epoch (as i64 bits) and h of the current attempt
     double *cs;     // [CS_FIELDS][64] integrator cold state
     double *part;   // [P][4][64]     harmonics partials (wave 0's slot unused)
-    int *edst;      // [2][64]        almanac status per buffer
+    int *edst;      // [DEV_MAX_ALM][2][64] almanac status per almanac wave and buffer
     int *pertst;    // [64]
     int *ctl;       // [16]
     double *rec;    // [rec_doubles]
@@ -1397,7 +1396,7 @@ DEVFN LdsMap carve_lds(char *smem, int n_waves, bool stm, int rec_lds_doubles, i
     m.step = p; p += 2 * DEV_LANES;
     m.cs = p; p += CS_FIELDS * DEV_LANES;
     m.part = p; p += DEV_MAX_WAVES * (quad ? 8 : 4) * DEV_LANES;  // = DEV_MAX_WAVES_STM * 16 * DEV_LANES: reused for the dual partials (quad: 16 waves x 8)
-    m.edst = (int *)p; p += DEV_LANES;       // 2*64 ints
+    m.edst = (int *)p; p += DEV_MAX_ALM * DEV_LANES;   // DEV_MAX_ALM * 2 * 64 ints
     m.pertst = (int *)p; p += DEV_LANES / 2; // 64 ints
     m.ctl = (int *)p; p += 8;
     m.inbD = m.pertD = m.sacc = m.partD = nullptr;
@@ -1428,7 +1427,7 @@ DEVFN LdsMap carve_lds(char *smem, int n_waves, bool stm, int rec_lds_doubles, i
 extern "C" size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles, int stm, int reuse_fields) {  // stm: 0 = plain, 1 = D3, 2 = quad layout
     const bool quad = stm == 2;
     size_t d = (size_t)DEV_MAX_STAGES * 6 * (quad ? DEV_LANES / 4 : DEV_LANES) + DEV_MAX_STAGES * DEV_MAX_STAGES + 3 * DEV_MAX_STAGES + 6 * DEV_LANES +
-               2 * ED_FIELDS * DEV_LANES + 2 * DEV_LANES + CS_FIELDS * DEV_LANES + (size_t)DEV_MAX_WAVES * (quad ? 8 : 4) * DEV_LANES + DEV_LANES +
+               2 * ED_FIELDS * DEV_LANES + 2 * DEV_LANES + CS_FIELDS * DEV_LANES + (size_t)DEV_MAX_WAVES * (quad ? 8 : 4) * DEV_LANES + DEV_MAX_ALM * DEV_LANES +
                DEV_LANES / 2 + 8 + (size_t)rec_doubles;
     d += quad ? (size_t)(10 + 15 + 6) * DEV_LANES : (stm ? (size_t)(20 + 27 + 12) * DEV_LANES : (size_t)(NIN + 9 + 6 + NIN + 9) * DEV_LANES);
     (void)n_waves;
@@ -1461,6 +1460,11 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     const bool has_tides = cfg->has_tides != 0;
 #endif
     const bool need_almanac = has_grav || has_drag || has_tides || cfg->n_slots > 0;
+    // role fan-out: this wave's share of the almanac / perturbation duties, and its status slot
+    const int amask = ALMANAC ? cfg->role_mask[wave] : 0;
+    const int pmask = PERT ? cfg->role_mask[wave] >> 16 : 0;
+    const int n_alm = cfg->n_alm;
+    int *const my_edst = L.edst + (ALMANAC ? cfg->role_slot[wave] : 0) * 2 * DEV_LANES;
     const bool rec_in_lds = cfg->rec_in_lds != 0;
     const bool dbg_skip_serial = (cfg->flags & DBG_SKIP_SERIAL) != 0;
     const bool dbg_skip_harm = (cfg->flags & DBG_SKIP_HARMONICS) != 0;
@@ -1556,7 +1560,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     // is computed by the almanac wave in the LAST window (where it has no next stage to prepare; buffer 0 is free by
     // then), the second is this attempt's own stage-0 data, kept aside.  Both are keyed by their integer epoch, so the
     // prologue only has to compare epochs - whatever the step logic did - and falls back to computing.
-    const int reuse_nf = (!STM && ALMANAC && !INTEG && need_almanac) ? cfg->ed_reuse : 0;
+    const int reuse_nf = (!STM && ALMANAC && !INTEG && need_almanac && cfg->n_alm == 1) ? cfg->ed_reuse : 0;  // (one almanac wave only: the epoch tags have one writer)
     if (reuse_nf > 0) { L.ed0_ep[lane] = INT64_MIN; L.spec_ep[lane] = INT64_MIN; }
     double nx_pos[3] = {0.0, 0.0, 0.0}, nx_s = 0.0, nx_t = 0.0, nx_u = 0.0, nx_kfac = 0.0;
     double m_cur[9], m_nx[9];
@@ -1614,16 +1618,16 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 compute = __any(!(hit_spec || hit_prev)) != 0;
                 if (!compute && !hit_spec) {
                     for (int f = 0; f < reuse_nf; ++f) L.ed[f * DEV_LANES + lane] = L.ed0[f * DEV_LANES + lane];
-                    L.edst[lane] = L.ed0st[lane];
+                    my_edst[lane] = L.ed0st[lane];
                 }
             }
             if (compute) {
-                int st = rec_in_lds ? epoch_data(cfg, (const double *)L.rec, ep, L.ed, lane) : epoch_data(cfg, records, ep, L.ed, lane);
-                L.edst[lane] = st;
+                int st = rec_in_lds ? epoch_data(cfg, (const double *)L.rec, ep, L.ed, lane, amask) : epoch_data(cfg, records, ep, L.ed, lane, amask);
+                my_edst[lane] = st;
             }
             if (reuse_nf > 0) {
                 for (int f = 0; f < reuse_nf; ++f) L.ed0[f * DEV_LANES + lane] = L.ed[f * DEV_LANES + lane];
-                L.ed0st[lane] = L.edst[lane];
+                L.ed0st[lane] = my_edst[lane];
                 L.ed0_ep[lane] = ep;
             }
         }
@@ -1657,7 +1661,12 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                         if (lane == 0) ((volatile int *)L.ctl)[4] = i + 1;
                     }
                     // (the almanac wave finished this stage's data before the barrier this wave has just passed)
-                    if (need_almanac && L.edst[(i & 1) * DEV_LANES + lane]) st_att = L.edst[(i & 1) * DEV_LANES + lane];
+                    if (need_almanac) {
+                        for (int a = 0; a < n_alm; ++a) {
+                            const int es = L.edst[(2 * a + (i & 1)) * DEV_LANES + lane];
+                            if (es) st_att = es;
+                        }
+                    }
                     s_ = nx_s; t_ = nx_t; u_ = nx_u; kfac = nx_kfac;
 #pragma unroll
                     for (int q = 0; q < 9; ++q) m_cur[q] = m_nx[q];
@@ -1678,7 +1687,12 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 }
 #pragma unroll
                 for (int e = 0; e < 6; ++e) ysb[e * DEV_LANES + lane] = ys[e];
-                if (need_almanac && L.edst[(i & 1) * DEV_LANES + lane]) st_att = L.edst[(i & 1) * DEV_LANES + lane];
+                if (need_almanac) {
+                    for (int a = 0; a < n_alm; ++a) {
+                        const int es = L.edst[(2 * a + (i & 1)) * DEV_LANES + lane];
+                        if (es) st_att = es;
+                    }
+                }
                 if (has_grav) {
                     // body-fixed position and the scaled inputs of the column recursion
 #pragma unroll
@@ -1756,9 +1770,9 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 if (!dbg_skip_serial || i == 0)  // (timing switch: reuse the data of stages 0/1)
                 {
                     volatile int *const fl = (pipe && !last_stage) ? (volatile int *)L.ctl + 2 : nullptr;
-                    st = rec_in_lds ? epoch_data(cfg, (const double *)L.rec, ep, edn, lane, fl, i + 1) : epoch_data(cfg, records, ep, edn, lane, fl, i + 1);
+                    st = rec_in_lds ? epoch_data(cfg, (const double *)L.rec, ep, edn, lane, amask, fl, i + 1) : epoch_data(cfg, records, ep, edn, lane, amask, fl, i + 1);
                 }
-                L.edst[((i + 1) & 1) * DEV_LANES + lane] = st;
+                my_edst[((i + 1) & 1) * DEV_LANES + lane] = st;
                 if (pipe && !last_stage) {  // tell the integrator wave (which publishes the inputs of stage i+1 inside this window)
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if (lane == 0) ((volatile int *)L.ctl)[2] = i + 1;
@@ -1769,15 +1783,26 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 double *const ysp = (pipe && (i & 1)) ? L.ys2 : L.ys;
                 double *const pertp = (pipe && (i & 1)) ? L.pert2 : L.pert;
                 double r[3] = {ysp[0 * DEV_LANES + lane], ysp[1 * DEV_LANES + lane], ysp[2 * DEV_LANES + lane]};
-                double a3[3] = {0.0, 0.0, 0.0}, f3[3] = {0.0, 0.0, 0.0};
-                if (has_pm && !dbg_skip_serial) point_masses_accel(cfg, edc, lane, r, a3);
-                if (has_srp && !dbg_skip_serial) {
-                    srp_force(cfg, edc, lane, r, p_cr, p_area, f3);
-                    f3[0] = f3[0] / p_mass; f3[1] = f3[1] / p_mass; f3[2] = f3[2] / p_mass;
-                }
+                // role fan-out: share DEV_PERT_PM = point masses (+ tides), share DEV_PERT_SRP = SRP (+ drag); every share
+                // writes only its own rows.  (STM: the rows of the plain path alias the dual ones and are not written.)
+                const bool do_pm = (pmask & DEV_PERT_PM) != 0, do_srp = (pmask & DEV_PERT_SRP) != 0;
+                if (!STM) {
+                    double a3[3] = {0.0, 0.0, 0.0}, f3[3] = {0.0, 0.0, 0.0};
+                    if (has_pm && do_pm && !dbg_skip_serial) point_masses_accel(cfg, edc, lane, r, a3);
+                    if (has_srp && do_srp && !dbg_skip_serial) {
+                        srp_force(cfg, edc, lane, r, p_cr, p_area, f3);
+                        f3[0] = f3[0] / p_mass; f3[1] = f3[1] / p_mass; f3[2] = f3[2] / p_mass;
+                    }
+                    if (do_pm) {
 #pragma unroll
-                for (int e = 0; e < 3; ++e) { pertp[e * DEV_LANES + lane] = a3[e]; pertp[(3 + e) * DEV_LANES + lane] = f3[e]; }
-                if (has_drag) {
+                        for (int e = 0; e < 3; ++e) pertp[e * DEV_LANES + lane] = a3[e];
+                    }
+                    if (do_srp) {
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) pertp[(3 + e) * DEV_LANES + lane] = f3[e];
+                    }
+                }
+                if (has_drag && do_srp) {
                     if (pipe && i > 0) {  // velocity of this stage: written by phase A, which runs beside this window
                         int spin = 0;
                         while (((volatile int *)L.ctl)[4] != i + 1 && ++spin < 4000000) __builtin_amdgcn_s_sleep(4);
@@ -1790,13 +1815,37 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
 #pragma unroll
                     for (int e = 0; e < 3; ++e) pertp[(6 + e) * DEV_LANES + lane] = d3f[e] / p_mass;
                 }
-                if (STM && QUAD) pert_gradients_q(cfg, edc, lane, ql, r, p_cr, p_area, p_mass, has_pm, has_srp, has_tides, L.pertD);
+                if (STM && QUAD) pert_gradients_q(cfg, edc, lane, ql, r, p_cr, p_area, p_mass, has_pm && do_pm, has_srp && do_srp, has_tides && do_pm, pmask, L.pertD);
                 else if (STM) pert_gradients(cfg, edc, lane, r, p_cr, p_area, p_mass, has_pm, has_srp, has_tides, L.pertD);
                 // third accel model (dynamics/sequence/config.rs:116-118): added to the point-mass slot, last, so that no
                 // live value of this role crosses the call
-                if (has_tides && !STM) tides_into_pert(cfg, edc, lane, ysp, pertp);
+                if (has_tides && !STM && do_pm) tides_into_pert(cfg, edc, lane, ysp, pertp);
             }
             double acc[3] = {0.0, 0.0, 0.0};
+            // quad layout: the position-only parts of phase C (two-body dual, the duals of s, t, u and (mu / r) / R_eq) are formed
+            // HERE, inside the window, where the integrator wave has nothing else to do
+            double q_acc[3] = {0.0, 0.0, 0.0}, q_gc[3] = {0.0, 0.0, 0.0};
+            D1 q_aux[4] = {d1c(0.0), d1c(0.0), d1c(0.0), d1c(0.0)};
+            if (INTEG && STM && QUAD) {
+                const D1 rad[3] = {d1seed(ys[0], 0, ql), d1seed(ys[1], 1, ql), d1seed(ys[2], 2, ql)};
+                const D1 fac = d1div(d1c(-cfg->mu_central), d1cube(d1norm(rad[0], rad[1], rad[2])));
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const D1 a = rad[q] * fac;
+                    q_acc[q] = a.v; q_gc[q] = a.d;
+                }
+                if (has_grav) {
+                    double m[9];
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) m[q] = edc[q * DEV_LANES + lane];
+                    const D1 x0 = d1seed(m[0] * ys[0] + m[1] * ys[1] + m[2] * ys[2], 0, ql);
+                    const D1 x1 = d1seed(m[3] * ys[0] + m[4] * ys[1] + m[5] * ys[2], 1, ql);
+                    const D1 x2 = d1seed(m[6] * ys[0] + m[7] * ys[1] + m[8] * ys[2], 2, ql);
+                    const D1 rD = d1norm(x0, x1, x2);
+                    q_aux[0] = d1div(x0, rD); q_aux[1] = d1div(x1, rD); q_aux[2] = d1div(x2, rD);
+                    q_aux[3] = d1div(d1div(d1c(cfg->g_mu), rD), d1c(cfg->g_re));
+                }
+            }
             if (INTEG) {
                 // two-body term of this stage (orbital.rs:86-92) and sum_{j<i} a_{i+1,j} k_j of the next one
                 const double rmag = norm3(ys[0], ys[1], ys[2]);
@@ -1867,9 +1916,10 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 pp[0 * DEV_LANES + lane] = 0.0; pp[1 * DEV_LANES + lane] = 0.0;
                 pp[2 * DEV_LANES + lane] = 0.0; pp[3 * DEV_LANES + lane] = 0.0;
             }
-            if (STM && QUAD && has_grav)
-                harmonics_partial_d1((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, L.inbD, L.partD + wave * 8 * DEV_LANES, lane);
-            else if (STM && has_grav)
+            if (STM && QUAD) {
+                if (has_grav && cfg->sched[DEV_SCHED_SOLO].n_ranges[wave] > 0)  // (a wave without columns keeps the zeros of its slot)
+                    harmonics_partial_d1((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, L.inbD, L.partD + wave * 8 * DEV_LANES, lane);
+            } else if (STM && has_grav)
                 harmonics_partial_dual((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, L.inbD, L.partD + wave * 16 * DEV_LANES, lane);
             if (!STM && has_grav && !dbg_skip_harm) {
                 // (ctl[1] is written before the barrier that precedes this read: B1 for stage 0, B2 of the previous stage otherwise;
@@ -1953,13 +2003,8 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 if (STM && QUAD) {
                     // the D3 block below, one partial per lane: Gc[i] = G[3 i + (ql - 1)]
                     double Gc[3], cv[3] = {0.0, 0.0, 0.0};
-                    const D1 rad[3] = {d1seed(ys[0], 0, ql), d1seed(ys[1], 1, ql), d1seed(ys[2], 2, ql)};
-                    const D1 fac = d1div(d1c(-cfg->mu_central), d1cube(d1norm(rad[0], rad[1], rad[2])));
 #pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        const D1 a = rad[q] * fac;
-                        acc[q] = a.v; Gc[q] = a.d;
-                    }
+                    for (int q = 0; q < 3; ++q) { acc[q] = q_acc[q]; Gc[q] = q_gc[q]; }
                     if (has_pm || has_tides) {
 #pragma unroll
                         for (int q = 0; q < 3; ++q) { acc[q] += L.pertD[q * DEV_LANES + lane]; Gc[q] += L.pertD[(3 + q) * DEV_LANES + lane]; }
@@ -1974,11 +2019,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                         double m[9];
 #pragma unroll
                         for (int q = 0; q < 9; ++q) m[q] = edc[q * DEV_LANES + lane];
-                        const D1 x0 = d1seed(m[0] * ys[0] + m[1] * ys[1] + m[2] * ys[2], 0, ql);
-                        const D1 x1 = d1seed(m[3] * ys[0] + m[4] * ys[1] + m[5] * ys[2], 1, ql);
-                        const D1 x2 = d1seed(m[6] * ys[0] + m[7] * ys[1] + m[8] * ys[2], 2, ql);
-                        const D1 rD = d1norm(x0, x1, x2);
-                        const D1 aux[4] = {d1div(x0, rD), d1div(x1, rD), d1div(x2, rD), d1div(d1div(d1c(cfg->g_mu), rD), d1c(cfg->g_re))};
+                        const D1 *const aux = q_aux;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) pD[q] = pD[q] * aux[3];
                         const D1 al[3] = {pD[0] + pD[3] * aux[0], pD[1] + pD[3] * aux[1], pD[2] + pD[3] * aux[2]};
@@ -2275,22 +2316,14 @@ DEVFN void propagate_body(const DevBatch &bt, const DevCfg *cfg_g, const HarmEnt
     }
     for (int q = (int)threadIdx.x; q < DEV_MAX_WAVES * (QUAD ? 8 : 4) * DEV_LANES; q += (int)blockDim.x) L.part[q] = 0.0;
 
-    // ---- role dispatch (wave-uniform): merged roles when the workgroup has fewer than three waves
-    if (nw == 1) {
-        role_loop<true, true, true, STM, QUAD>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
-    } else if (nw == 2) {
-        if (wave == 0) role_loop<true, false, false, STM, QUAD>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
-        else role_loop<false, true, true, STM, QUAD>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
-    } else if (cfg->merge_roles) {
-        // almanac + perturbations share wave 1 (their duties fit in one harmonics window), one more column worker
-        if (wave == 0) role_loop<true, false, false, STM, QUAD>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
-        else if (wave == 1) role_loop<false, true, true, STM, QUAD>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
-        else role_loop<false, false, false, STM, QUAD>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
-    } else {
-        if (wave == 0) role_loop<true, false, false, STM, QUAD>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
-        else if (wave == 1) role_loop<false, true, false, STM, QUAD>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
-        else if (wave == 2) role_loop<false, false, true, STM, QUAD>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
-        else role_loop<false, false, false, STM, QUAD>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw);
+    // ---- role dispatch (wave-uniform): the host deals the duties (cfg->role_kind / role_mask, see build_schedule)
+    switch (cfg->role_kind[wave]) {
+    case DEV_ROLE_ALL: role_loop<true, true, true, STM, QUAD>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw); break;
+    case DEV_ROLE_INTEG: role_loop<true, false, false, STM, QUAD>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw); break;
+    case DEV_ROLE_ALMANAC: role_loop<false, true, false, STM, QUAD>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw); break;
+    case DEV_ROLE_PERT: role_loop<false, false, true, STM, QUAD>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw); break;
+    case DEV_ROLE_ALMANAC_PERT: role_loop<false, true, true, STM, QUAD>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw); break;
+    default: role_loop<false, false, false, STM, QUAD>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw); break;
     }
 }
 

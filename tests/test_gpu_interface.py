@@ -54,7 +54,8 @@ def test_monte_carlo_run_until_epoch_on_gpu():
     rslts = mc.run_until_epoch(prop, almanac, end, 10)
     assert [r.index for r in rslts.runs] == list(range(10)) and all(r.result.epoch_ns == end for r in rslts.runs)
     mean, cov = rslts.mean_and_covariance()
-    assert mean.shape == (6,) and cov.shape == (6, 6) and np.all(np.linalg.eigvalsh(cov) > -1e-12)
+    assert mean.shape == (9,) and cov.shape == (9, 9) and np.all(np.linalg.eigvalsh(cov) > -1e-12)   # [r, v, Cr, Cd, prop mass]
+    np.testing.assert_allclose(mean[:6], rslts.final_rv().mean(axis=0), rtol=1e-12)
     # the GPU ensemble equals the oracle's run on the same dispersed states
     from nyx_amd.propagator import pack_spacecraft
     batch = pack_spacecraft([r.dispersed_state for r in rslts.runs], False)

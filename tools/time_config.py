@@ -40,6 +40,10 @@ ev = int(st.n_evals.sum())
 print(f"config {cfg_id}: n={n} hours={hours:g} waves={waves or 'auto'}: device {ms:.2f} ms, evals {ev} -> {ev / ms * 1e3:.3e} evals/s, "
       f"{ms * 1e3 / max(ev / n, 1):.2f} us per evaluation per trajectory-lane, acc {int(st.n_accepted.sum())} rej {int(st.n_rejected.sum())} "
       f"bad {(st.status != 0).sum()}, algorithmic {ev * w['flop'] / ms / 1e9:.2f} TFLOP/s, helpers {ctx.last_coop_helpers()}")
+wb = (C.c_double * 17)()
+ctx._lib.nyx_hip_debug_weights.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+if ctx._lib.nyx_hip_debug_weights(ctx._h, wb) == 0:
+    print("  column weights " + " ".join(f"{x:.2f}" for x in wb[:16]) + f" | window spread at calibration {wb[16]:.3f}")
 if os.environ.get("NYX_HIP_PROFILE"):
     buf = (C.c_int64 * 136)()
     ctx._lib.nyx_hip_debug_profile.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
