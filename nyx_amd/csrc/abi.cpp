@@ -376,33 +376,60 @@ static void assign_roles(nyx_hip_ctx *ctx, int n_waves, bool fanout, double *hc)
     if (n_waves == 2 || dc.merge_roles) { dc.role_kind[1] = DEV_ROLE_ALMANAC_PERT; dc.role_mask[1] = all_alm | all_pert; hc[1] = rh[1] + rh[2]; return; }
     int n_alm = 1, n_pert = 1;
     if (fanout && fanout_role_waves(ctx, &n_alm, &n_pert) <= n_waves && n_alm >= 1 && n_pert >= 1) {
-        int um[8]; double uc[8];
-        const int units = fanout_almanac_units(dc, um, uc);
-        int order[8];
-        for (int k = 0; k < units; ++k) order[k] = k;
-        std::sort(order, order + units, [&](int a, int b) { return uc[a] > uc[b]; });
-        double load[DEV_MAX_ALM] = {0.0, 0.0, 0.0};
-        for (int a = 0; a < n_alm; ++a) { dc.role_kind[1 + a] = DEV_ROLE_ALMANAC; dc.role_slot[1 + a] = a; }
-        for (int k = 0; k < units; ++k) {  // longest unit first onto the least loaded wave
-            int best = 0;
-            for (int a = 1; a < n_alm; ++a) if (load[a] < load[best]) best = a;
-            dc.role_mask[1 + best] |= um[order[k]];
-            load[best] += uc[order[k]];
-        }
-        for (int a = 0; a < n_alm; ++a) hc[1 + a] = load[a];
-        dc.n_alm = n_alm;
-        int w = 1 + n_alm;
-        const double pm_cost = 6.0 * dc.n_pm + (dc.has_tides ? 14.0 + 8.0 * dc.t_n : 0.0);
-        const double srp_cost = (dc.has_srp ? 6.0 + 6.0 * dc.n_shadow : 0.0) + (dc.has_drag ? 10.0 : 0.0);
-        if (n_pert == 2) {
-            dc.role_kind[w] = DEV_ROLE_PERT; dc.role_mask[w] = DEV_PERT_PM << 16; hc[w] = pm_cost; ++w;
-            dc.role_kind[w] = DEV_ROLE_PERT; dc.role_mask[w] = DEV_PERT_SRP << 16; hc[w] = srp_cost; ++w;
-        } else {
-            dc.role_kind[w] = DEV_ROLE_PERT; dc.role_mask[w] = all_pert; hc[w] = pm_cost + srp_cost; ++w;
-        }
         const bool stm = (dc.flags & NYX_HIP_FLAG_STM) != 0;
-        if (stm) for (int k = 1 + n_alm; k < w; ++k) hc[k] *= 3.0;  // (dual perturbations: ~3x the real ones)
-        return;
+        // the duties: almanac shares (longest unit first onto the least loaded share), then the perturbation shares
+        struct Duty { int kind, mask, slot; double cost; };
+        std::vector<Duty> duties;
+        {
+            int um[8]; double uc[8];
+            const int units = fanout_almanac_units(dc, um, uc);
+            int order[8];
+            for (int k = 0; k < units; ++k) order[k] = k;
+            std::sort(order, order + units, [&](int a, int b) { return uc[a] > uc[b]; });
+            double load[DEV_MAX_ALM] = {0.0, 0.0, 0.0};
+            int amask[DEV_MAX_ALM] = {0, 0, 0};
+            for (int k = 0; k < units; ++k) {
+                int best = 0;
+                for (int a = 1; a < n_alm; ++a) if (load[a] < load[best]) best = a;
+                amask[best] |= um[order[k]];
+                load[best] += uc[order[k]];
+            }
+            for (int a = 0; a < n_alm; ++a) duties.push_back({DEV_ROLE_ALMANAC, amask[a], a, load[a]});
+            dc.n_alm = n_alm;
+        }
+        // (measured on the device, in units of ~250 cycles: a plain point mass 4, a dual one 11; SRP with its occultation 12 + 8 per
+        //  shadow body, dual 25 + 25; drag 10; tides 14 + 8 per perturber)
+        const double pm_cost = (stm ? 11.0 : 4.0) * dc.n_pm + (dc.has_tides ? (stm ? 3.0 : 1.0) * (14.0 + 8.0 * dc.t_n) : 0.0);
+        const double srp_cost = (dc.has_srp ? (stm ? 25.0 + 25.0 * dc.n_shadow : 12.0 + 8.0 * dc.n_shadow) : 0.0) + (dc.has_drag ? 10.0 : 0.0);
+        if (n_pert == 2) {
+            duties.push_back({DEV_ROLE_PERT, DEV_PERT_PM << 16, 0, pm_cost});
+            duties.push_back({DEV_ROLE_PERT, DEV_PERT_SRP << 16, 0, srp_cost});
+        } else {
+            duties.push_back({DEV_ROLE_PERT, all_pert, 0, pm_cost + srp_cost});
+        }
+        // Placement: wave w runs on SIMD w % 4, and a force evaluation is bound by the busiest SIMD's role work (the role code
+        // is VALU-heavy: sincos, Chebyshev chains, divisions).  Heaviest duty first onto the least loaded SIMD; the integrator
+        // (wave 0, ~50 units with its phases A and C) sits on SIMD 0.
+        double simd_load[4] = {stm ? 52.0 : 26.0, 0.0, 0.0, 0.0};
+        bool taken[DEV_MAX_WAVES] = {true};
+        std::sort(duties.begin(), duties.end(), [](const Duty &a, const Duty &b) { return a.cost > b.cost; });
+        bool placed_all = true;
+        for (const Duty &d : duties) {
+            int best_w = -1;
+            double best_load = 1e300;
+            for (int sd = 0; sd < 4; ++sd) {
+                int w = -1;
+                for (int k = sd; k < n_waves; k += 4) if (!taken[k]) { w = k; break; }
+                if (w >= 0 && simd_load[sd] < best_load) { best_load = simd_load[sd]; best_w = w; }
+            }
+            if (best_w < 0) { placed_all = false; break; }
+            taken[best_w] = true;
+            simd_load[best_w % 4] += d.cost;
+            dc.role_kind[best_w] = d.kind; dc.role_mask[best_w] = d.mask; dc.role_slot[best_w] = d.slot; hc[best_w] = d.cost;
+        }
+        if (placed_all) return;
+        for (int w = 1; w < DEV_MAX_WAVES; ++w) { dc.role_kind[w] = DEV_ROLE_COLUMNS; dc.role_mask[w] = 0; dc.role_slot[w] = 0; hc[w] = 0.0; }
+        dc.n_alm = 1;
     }
     dc.role_kind[1] = DEV_ROLE_ALMANAC; dc.role_mask[1] = all_alm; hc[1] = rh[1];
     dc.role_kind[2] = DEV_ROLE_PERT; dc.role_mask[2] = all_pert; hc[2] = rh[2];
@@ -484,7 +511,7 @@ static int pick_waves(const nyx_hip_ctx *ctx, int64_t n) {
     const bool stm = (ctx->host_cfg.flags & NYX_HIP_FLAG_STM) != 0;
     if (stm && pick_quad(ctx, n)) {  // quad layout: 128 VGPRs per wave like the plain kernel
         if (ctx->forced_waves > 0) return std::min(ctx->forced_waves, DEV_MAX_WAVES);
-        if (!ctx->host_cfg.has_grav) return want_fanout(ctx, true) ? std::max(3, fanout_role_waves(ctx)) : 3;
+        if (!ctx->host_cfg.has_grav) return want_fanout(ctx, true) ? (fanout_role_waves(ctx) > 4 ? 8 : std::max(3, fanout_role_waves(ctx))) : 3;
         return ctx->host_cfg.deg < 8 ? 8 : 16;
     }
     if (stm) {  // dual-number variant: 256 VGPRs per wave, at most DEV_MAX_WAVES_STM waves
@@ -495,7 +522,7 @@ static int pick_waves(const nyx_hip_ctx *ctx, int64_t n) {
     // no harmonics: integrator + almanac + perturbation waves form a 3-stage pipeline
     if (!ctx->host_cfg.has_grav) {
         if (!(ctx->host_cfg.n_slots > 0 || ctx->host_cfg.has_drag || ctx->host_cfg.has_tides)) return 1;
-        return want_fanout(ctx, false) ? std::max(3, fanout_role_waves(ctx)) : 3;
+        return want_fanout(ctx, false) ? (fanout_role_waves(ctx) > 4 ? 8 : std::max(3, fanout_role_waves(ctx))) : 3;  // (8: two role waves per SIMD can be placed)
     }
     // Fill the 256 CUs: workgroups = ceil(n/64); with fewer than ~2 workgroups per CU the column
     // split is what creates the waves that keep the SIMDs busy.

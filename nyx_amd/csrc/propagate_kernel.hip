@@ -45,6 +45,7 @@ typedef const CAS HarmEntry *HarmPtr;
 typedef const CAS ColHdr *ColPtr;
 
 #define DEVFN static __device__ __forceinline__
+typedef const __attribute__((address_space(3))) double *LdsCPtr;
 
 DEVFN double norm3(double x, double y, double z) { return sqrt(x * x + y * y + z * z); }
 DEVFN double cube(double x) { return x * (x * x); }  // f64::powi(3)
@@ -771,9 +772,12 @@ static __device__ __attribute__((noinline)) void harmonics_partial_dual(uint64_t
     }
 }
 
-// Quad layout (D1): 5 inputs and 4 partial sums of (value, this lane's partial) through LDS: 10 + 8 doubles per lane.
+// Quad layout (D1): 5 inputs of (value, this lane's partial) in, 4 partial sums out, through LDS.  The slot of a wave is
+// QSLOT doubles: [4 sums][64] partials, then [4 sums][16] values (the value is the same in the four lanes of a quad).
+#define QSLOT (4 * DEV_LANES + 4 * (DEV_LANES / 4))
+typedef __attribute__((address_space(3))) double *LdsPtr;
 static __device__ __attribute__((noinline)) void harmonics_partial_d1(uint64_t cfg_u, uint64_t htab_u, uint64_t cols_u, int wave_v,
-                                                                    const double *inbQ, double *outQ, int lane) {
+                                                                    LdsCPtr inbQ, LdsPtr outQ, int lane) {
     CfgPtr cfg = (CfgPtr)uniform_u64(cfg_u);
     HarmPtr htab = (HarmPtr)uniform_u64(htab_u);
     ColPtr cols = (ColPtr)uniform_u64(cols_u);
@@ -784,7 +788,7 @@ static __device__ __attribute__((noinline)) void harmonics_partial_d1(uint64_t c
     const Partial4T<D1> pd = harmonics_core<D1>(cfg, htab, cols, wave, DEV_SCHED_SOLO, in[0], in[1], in[2], in[3], in[4]);
     const D1 o4[4] = {pd.x, pd.y, pd.z, pd.w};
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { outQ[(2 * q + 0) * DEV_LANES + lane] = o4[q].v; outQ[(2 * q + 1) * DEV_LANES + lane] = o4[q].d; }
+    for (int q = 0; q < 4; ++q) { outQ[q * DEV_LANES + lane] = o4[q].d; outQ[4 * DEV_LANES + q * (DEV_LANES / 4) + (lane >> 2)] = o4[q].v; }
 }
 
 // Quad-lane exchange (DPP quad_perm broadcast of lane SEL of every quad; two 32-bit moves per double).
@@ -1091,7 +1095,6 @@ DEVFN double error_estimate(int ec, const double *e, const double *cand, const d
 // Fold of the 15 workers' partial accelerations (fixed wave order => deterministic).  Kept out of line on purpose:
 // inside the integrator role (at its 128-VGPR cap) the scheduler serialised the 60 LDS reads at one LDS latency each
 // (5 k cycles on the critical path of every force evaluation); on its own the function batches them.
-typedef const __attribute__((address_space(3))) double *LdsCPtr;
 static __device__ __attribute__((noinline)) Partial4 fold_partials(LdsCPtr part, int lane, double px, double py, double pz, double pw) {
     double v[4][DEV_MAX_WAVES - 1];
 #pragma unroll
@@ -1295,6 +1298,91 @@ DEVFN bool stm_update_q(double *phi, double h, const double *sacc, int lane, int
     return quad_or(nan ? 1 : 0) != 0;
 }
 
+// Phase C of the quad layout (assembly of f(x) and of this lane's column of A = df/dx from the partial sums, the
+// perturbation rows and the position-only pieces formed in the window; accumulation of sum b_i A_i; k_i), OUT OF LINE: inside
+// the integrator role (128 VGPRs = 64 doubles for everything it keeps live) it ran through scratch, 10 k cycles per
+// evaluation; on its own it has the whole register file.  Everything goes through LDS: `qpre` rows 0..2 two-body
+// acceleration, 3..5 this lane's column of its gradient, 6..13 the duals of s, t, u and (mu / r) / R_eq.
+#define QPRE_ROWS 14
+#define PC_HAS_PM 1
+#define PC_HAS_GRAV 2
+#define PC_HAS_SRP 4
+// (LDS pointers are passed as such: through generic pointers every access pays an address-space test)
+static __device__ __attribute__((noinline)) void phase_c_quad(LdsCPtr pertD, LdsCPtr partD, LdsCPtr edc, LdsCPtr qpre,
+                                                            LdsCPtr ysl, LdsPtr sacc, LdsPtr kb, int kb_str, double b_i, int nw_v,
+                                                            int flags_v, int lane, int ql, int64_t *pslot = nullptr) {
+    const int64_t pc0 = pslot ? (int64_t)__builtin_readcyclecounter() : 0;
+    const int nw = __builtin_amdgcn_readfirstlane(nw_v);
+    const int flags = __builtin_amdgcn_readfirstlane(flags_v);
+    double acc[3], Gc[3], cv[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { acc[q] = qpre[q * DEV_LANES + lane]; Gc[q] = qpre[(3 + q) * DEV_LANES + lane]; }
+    if (flags & PC_HAS_PM) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { acc[q] += pertD[q * DEV_LANES + lane]; Gc[q] += pertD[(3 + q) * DEV_LANES + lane]; }
+    }
+    if (flags & PC_HAS_GRAV) {
+        D1 pD[4] = {d1c(0.0), d1c(0.0), d1c(0.0), d1c(0.0)};
+        for (int w0 = 0; w0 < nw; w0 += 4) {  // fixed wave order; four waves' worth of loads in flight
+            double v[4][8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                LdsCPtr pp = partD + (w0 + k < nw ? w0 + k : 0) * QSLOT;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { v[k][2 * q] = pp[4 * DEV_LANES + q * (DEV_LANES / 4) + (lane >> 2)]; v[k][2 * q + 1] = pp[q * DEV_LANES + lane]; }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (w0 + k < nw) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { pD[q].v += v[k][2 * q]; pD[q].d += v[k][2 * q + 1]; }
+                }
+            }
+        }
+        if (pslot && lane == 0) pslot[5] += (int64_t)__builtin_readcyclecounter() - pc0;
+        double m[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) m[q] = edc[q * DEV_LANES + lane];
+        D1 aux[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { aux[q].v = qpre[(6 + 2 * q) * DEV_LANES + lane]; aux[q].d = qpre[(7 + 2 * q) * DEV_LANES + lane]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pD[q] = pD[q] * aux[3];
+        const D1 al[3] = {pD[0] + pD[3] * aux[0], pD[1] + pD[3] * aux[1], pD[2] + pD[3] * aux[2]};
+        // a = R^T a_bf ; G_h = R^T G_bf R: the first product is linear in the partial slot (this lane's), the second
+        // mixes the three slots: fetched from the quad's lanes 1..3; this lane forms column b = ql - 1
+        double tmpc[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            acc[a] += m[0 + a] * al[0].v + m[3 + a] * al[1].v + m[6 + a] * al[2].v;
+            tmpc[a] = m[0 + a] * al[0].d + m[3 + a] * al[1].d + m[6 + a] * al[2].d;
+        }
+        const int b = ql > 0 ? ql - 1 : 0;
+        const double mb0 = edc[(0 + b) * DEV_LANES + lane], mb1 = edc[(3 + b) * DEV_LANES + lane], mb2 = edc[(6 + b) * DEV_LANES + lane];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double t0 = quad_bcast<1>(tmpc[a]), t1 = quad_bcast<2>(tmpc[a]), t2 = quad_bcast<3>(tmpc[a]);
+            Gc[a] += t0 * mb0 + t1 * mb1 + t2 * mb2;
+        }
+    }
+    if (flags & PC_HAS_SRP) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            acc[q] += pertD[(6 + q) * DEV_LANES + lane]; cv[q] = pertD[(12 + q) * DEV_LANES + lane];
+            Gc[q] += pertD[(9 + q) * DEV_LANES + lane];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        sacc[q * DEV_LANES + lane] += b_i * Gc[q];
+        sacc[(3 + q) * DEV_LANES + lane] += b_i * cv[q];
+    }
+    // k_i = [velocity of the stage state, f(x)]
+#pragma unroll
+    for (int e = 0; e < 3; ++e) { kb[e * kb_str] = ysl[(3 + e) * DEV_LANES + lane]; kb[(3 + e) * kb_str] = acc[e]; }
+    if (pslot && lane == 0) pslot[6] += (int64_t)__builtin_readcyclecounter() - pc0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // The kernel
 // ---------------------------------------------------------------------------------------------
@@ -1383,6 +1471,7 @@ struct LdsMap {
     double *inbD;   // [20][64]       5 dual inputs (zr, zi, rho_u, rho, 1/rho)
     double *pertD;  // [27][64]       a_pm(3) G_pm(9) f_srp/m(3) G_srp/m(9) c_srp(3)
     double *sacc;   // [12][64]       sum_i b_i * (G_i (9, row-major), c_i (3)) of the current attempt
+    double *qpre;   // [QPRE_ROWS][64] quad layout: position-only pieces of phase C, formed in the window
     double *partD;  // [P][16][64]    dual harmonics partials
 };
 
@@ -1395,16 +1484,17 @@ DEVFN LdsMap carve_lds(char *smem, int n_waves, bool stm, int rec_lds_doubles, i
     m.ed = p; p += 2 * ED_FIELDS * DEV_LANES;
     m.step = p; p += 2 * DEV_LANES;
     m.cs = p; p += CS_FIELDS * DEV_LANES;
-    m.part = p; p += DEV_MAX_WAVES * (quad ? 8 : 4) * DEV_LANES;  // = DEV_MAX_WAVES_STM * 16 * DEV_LANES: reused for the dual partials (quad: 16 waves x 8)
+    m.part = p; p += quad ? DEV_MAX_WAVES * QSLOT : DEV_MAX_WAVES * 4 * DEV_LANES;  // = DEV_MAX_WAVES_STM * 16 * DEV_LANES: reused for the dual partials
     m.edst = (int *)p; p += DEV_MAX_ALM * DEV_LANES;   // DEV_MAX_ALM * 2 * 64 ints
     m.pertst = (int *)p; p += DEV_LANES / 2; // 64 ints
     m.ctl = (int *)p; p += 8;
-    m.inbD = m.pertD = m.sacc = m.partD = nullptr;
+    m.inbD = m.pertD = m.sacc = m.partD = m.qpre = nullptr;
     if (stm) {
         // the plain inb / pert slots alias the head of their dual counterparts (written first, overwritten after)
         m.inbD = p; m.inb = p; p += (quad ? 10 : 20) * DEV_LANES;
         m.pertD = p; m.pert = p; p += (quad ? 15 : 27) * DEV_LANES;
         m.sacc = p; p += (quad ? 6 : 12) * DEV_LANES;
+        m.qpre = p; p += (quad ? QPRE_ROWS : 0) * DEV_LANES;
         m.partD = m.part;
     } else {
         m.inb = p; p += NIN * DEV_LANES;
@@ -1427,9 +1517,9 @@ DEVFN LdsMap carve_lds(char *smem, int n_waves, bool stm, int rec_lds_doubles, i
 extern "C" size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles, int stm, int reuse_fields) {  // stm: 0 = plain, 1 = D3, 2 = quad layout
     const bool quad = stm == 2;
     size_t d = (size_t)DEV_MAX_STAGES * 6 * (quad ? DEV_LANES / 4 : DEV_LANES) + DEV_MAX_STAGES * DEV_MAX_STAGES + 3 * DEV_MAX_STAGES + 6 * DEV_LANES +
-               2 * ED_FIELDS * DEV_LANES + 2 * DEV_LANES + CS_FIELDS * DEV_LANES + (size_t)DEV_MAX_WAVES * (quad ? 8 : 4) * DEV_LANES + DEV_MAX_ALM * DEV_LANES +
+               2 * ED_FIELDS * DEV_LANES + 2 * DEV_LANES + CS_FIELDS * DEV_LANES + (size_t)(quad ? DEV_MAX_WAVES * QSLOT : DEV_MAX_WAVES * 4 * DEV_LANES) + DEV_MAX_ALM * DEV_LANES +
                DEV_LANES / 2 + 8 + (size_t)rec_doubles;
-    d += quad ? (size_t)(10 + 15 + 6) * DEV_LANES : (stm ? (size_t)(20 + 27 + 12) * DEV_LANES : (size_t)(NIN + 9 + 6 + NIN + 9) * DEV_LANES);
+    d += quad ? (size_t)(10 + 15 + 6 + QPRE_ROWS) * DEV_LANES : (stm ? (size_t)(20 + 27 + 12) * DEV_LANES : (size_t)(NIN + 9 + 6 + NIN + 9) * DEV_LANES);
     (void)n_waves;
     if (reuse_fields > 0) d += (size_t)reuse_fields * DEV_LANES + 2 * DEV_LANES + DEV_LANES / 2;
     return d * sizeof(double) + 64;
@@ -1824,9 +1914,9 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             double acc[3] = {0.0, 0.0, 0.0};
             // quad layout: the position-only parts of phase C (two-body dual, the duals of s, t, u and (mu / r) / R_eq) are formed
             // HERE, inside the window, where the integrator wave has nothing else to do
-            double q_acc[3] = {0.0, 0.0, 0.0}, q_gc[3] = {0.0, 0.0, 0.0};
-            D1 q_aux[4] = {d1c(0.0), d1c(0.0), d1c(0.0), d1c(0.0)};
             if (INTEG && STM && QUAD) {
+                double q_acc[3], q_gc[3];
+                D1 q_aux[4] = {d1c(0.0), d1c(0.0), d1c(0.0), d1c(0.0)};
                 const D1 rad[3] = {d1seed(ys[0], 0, ql), d1seed(ys[1], 1, ql), d1seed(ys[2], 2, ql)};
                 const D1 fac = d1div(d1c(-cfg->mu_central), d1cube(d1norm(rad[0], rad[1], rad[2])));
 #pragma unroll
@@ -1845,6 +1935,10 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     q_aux[0] = d1div(x0, rD); q_aux[1] = d1div(x1, rD); q_aux[2] = d1div(x2, rD);
                     q_aux[3] = d1div(d1div(d1c(cfg->g_mu), rD), d1c(cfg->g_re));
                 }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { L.qpre[q * DEV_LANES + lane] = q_acc[q]; L.qpre[(3 + q) * DEV_LANES + lane] = q_gc[q]; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { L.qpre[(6 + 2 * q) * DEV_LANES + lane] = q_aux[q].v; L.qpre[(7 + 2 * q) * DEV_LANES + lane] = q_aux[q].d; }
             }
             if (INTEG) {
                 // two-body term of this stage (orbital.rs:86-92) and sum_{j<i} a_{i+1,j} k_j of the next one
@@ -1918,7 +2012,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             }
             if (STM && QUAD) {
                 if (has_grav && cfg->sched[DEV_SCHED_SOLO].n_ranges[wave] > 0)  // (a wave without columns keeps the zeros of its slot)
-                    harmonics_partial_d1((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, L.inbD, L.partD + wave * 8 * DEV_LANES, lane);
+                    harmonics_partial_d1((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, (LdsCPtr)L.inbD, (LdsPtr)(L.partD + wave * QSLOT), lane);
             } else if (STM && has_grav)
                 harmonics_partial_dual((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, L.inbD, L.partD + wave * 16 * DEV_LANES, lane);
             if (!STM && has_grav && !dbg_skip_harm) {
@@ -2001,57 +2095,11 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     acc[0] += pertc[6 * DEV_LANES + lane]; acc[1] += pertc[7 * DEV_LANES + lane]; acc[2] += pertc[8 * DEV_LANES + lane];
                 }
                 if (STM && QUAD) {
-                    // the D3 block below, one partial per lane: Gc[i] = G[3 i + (ql - 1)]
-                    double Gc[3], cv[3] = {0.0, 0.0, 0.0};
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) { acc[q] = q_acc[q]; Gc[q] = q_gc[q]; }
-                    if (has_pm || has_tides) {
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) { acc[q] += L.pertD[q * DEV_LANES + lane]; Gc[q] += L.pertD[(3 + q) * DEV_LANES + lane]; }
-                    }
-                    if (has_grav) {
-                        D1 pD[4] = {d1c(0.0), d1c(0.0), d1c(0.0), d1c(0.0)};
-                        for (int w = 0; w < nw; ++w) {  // fixed wave order
-                            const double *pp = L.partD + w * 8 * DEV_LANES;
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) { pD[q].v += pp[(2 * q + 0) * DEV_LANES + lane]; pD[q].d += pp[(2 * q + 1) * DEV_LANES + lane]; }
-                        }
-                        double m[9];
-#pragma unroll
-                        for (int q = 0; q < 9; ++q) m[q] = edc[q * DEV_LANES + lane];
-                        const D1 *const aux = q_aux;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) pD[q] = pD[q] * aux[3];
-                        const D1 al[3] = {pD[0] + pD[3] * aux[0], pD[1] + pD[3] * aux[1], pD[2] + pD[3] * aux[2]};
-                        // a = R^T a_bf ; G_h = R^T G_bf R: the first product is linear in the partial slot (this lane's), the second
-                        // mixes the three slots: fetched from the quad's lanes 1..3; this lane forms column b = ql - 1
-                        double tmpc[3];
-#pragma unroll
-                        for (int a = 0; a < 3; ++a) {
-                            acc[a] += m[0 + a] * al[0].v + m[3 + a] * al[1].v + m[6 + a] * al[2].v;
-                            tmpc[a] = m[0 + a] * al[0].d + m[3 + a] * al[1].d + m[6 + a] * al[2].d;
-                        }
-                        const int b = ql > 0 ? ql - 1 : 0;
-                        const double mb0 = edc[(0 + b) * DEV_LANES + lane], mb1 = edc[(3 + b) * DEV_LANES + lane], mb2 = edc[(6 + b) * DEV_LANES + lane];
-#pragma unroll
-                        for (int a = 0; a < 3; ++a) {
-                            const double t0 = quad_bcast<1>(tmpc[a]), t1 = quad_bcast<2>(tmpc[a]), t2 = quad_bcast<3>(tmpc[a]);
-                            Gc[a] += t0 * mb0 + t1 * mb1 + t2 * mb2;
-                        }
-                    }
-                    if (has_srp) {
-#pragma unroll
-                        for (int q = 0; q < 3; ++q) {
-                            acc[q] += L.pertD[(6 + q) * DEV_LANES + lane]; cv[q] = L.pertD[(12 + q) * DEV_LANES + lane];
-                            Gc[q] += L.pertD[(9 + q) * DEV_LANES + lane];
-                        }
-                    }
-                    const double b_i = B_COEF(i);
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        L.sacc[q * DEV_LANES + lane] += b_i * Gc[q];
-                        L.sacc[(3 + q) * DEV_LANES + lane] += b_i * cv[q];
-                    }
+                    // (out of line, see phase_c_quad: it also writes k_i)
+                    phase_c_quad((LdsCPtr)L.pertD, (LdsCPtr)L.partD, (LdsCPtr)edc, (LdsCPtr)L.qpre, (LdsCPtr)L.ys, (LdsPtr)L.sacc,
+                                 (LdsPtr)(kbuf + (i * 6) * KB_STR + kb_li), KB_STR, B_COEF(i), nw,
+                                 ((has_pm || has_tides) ? PC_HAS_PM : 0) | (has_grav ? PC_HAS_GRAV : 0) | (has_srp ? PC_HAS_SRP : 0), lane, ql,
+                                 prof_on ? bt.prof + 16 * 8 : nullptr);
                 } else if (STM) {
                     // dual path (dual_eom, spacecraft.rs:312-363): f(x) and A = df/dx; the derivative written to k_i is
                     // the dual path's real part, as in the reference's STM branch (spacecraft.rs:208-224)
@@ -2118,8 +2166,10 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
 #pragma unroll
                     for (int q = 0; q < 3; ++q) L.sacc[(9 + q) * DEV_LANES + lane] += b_i * cv[q];
                 }
-                KB(i, 0) = ys[3]; KB(i, 1) = ys[4]; KB(i, 2) = ys[5];
-                KB(i, 3) = acc[0]; KB(i, 4) = acc[1]; KB(i, 5) = acc[2];
+                if (!(STM && QUAD)) {
+                    KB(i, 0) = ys[3]; KB(i, 1) = ys[4]; KB(i, 2) = ys[5];
+                    KB(i, 3) = acc[0]; KB(i, 4) = acc[1]; KB(i, 5) = acc[2];
+                }
             }
             if (prof_on) prof_acc[3] += (int64_t)__builtin_readcyclecounter() - ptc_;
         }
@@ -2314,7 +2364,8 @@ DEVFN void propagate_body(const DevBatch &bt, const DevCfg *cfg_g, const HarmEnt
         // ctl[1]: 1 while this workgroup shares its columns with the helpers
         L.ctl[1] = (!STM && bt.coop_helpers > 0 && cfg->has_grav) ? 1 : 0;
     }
-    for (int q = (int)threadIdx.x; q < DEV_MAX_WAVES * (QUAD ? 8 : 4) * DEV_LANES; q += (int)blockDim.x) L.part[q] = 0.0;
+    for (int q = (int)threadIdx.x; q < (QUAD ? DEV_MAX_WAVES * QSLOT : DEV_MAX_WAVES * 4 * DEV_LANES); q += (int)blockDim.x) L.part[q] = 0.0;
+
 
     // ---- role dispatch (wave-uniform): the host deals the duties (cfg->role_kind / role_mask, see build_schedule)
     switch (cfg->role_kind[wave]) {

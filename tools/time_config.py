@@ -52,6 +52,7 @@ if os.environ.get("NYX_HIP_PROFILE"):
         ne = evals_last_launch
         print("  wg0 cycles per eval (phaseA, duty, harmonics, phaseC, stepctl | total, barrier-wait) clock %.0f MHz, %d evals" %
               (p[0, 5] / max(p[0, 7], 1) * 100.0, ne))
+        print(f"  (phase C of the quad layout: fold of the partial sums done after {p[16, 5] / ne:.0f} cycles, function {p[16, 6] / ne:.0f} cycles)")
         for wv in range(16):
             if p[wv, 5]:
                 print(f"   wave {wv:2d}: " + " ".join(f"{p[wv, q] / ne:9.0f}" for q in (0, 1, 2, 3, 4)) + f" | {p[wv, 5] / ne:9.0f} {p[wv, 6] / ne:9.0f}")
