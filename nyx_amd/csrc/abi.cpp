@@ -271,7 +271,7 @@ static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, con
     // before that (and with calibration off) a structural guess by age class is used.
     double per_wave[DEV_MAX_WAVES];
     {
-        const nyx_hip_ctx::WKey key(n_waves, (ctx->host_cfg.pipe && !(ctx->host_cfg.flags & NYX_HIP_FLAG_STM)) ? 1 : 0, ctx->sched_quad ? 1 : 0,
+        const nyx_hip_ctx::WKey key(n_waves, (ctx->host_cfg.pipe && (!(ctx->host_cfg.flags & NYX_HIP_FLAG_STM) || ctx->sched_quad)) ? 1 : 0, ctx->sched_quad ? 1 : 0,
                                     all_columns ? -1 : (int)(ctx->host_cfg.coop_frac * 10.0 + 0.5));
         const auto it = ctx->weights.find(key);
         static const double age[4] = {1.3, 1.2, 0.9, 0.6};
@@ -1054,7 +1054,7 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
     {
         // the column weights of this launch's workgroup shape: measured once per context (see calibrate())
         const bool stm_k = (ctx->host_cfg.flags & NYX_HIP_FLAG_STM) != 0;
-        const nyx_hip_ctx::WKey key(nw, (ctx->host_cfg.pipe && !stm_k) ? 1 : 0, ctx->sched_quad ? 1 : 0,
+        const nyx_hip_ctx::WKey key(nw, (ctx->host_cfg.pipe && (!stm_k || ctx->sched_quad)) ? 1 : 0, ctx->sched_quad ? 1 : 0,
                                     bt.coop_helpers > 0 ? (int)(ctx->host_cfg.coop_frac * 10.0 + 0.5) : -1);
         ctx->last_key = key;
         const int64_t span = use_end ? INT64_MAX : (duration_ns < 0 ? -duration_ns : duration_ns);
@@ -1529,7 +1529,9 @@ extern "C" int32_t nyx_hip_predict_until(nyx_hip_ctx *ctx, const nyx_hip_states_
         // the segment launches carry a per-trajectory duration array and are too short to calibrate on themselves: measure
         // the column weights of their workgroup shape once per context, on the staged states (identity STM set above)
         const int nw_c = pick_waves(ctx, n);
-        const nyx_hip_ctx::WKey key(nw_c, 0, pick_quad(ctx, n) ? 1 : 0, -1);
+        const bool quad_c = pick_quad(ctx, n);
+        const bool pipe_c = quad_c && nw_c == DEV_MAX_WAVES && !(std::getenv("NYX_HIP_PIPE") && std::atoi(std::getenv("NYX_HIP_PIPE")) == 0);
+        const nyx_hip_ctx::WKey key(nw_c, pipe_c ? 1 : 0, quad_c ? 1 : 0, -1);
         if (calibration_on(ctx) && ctx->host_cfg.has_grav && nw_c >= 8 && n >= 16 && !ctx->weights.count(key)) {
             if (int rc = calibrate(ctx, &sg.din, stream)) return rc;
             HIP_TRY(hipEventRecord(ctx->ev0, stream));  // (the timed region is the segment loop, not the one-off calibration)

@@ -777,7 +777,7 @@ static __device__ __attribute__((noinline)) void harmonics_partial_dual(uint64_t
 #define QSLOT (4 * DEV_LANES + 4 * (DEV_LANES / 4))
 typedef __attribute__((address_space(3))) double *LdsPtr;
 static __device__ __attribute__((noinline)) void harmonics_partial_d1(uint64_t cfg_u, uint64_t htab_u, uint64_t cols_u, int wave_v,
-                                                                    LdsCPtr inbQ, LdsPtr outQ, int lane) {
+                                                                    LdsCPtr inbQ, LdsPtr outQ, int lane, volatile int *gate, int need_v) {
     CfgPtr cfg = (CfgPtr)uniform_u64(cfg_u);
     HarmPtr htab = (HarmPtr)uniform_u64(htab_u);
     ColPtr cols = (ColPtr)uniform_u64(cols_u);
@@ -787,8 +787,26 @@ static __device__ __attribute__((noinline)) void harmonics_partial_d1(uint64_t c
     for (int q = 0; q < 5; ++q) { in[q].v = inbQ[(2 * q + 0) * DEV_LANES + lane]; in[q].d = inbQ[(2 * q + 1) * DEV_LANES + lane]; }
     const Partial4T<D1> pd = harmonics_core<D1>(cfg, htab, cols, wave, DEV_SCHED_SOLO, in[0], in[1], in[2], in[3], in[4]);
     const D1 o4[4] = {pd.x, pd.y, pd.z, pd.w};
+    // pipelined stage loop: the slot still holds the previous stage's sums until the integrator wave has folded them
+    const int need = __builtin_amdgcn_readfirstlane(need_v);
+    if (need > 0) {
+        int spin = 0;
+        while (*gate < need && ++spin < 4000000) __builtin_amdgcn_s_sleep(1);
+    }
 #pragma unroll
     for (int q = 0; q < 4; ++q) { outQ[q * DEV_LANES + lane] = o4[q].d; outQ[4 * DEV_LANES + q * (DEV_LANES / 4) + (lane >> 2)] = o4[q].v; }
+}
+
+// The five inputs of the column recursion as one-partial duals of the body-fixed position (quad layout), into `dst` [10][64].
+DEVFN void publish_d1_inputs(CfgPtr cfg, double rb0, double rb1, double rb2, int ql, double *dst, int lane) {
+    const D1 x0 = d1seed(rb0, 0, ql), x1 = d1seed(rb1, 1, ql), x2 = d1seed(rb2, 2, ql);
+    const D1 rD = d1norm(x0, x1, x2);
+    const D1 sD = d1div(x0, rD), tD = d1div(x1, rD), uD = d1div(x2, rD);
+    const D1 rhoD = d1div(d1c(cfg->g_re), rD);
+    const D1 invD = rD * cfg->g_inv_re;
+    const D1 pub[5] = {rhoD * sD, rhoD * tD, rhoD * uD, rhoD, invD};
+#pragma unroll
+    for (int q = 0; q < 5; ++q) { dst[(2 * q + 0) * DEV_LANES + lane] = pub[q].v; dst[(2 * q + 1) * DEV_LANES + lane] = pub[q].d; }
 }
 
 // Quad-lane exchange (DPP quad_perm broadcast of lane SEL of every quad; two 32-bit moves per double).
@@ -1303,14 +1321,15 @@ DEVFN bool stm_update_q(double *phi, double h, const double *sacc, int lane, int
 // the integrator role (128 VGPRs = 64 doubles for everything it keeps live) it ran through scratch, 10 k cycles per
 // evaluation; on its own it has the whole register file.  Everything goes through LDS: `qpre` rows 0..2 two-body
 // acceleration, 3..5 this lane's column of its gradient, 6..13 the duals of s, t, u and (mu / r) / R_eq.
-#define QPRE_ROWS 14
+#define QPRE_ROWS 23  /* + rows 14..22: the DCM of the stage (the almanac wave recycles its LDS buffer in the pipelined loop) */
 #define PC_HAS_PM 1
 #define PC_HAS_GRAV 2
 #define PC_HAS_SRP 4
 // (LDS pointers are passed as such: through generic pointers every access pays an address-space test)
-static __device__ __attribute__((noinline)) void phase_c_quad(LdsCPtr pertD, LdsCPtr partD, LdsCPtr edc, LdsCPtr qpre,
+static __device__ __attribute__((noinline)) void phase_c_quad(LdsCPtr pertD, LdsCPtr partD, LdsCPtr qpre,
                                                             LdsCPtr ysl, LdsPtr sacc, LdsPtr kb, int kb_str, double b_i, int nw_v,
-                                                            int flags_v, int lane, int ql, int64_t *pslot = nullptr) {
+                                                            int flags_v, int lane, int ql, volatile int *gate, int gate_val_v,
+                                                            int64_t *pslot = nullptr) {
     const int64_t pc0 = pslot ? (int64_t)__builtin_readcyclecounter() : 0;
     const int nw = __builtin_amdgcn_readfirstlane(nw_v);
     const int flags = __builtin_amdgcn_readfirstlane(flags_v);
@@ -1339,10 +1358,17 @@ static __device__ __attribute__((noinline)) void phase_c_quad(LdsCPtr pertD, Lds
                 }
             }
         }
+        {   // the sums are in registers: the column waves may write the next stage's into their slots
+            const int gate_val = __builtin_amdgcn_readfirstlane(gate_val_v);
+            if (gate_val > 0) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) *gate = gate_val;
+            }
+        }
         if (pslot && lane == 0) pslot[5] += (int64_t)__builtin_readcyclecounter() - pc0;
         double m[9];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) m[q] = edc[q * DEV_LANES + lane];
+        for (int q = 0; q < 9; ++q) m[q] = qpre[(14 + q) * DEV_LANES + lane];
         D1 aux[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) { aux[q].v = qpre[(6 + 2 * q) * DEV_LANES + lane]; aux[q].d = qpre[(7 + 2 * q) * DEV_LANES + lane]; }
@@ -1358,12 +1384,15 @@ static __device__ __attribute__((noinline)) void phase_c_quad(LdsCPtr pertD, Lds
             tmpc[a] = m[0 + a] * al[0].d + m[3 + a] * al[1].d + m[6 + a] * al[2].d;
         }
         const int b = ql > 0 ? ql - 1 : 0;
-        const double mb0 = edc[(0 + b) * DEV_LANES + lane], mb1 = edc[(3 + b) * DEV_LANES + lane], mb2 = edc[(6 + b) * DEV_LANES + lane];
+        const double mb0 = qpre[(14 + b) * DEV_LANES + lane], mb1 = qpre[(17 + b) * DEV_LANES + lane], mb2 = qpre[(20 + b) * DEV_LANES + lane];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
             const double t0 = quad_bcast<1>(tmpc[a]), t1 = quad_bcast<2>(tmpc[a]), t2 = quad_bcast<3>(tmpc[a]);
             Gc[a] += t0 * mb0 + t1 * mb1 + t2 * mb2;
         }
+    } else {
+        const int gate_val = __builtin_amdgcn_readfirstlane(gate_val_v);
+        if (gate_val > 0 && lane == 0) *gate = gate_val;
     }
     if (flags & PC_HAS_SRP) {
 #pragma unroll
@@ -1505,6 +1534,10 @@ DEVFN LdsMap carve_lds(char *smem, int n_waves, bool stm, int rec_lds_doubles, i
         m.ys2 = p; p += 6 * DEV_LANES;
         m.inb2 = p; p += NIN * DEV_LANES;
         m.pert2 = p; p += 9 * DEV_LANES;
+    } else if (quad) {  // pipelined stage loop of the quad layout: second set of the dual buffers
+        m.ys2 = p; p += 6 * DEV_LANES;
+        m.inb2 = p; p += 10 * DEV_LANES;
+        m.pert2 = p; p += 15 * DEV_LANES;
     }
     m.rec = p; p += rec_lds_doubles;
     m.ed0 = p; p += reuse_fields * DEV_LANES;
@@ -1519,7 +1552,7 @@ extern "C" size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles, int stm, in
     size_t d = (size_t)DEV_MAX_STAGES * 6 * (quad ? DEV_LANES / 4 : DEV_LANES) + DEV_MAX_STAGES * DEV_MAX_STAGES + 3 * DEV_MAX_STAGES + 6 * DEV_LANES +
                2 * ED_FIELDS * DEV_LANES + 2 * DEV_LANES + CS_FIELDS * DEV_LANES + (size_t)(quad ? DEV_MAX_WAVES * QSLOT : DEV_MAX_WAVES * 4 * DEV_LANES) + DEV_MAX_ALM * DEV_LANES +
                DEV_LANES / 2 + 8 + (size_t)rec_doubles;
-    d += quad ? (size_t)(10 + 15 + 6 + QPRE_ROWS) * DEV_LANES : (stm ? (size_t)(20 + 27 + 12) * DEV_LANES : (size_t)(NIN + 9 + 6 + NIN + 9) * DEV_LANES);
+    d += quad ? (size_t)(10 + 15 + 6 + QPRE_ROWS + 6 + 10 + 15) * DEV_LANES : (stm ? (size_t)(20 + 27 + 12) * DEV_LANES : (size_t)(NIN + 9 + 6 + NIN + 9) * DEV_LANES);
     (void)n_waves;
     if (reuse_fields > 0) d += (size_t)reuse_fields * DEV_LANES + 2 * DEV_LANES + DEV_LANES / 2;
     return d * sizeof(double) + 64;
@@ -1644,7 +1677,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     // has written, ctl[3] = number of stages whose partial sums the integrator has folded (a worker does not overwrite
     // its slot before that), ctl[4] = last stage whose velocity is published (drag is the one position-AND-velocity term
     // of the perturbation wave).  Same arithmetic in the same order as the plain loop: bit-identical results.
-    const bool pipe = !STM && !(INTEG && (ALMANAC || PERT)) && cfg->pipe != 0 && has_grav;
+    const bool pipe = (!STM || QUAD) && !(INTEG && (ALMANAC || PERT)) && cfg->pipe != 0 && has_grav;
     // Epoch data carried between attempts (almanac wave, host-enabled when the stage count is even and LDS has room).
     // Stage 0 of the next attempt sits at t + h if this attempt is accepted and at t again if it is rejected: the first
     // is computed by the almanac wave in the LAST window (where it has no next stage to prepare; buffer 0 is free by
@@ -1802,16 +1835,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     inbb[3 * DEV_LANES + lane] = rho;
                     inbb[4 * DEV_LANES + lane] = r_ * cfg->g_inv_re;
                     if (STM && QUAD) {
-                        const D1 x0 = d1seed(rb0, 0, ql), x1 = d1seed(rb1, 1, ql), x2 = d1seed(rb2, 2, ql);
-                        const D1 rD = d1norm(x0, x1, x2);
-                        const D1 sD = d1div(x0, rD), tD = d1div(x1, rD), uD = d1div(x2, rD);
-                        const D1 rhoD = d1div(d1c(cfg->g_re), rD);
-                        const D1 invD = rD * cfg->g_inv_re;
-                        const D1 pub[5] = {rhoD * sD, rhoD * tD, rhoD * uD, rhoD, invD};
-#pragma unroll
-                        for (int q = 0; q < 5; ++q) {
-                            L.inbD[(2 * q + 0) * DEV_LANES + lane] = pub[q].v; L.inbD[(2 * q + 1) * DEV_LANES + lane] = pub[q].d;
-                        }
+                        publish_d1_inputs(cfg, rb0, rb1, rb2, ql, inbb, lane);  // (inb aliases the head of inbD: written after the plain rows)
                     } else if (STM) {
                         // the same quantities as duals seeded in the BODY-FIXED frame (gravity_field.rs:285-291)
                         const D3 x0 = {rb0, 1.0, 0.0, 0.0}, x1 = {rb1, 0.0, 1.0, 0.0}, x2 = {rb2, 0.0, 0.0, 1.0};
@@ -1859,11 +1883,11 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 int st = NYX_HIP_OK;
                 if (!dbg_skip_serial || i == 0)  // (timing switch: reuse the data of stages 0/1)
                 {
-                    volatile int *const fl = (pipe && !last_stage) ? (volatile int *)L.ctl + 2 : nullptr;
+                    volatile int *const fl = (pipe && !last_stage && (amask & DEV_ROLE_DCM)) ? (volatile int *)L.ctl + 2 : nullptr;
                     st = rec_in_lds ? epoch_data(cfg, (const double *)L.rec, ep, edn, lane, amask, fl, i + 1) : epoch_data(cfg, records, ep, edn, lane, amask, fl, i + 1);
                 }
                 my_edst[((i + 1) & 1) * DEV_LANES + lane] = st;
-                if (pipe && !last_stage) {  // tell the integrator wave (which publishes the inputs of stage i+1 inside this window)
+                if (pipe && !last_stage && (amask & DEV_ROLE_DCM)) {  // tell the integrator wave (which publishes the inputs of stage i+1 inside this window)
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if (lane == 0) ((volatile int *)L.ctl)[2] = i + 1;
                 }
@@ -1905,41 +1929,13 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
 #pragma unroll
                     for (int e = 0; e < 3; ++e) pertp[(6 + e) * DEV_LANES + lane] = d3f[e] / p_mass;
                 }
-                if (STM && QUAD) pert_gradients_q(cfg, edc, lane, ql, r, p_cr, p_area, p_mass, has_pm && do_pm, has_srp && do_srp, has_tides && do_pm, pmask, L.pertD);
+                if (STM && QUAD) pert_gradients_q(cfg, edc, lane, ql, r, p_cr, p_area, p_mass, has_pm && do_pm, has_srp && do_srp, has_tides && do_pm, pmask, pertp);
                 else if (STM) pert_gradients(cfg, edc, lane, r, p_cr, p_area, p_mass, has_pm, has_srp, has_tides, L.pertD);
                 // third accel model (dynamics/sequence/config.rs:116-118): added to the point-mass slot, last, so that no
                 // live value of this role crosses the call
                 if (has_tides && !STM && do_pm) tides_into_pert(cfg, edc, lane, ysp, pertp);
             }
             double acc[3] = {0.0, 0.0, 0.0};
-            // quad layout: the position-only parts of phase C (two-body dual, the duals of s, t, u and (mu / r) / R_eq) are formed
-            // HERE, inside the window, where the integrator wave has nothing else to do
-            if (INTEG && STM && QUAD) {
-                double q_acc[3], q_gc[3];
-                D1 q_aux[4] = {d1c(0.0), d1c(0.0), d1c(0.0), d1c(0.0)};
-                const D1 rad[3] = {d1seed(ys[0], 0, ql), d1seed(ys[1], 1, ql), d1seed(ys[2], 2, ql)};
-                const D1 fac = d1div(d1c(-cfg->mu_central), d1cube(d1norm(rad[0], rad[1], rad[2])));
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const D1 a = rad[q] * fac;
-                    q_acc[q] = a.v; q_gc[q] = a.d;
-                }
-                if (has_grav) {
-                    double m[9];
-#pragma unroll
-                    for (int q = 0; q < 9; ++q) m[q] = edc[q * DEV_LANES + lane];
-                    const D1 x0 = d1seed(m[0] * ys[0] + m[1] * ys[1] + m[2] * ys[2], 0, ql);
-                    const D1 x1 = d1seed(m[3] * ys[0] + m[4] * ys[1] + m[5] * ys[2], 1, ql);
-                    const D1 x2 = d1seed(m[6] * ys[0] + m[7] * ys[1] + m[8] * ys[2], 2, ql);
-                    const D1 rD = d1norm(x0, x1, x2);
-                    q_aux[0] = d1div(x0, rD); q_aux[1] = d1div(x1, rD); q_aux[2] = d1div(x2, rD);
-                    q_aux[3] = d1div(d1div(d1c(cfg->g_mu), rD), d1c(cfg->g_re));
-                }
-#pragma unroll
-                for (int q = 0; q < 3; ++q) { L.qpre[q * DEV_LANES + lane] = q_acc[q]; L.qpre[(3 + q) * DEV_LANES + lane] = q_gc[q]; }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { L.qpre[(6 + 2 * q) * DEV_LANES + lane] = q_aux[q].v; L.qpre[(7 + 2 * q) * DEV_LANES + lane] = q_aux[q].d; }
-            }
             if (INTEG) {
                 // two-body term of this stage (orbital.rs:86-92) and sum_{j<i} a_{i+1,j} k_j of the next one
                 const double rmag = norm3(ys[0], ys[1], ys[2]);
@@ -1993,12 +1989,45 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     inbn[2 * DEV_LANES + lane] = rho * nx_u;
                     inbn[3 * DEV_LANES + lane] = rho;
                     inbn[4 * DEV_LANES + lane] = r_ * cfg->g_inv_re;
+                    if (STM && QUAD) publish_d1_inputs(cfg, rb0, rb1, rb2, ql, inbn, lane);
                     shared_nx = coop_on;
                     if (lane == 0) L.ctl[1] = coop_on ? 1 : 0;  // the workers read it after B2(i), for stage i+1
                     if (coop_on) {
                         seq_nx = ++coop_seq;
                         coop_post(cbox, bt.coop_posted + coop_widx, lane, seq_nx, inbn);
                     }
+                }
+            }
+            // quad layout: the position-only parts of phase C (two-body dual, the duals of s, t, u and (mu / r) / R_eq) are formed
+            // HERE, inside the window, where the integrator wave has nothing else to do (after the next stage's inputs: those gate the column waves)
+            if (INTEG && STM && QUAD) {
+                double q_acc[3], q_gc[3];
+                D1 q_aux[4] = {d1c(0.0), d1c(0.0), d1c(0.0), d1c(0.0)};
+                const D1 rad[3] = {d1seed(ys[0], 0, ql), d1seed(ys[1], 1, ql), d1seed(ys[2], 2, ql)};
+                const D1 fac = d1div(d1c(-cfg->mu_central), d1cube(d1norm(rad[0], rad[1], rad[2])));
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    const D1 a = rad[q] * fac;
+                    q_acc[q] = a.v; q_gc[q] = a.d;
+                }
+                if (has_grav) {
+                    double m[9];
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) m[q] = edc[q * DEV_LANES + lane];
+                    const D1 x0 = d1seed(m[0] * ys[0] + m[1] * ys[1] + m[2] * ys[2], 0, ql);
+                    const D1 x1 = d1seed(m[3] * ys[0] + m[4] * ys[1] + m[5] * ys[2], 1, ql);
+                    const D1 x2 = d1seed(m[6] * ys[0] + m[7] * ys[1] + m[8] * ys[2], 2, ql);
+                    const D1 rD = d1norm(x0, x1, x2);
+                    q_aux[0] = d1div(x0, rD); q_aux[1] = d1div(x1, rD); q_aux[2] = d1div(x2, rD);
+                    q_aux[3] = d1div(d1div(d1c(cfg->g_mu), rD), d1c(cfg->g_re));
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { L.qpre[q * DEV_LANES + lane] = q_acc[q]; L.qpre[(3 + q) * DEV_LANES + lane] = q_gc[q]; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { L.qpre[(6 + 2 * q) * DEV_LANES + lane] = q_aux[q].v; L.qpre[(7 + 2 * q) * DEV_LANES + lane] = q_aux[q].d; }
+                if (has_grav) {  // the DCM of this stage, for phase C (its LDS buffer is recycled by the almanac wave in the pipelined loop)
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) L.qpre[(14 + q) * DEV_LANES + lane] = edc[q * DEV_LANES + lane];
                 }
             }
             if (prof_on) prof_acc[1] += (int64_t)__builtin_readcyclecounter() - ptw_;
@@ -2012,7 +2041,8 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             }
             if (STM && QUAD) {
                 if (has_grav && cfg->sched[DEV_SCHED_SOLO].n_ranges[wave] > 0)  // (a wave without columns keeps the zeros of its slot)
-                    harmonics_partial_d1((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, (LdsCPtr)L.inbD, (LdsPtr)(L.partD + wave * QSLOT), lane);
+                    harmonics_partial_d1((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, (LdsCPtr)((pipe && (i & 1)) ? L.inb2 : L.inbD),
+                                         (LdsPtr)(L.partD + wave * QSLOT), lane, (volatile int *)L.ctl + 3, pipe ? i : 0);
             } else if (STM && has_grav)
                 harmonics_partial_dual((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, L.inbD, L.partD + wave * 16 * DEV_LANES, lane);
             if (!STM && has_grav && !dbg_skip_harm) {
@@ -2096,10 +2126,11 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 }
                 if (STM && QUAD) {
                     // (out of line, see phase_c_quad: it also writes k_i)
-                    phase_c_quad((LdsCPtr)L.pertD, (LdsCPtr)L.partD, (LdsCPtr)edc, (LdsCPtr)L.qpre, (LdsCPtr)L.ys, (LdsPtr)L.sacc,
+                    phase_c_quad((LdsCPtr)((pipe && (i & 1)) ? L.pert2 : L.pertD), (LdsCPtr)L.partD, (LdsCPtr)L.qpre,
+                                 (LdsCPtr)((pipe && (i & 1)) ? L.ys2 : L.ys), (LdsPtr)L.sacc,
                                  (LdsPtr)(kbuf + (i * 6) * KB_STR + kb_li), KB_STR, B_COEF(i), nw,
                                  ((has_pm || has_tides) ? PC_HAS_PM : 0) | (has_grav ? PC_HAS_GRAV : 0) | (has_srp ? PC_HAS_SRP : 0), lane, ql,
-                                 prof_on ? bt.prof + 16 * 8 : nullptr);
+                                 (volatile int *)L.ctl + 3, pipe ? i + 1 : 0, prof_on ? bt.prof + 16 * 8 : nullptr);
                 } else if (STM) {
                     // dual path (dual_eom, spacecraft.rs:312-363): f(x) and A = df/dx; the derivative written to k_i is
                     // the dual path's real part, as in the reference's STM branch (spacecraft.rs:208-224)
