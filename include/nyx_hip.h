@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NYX_HIP_ABI_VERSION 2
+#define NYX_HIP_ABI_VERSION 3
 
 /* ---- IntegratorMethod: nyx-core/src/propagators/rk_methods/mod.rs:65-79 ---- */
 enum nyx_hip_method {
@@ -122,15 +122,34 @@ typedef struct nyx_hip_body {
     double mean_radius_km;
 } nyx_hip_body_t;
 
-/* IAU-style body-fixed orientation w.r.t. the inertial integration frame
- * (replaces almanac.transform_to / almanac.rotate at gravity_field.rs:150-154,
- * 258-265): alpha = ra[0] + ra[1]*T + ra[2]*T^2 (deg, T in Julian centuries TDB),
- * delta likewise, W = w[0] + w[1]*d + w[2]*d^2 (deg, d in days TDB);
- * DCM(inertial->fixed) = R3(W) R1(90deg - delta) R3(90deg + alpha). */
+/* Body-fixed orientation w.r.t. the inertial integration frame (replaces almanac.transform_to / almanac.rotate at
+ * gravity_field.rs:150-154, 258-265, drag.rs:184-189, 223-228).  Two kinds, as ANISE has them:
+ *
+ * NYX_HIP_ROT_IAU (planetary constants, PCK text kernels): alpha = ra[0] + ra[1]*T + ra[2]*T^2 (deg, T in Julian
+ *   centuries TDB), delta likewise, W = w[0] + w[1]*d + w[2]*d^2 (deg, d in days TDB), plus the trigonometric
+ *   (nutation-precession) series of the IAU reports, BODYnnn_NUT_PREC_*: theta_k = angle[k][0] + angle[k][1]*T,
+ *   alpha += ra_k sin theta_k, delta += dec_k cos theta_k, W += w_k sin theta_k (IAU_MOON has 13 terms, IAU_EARTH none);
+ *   DCM(inertial->fixed) = R3(W) R1(90deg - delta) R3(90deg + alpha).
+ * NYX_HIP_ROT_EULER_CHEBY (binary PCK, type 2: ITRF93 from the Earth high-precision BPCs, MOON_PA): three Euler
+ *   angles (rad) as Chebyshev records [mid_et_s, radius_s, A1[n], A2[n], A3[n]] held as one of config.segments;
+ *   DCM(base->fixed) = R3(A3) R1(A2) R3(A1) (SPICE EUL2M(w, delta, phi, 3, 1, 3)), times `base_dcm` = inertial
+ *   integration frame -> the segment's base frame (identity for J2000-based files, the obliquity rotation for the
+ *   ECLIPJ2000-based Earth BPCs), flattened by the host like the ephemeris chains. */
+enum nyx_hip_rotation_kind { NYX_HIP_ROT_IAU = 0, NYX_HIP_ROT_EULER_CHEBY = 1 };
+#define NYX_HIP_MAX_NUT_PREC 16
 typedef struct nyx_hip_rotation {
     double ra_deg[3];
     double dec_deg[3];
     double w_deg[3];
+    int32_t kind;       /* enum nyx_hip_rotation_kind */
+    int32_t n_nut_prec; /* IAU: number of trigonometric terms (0 = polynomials only) */
+    double nut_prec_angle_deg[NYX_HIP_MAX_NUT_PREC][2];
+    double nut_prec_ra[NYX_HIP_MAX_NUT_PREC];
+    double nut_prec_dec[NYX_HIP_MAX_NUT_PREC];
+    double nut_prec_w[NYX_HIP_MAX_NUT_PREC];
+    int32_t euler_segment; /* EULER_CHEBY: index into config.segments */
+    int32_t _pad;
+    double base_dcm[9];    /* EULER_CHEBY: row-major */
 } nyx_hip_rotation_t;
 
 /* GravityFieldData + frame constants: io/gravity.rs:90-96, gravity_field.rs:195-207.

@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_CHAIN = 4
 MAX_BODIES = 8
 MAX_SEGMENTS = 16
@@ -72,8 +72,16 @@ class Body(C.Structure):
     ]
 
 
+MAX_NUT_PREC = 16
+ROT_IAU, ROT_EULER_CHEBY = 0, 1
+
+
 class Rotation(C.Structure):
-    _fields_ = [("ra_deg", C.c_double * 3), ("dec_deg", C.c_double * 3), ("w_deg", C.c_double * 3)]
+    _fields_ = [("ra_deg", C.c_double * 3), ("dec_deg", C.c_double * 3), ("w_deg", C.c_double * 3),
+                ("kind", C.c_int32), ("n_nut_prec", C.c_int32),
+                ("nut_prec_angle_deg", (C.c_double * 2) * MAX_NUT_PREC),
+                ("nut_prec_ra", C.c_double * MAX_NUT_PREC), ("nut_prec_dec", C.c_double * MAX_NUT_PREC), ("nut_prec_w", C.c_double * MAX_NUT_PREC),
+                ("euler_segment", C.c_int32), ("_pad", C.c_int32), ("base_dcm", C.c_double * 9)]
 
 
 class GravityField(C.Structure):

@@ -171,6 +171,25 @@ extern "C" int64_t nyx_hip_abi_sizeof(int32_t which) {
     }
 }
 
+// nyx_hip_rotation_t -> DevRot (validated by check_rotation() first)
+static void copy_rotation(DevRot &d, const nyx_hip_rotation_t &r) {
+    std::memset(&d, 0, sizeof d);
+    for (int k = 0; k < 3; ++k) { d.ra[k] = r.ra_deg[k]; d.dec[k] = r.dec_deg[k]; d.w[k] = r.w_deg[k]; }
+    d.kind = r.kind; d.n_np = r.n_nut_prec;
+    for (int k = 0; k < r.n_nut_prec; ++k) {
+        d.np_ang[k][0] = r.nut_prec_angle_deg[k][0]; d.np_ang[k][1] = r.nut_prec_angle_deg[k][1];
+        d.np_ra[k] = r.nut_prec_ra[k]; d.np_dec[k] = r.nut_prec_dec[k]; d.np_w[k] = r.nut_prec_w[k];
+    }
+    d.euler_seg = r.euler_segment;
+    for (int k = 0; k < 9; ++k) d.base[k] = r.base_dcm[k];
+}
+static const char *check_rotation(const nyx_hip_rotation_t &r, int n_segments) {
+    if (r.kind != NYX_HIP_ROT_IAU && r.kind != NYX_HIP_ROT_EULER_CHEBY) return "unknown orientation kind";
+    if (r.n_nut_prec < 0 || r.n_nut_prec > NYX_HIP_MAX_NUT_PREC) return "n_nut_prec outside 0..NYX_HIP_MAX_NUT_PREC";
+    if (r.kind == NYX_HIP_ROT_EULER_CHEBY && (r.euler_segment < 0 || r.euler_segment >= n_segments)) return "euler_segment is not one of config.segments";
+    return nullptr;
+}
+
 static double ns_to_seconds_host(int64_t ns) {  // Duration::to_seconds for |ns| < 1 century, ns >= 0
     int64_t q = ns / 1000000000LL, r = ns % 1000000000LL;
     return (double)q + (double)r * 1e-9;
@@ -654,6 +673,10 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
             return NYX_HIP_RC_UNSUPPORTED;
         }
     }
+    for (const nyx_hip_rotation_t *r : {cfg->gravity ? &cfg->gravity->rotation : nullptr, cfg->drag ? &cfg->drag->rotation : nullptr,
+                                        cfg->tides ? &cfg->tides->rotation : nullptr})
+        if (r)
+            if (const char *why = check_rotation(*r, cfg->n_segments)) { nyx_set_error("body-fixed orientation: %s", why); return NYX_HIP_RC_BAD_ARG; }
     if (nyx_hip_device_count() <= device || device < 0) { nyx_set_error("no HIP device %d", device); return NYX_HIP_RC_NO_DEVICE; }
     HIP_TRY(hipSetDevice(device));
 
@@ -727,7 +750,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
         dc.t_k2_5 = td->k2 / (2.0 * 2.0 + 1.0);
         dc.t_k3_7 = td->k3 / (2.0 * 3.0 + 1.0);
         dc.t_mu = td->mu_km3_s2; dc.t_re = td->eq_radius_km;
-        for (int k = 0; k < 3; ++k) { dc.t_rot.ra[k] = td->rotation.ra_deg[k]; dc.t_rot.dec[k] = td->rotation.dec_deg[k]; dc.t_rot.w[k] = td->rotation.w_deg[k]; }
+        copy_rotation(dc.t_rot, td->rotation);
         for (int j = 0; j < td->n_perturbers; ++j) {
             const int b = td->perturber_body[j];
             const int sl = slot_for(b);
@@ -763,7 +786,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
         if (g->degree < 1 || !g->c_nm || !g->s_nm) { delete ctx; nyx_set_error("bad gravity field"); return NYX_HIP_RC_BAD_ARG; }
         dc.has_grav = 1; dc.deg = g->degree; dc.ord = std::min(g->order, g->degree);
         dc.g_mu = g->mu_km3_s2; dc.g_re = g->eq_radius_km; dc.g_inv_re = 1.0 / g->eq_radius_km;
-        for (int k = 0; k < 3; ++k) { dc.g_rot.ra[k] = g->rotation.ra_deg[k]; dc.g_rot.dec[k] = g->rotation.dec_deg[k]; dc.g_rot.w[k] = g->rotation.w_deg[k]; }
+        copy_rotation(dc.g_rot, g->rotation);
         int n_cols = 0;
         build_harmonics(g, tab, cols, ctx->col_len, n_cols);
         dc.n_cols = n_cols;
@@ -774,7 +797,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
         dc.has_drag = 1; dc.drag_density = dg->density;
         dc.drag_rho0 = dg->rho0; dc.drag_r0 = dg->r0; dc.drag_ref_alt_m = dg->ref_alt_m; dc.drag_max_alt_m = dg->max_alt_m;
         dc.drag_re = dg->eq_radius_km;
-        for (int k = 0; k < 3; ++k) { dc.d_rot.ra[k] = dg->rotation.ra_deg[k]; dc.d_rot.dec[k] = dg->rotation.dec_deg[k]; dc.d_rot.w[k] = dg->rotation.w_deg[k]; }
+        copy_rotation(dc.d_rot, dg->rotation);
     }
     // serial duties of the role waves per force evaluation, in units of one harmonics term (~10 f64 ops):
     // integrator: stage combination, body-fixed transform, fold of the partials; almanac: 3 sincos + Chebyshev

@@ -45,8 +45,14 @@ struct DevSched {
  * answers). */
 enum { DEV_SCHED_SOLO = 0, DEV_SCHED_PRIMARY = 1, DEV_SCHED_HELPER = 2, DEV_N_SCHED = 3 };
 
-struct DevRot {
+#define DEV_MAX_NUT_PREC 16
+struct DevRot { /* nyx_hip_rotation_t, flattened */
     double ra[3], dec[3], w[3];
+    int32_t kind, n_np;                          /* NYX_HIP_ROT_*; number of trigonometric terms */
+    double np_ang[DEV_MAX_NUT_PREC][2];          /* theta_k = [0] + [1] * T (deg) */
+    double np_ra[DEV_MAX_NUT_PREC], np_dec[DEV_MAX_NUT_PREC], np_w[DEV_MAX_NUT_PREC];
+    int32_t euler_seg, _pad;                     /* EULER_CHEBY: index into DevCfg.seg */
+    double base[9];
 };
 
 struct DevCfg {

@@ -59,30 +59,6 @@ DEVFN double clamp02(double x) { return x < 0.0 ? 0.0 : (x > 2.0 ? 2.0 : x); }
 // bp[DEV_MAX_SLOTS][3] (slot positions w.r.t. the integration centre).  Field-major: slot[f * 64 + lane].
 #define ED_FIELDS (9 + 3 * DEV_MAX_SLOTS)
 
-DEVFN void rotation_dcm(const CAS DevRot &rot, double et_s, double *m) {
-    const double DEG = 3.14159265358979323846 / 180.0;
-    const double HALF_PI = 1.57079632679489661923;
-    const double d = et_s / 86400.0;
-    const double T = et_s / (86400.0 * 36525.0);
-    const double ra = (rot.ra[0] + rot.ra[1] * T + rot.ra[2] * T * T) * DEG;
-    const double dec = (rot.dec[0] + rot.dec[1] * T + rot.dec[2] * T * T) * DEG;
-    const double w = (rot.w[0] + rot.w[1] * d + rot.w[2] * d * d) * DEG;
-    const double a1 = HALF_PI + ra, a2 = HALF_PI - dec, a3 = w;
-    double s1, c1, s2, c2, s3, c3;
-    sincos(a1, &s1, &c1);
-    sincos(a2, &s2, &c2);
-    sincos(a3, &s3, &c3);
-    m[0] = c3 * c1 - s3 * c2 * s1;
-    m[1] = c3 * s1 + s3 * c2 * c1;
-    m[2] = s3 * s2;
-    m[3] = -s3 * c1 - c3 * c2 * s1;
-    m[4] = -s3 * s1 + c3 * c2 * c1;
-    m[5] = c3 * s2;
-    m[6] = s2 * s1;
-    m[7] = -s2 * c1;
-    m[8] = c2;
-}
-
 // SPK type 2 evaluation (Clenshaw); record index is per lane, metadata is uniform.  `records` is the
 // LDS copy of the segment table when it fits (cfg->rec_in_lds), else the global array.  The 16-wide
 // coefficient window is loaded before the recurrence starts (the table is padded by 16 doubles), so the
@@ -119,6 +95,75 @@ DEVFN int cheby_eval(const CAS DevSeg &sg, P records, double et_s, double *r3) {
     return st;
 }
 
+// Body-fixed orientation (nyx_hip_rotation_t, see include/nyx_hip.h): the IAU phase angles with their trigonometric series, or
+// the Chebyshev Euler angles of a binary PCK.  `w_rate` (optional): dW/dt in rad/s (the drag model's velocity transform).
+DEVFN void r3r1r3(double a1, double a2, double a3, double *m) {
+    double s1, c1, s2, c2, s3, c3;
+    sincos(a1, &s1, &c1);
+    sincos(a2, &s2, &c2);
+    sincos(a3, &s3, &c3);
+    m[0] = c3 * c1 - s3 * c2 * s1;
+    m[1] = c3 * s1 + s3 * c2 * c1;
+    m[2] = s3 * s2;
+    m[3] = -s3 * c1 - c3 * c2 * s1;
+    m[4] = -s3 * s1 + c3 * c2 * c1;
+    m[5] = c3 * s2;
+    m[6] = s2 * s1;
+    m[7] = -s2 * c1;
+    m[8] = c2;
+}
+template <typename P>
+DEVFN int rotation_dcm(CfgPtr cfg, const CAS DevRot &rot, P records, double et_s, double *m, double *w_rate = nullptr) {
+    const double DEG = 3.14159265358979323846 / 180.0;
+    const double HALF_PI = 1.57079632679489661923;
+    if (rot.kind == NYX_HIP_ROT_EULER_CHEBY) {  // (uniform)
+        const CAS DevSeg &sg = cfg->seg[rot.euler_seg];
+        double ang[3];
+        const int st = cheby_eval(sg, records, et_s, ang);
+        double e[9];
+        r3r1r3(ang[0], ang[1], ang[2], e);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) m[3 * i + j] = e[3 * i + 0] * rot.base[0 + j] + e[3 * i + 1] * rot.base[3 + j] + e[3 * i + 2] * rot.base[6 + j];
+        if (w_rate) {  // derivative of the third angle's series: sum c_j T_j'(t) / radius
+            int idx = (int)floor((et_s - sg.init_et) / sg.interval);
+            idx = idx < 0 ? 0 : (idx >= sg.n_rec ? sg.n_rec - 1 : idx);
+            P rec = records + sg.offset + idx * sg.stride;
+            const double t = (et_s - rec[0]) / rec[1];
+            P cf = rec + 2 + 2 * sg.n_coef;
+            double tjm1 = 1.0, tj = t, djm1 = 0.0, dj = 1.0, acc = 0.0;
+            for (int j = 1; j < sg.n_coef; ++j) {
+                acc = acc + cf[j] * dj;
+                const double tn = 2.0 * t * tj - tjm1;
+                const double dn = 2.0 * tj + 2.0 * t * dj - djm1;
+                tjm1 = tj; tj = tn; djm1 = dj; dj = dn;
+            }
+            *w_rate = acc / rec[1];
+        }
+        return st;
+    }
+    const double d = et_s / 86400.0;
+    const double T = et_s / (86400.0 * 36525.0);
+    double ra = rot.ra[0] + rot.ra[1] * T + rot.ra[2] * T * T;
+    double dec = rot.dec[0] + rot.dec[1] * T + rot.dec[2] * T * T;
+    double w = rot.w[0] + rot.w[1] * d + rot.w[2] * d * d;
+    double wd = rot.w[1] + 2.0 * rot.w[2] * d;
+    const int np = rot.n_np;
+    for (int k = 0; k < np; ++k) {
+        const double th = (rot.np_ang[k][0] + rot.np_ang[k][1] * T) * DEG;
+        double sn, cs;
+        sincos(th, &sn, &cs);
+        ra = ra + rot.np_ra[k] * sn;
+        dec = dec + rot.np_dec[k] * cs;
+        w = w + rot.np_w[k] * sn;
+        wd = wd + rot.np_w[k] * cs * (rot.np_ang[k][1] * DEG / 36525.0);
+    }
+    r3r1r3(HALF_PI + ra * DEG, HALF_PI - dec * DEG, w * DEG, m);
+    if (w_rate) *w_rate = wd * DEG / 86400.0;
+    return NYX_HIP_OK;
+}
+
 template <typename P>
 // `dcm_flag` (pipelined stage loop): LDS word that is set to `dcm_val` as soon as the DCM is written - the integrator wave
 // needs only that to form the next stage's recursion inputs, the body positions are for the next window.
@@ -129,9 +174,11 @@ DEVFN int epoch_data(CfgPtr cfg, P records, int64_t epoch_ns, double *slot, int 
     int status = NYX_HIP_OK;
     if ((amask & DEV_ROLE_DCM) && (cfg->has_grav || cfg->has_drag || cfg->has_tides)) {  // (ctx_create requires these body-fixed frames to coincide)
         double m[9];
-        if (cfg->has_grav) rotation_dcm(cfg->g_rot, et, m);
-        else if (cfg->has_drag) rotation_dcm(cfg->d_rot, et, m);
-        else rotation_dcm(cfg->t_rot, et, m);
+        int st;
+        if (cfg->has_grav) st = rotation_dcm(cfg, cfg->g_rot, records, et, m);
+        else if (cfg->has_drag) st = rotation_dcm(cfg, cfg->d_rot, records, et, m);
+        else st = rotation_dcm(cfg, cfg->t_rot, records, et, m);
+        if (st) status = st;
 #pragma unroll
         for (int q = 0; q < 9; ++q) slot[q * DEV_LANES + lane] = m[q];
     }
@@ -272,14 +319,23 @@ DEVFN double powi_dev(double x, int n) {
 // Drag::eom (reference dynamics/drag.rs:181-284) with its unit / frame quirks, as restated in the oracle (drag_eom):
 // velocity in the drag frame = R v - w x (R r) with w = W_dot z_body; Exponential mixes metres and km; the relative
 // velocity is (inertial velocity) - (drag-frame velocity components).  `m` = DCM inertial -> drag frame of this stage.
-DEVFN void drag_force(CfgPtr cfg, const double *ed, int lane, double et_s, const double *r, const double *v, double cd, double area,
+// dW/dt of an orientation (rad/s) without its DCM: the polynomial rate, plus the series / Chebyshev terms when there are any
+DEVFN double rotation_w_rate(CfgPtr cfg, const CAS DevRot &rot, const double *records, double et_s) {
+    const double DEG = 3.14159265358979323846 / 180.0;
+    if (rot.kind == NYX_HIP_ROT_IAU && rot.n_np == 0) return (rot.w[1] + 2.0 * rot.w[2] * (et_s / 86400.0)) * DEG / 86400.0;
+    double m[9], wr = 0.0;
+    (void)rotation_dcm(cfg, rot, records, et_s, m, &wr);
+    return wr;
+}
+
+DEVFN void drag_force(CfgPtr cfg, const double *records, const double *ed, int lane, double et_s, const double *r, const double *v, double cd, double area,
                       double *force) {
     double m[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q) m[q] = ed[q * DEV_LANES + lane];
     const double DEG = 3.14159265358979323846 / 180.0;
     const double d = et_s / 86400.0;
-    const double wdot = (cfg->d_rot.w[1] + 2.0 * cfg->d_rot.w[2] * d) * DEG / 86400.0;
+    const double wdot = rotation_w_rate(cfg, cfg->d_rot, records, et_s);
     double rb[3], vb[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -1925,7 +1981,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     const double vv[3] = {ysp[3 * DEV_LANES + lane], ysp[4 * DEV_LANES + lane], ysp[5 * DEV_LANES + lane]};
                     const int64_t ep = __double_as_longlong(L.step[lane]) + seconds_to_ns(C_COEF(i) * L.step[DEV_LANES + lane]);
                     double d3f[3];
-                    drag_force(cfg, edc, lane, ns_to_seconds(ep), r, vv, p_cd, p_darea, d3f);
+                    drag_force(cfg, rec_in_lds ? (const double *)L.rec : records, edc, lane, ns_to_seconds(ep), r, vv, p_cd, p_darea, d3f);
 #pragma unroll
                     for (int e = 0; e < 3; ++e) pertp[(6 + e) * DEV_LANES + lane] = d3f[e] / p_mass;
                 }

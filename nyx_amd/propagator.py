@@ -157,17 +157,36 @@ class ChebySegment:
 
 @dataclass
 class Rotation:
-    """IAU polynomial orientation (PCK): alpha/delta in deg + deg/century, W in deg + deg/day."""
+    """Body-fixed orientation as ANISE's planetary data hold it (`nyx_hip_rotation_t`): the IAU phase angles (PCK: alpha /
+    delta in deg + deg/century, W in deg + deg/day) with their trigonometric nutation-precession series, or - `euler` set -
+    Chebyshev Euler angles of a binary PCK (ITRF93, MOON_PA): a `ChebySegment` of [A1, A2, A3] in radians with
+    DCM(base->fixed) = R3(A3) R1(A2) R3(A1) and `base_dcm` = integration frame -> base frame."""
 
     ra_deg: Sequence[float] = (0.0, 0.0, 0.0)
     dec_deg: Sequence[float] = (90.0, 0.0, 0.0)
     w_deg: Sequence[float] = (0.0, 0.0, 0.0)
+    nut_prec_angles_deg: Sequence[Sequence[float]] = ()   # [(theta0, theta1 per century), ...]
+    nut_prec_ra: Sequence[float] = ()
+    nut_prec_dec: Sequence[float] = ()
+    nut_prec_w: Sequence[float] = ()
+    euler: Optional["ChebySegment"] = None
+    base_dcm: Sequence[float] = (1.0, 0.0, 0.0, 0.0, 1.0, 0.0, 0.0, 0.0, 1.0)
 
 
 # pck00008 Earth (IAU 2000): alpha0 = 0 - 0.641 T, delta0 = 90 - 0.557 T, W = 190.147 + 360.9856235 d
 IAU_EARTH_ROTATION = Rotation((0.0, -0.641, 0.0), (90.0, -0.557, 0.0), (190.147, 360.9856235, 0.0))
-# pck00008 Moon, polynomial part only (the trig series is out of scope of the descriptor for now)
+# pck00008 Moon, polynomial part only
 IAU_MOON_ROTATION_POLY = Rotation((269.9949, 0.0031, 0.0), (66.5392, 0.0130, 0.0), (38.3213, 13.17635815, -1.4e-12))
+# pck00008 Moon with its 13-term series (BODY3_NUT_PREC_ANGLES E1..E13, BODY301_NUT_PREC_RA / _DEC / _PM; IAU/IAG 2000
+# report, restated from the published table - the descriptor is data: a caller with ANISE passes its PlanetaryData)
+_E_MOON = ((125.045, -1935.5364525000), (250.089, -3871.0729050000), (260.008, 475263.3328725000), (176.625, 487269.6299850000),
+           (357.529, 35999.0509575000), (311.589, 964468.4993100000), (134.963, 477198.8675605000), (276.617, 12006.3007650000),
+           (34.226, 63863.5132425000), (15.134, -5806.6093575000), (119.743, 131.8406400000), (239.961, 6003.1503825000),
+           (25.053, 473327.2793700000))
+IAU_MOON_ROTATION = Rotation((269.9949, 0.0031, 0.0), (66.5392, 0.0130, 0.0), (38.3213, 13.17635815, -1.4e-12), _E_MOON,
+                             (-3.8787, -0.1204, 0.0700, -0.0172, 0.0, 0.0072, 0.0, 0.0, 0.0, -0.0052, 0.0, 0.0, 0.0043),
+                             (1.5419, 0.0239, -0.0278, 0.0068, 0.0, -0.0029, 0.0009, 0.0, 0.0, 0.0008, 0.0, 0.0, -0.0009),
+                             (3.5610, 0.1208, -0.0642, 0.0158, 0.0252, -0.0066, -0.0047, -0.0046, 0.0028, 0.0052, 0.0040, 0.0019, -0.0044))
 
 
 @dataclass
@@ -419,16 +438,29 @@ def compile_config(dynamics: SpacecraftDynamics, method: IntegratorMethod, opts:
     cfg.central_mu_km3_s2 = float(central.mu_km3_s2)
     cfg.speed_of_light_km_s = SPEED_OF_LIGHT_KM_S
 
-    # segments
-    segs = (_abi.ChebySegment * max(1, len(almanac.segments)))()
-    for i, s in enumerate(almanac.segments):
+    # segments: the almanac's ephemeris segments, then the Euler-angle segments of the orientations that have one
+    all_segments = list(almanac.segments)
+    euler_index = {}
+
+    def euler_segment_of(rot: Optional[Rotation]) -> int:
+        if rot is None or rot.euler is None:
+            return -1
+        if id(rot.euler) not in euler_index:
+            euler_index[id(rot.euler)] = len(all_segments)
+            all_segments.append(rot.euler)
+        return euler_index[id(rot.euler)]
+
+    for m_ in list(dynamics.orbital_dyn.accel_models) + list(dynamics.force_models):
+        euler_segment_of(getattr(getattr(m_, "frame", None), "rotation", None))
+    segs = (_abi.ChebySegment * max(1, len(all_segments)))()
+    for i, s in enumerate(all_segments):
         rec = np.ascontiguousarray(s.records, dtype=np.float64)
         keep.append(rec)
         segs[i].init_et_s, segs[i].interval_s = float(s.init_et_s), float(s.interval_s)
         segs[i].n_records, segs[i].n_coeffs = rec.shape[0], s.n_coeffs
         segs[i].records = rec.ctypes.data_as(_abi.c_double_p)
     keep.append(segs)
-    cfg.n_segments = len(almanac.segments)
+    cfg.n_segments = len(all_segments)
     cfg.segments = C.cast(segs, C.POINTER(_abi.ChebySegment))
 
     # bodies actually used, central body first
@@ -483,6 +515,19 @@ def compile_config(dynamics: SpacecraftDynamics, method: IntegratorMethod, opts:
         rot = rot or Rotation()
         for k in range(3):
             dst.ra_deg[k], dst.dec_deg[k], dst.w_deg[k] = float(rot.ra_deg[k]), float(rot.dec_deg[k]), float(rot.w_deg[k])
+        n = len(rot.nut_prec_angles_deg)
+        if n > _abi.MAX_NUT_PREC or max(len(rot.nut_prec_ra), len(rot.nut_prec_dec), len(rot.nut_prec_w)) > n:
+            raise ValueError(f"at most {_abi.MAX_NUT_PREC} nutation-precession angles, and no more coefficients than angles")
+        dst.n_nut_prec = n
+        for k in range(n):
+            dst.nut_prec_angle_deg[k][0], dst.nut_prec_angle_deg[k][1] = float(rot.nut_prec_angles_deg[k][0]), float(rot.nut_prec_angles_deg[k][1])
+            dst.nut_prec_ra[k] = float(rot.nut_prec_ra[k]) if k < len(rot.nut_prec_ra) else 0.0
+            dst.nut_prec_dec[k] = float(rot.nut_prec_dec[k]) if k < len(rot.nut_prec_dec) else 0.0
+            dst.nut_prec_w[k] = float(rot.nut_prec_w[k]) if k < len(rot.nut_prec_w) else 0.0
+        dst.kind = _abi.ROT_EULER_CHEBY if rot.euler is not None else _abi.ROT_IAU
+        dst.euler_segment = euler_segment_of(rot)
+        for k in range(9):
+            dst.base_dcm[k] = float(rot.base_dcm[k])
 
     if gf:
         g = gf[0]

@@ -131,17 +131,14 @@ void nyx_oracle_body_position(const nyx_hip_config_t *cfg, int32_t body, int64_t
     if (status) *status = st;
 }
 
-/* IAU orientation: DCM(inertial -> body-fixed) = R3(W) R1(pi/2 - dec) R3(pi/2 + ra),
- * angles from PCK-style polynomials (T centuries / d days past J2000 TDB).
- * Replaces almanac.transform_to / almanac.rotate at gravity_field.rs:150-154,258-265. */
-static void rotation_dcm(const nyx_hip_rotation_t *rot, double et_s, double m[3][3]) {
-    const double DEG = M_PI / 180.0;
-    const double d = et_s / 86400.0;
-    const double T = et_s / (86400.0 * 36525.0);
-    const double ra = (rot->ra_deg[0] + rot->ra_deg[1] * T + rot->ra_deg[2] * T * T) * DEG;
-    const double dec = (rot->dec_deg[0] + rot->dec_deg[1] * T + rot->dec_deg[2] * T * T) * DEG;
-    const double w = (rot->w_deg[0] + rot->w_deg[1] * d + rot->w_deg[2] * d * d) * DEG;
-    const double a1 = M_PI_2 + ra, a2 = M_PI_2 - dec, a3 = w;
+/* Body-fixed orientation (nyx_hip_rotation_t).  Replaces almanac.transform_to / almanac.rotate at
+ * gravity_field.rs:150-154,258-265.  IAU kind: DCM(inertial -> body-fixed) = R3(W) R1(pi/2 - dec) R3(pi/2 + ra), angles
+ * from the PCK polynomials (T centuries / d days past J2000 TDB) plus the trigonometric nutation-precession series
+ * (SPICE TISBOD: alpha += a_k sin theta_k, delta += d_k cos theta_k, W += w_k sin theta_k).  Euler/Chebyshev kind (binary
+ * PCK type 2, SPICE PCKE02 + EUL2M(w, delta, phi, 3, 1, 3)): three Chebyshev angles of the segment, R3(A3) R1(A2) R3(A1),
+ * times the constant base rotation.  `w_rate` (optional): dW/dt (resp. dA3/dt) in rad/s, what the drag model's
+ * velocity transform uses. */
+static void r3r1r3(double a1, double a2, double a3, double m[3][3]) {
     const double c1 = cos(a1), s1 = sin(a1);
     const double c2 = cos(a2), s2 = sin(a2);
     const double c3 = cos(a3), s3 = sin(a3);
@@ -157,11 +154,65 @@ static void rotation_dcm(const nyx_hip_rotation_t *rot, double et_s, double m[3]
     m[2][2] = c2;
 }
 
-void nyx_oracle_rotation_dcm(const nyx_hip_rotation_t *rot, int64_t epoch_ns, double *dcm9) {
+static int rotation_dcm_rate(const nyx_hip_rotation_t *rot, const nyx_hip_cheby_segment_t *segs, double et_s, double m[3][3], double *w_rate) {
+    const double DEG = M_PI / 180.0;
+    if (rot->kind == NYX_HIP_ROT_EULER_CHEBY) {
+        const nyx_hip_cheby_segment_t *seg = &segs[rot->euler_segment];
+        double ang[3];
+        int st = cheby_eval(seg, et_s, ang);
+        if (st) return st;
+        double e[3][3];
+        r3r1r3(ang[0], ang[1], ang[2], e);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j)
+                m[i][j] = e[i][0] * rot->base_dcm[0 + j] + e[i][1] * rot->base_dcm[3 + j] + e[i][2] * rot->base_dcm[6 + j];
+        if (w_rate) { /* derivative of the third angle's Chebyshev series: sum c_j T_j'(t) / radius, T_j' by its recurrence */
+            const int nc = seg->n_coeffs;
+            long idx = (long)floor((et_s - seg->init_et_s) / seg->interval_s);
+            if (idx >= seg->n_records) idx = seg->n_records - 1;
+            const double *rec = seg->records + (size_t)idx * (size_t)(2 + 3 * nc);
+            const double t = (et_s - rec[0]) / rec[1];
+            const double *cf = rec + 2 + 2 * nc;
+            double tjm1 = 1.0, tj = t, djm1 = 0.0, dj = 1.0, acc = 0.0; /* T_0, T_1, T_0', T_1' */
+            for (int j = 1; j < nc; ++j) {
+                acc = acc + cf[j] * dj;
+                const double tn = 2.0 * t * tj - tjm1;
+                const double dn = 2.0 * tj + 2.0 * t * dj - djm1;
+                tjm1 = tj; tj = tn; djm1 = dj; dj = dn;
+            }
+            *w_rate = acc / rec[1];
+        }
+        return NYX_HIP_OK;
+    }
+    const double d = et_s / 86400.0;
+    const double T = et_s / (86400.0 * 36525.0);
+    double ra = rot->ra_deg[0] + rot->ra_deg[1] * T + rot->ra_deg[2] * T * T;
+    double dec = rot->dec_deg[0] + rot->dec_deg[1] * T + rot->dec_deg[2] * T * T;
+    double w = rot->w_deg[0] + rot->w_deg[1] * d + rot->w_deg[2] * d * d;
+    double wd = rot->w_deg[1] + 2.0 * rot->w_deg[2] * d; /* deg / day */
+    for (int k = 0; k < rot->n_nut_prec; ++k) {
+        const double th = (rot->nut_prec_angle_deg[k][0] + rot->nut_prec_angle_deg[k][1] * T) * DEG;
+        const double sn = sin(th), cs = cos(th);
+        ra = ra + rot->nut_prec_ra[k] * sn;
+        dec = dec + rot->nut_prec_dec[k] * cs;
+        w = w + rot->nut_prec_w[k] * sn;
+        wd = wd + rot->nut_prec_w[k] * cs * (rot->nut_prec_angle_deg[k][1] * DEG / 36525.0);
+    }
+    r3r1r3(M_PI_2 + ra * DEG, M_PI_2 - dec * DEG, w * DEG, m);
+    if (w_rate) *w_rate = wd * DEG / 86400.0;
+    return NYX_HIP_OK;
+}
+
+static int rotation_dcm(const nyx_hip_rotation_t *rot, const nyx_hip_cheby_segment_t *segs, double et_s, double m[3][3]) {
+    return rotation_dcm_rate(rot, segs, et_s, m, NULL);
+}
+
+int32_t nyx_oracle_rotation_dcm(const nyx_hip_rotation_t *rot, const nyx_hip_cheby_segment_t *segments, int64_t epoch_ns, double *dcm9, double *w_rate) {
     double m[3][3];
-    rotation_dcm(rot, nyx_oracle_ns_to_seconds(epoch_ns), m);
+    int st = rotation_dcm_rate(rot, segments, nyx_oracle_ns_to_seconds(epoch_ns), m, w_rate);
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) dcm9[3 * i + j] = m[i][j];
+    return st;
 }
 
 /* Area of a circular segment of radius r cut at distance d from the centre. */
@@ -276,10 +327,10 @@ static void prepared_free(prepared_t *p) {
 /* GravityField::eom, gravity_field.rs:148-268                                 */
 /* ------------------------------------------------------------------------- */
 
-static void gravity_eom(const nyx_hip_gravity_field_t *g, const grav_tables_t *t, double et_s, const double *r_in,
-                        double *acc, double *a_work, double *rm_work, double *im_work) {
+static int gravity_eom(const nyx_hip_gravity_field_t *g, const nyx_hip_cheby_segment_t *segs, const grav_tables_t *t, double et_s, const double *r_in,
+                       double *acc, double *a_work, double *rm_work, double *im_work) {
     double dcm[3][3];
-    rotation_dcm(&g->rotation, et_s, dcm);
+    { int st = rotation_dcm(&g->rotation, segs, et_s, dcm); if (st) return st; }
     /* almanac.transform_to(osc, frame): same centre, rotate the position (:150-154) */
     double rb[3];
     for (int i = 0; i < 3; ++i) rb[i] = dcm[i][0] * r_in[0] + dcm[i][1] * r_in[1] + dcm[i][2] * r_in[2];
@@ -334,6 +385,7 @@ static void gravity_eom(const nyx_hip_gravity_field_t *g, const grav_tables_t *t
     const double al[3] = {ax + aw * s_, ay + aw * t_, az + aw * u_};
     /* dcm.rot_mat (fixed -> inertial) = transpose (:258-267) */
     for (int i = 0; i < 3; ++i) acc[i] = dcm[0][i] * al[0] + dcm[1][i] * al[1] + dcm[2][i] * al[2];
+    return NYX_HIP_OK;
 }
 
 void nyx_oracle_gravity_accel(const nyx_hip_gravity_field_t *g, int64_t epoch_ns, const double *r3, double *a3) {
@@ -341,7 +393,7 @@ void nyx_oracle_gravity_accel(const nyx_hip_gravity_field_t *g, int64_t epoch_ns
     grav_tables_build(g, &t);
     double *a = malloc(sizeof(double) * (size_t)t.ld * t.ld);
     double *rm = malloc(sizeof(double) * (size_t)(t.deg + 2)), *im = malloc(sizeof(double) * (size_t)(t.deg + 2));
-    gravity_eom(g, &t, nyx_oracle_ns_to_seconds(epoch_ns), r3, a3, a, rm, im);
+    (void)gravity_eom(g, NULL, &t, nyx_oracle_ns_to_seconds(epoch_ns), r3, a3, a, rm, im);  /* (IAU-oriented fields only) */
     free(a); free(rm); free(im);
     grav_tables_free(&t);
 }
@@ -386,10 +438,10 @@ static d3 d3norm(const d3 *v) {
 
 /* GravityField::gradient, gravity_field.rs:273-431: same recursion on duals seeded
  * in the body-fixed frame; returns accel (inertial) and dcm * grad_local * dcm^T. */
-static void gravity_gradient(const nyx_hip_gravity_field_t *g, const grav_tables_t *t, double et_s,
-                             const double *r_in, double *acc, double grad[3][3]) {
+static int gravity_gradient(const nyx_hip_gravity_field_t *g, const nyx_hip_cheby_segment_t *segs, const grav_tables_t *t, double et_s,
+                            const double *r_in, double *acc, double grad[3][3]) {
     double dcm[3][3];
-    rotation_dcm(&g->rotation, et_s, dcm);
+    { int st = rotation_dcm(&g->rotation, segs, et_s, dcm); if (st) return st; }
     double rb[3];
     for (int i = 0; i < 3; ++i) rb[i] = dcm[i][0] * r_in[0] + dcm[i][1] * r_in[1] + dcm[i][2] * r_in[2];
     d3 rad[3];
@@ -450,6 +502,7 @@ static void gravity_gradient(const nyx_hip_gravity_field_t *g, const grav_tables
     for (int i = 0; i < 3; ++i)
         for (int j = 0; j < 3; ++j) grad[i][j] = tmp[i][0] * dcm[0][j] + tmp[i][1] * dcm[1][j] + tmp[i][2] * dcm[2][j];
     free(a); free(rm); free(im);
+    return NYX_HIP_OK;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -528,7 +581,7 @@ static double tide_vr11(int n, int m) {
 static int tides_eom(const nyx_hip_config_t *cfg, double et_s, const double *r_in, double *acc) {
     const nyx_hip_solid_tides_t *td = cfg->tides;
     double dcm[3][3], dc[4][4], ds[4][4];
-    rotation_dcm(&td->rotation, et_s, dcm);
+    { int st0 = rotation_dcm(&td->rotation, cfg->segments, et_s, dcm); if (st0) return st0; }
     int st = tides_deltas(cfg, et_s, dcm, dc, ds);
     if (st) return st;
     double rb[3];
@@ -580,7 +633,7 @@ static int tides_eom(const nyx_hip_config_t *cfg, double et_s, const double *r_i
 static int tides_gradient(const nyx_hip_config_t *cfg, double et_s, const double *r_in, double *acc, double grad[3][3]) {
     const nyx_hip_solid_tides_t *td = cfg->tides;
     double dcm[3][3], dc[4][4], ds[4][4];
-    rotation_dcm(&td->rotation, et_s, dcm);
+    { int st0 = rotation_dcm(&td->rotation, cfg->segments, et_s, dcm); if (st0) return st0; }
     int st = tides_deltas(cfg, et_s, dcm, dc, ds);
     if (st) return st;
     double rb[3];
@@ -655,7 +708,7 @@ int32_t nyx_oracle_tides_accel(const nyx_hip_config_t *cfg, int64_t epoch_ns, co
     }
     if (dc16 && ds16) {
         double dcm[3][3], dc[4][4], ds[4][4];
-        rotation_dcm(&cfg->tides->rotation, et, dcm);
+        (void)rotation_dcm(&cfg->tides->rotation, cfg->segments, et, dcm);
         st = tides_deltas(cfg, et, dcm, dc, ds);
         memcpy(dc16, dc, sizeof dc);
         memcpy(ds16, ds, sizeof ds);
@@ -793,15 +846,12 @@ static int srp_gradient(const nyx_hip_config_t *cfg, double et_s, const double *
 static int drag_eom(const nyx_hip_config_t *cfg, double et_s, const double *r, const double *v, double cd, double area,
                     double *force) {
     const nyx_hip_drag_t *dg = cfg->drag;
-    double m[3][3];
-    rotation_dcm(&dg->rotation, et_s, m);
+    double m[3][3], wdot;
+    { int st = rotation_dcm_rate(&dg->rotation, cfg->segments, et_s, m, &wdot); if (st) return st; }
     /* transform_to(orbit, drag frame): r' = R r, v' = R v + dR/dt r.  dR/dt from the
      * twist rate only would be an approximation; ANISE differentiates all three
      * angles.  We use a symmetric finite difference-free analytic form: dR/dt = -[w]x R
      * with w = W_dot * z_body (pole drift neglected: |ra_dot|,|dec_dot| ~ 1e-13 rad/s). */
-    const double DEG = M_PI / 180.0;
-    const double d = et_s / 86400.0;
-    const double wdot = (dg->rotation.w_deg[1] + 2.0 * dg->rotation.w_deg[2] * d) * DEG / 86400.0;
     double rb[3], vb[3];
     for (int i = 0; i < 3; ++i) {
         rb[i] = m[i][0] * r[0] + m[i][1] * r[1] + m[i][2] * r[2];
@@ -895,7 +945,7 @@ static int dual_eom(const prepared_t *p, double et_s, const double *y9, const sc
     }
     if (cfg->gravity) {
         double acc[3], g3[3][3];
-        gravity_gradient(cfg->gravity, &p->gt, et_s, r, acc, g3);
+        { int st = gravity_gradient(cfg->gravity, cfg->segments, &p->gt, et_s, r, acc, g3); if (st) return st; }
         for (int i = 0; i < 3; ++i) {
             fx[i + 3] += acc[i];
             for (int j = 0; j < 3; ++j) G(i + 3, j) += g3[i][j];
@@ -971,7 +1021,7 @@ static int sc_eom(const prepared_t *p, int64_t ctx_epoch_ns, double dt_s, const 
     }
     if (cfg->gravity) {
         double a[3];
-        gravity_eom(cfg->gravity, &p->gt, et_s, r, a, w->a_work, w->rm, w->im);
+        { int st = gravity_eom(cfg->gravity, cfg->segments, &p->gt, et_s, r, a, w->a_work, w->rm, w->im); if (st) return st; }
         for (int c = 0; c < 3; ++c) dy[3 + c] += a[c];
     }
     if (cfg->tides) { /* third accel model of Dynamics::build (dynamics/sequence/config.rs:105-118) */

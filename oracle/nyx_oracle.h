@@ -49,7 +49,8 @@ int32_t nyx_oracle_dual_eom(const nyx_hip_config_t *cfg, int64_t epoch_ns, const
 
 /* Individual model terms, for unit tests. */
 void nyx_oracle_body_position(const nyx_hip_config_t *cfg, int32_t body, int64_t epoch_ns, double *r3, int32_t *status);
-void nyx_oracle_rotation_dcm(const nyx_hip_rotation_t *rot, int64_t epoch_ns, double *dcm9_rowmajor);
+/* `segments`: config.segments (needed by the Euler/Chebyshev kind; may be NULL for IAU); `w_rate` optional (rad/s). */
+int32_t nyx_oracle_rotation_dcm(const nyx_hip_rotation_t *rot, const nyx_hip_cheby_segment_t *segments, int64_t epoch_ns, double *dcm9_rowmajor, double *w_rate);
 void nyx_oracle_gravity_accel(const nyx_hip_gravity_field_t *g, int64_t epoch_ns, const double *r3, double *a3);
 /* SolidTides::eom / gradient (dynamics/solid_tides.rs:238-559); grad and the delta tables ([n][m], 4x4) are optional. */
 int32_t nyx_oracle_tides_accel(const nyx_hip_config_t *cfg, int64_t epoch_ns, const double *r3, double *a3, double *grad9_rowmajor,

@@ -39,7 +39,8 @@ def load():
                                         C.c_double, _abi.c_double_p, _abi.c_double_p]
     lib.nyx_oracle_dual_eom.restype = C.c_int32
     lib.nyx_oracle_body_position.argtypes = [C.POINTER(_abi.Config), C.c_int32, C.c_int64, _abi.c_double_p, _abi.c_int32_p]
-    lib.nyx_oracle_rotation_dcm.argtypes = [C.POINTER(_abi.Rotation), C.c_int64, _abi.c_double_p]
+    lib.nyx_oracle_rotation_dcm.argtypes = [C.POINTER(_abi.Rotation), C.POINTER(_abi.ChebySegment), C.c_int64, _abi.c_double_p, _abi.c_double_p]
+    lib.nyx_oracle_rotation_dcm.restype = C.c_int32
     lib.nyx_oracle_gravity_accel.argtypes = [C.POINTER(_abi.GravityField), C.c_int64, _abi.c_double_p, _abi.c_double_p]
     lib.nyx_oracle_occultation_factor.argtypes = [C.POINTER(_abi.Config), C.c_int32, C.c_int32, C.c_int64, _abi.c_double_p, _abi.c_int32_p]
     lib.nyx_oracle_occultation_factor.restype = C.c_double

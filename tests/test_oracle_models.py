@@ -39,7 +39,7 @@ def test_gravity_is_gradient_of_potential():
     lib = oracle_lib.load()
     r = leo_nominal()[:3]
     dcm = np.zeros(9)
-    lib.nyx_oracle_rotation_dcm(C.byref(g.rotation), EPOCH0_NS, dcm.ctypes.data_as(_abi.c_double_p))
+    lib.nyx_oracle_rotation_dcm(C.byref(g.rotation), None, EPOCH0_NS, dcm.ctypes.data_as(_abi.c_double_p), None)
     R = dcm.reshape(3, 3)
     assert np.allclose(R @ R.T, np.eye(3), atol=1e-14)
     acc = np.zeros(3)
