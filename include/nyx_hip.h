@@ -360,7 +360,12 @@ enum nyx_hip_event_scalar {
     NYX_HIP_EV_SMA_KM = 3,
     NYX_HIP_EV_ECC = 4,
     NYX_HIP_EV_X_KM = 5, NYX_HIP_EV_Y_KM = 6, NYX_HIP_EV_Z_KM = 7,
-    NYX_HIP_EV_VX_KM_S = 8, NYX_HIP_EV_VY_KM_S = 9, NYX_HIP_EV_VZ_KM_S = 10
+    NYX_HIP_EV_VX_KM_S = 8, NYX_HIP_EV_VY_KM_S = 9, NYX_HIP_EV_VZ_KM_S = 10,
+    /* geometric scalars, normally evaluated in a body-fixed `frame` (tests/propagation/stopcond.rs:252-312) */
+    NYX_HIP_EV_LONGITUDE_DEG = 11,   /* OrbitalElement::Longitude: atan2(y, x) in [0, 360), an angle */
+    NYX_HIP_EV_DECLINATION_DEG = 12, /* OrbitalElement::Declination: asin(z / |r|) */
+    NYX_HIP_EV_LATITUDE_DEG = 13,    /* OrbitalElement::Latitude: GEODETIC latitude on the frame's ellipsoid */
+    NYX_HIP_EV_HEIGHT_KM = 14        /* OrbitalElement::Height: geodetic height above that ellipsoid */
 };
 typedef struct nyx_hip_event {
     int32_t scalar;             /* enum nyx_hip_event_scalar */
@@ -368,6 +373,14 @@ typedef struct nyx_hip_event {
     double desired;             /* Condition::Equals(desired) */
     double value_precision;     /* the search ends when |event value| is below this */
     int64_t epoch_precision_ns; /* ... or when the bracket is narrower than this (then: not found in the bracket) */
+    /* until_nth_event's `event_frame: Option<Frame>` (event.rs:104-117): when set, every state is expressed in this
+     * body-fixed frame of the SAME centre before the scalar is evaluated (position R r, velocity R v - w x R r with
+     * w = dW/dt about the frame's pole).  NYX_HIP_ROT_IAU orientations only. */
+    int32_t has_frame;
+    int32_t _pad;
+    double frame_eq_radius_km; /* the frame's ellipsoid (geodetic scalars): mean equatorial radius ... */
+    double frame_flattening;   /* ... and flattening (a - c) / a */
+    nyx_hip_rotation_t frame;
 } nyx_hip_event_t;
 
 /* Batch form of `prop.with(state, almanac).until_nth_event(max_duration, &event, None, trigger)` (host arrays).

@@ -200,12 +200,13 @@ class Traj(C.Structure):
 MAX_PROCESS_NOISE = 4
 # enum nyx_hip_event_scalar
 (EV_TRUE_ANOMALY_DEG, EV_RMAG_KM, EV_VMAG_KM_S, EV_SMA_KM, EV_ECC, EV_X_KM, EV_Y_KM, EV_Z_KM, EV_VX_KM_S, EV_VY_KM_S,
- EV_VZ_KM_S) = range(11)
+ EV_VZ_KM_S, EV_LONGITUDE_DEG, EV_DECLINATION_DEG, EV_LATITUDE_DEG, EV_HEIGHT_KM) = range(15)
 
 
 class EventC(C.Structure):
     _fields_ = [("scalar", C.c_int32), ("trigger", C.c_int32), ("desired", C.c_double), ("value_precision", C.c_double),
-                ("epoch_precision_ns", C.c_int64)]
+                ("epoch_precision_ns", C.c_int64), ("has_frame", C.c_int32), ("_pad", C.c_int32),
+                ("frame_eq_radius_km", C.c_double), ("frame_flattening", C.c_double), ("frame", Rotation)]
 
 
 

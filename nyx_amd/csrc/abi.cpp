@@ -996,7 +996,7 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
     bt.asrp = in->srp_area_m2; bt.adrag = in->drag_area_m2; bt.step_in = in->step_ns;
     bt.dur_ns = dur_ns;
     if (ev) {  // stop condition: only the ev_* fields of `ev` are read
-        bt.ev_on = 1; bt.ev_scalar = ev->ev_scalar; bt.ev_trigger = ev->ev_trigger; bt.ev_desired = ev->ev_desired; bt.ev_mu = ev->ev_mu;
+        bt.ev_on = 1; bt.ev = ev->ev; bt.ev_mu = ev->ev_mu;
         bt.ev_prev = ev->ev_prev; bt.ev_count = ev->ev_count; bt.ev_found = ev->ev_found;
     }
     if (ctx->host_cfg.flags & NYX_HIP_FLAG_STM) {
@@ -1439,7 +1439,16 @@ extern "C" int32_t nyx_hip_propagate_until_event(nyx_hip_ctx *ctx, const nyx_hip
                                                  const nyx_hip_event_t *event, nyx_hip_states_t *out, nyx_hip_step_stats_t *stats,
                                                  nyx_hip_traj_t *traj, int32_t *crossings) {
     if (!ctx || !event) { nyx_set_error("until_event: ctx and event are mandatory"); return NYX_HIP_RC_BAD_ARG; }
-    if (event->scalar < NYX_HIP_EV_TRUE_ANOMALY_DEG || event->scalar > NYX_HIP_EV_VZ_KM_S || event->trigger < 1 ||
+    if (event->has_frame && (event->frame.kind != NYX_HIP_ROT_IAU || event->frame.n_nut_prec < 0 || event->frame.n_nut_prec > NYX_HIP_MAX_NUT_PREC)) {
+        nyx_set_error("until_event: the event frame must be an IAU-oriented frame (NYX_HIP_ROT_IAU)");
+        return NYX_HIP_RC_UNSUPPORTED;
+    }
+    if ((event->scalar == NYX_HIP_EV_LATITUDE_DEG || event->scalar == NYX_HIP_EV_HEIGHT_KM) &&
+        !(event->frame_eq_radius_km > 0.0 && event->frame_flattening >= 0.0 && event->frame_flattening < 1.0)) {
+        nyx_set_error("until_event: geodetic scalars need the frame's ellipsoid (frame_eq_radius_km > 0, 0 <= flattening < 1)");
+        return NYX_HIP_RC_BAD_ARG;
+    }
+    if (event->scalar < NYX_HIP_EV_TRUE_ANOMALY_DEG || event->scalar > NYX_HIP_EV_HEIGHT_KM || event->trigger < 1 ||
         event->epoch_precision_ns < 0 || !(event->value_precision >= 0.0)) {
         nyx_set_error("until_event: bad event (scalar, trigger >= 1, precisions >= 0)");
         return NYX_HIP_RC_BAD_ARG;
@@ -1461,7 +1470,7 @@ extern "C" int32_t nyx_hip_propagate_until_event(nyx_hip_ctx *ctx, const nyx_hip
     if (int rc = evbuf.alloc((size_t)n * 16)) return rc;
     DevBatch ev;
     std::memset(&ev, 0, sizeof ev);
-    ev.ev_scalar = event->scalar; ev.ev_trigger = event->trigger; ev.ev_desired = event->desired;
+    ev.ev = *event;
     ev.ev_mu = ctx->host_cfg.mu_central;
     ev.ev_prev = evbuf.as<double>();
     ev.ev_count = (int32_t *)(evbuf.as<double>() + n);

@@ -6,6 +6,8 @@
 
 #include <stdint.h>
 
+#include "../../include/nyx_hip.h"
+
 #define DEV_MAX_STAGES 16
 #define DEV_MAX_SLOTS 4   /* non-central bodies whose position is evaluated per stage */
 #define DEV_MAX_SEG 8
@@ -155,8 +157,9 @@ struct DevBatch { /* device pointers of one launch */
     const double *x, *y, *z, *vx, *vy, *vz, *cr, *cd, *mprop, *mdry, *mextra, *asrp, *adrag;
     const int64_t *step_in;
     /* stop condition (propagators/event.rs:88-146); ev_on = 0 => none */
-    int32_t ev_on, ev_scalar, ev_trigger, _pad2;
-    double ev_desired, ev_mu;
+    int32_t ev_on, _pad2;
+    double ev_mu;
+    nyx_hip_event_t ev; /* scalar, trigger, desired value, observer frame */
     double *ev_prev;   /* [n] event value of the previous accepted state */
     int32_t *ev_count; /* [n] crossings so far */
     int32_t *ev_found; /* [n] 1 when the propagation stopped on the event */

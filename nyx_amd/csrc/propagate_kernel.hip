@@ -1485,15 +1485,15 @@ static __device__ __attribute__((noinline)) void phase_c_quad(LdsCPtr pertD, Lds
 // The `enough_crossings` closure of until_nth_event (propagators/event.rs:108-146) for one accepted state: the event
 // state (previous value, crossings) lives in global memory, touched once per accepted step and only when a stop
 // condition is set; out of line so that the integrator's register allocation does not see it.
-static __device__ __attribute__((noinline)) bool event_step(int scalar, int trigger, double desired, double mu, double *prev, int32_t *count,
+static __device__ __attribute__((noinline)) bool event_step(const nyx_hip_event_t *ev, double mu, int64_t epoch_ns, double *prev, int32_t *count,
                                                             double y0, double y1, double y2, double y3, double y4, double y5) {
     const double y[6] = {y0, y1, y2, y3, y4, y5};
-    const double y_next = ev_eval(scalar, desired, mu, y);
+    const double y_next = ev_eval(*ev, mu, epoch_ns, y);
     int n = *count;
-    if (ev_crossing(scalar, *prev, y_next)) n += 1;
+    if (ev_crossing(ev->scalar, *prev, y_next)) n += 1;
     *prev = y_next;
     *count = n;
-    return n >= trigger;
+    return n >= ev->trigger;
 }
 
 struct ColdState {
@@ -1694,7 +1694,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
         cold_store(L.cs, lane, c);
         if (bt.ev_on && wr) {  // y_prev of the start state (event.rs:104-106)
             const double y0[6] = {c.y[0], c.y[1], c.y[2], c.y[3], c.y[4], c.y[5]};
-            bt.ev_prev[gid] = ev_eval(bt.ev_scalar, bt.ev_desired, bt.ev_mu, y0);
+            bt.ev_prev[gid] = ev_eval(bt.ev, bt.ev_mu, c.epoch, y0);
             bt.ev_count[gid] = 0;
             bt.ev_found[gid] = 0;
         }
@@ -2329,7 +2329,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     // not published (instance.rs:243-252)
                     bool ev_hit = false;
                     if (bt.ev_on && valid && !c.is_final)  // (quad layout: the four lanes read and write the same words with the same values)
-                        ev_hit = event_step(bt.ev_scalar, bt.ev_trigger, bt.ev_desired, bt.ev_mu, bt.ev_prev + gid, bt.ev_count + gid, y[0], y[1],
+                        ev_hit = event_step(&bt.ev, bt.ev_mu, c.epoch, bt.ev_prev + gid, bt.ev_count + gid, y[0], y[1],
                                             y[2], y[3], y[4], y[5]);
                     if (ev_hit) {
                         if (wr) bt.ev_found[gid] = 1;

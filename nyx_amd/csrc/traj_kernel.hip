@@ -271,7 +271,7 @@ namespace {
 DEVFN int ev_at(const nyx_hip_traj_t &traj, const View &v, const nyx_hip_event_t &ev, double mu, int64_t epoch_ns, double &value) {
     double s6[6];
     const int st = traj_at(traj, v, epoch_ns, s6);
-    value = ev_eval(ev.scalar, ev.desired, mu, s6);
+    value = ev_eval(ev, mu, epoch_ns, s6);
     return st;
 }
 

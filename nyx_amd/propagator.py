@@ -197,9 +197,10 @@ class Frame:
     mu_km3_s2: float
     mean_equatorial_radius_km: float = 0.0
     rotation: Optional[Rotation] = None  # None => inertial (J2000 orientation)
+    flattening: float = 0.0              # (a - c) / a of the frame's ellipsoid (geodetic event scalars)
 
     def with_mu_km3_s2(self, mu: float) -> "Frame":
-        return Frame(self.naif_id, mu, self.mean_equatorial_radius_km, self.rotation)
+        return Frame(self.naif_id, mu, self.mean_equatorial_radius_km, self.rotation, self.flattening)
 
 
 class Almanac:
@@ -815,6 +816,7 @@ class Event:
     desired: float
     value_precision: float = 1e-7           # deg / km / km/s: tight enough for the reference's own 1e-6 deg assertions
     epoch_precision_ns: int = 1_000         # 1 us: a bracket narrower than this without a hit is "not found"
+    frame: Optional[Frame] = None           # until_nth_event's `event_frame` (event.rs:104-117): an IAU-oriented frame of the same centre
 
     @classmethod
     def apoapsis(cls):
@@ -825,7 +827,24 @@ class Event:
         return cls(_abi.EV_TRUE_ANOMALY_DEG, 0.0)
 
     def as_c(self, trigger: int) -> "_abi.EventC":
-        return _abi.EventC(int(self.scalar), int(trigger), float(self.desired), float(self.value_precision), int(self.epoch_precision_ns))
+        c = _abi.EventC()
+        c.scalar, c.trigger, c.desired = int(self.scalar), int(trigger), float(self.desired)
+        c.value_precision, c.epoch_precision_ns = float(self.value_precision), int(self.epoch_precision_ns)
+        if self.frame is not None:
+            rot = self.frame.rotation or Rotation()
+            if rot.euler is not None:
+                raise NotImplementedError("event frames are IAU-oriented frames on the device path")
+            c.has_frame = 1 if self.frame.rotation is not None else 0
+            c.frame_eq_radius_km, c.frame_flattening = float(self.frame.mean_equatorial_radius_km), float(self.frame.flattening)
+            for k in range(3):
+                c.frame.ra_deg[k], c.frame.dec_deg[k], c.frame.w_deg[k] = float(rot.ra_deg[k]), float(rot.dec_deg[k]), float(rot.w_deg[k])
+            c.frame.n_nut_prec = len(rot.nut_prec_angles_deg)
+            for k in range(c.frame.n_nut_prec):
+                c.frame.nut_prec_angle_deg[k][0], c.frame.nut_prec_angle_deg[k][1] = float(rot.nut_prec_angles_deg[k][0]), float(rot.nut_prec_angles_deg[k][1])
+                c.frame.nut_prec_ra[k] = float(rot.nut_prec_ra[k]) if k < len(rot.nut_prec_ra) else 0.0
+                c.frame.nut_prec_dec[k] = float(rot.nut_prec_dec[k]) if k < len(rot.nut_prec_dec) else 0.0
+                c.frame.nut_prec_w[k] = float(rot.nut_prec_w[k]) if k < len(rot.nut_prec_w) else 0.0
+        return c
 
 
 class TrajError(Exception):

@@ -1199,12 +1199,43 @@ typedef struct {
  * on what nyx-core itself fixes: the crossing rule (propagators/event.rs:124-141) and the assertions of
  * tests/propagation/stopcond.rs (third apoapsis inside [2P, 3P], |180 - TA| < 1e-6 deg, ...).
  * --------------------------------------------------------------------------------------------- */
-static int ev_is_angle(int scalar) { return scalar == NYX_HIP_EV_TRUE_ANOMALY_DEG; }
+static int ev_is_angle(int scalar) { return scalar == NYX_HIP_EV_TRUE_ANOMALY_DEG || scalar == NYX_HIP_EV_LONGITUDE_DEG; }
 
-static double ev_scalar(int scalar, double mu, const double *y) {
+/* Geodetic latitude (deg) and height (km) on the frame's ellipsoid: the classical iteration (Vallado, Algorithm 12);
+ * anise's Orbit::latitude_deg / height_km (absent crate) - PARITY UNPINNED. */
+static void ev_geodetic(double a, double f, const double *y, double *lat_deg, double *height_km) {
+    const double e2 = f * (2.0 - f);
+    const double r_delta = sqrt(y[0] * y[0] + y[1] * y[1]);
+    double lat = atan2(y[2], r_delta), c = a;
+    for (int it = 0; it < 20; ++it) {
+        const double sl = sin(lat);
+        c = a / sqrt(1.0 - e2 * sl * sl);
+        const double nl = atan2(y[2] + c * e2 * sl, r_delta);
+        const int done = fabs(nl - lat) < 1e-12;
+        lat = nl;
+        if (done) break;
+    }
+    *lat_deg = lat * (180.0 / M_PI);
+    const double sl = sin(lat), cl = cos(lat);
+    c = a / sqrt(1.0 - e2 * sl * sl);
+    *height_km = (fabs(cl) > 1e-6) ? r_delta / cl - c : fabs(y[2]) / fabs(sl) - c * (1.0 - e2);
+}
+
+static double ev_scalar(const nyx_hip_event_t *ev, double mu, const double *y) {
+    const int scalar = ev->scalar;
     const double *r = y, *v = y + 3;
     const double rmag = norm3(r), vmag = norm3(v);
     switch (scalar) {
+    case NYX_HIP_EV_LONGITUDE_DEG: {
+        const double deg = atan2(y[1], y[0]) * (180.0 / M_PI);
+        return deg < 0.0 ? deg + 360.0 : deg;
+    }
+    case NYX_HIP_EV_DECLINATION_DEG: return asin(y[2] / rmag) * (180.0 / M_PI);
+    case NYX_HIP_EV_LATITUDE_DEG: case NYX_HIP_EV_HEIGHT_KM: {
+        double lat, h;
+        ev_geodetic(ev->frame_eq_radius_km, ev->frame_flattening, y, &lat, &h);
+        return scalar == NYX_HIP_EV_LATITUDE_DEG ? lat : h;
+    }
     case NYX_HIP_EV_RMAG_KM: return rmag;
     case NYX_HIP_EV_VMAG_KM_S: return vmag;
     case NYX_HIP_EV_X_KM: case NYX_HIP_EV_Y_KM: case NYX_HIP_EV_Z_KM: return y[scalar - NYX_HIP_EV_X_KM];
@@ -1232,9 +1263,24 @@ static double ev_scalar(int scalar, double mu, const double *y) {
     return deg < 0.0 ? deg + 360.0 : deg;
 }
 
-/* Event::eval for Condition::Equals: value - desired, wrapped to [-180, 180) for angles */
-static double ev_eval(const nyx_hip_event_t *ev, double mu, const double *y) {
-    const double d = ev_scalar(ev->scalar, mu, y) - ev->desired;
+/* Event::eval for Condition::Equals: value - desired, wrapped to [-180, 180) for angles.  With an observer frame
+ * (until_nth_event's event_frame, event.rs:104-117) the state is first expressed in that body-fixed frame:
+ * almanac.transform_to(orbit, frame) for a frame of the same centre = rotation of position and velocity. */
+static double ev_eval(const nyx_hip_event_t *ev, double mu, int64_t epoch_ns, const double *y_in) {
+    double yf[6];
+    const double *y = y_in;
+    if (ev->has_frame) {
+        double m[3][3], wdot;
+        (void)rotation_dcm_rate(&ev->frame, NULL, nyx_oracle_ns_to_seconds(epoch_ns), m, &wdot);
+        for (int i = 0; i < 3; ++i) {
+            yf[i] = m[i][0] * y_in[0] + m[i][1] * y_in[1] + m[i][2] * y_in[2];
+            yf[3 + i] = m[i][0] * y_in[3] + m[i][1] * y_in[4] + m[i][2] * y_in[5];
+        }
+        yf[3] = yf[3] + wdot * yf[1];
+        yf[4] = yf[4] - wdot * yf[0];
+        y = yf;
+    }
+    const double d = ev_scalar(ev, mu, y) - ev->desired;
     if (!ev_is_angle(ev->scalar)) return d;
     double w = fmod(d + 180.0, 360.0);
     if (w < 0.0) w += 360.0;
@@ -1245,7 +1291,7 @@ static double signum_(double x) { return x != x ? x : (signbit(x) ? -1.0 : 1.0);
 
 /* the `enough_crossings` closure (event.rs:108-146) */
 static int ev_step(inst_t *s) {
-    const double y_next = ev_eval(s->ev, s->p->cfg->central_mu_km3_s2, s->y);
+    const double y_next = ev_eval(s->ev, s->p->cfg->central_mu_km3_s2, s->epoch_ns, s->y);
     const double delta = fabs(y_next - s->ev_prev);
     if (ev_is_angle(s->ev->scalar)) {
         if (signum_(s->ev_prev) != signum_(y_next) && delta < 180.0) s->ev_count += 1;
@@ -1618,7 +1664,7 @@ static int ev_at(const nyx_hip_traj_t *traj, int64_t n, int64_t i, const nyx_hip
     double s6[6];
     const int st = nyx_oracle_traj_at(traj, n, i, epoch_ns, s6);
     if (st != NYX_HIP_INTERP_OK) return st;
-    *value = ev_eval(ev, mu, s6);
+    *value = ev_eval(ev, mu, epoch_ns, s6);
     return NYX_HIP_INTERP_OK;
 }
 
@@ -1677,7 +1723,7 @@ int32_t nyx_oracle_until_event(const nyx_hip_config_t *cfg, const nyx_hip_states
         traj->len[i] = 0;
         traj_push(s);
         s->ev = ev;
-        s->ev_prev = ev_eval(ev, cfg->central_mu_km3_s2, s->y); /* y_prev of the start state (event.rs:104-106) */
+        s->ev_prev = ev_eval(ev, cfg->central_mu_km3_s2, s->epoch_ns, s->y); /* y_prev of the start state (event.rs:104-106) */
         int st = propagate(s, max_duration_ns);
         inst_store(s, out, stats, i, st);
         if (crossings) crossings[i] = s->ev_count;

@@ -98,3 +98,33 @@ def test_front_ends_mirror_the_reference():
     assert len(got) == 5 and all(abs(np.linalg.norm(g.rv[:3]) - 6700.0) < 1e-6 for g in got)
     none = prop.many_until_event(scs, almanac, 3 * 3600 * S, nx.Event(_abi.EV_RMAG_KM, 9000.0))
     assert none == []
+
+
+@pytest.mark.parametrize("scalar,desired,framed", [(_abi.EV_LONGITUDE_DEG, 0.0, False), (_abi.EV_LATITUDE_DEG, 2.0, True),
+                                                    (_abi.EV_DECLINATION_DEG, -10.0, True), (_abi.EV_HEIGHT_KM, 330.0, True),
+                                                    (_abi.EV_LONGITUDE_DEG, 135.0, True)])
+def test_geometric_scalars_and_observer_frame_device_vs_oracle(scalar, desired, framed):
+    """tests/propagation/stopcond.rs:252-312 (line_of_nodes, latitude with event_frame = IAU_EARTH) and their neighbours:
+    the device finds the same event as the oracle (two-body: to nanoseconds), per trajectory of a dispersed batch."""
+    from scenarios import two_body_setup
+    from test_oracle_events import IAU_EARTH_SHAPED
+    prop, almanac, central = two_body_setup(nx.IntegratorMethod.DormandPrince78, nx.IntegratorOptions(), ephem_mu())
+    compiled = prop.compile(almanac, central)
+    b = dispersed_leo_batch(70, seed=31)
+    ev = nx.Event(scalar, desired, value_precision=1e-7, frame=IAU_EARTH_SHAPED if framed else None)
+    ctx = nx.GpuContext(compiled)
+    out, st, traj, cr = ctx.propagate_until_event(b, 4 * 3600 * S, ev, trigger=2, capacity=600)
+    ctx.close()
+    ref, rst, rtraj, rcr = oracle_lib.propagate_until_event(compiled, b, 4 * 3600 * S, ev, trigger=2, capacity=600)
+    np.testing.assert_array_equal(st.status, rst.status)
+    np.testing.assert_array_equal(cr, rcr)
+    ok = st.status == 0
+    assert ok.sum() >= 60
+    assert np.abs(out.epoch_ns[ok] - ref.epoch_ns[ok]).max() <= 50          # ns
+    d = out.rv()[ok] - ref.rv()[ok]
+    assert np.linalg.norm(d[:, :3], axis=1).max() < 1e-6
+
+
+def ephem_mu():
+    from nyx_amd import ephem
+    return ephem.MU_EARTH

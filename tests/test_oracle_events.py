@@ -88,3 +88,64 @@ def test_non_angle_scalars_and_batches():
     sma = nx.Event(_abi.EV_SMA_KM, 1.0)                                              # never crossed: constant of the motion
     out, st, _, crossings = oracle_lib.propagate_until_event(compiled, batch, p // 2, sma)
     assert (st.status == _abi.ERR_EVENT_NOT_FOUND).all() and (crossings == 0).all()
+
+
+# ---- geometric scalars and the observer frame (tests/propagation/stopcond.rs:252-312) -------------------------------------
+EPOCH_2008_02_29_NOON_UTC_NS = (2981 * 86400) * nx.NS_PER_S + 65_184_000_000   # ET past J2000 (TT - UTC = 65.184 s in 2008)
+IAU_EARTH_SHAPED = nx.Frame(nx.EARTH, 398600.435436096, 6378.14, nx.IAU_EARTH_ROTATION, flattening=(6378.14 - 6356.75) / 6378.14)  # pck08 radii
+
+
+def _stopcond_state(n=1):
+    b = nx._abi.StateBatch(n)
+    b.set_rv(np.tile(np.array([-2436.45, -2436.45, 6891.037, 5.088611, -5.088611, 0.0]), (n, 1)))
+    b.epoch_ns[:] = EPOCH_2008_02_29_NOON_UTC_NS
+    return b
+
+
+def test_line_of_nodes_longitude_event():
+    # stopcond.rs:252-281: Event(Longitude, Equals(0)), two-body, RK89 default, 3 periods, no event frame
+    from scenarios import two_body_setup
+    prop, almanac, central = two_body_setup(nx.IntegratorMethod.RungeKutta89, nx.IntegratorOptions(), 398600.435436096)
+    compiled = prop.compile(almanac, central)
+    rv0 = _stopcond_state().rv()[0]
+    period = 2 * np.pi * np.sqrt(_sma(rv0, central.mu_km3_s2) ** 3 / central.mu_km3_s2)
+    ev = nx.Event(nx._abi.EV_LONGITUDE_DEG, 0.0)
+    out, st, traj, cr = oracle_lib.propagate_until_event(compiled, _stopcond_state(), int(3 * period * 1e9), ev, trigger=1, capacity=1024)
+    assert st.status[0] == 0
+    lon = np.degrees(np.arctan2(out.rv()[0, 1], out.rv()[0, 0]))
+    assert abs(lon) < 1e-3                                    # the reference's assertion
+    assert abs(lon) < 1e-6                                    # ... and what the search actually reaches
+
+
+def test_geodetic_latitude_event_in_iau_earth():
+    # stopcond.rs:283-312: Event(Latitude, Equals(2.0)) with event_frame = IAU_EARTH, DP78 default, 3 periods
+    from scenarios import two_body_setup
+    prop, almanac, central = two_body_setup(nx.IntegratorMethod.DormandPrince78, nx.IntegratorOptions(), 398600.435436096)
+    compiled = prop.compile(almanac, central)
+    rv0 = _stopcond_state().rv()[0]
+    period = 2 * np.pi * np.sqrt(_sma(rv0, central.mu_km3_s2) ** 3 / central.mu_km3_s2)
+    ev = nx.Event(nx._abi.EV_LATITUDE_DEG, 2.0, frame=IAU_EARTH_SHAPED)
+    out, st, traj, cr = oracle_lib.propagate_until_event(compiled, _stopcond_state(), int(3 * period * 1e9), ev, trigger=1, capacity=1024)
+    assert st.status[0] == 0
+    # independent evaluation of the geodetic latitude of the returned state in the rotating frame (closed-form Bowring check)
+    from rotation_cases import dcm_from_angles, iau_angles_rad
+    m = dcm_from_angles(iau_angles_rad(nx.IAU_EARTH_ROTATION, nx.to_seconds(int(out.epoch_ns[0]))))
+    rb = m @ out.rv()[0, :3]
+    a, f = IAU_EARTH_SHAPED.mean_equatorial_radius_km, IAU_EARTH_SHAPED.flattening
+    e2 = f * (2 - f)
+    p = np.hypot(rb[0], rb[1])
+    lat = np.arctan2(rb[2], p * (1 - e2))
+    for _ in range(10):   # fixed-point iteration on the geodetic latitude
+        n = a / np.sqrt(1 - e2 * np.sin(lat) ** 2)
+        h = p / np.cos(lat) - n
+        lat = np.arctan2(rb[2], p * (1 - e2 * n / (n + h)))
+    assert abs(2.0 - np.degrees(lat)) < 1e-3                  # the reference's assertion
+    assert abs(2.0 - np.degrees(lat)) < 1e-6
+    # geodetic, not geocentric: the declination of the same state differs by the ellipsoid's ~0.01 deg at this latitude
+    decl = np.degrees(np.arcsin(rb[2] / np.linalg.norm(rb)))
+    assert 1e-3 < abs(decl - 2.0) < 0.05
+
+
+def _sma(rv, mu):
+    r, v = np.linalg.norm(rv[:3]), np.linalg.norm(rv[3:])
+    return -mu / (2 * (v * v / 2 - mu / r))
