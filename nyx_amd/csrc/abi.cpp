@@ -1466,11 +1466,13 @@ extern "C" int32_t nyx_hip_propagate_until_event(nyx_hip_ctx *ctx, const nyx_hip
     if (int rc = stage_batch(ctx, in, out, sg)) return rc;
     DevTraj dtraj;
     if (int rc = dtraj.alloc(traj->capacity, n)) return rc;
-    DevBuf evbuf;  // prev (f64), count, found (i32)
+    DevBuf evbuf, evdesc;  // prev (f64), count, found (i32); the event descriptor itself
     if (int rc = evbuf.alloc((size_t)n * 16)) return rc;
+    if (int rc = evdesc.alloc(sizeof(nyx_hip_event_t))) return rc;
+    HIP_TRY(hipMemcpy(evdesc.p, event, sizeof(nyx_hip_event_t), hipMemcpyHostToDevice));
     DevBatch ev;
     std::memset(&ev, 0, sizeof ev);
-    ev.ev = *event;
+    ev.ev = evdesc.as<nyx_hip_event_t>();
     ev.ev_mu = ctx->host_cfg.mu_central;
     ev.ev_prev = evbuf.as<double>();
     ev.ev_count = (int32_t *)(evbuf.as<double>() + n);

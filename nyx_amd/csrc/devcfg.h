@@ -159,7 +159,8 @@ struct DevBatch { /* device pointers of one launch */
     /* stop condition (propagators/event.rs:88-146); ev_on = 0 => none */
     int32_t ev_on, _pad2;
     double ev_mu;
-    nyx_hip_event_t ev; /* scalar, trigger, desired value, observer frame */
+    const nyx_hip_event_t *ev; /* DEVICE copy of the event (scalar, trigger, desired value, observer frame).  A pointer on purpose: by
+                                  value its address would be taken (event_step) and the whole launch descriptor would move to scratch */
     double *ev_prev;   /* [n] event value of the previous accepted state */
     int32_t *ev_count; /* [n] crossings so far */
     int32_t *ev_found; /* [n] 1 when the propagation stopped on the event */

@@ -1024,6 +1024,8 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
                     const CoopBox *b = bt.coop_box + owner_c;
                     coop_acquire();
                     const unsigned par = seq_c & 1u;
+                    // (measured: fetching only after the claim has succeeded costs 7 % of the north-star run - the helper's job
+                    //  latency is what bounds its share)
                     const double v0 = coop_loadd(&b->in[par][0][lane]), v1 = coop_loadd(&b->in[par][1][lane]),
                                  v2 = coop_loadd(&b->in[par][2][lane]), v3 = coop_loadd(&b->in[par][3][lane]),
                                  v4 = coop_loadd(&b->in[par][4][lane]);
@@ -1694,7 +1696,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
         cold_store(L.cs, lane, c);
         if (bt.ev_on && wr) {  // y_prev of the start state (event.rs:104-106)
             const double y0[6] = {c.y[0], c.y[1], c.y[2], c.y[3], c.y[4], c.y[5]};
-            bt.ev_prev[gid] = ev_eval(bt.ev, bt.ev_mu, c.epoch, y0);
+            bt.ev_prev[gid] = ev_eval(*bt.ev, bt.ev_mu, c.epoch, y0);
             bt.ev_count[gid] = 0;
             bt.ev_found[gid] = 0;
         }
@@ -2329,7 +2331,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     // not published (instance.rs:243-252)
                     bool ev_hit = false;
                     if (bt.ev_on && valid && !c.is_final)  // (quad layout: the four lanes read and write the same words with the same values)
-                        ev_hit = event_step(&bt.ev, bt.ev_mu, c.epoch, bt.ev_prev + gid, bt.ev_count + gid, y[0], y[1],
+                        ev_hit = event_step(bt.ev, bt.ev_mu, c.epoch, bt.ev_prev + gid, bt.ev_count + gid, y[0], y[1],
                                             y[2], y[3], y[4], y[5]);
                     if (ev_hit) {
                         if (wr) bt.ev_found[gid] = 1;
@@ -2421,7 +2423,7 @@ DEVFN void propagate_body(const DevBatch &bt, const DevCfg *cfg_g, const HarmEnt
     if (!STM && bt.coop_helpers > 0) {
         const int64_t n_own = (bt.n + DEV_LANES - 1) / DEV_LANES;
         if ((int64_t)blockIdx.x >= n_own) {
-            if ((int)blockIdx.x >= bt.coop_base && !bt.coop_mute) helper_body(bt, cfg, htab, cols, smem, lane, wave);
+            if ((int)blockIdx.x >= bt.coop_base && !(bt.coop_mute & 1)) helper_body(bt, cfg, htab, cols, smem, lane, wave);
             return;
         }
     }
