@@ -70,11 +70,12 @@ def algorithmic_flop_per_eval(degree, n_pm, srp, n_shadow, stm):
 
 def executed_flop_per_eval(degree, stm):
     """What the kernel issues for the harmonics (disassembly of harmonics_partial: 7 v_fma_f64 + 2 v_mul_f64 = 16 FLOP per
-    table entry, (N+1)(N+4)/2 entries; x4 for the dual variant) — reported beside the algorithmic figure."""
+    table entry, (N+1)(N+2)/2 entries - columns c = 1..N+1 of N+2-c rows; the quad-layout dual variant issues 22 f64
+    instructions = 37 FLOP per entry and quad of lanes) — reported beside the algorithmic figure."""
     if degree <= 0:
         return None
-    entries = (degree + 1) * (degree + 4) / 2
-    return entries * 16.0 * (4.0 if stm else 1.0)
+    entries = (degree + 1) * (degree + 2) / 2
+    return entries * (37.0 if stm else 16.0)
 
 
 def geo_batch(n, seed):

@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Turns the scratch output of tools/profile_round.sh (gpurun_out/prof_cfgN/) into the tracked summaries under profiles/:
+roundNN_cfgN_bench.json, _kernel_trace_stats.md, _pmc.md and _hbm_traffic.json (what bench.py's roofline.traffic reads).
+usage: tools/make_profiles.py <round tag, e.g. round02> [configs...]"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+cfgs = [int(x) for x in sys.argv[2:]] or [2, 3, 4, 5]
+CLOCK_HZ, SIMDS = 2.4e9, 1024
+degree_of = {2: 70, 3: 0, 4: 21, 5: 150}
+for cfg in cfgs:
+    src = os.path.join(ROOT, "gpurun_out", f"prof_cfg{cfg}")
+    if not os.path.isdir(src):
+        continue
+    line = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
+    json.dump(line, open(os.path.join(ROOT, "profiles", f"{tag}_cfg{cfg}_bench.json"), "w"), indent=1)
+    shutil.copy(os.path.join(src, "kernel_trace_stats.md"), os.path.join(ROOT, "profiles", f"{tag}_cfg{cfg}_kernel_trace_stats.md"))
+    per = collections.defaultdict(list)
+    for f in glob.glob(src + "/pmc_*/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "nyx_propagate" in r.get("Kernel_Name", ""):
+                per[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    # the dominant dispatch of the command = the timed launch (the short calibration launches of a fresh context are the others);
+    # config 4 launches one segment kernel per time update: all alike, take the mean
+    pick = (lambda v: sum(v) / len(v)) if cfg == 4 else max
+    c = {k: pick(v) for k, v in per.items()}
+    launches = 60 if cfg == 4 else 1
+    k_ms = line["kernel_ms"] / launches
+    simd_cycles = SIMDS * k_ms * 1e-3 * CLOCK_HZ
+    fetch_b, write_b = c.get("FETCH_SIZE", 0.0) * 1024.0, c.get("WRITE_SIZE", 0.0) * 1024.0
+    traffic = 2.0 * fetch_b + write_b   # MI355X_MICROARCH.md, HBM: FETCH_SIZE reports half of the bytes on gfx950; WRITE_SIZE as is
+    out = [f"# {tag}, BASELINE config {cfg}: PMC counters of the dominant kernel (rocprofv3 --pmc, one counter set per pass)", "",
+           f"command: `python bench.py --config {cfg} --steps 1 --warmup 0 --no-cpu-baseline --no-dense-output --no-host-call`; "
+           f"values per launch of `{'nyx_propagate_kernel_stmq' if cfg == 4 else 'nyx_propagate_kernel'}` "
+           f"({'mean over the segment launches' if cfg == 4 else 'the timed launch: the largest dispatch of the command'}); "
+           f"kernel time {k_ms:.3f} ms (bench line of the same build).", "",
+           "| counter | per launch |", "|---|---:|"]
+    for k in sorted(c):
+        out.append(f"| {k} | {c[k]:.6g} |")
+    out += ["", "Derived:", ""]
+    if "SQ_ACTIVE_INST_VALU" in c:
+        out.append(f"* VALU issue: SQ_ACTIVE_INST_VALU x 4 cycles = {c['SQ_ACTIVE_INST_VALU'] * 4:.4g} of {simd_cycles:.4g} SIMD-cycles "
+                   f"(1024 SIMDs x kernel time x 2.4 GHz) = **{c['SQ_ACTIVE_INST_VALU'] * 4 / simd_cycles:.3f}** of all issue slots on the chip "
+                   f"(every VALU instruction, not only f64)")
+    if degree_of.get(cfg, 0) > 0:
+        nd = degree_of[cfg]
+        entries = (nd + 1) * (nd + 2) / 2
+        instr, traj_per_wave = (22.0, 16.0) if cfg == 4 else (9.0, 64.0)
+        ex = line["force_evals_per_launch"] / launches / traj_per_wave * entries * instr * 4.0
+        out.append(f"* f64 issue of the harmonics alone ({instr:.0f} f64 instructions per table entry per wave of {traj_per_wave:.0f} trajectories, "
+                   f"{entries:.0f} entries, 4 cycles each): {ex:.4g} SIMD-cycles = **{ex / simd_cycles:.3f}** of the chip's")
+    out.append(f"* HBM: FETCH_SIZE {fetch_b / 1e6:.4g} MB (x2 on gfx950 per MI355X_MICROARCH.md) + WRITE_SIZE {write_b / 1e6:.4g} MB = "
+               f"**{traffic / 1e6:.5g} MB per launch** = {traffic / (k_ms * 1e-3) / 1e9:.4g} GB/s = {traffic / (k_ms * 1e-3) / 8e12:.2e} of the 8 TB/s peak; "
+               f"algorithmic: {line['config']['trajectories_per_gpu'] * 272 / 1e6:.3g} MB")
+    open(os.path.join(ROOT, "profiles", f"{tag}_cfg{cfg}_pmc.md"), "w").write("\n".join(out) + "\n")
+    n = line["config"]["trajectories_per_gpu"]
+    w = line["config"]["workload"]
+    hours = {2: 24.0, 3: 720.0, 4: 1.0, 5: 72.0}[cfg]
+    degree = {2: 70, 3: 0, 4: 21, 5: 150}[cfg]
+    json.dump({"config": cfg, "n": n, "hours": hours, "degree": degree, "hbm_bytes_per_launch": traffic * launches,
+               "fetch_size_bytes_raw": fetch_b * launches, "write_size_bytes": write_b * launches,
+               "note": "2 x FETCH_SIZE + WRITE_SIZE of the timed step (gfx950 correction of MI355X_MICROARCH.md), rocprofv3 --pmc, separate passes",
+               "workload": w}, open(os.path.join(ROOT, "profiles", f"{tag}_cfg{cfg}_hbm_traffic.json"), "w"), indent=1)
+    print(f"config {cfg}: value {line['value']:.1f} {line['unit']}, kernel {line['kernel_ms']:.2f} ms, frac {line['roofline']['frac']:.4f}, traffic {traffic * launches / 1e6:.4g} MB")
