@@ -402,12 +402,19 @@ int32_t nyx_hip_propagate_until_event(nyx_hip_ctx *ctx, const nyx_hip_states_t *
  * The context must have been created with NYX_HIP_FLAG_STM.  The propagation starts from an identity STM
  * (`nominal_state().with_stm()`, mod.rs:452); in->stm is not read. */
 #define NYX_HIP_MAX_PROCESS_NOISE 4
-typedef struct nyx_hip_process_noise { /* ProcessNoise<U3> (od/snc.rs:40-59), inertial and constant */
+enum nyx_hip_local_frame { NYX_HIP_FRAME_INERTIAL = 0, NYX_HIP_FRAME_RIC = 1, NYX_HIP_FRAME_VNC = 2 };
+typedef struct nyx_hip_process_noise { /* ProcessNoise<U3> (od/snc.rs:40-59) */
     double diag[3];          /* ProcessNoise::diag (from_diagonal / from_velocity_km_s, snc.rs:108-135, 288-309) */
     int64_t disable_time_ns; /* no noise when the time update spans more than this (snc.rs:178-186, 248-250) */
     int64_t start_time_ns;   /* start_time, read when has_start_time != 0 (snc.rs:168-175) */
     int32_t has_start_time;
+    int32_t local_frame;     /* enum nyx_hip_local_frame: the frame the diagonal is given in; rotated into the state frame at the
+                                nominal orbit and only the DIAGONAL kept, as the reference does (snc.rs:219-239) */
+    int32_t has_decay;       /* ProcessNoise::with_decay (snc.rs:145-160): diag_i * exp(-decay_i * (epoch - init_epoch)) (:193-197) */
     int32_t _pad;
+    double decay_s[3];       /* decay constants, 1/s */
+    int64_t init_epoch_ns;   /* ProcessNoise::init_epoch = the epoch of the initial estimate (kalman/initializers.rs:75-101);
+                                INT64_MIN = every trajectory's own start epoch */
 } nyx_hip_process_noise_t;
 
 typedef struct nyx_hip_predict {

@@ -210,9 +210,13 @@ class EventC(C.Structure):
 
 
 
+FRAME_INERTIAL, FRAME_RIC, FRAME_VNC = 0, 1, 2
+
+
 class ProcessNoiseC(C.Structure):
     _fields_ = [("diag", C.c_double * 3), ("disable_time_ns", C.c_int64), ("start_time_ns", C.c_int64),
-                ("has_start_time", C.c_int32), ("_pad", C.c_int32)]
+                ("has_start_time", C.c_int32), ("local_frame", C.c_int32), ("has_decay", C.c_int32), ("_pad", C.c_int32),
+                ("decay_s", C.c_double * 3), ("init_epoch_ns", C.c_int64)]
 
 
 class Predict(C.Structure):

@@ -1508,6 +1508,11 @@ extern "C" int32_t nyx_hip_predict_until(nyx_hip_ctx *ctx, const nyx_hip_states_
     if (!(ctx->host_cfg.flags & NYX_HIP_FLAG_STM)) { nyx_set_error("predict: the context must be created with NYX_HIP_FLAG_STM"); return NYX_HIP_RC_BAD_ARG; }
     if (cfg->max_step_ns <= 0) { nyx_set_error("predict: max_step_ns must be > 0"); return NYX_HIP_RC_BAD_ARG; }
     if (cfg->n_process_noise < 0 || cfg->n_process_noise > NYX_HIP_MAX_PROCESS_NOISE) { nyx_set_error("predict: n_process_noise out of range"); return NYX_HIP_RC_BAD_ARG; }
+    for (int q = 0; q < cfg->n_process_noise; ++q)
+        if (cfg->process_noise[q].local_frame < NYX_HIP_FRAME_INERTIAL || cfg->process_noise[q].local_frame > NYX_HIP_FRAME_VNC) {
+            nyx_set_error("predict: process noise %d: local frame not on the device path (inertial, RIC, VNC)", q);
+            return NYX_HIP_RC_UNSUPPORTED;
+        }
     if (hist && (hist->capacity < 0 || !hist->n_updates)) { nyx_set_error("predict: hist->n_updates is mandatory, capacity >= 0"); return NYX_HIP_RC_BAD_ARG; }
     if (int rc = check_states(in, "in")) return rc;
     if (int rc = check_states(out, "out")) return rc;
@@ -1527,10 +1532,10 @@ extern "C" int32_t nyx_hip_predict_until(nyx_hip_ctx *ctx, const nyx_hip_states_
     const int64_t cap = hist ? hist->capacity : 0;
     const size_t slots = (size_t)cap * (size_t)n;
     DevBuf covar, sdev, work, h_epoch, h_state, h_stm, h_covar, h_sdev;
-    // work: prev_epoch, dur, acc x3 (int64) then status, n_updates (int32)
+    // work: prev_epoch, dur, acc x3, init_epoch (int64) then status, n_updates (int32)
     if (int rc = covar.alloc((size_t)n * 81 * 8)) return rc;
     if (int rc = sdev.alloc((size_t)n * 9 * 8)) return rc;
-    if (int rc = work.alloc((size_t)n * (5 * 8 + 2 * 4))) return rc;
+    if (int rc = work.alloc((size_t)n * (6 * 8 + 2 * 4))) return rc;
     HIP_TRY(hipMemcpy(covar.p, est->covar, (size_t)n * 81 * 8, hipMemcpyHostToDevice));
     if (est->state_dev) HIP_TRY(hipMemcpy(sdev.p, est->state_dev, (size_t)n * 9 * 8, hipMemcpyHostToDevice));
     else HIP_TRY(hipMemset(sdev.p, 0, (size_t)n * 9 * 8));
@@ -1545,7 +1550,8 @@ extern "C" int32_t nyx_hip_predict_until(nyx_hip_ctx *ctx, const nyx_hip_states_
     a.covar = covar.as<double>(); a.state_dev = sdev.as<double>();
     int64_t *w64 = work.as<int64_t>();
     a.prev_epoch = w64; a.dur = w64 + n; a.acc_n_acc = w64 + 2 * n; a.acc_n_rej = w64 + 3 * n; a.acc_n_evals = w64 + 4 * n;
-    a.status = (int32_t *)(w64 + 5 * n); a.hist.n_updates = a.status + n;
+    a.init_epoch = w64 + 5 * n;
+    a.status = (int32_t *)(w64 + 6 * n); a.hist.n_updates = a.status + n;
     a.hist.capacity = cap;
     if (hist && slots) {
         if (hist->epoch_ns) { if (int rc = h_epoch.alloc(slots * 8)) return rc; a.hist.epoch_ns = h_epoch.as<int64_t>(); }

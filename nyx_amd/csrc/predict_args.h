@@ -17,6 +17,7 @@ struct PredictArgs {
     double *covar;        // [n][81]
     double *state_dev;    // [n][9]
     int64_t *prev_epoch;  // [n] epoch of the previous estimate
+    int64_t *init_epoch;  // [n] epoch of the initial estimate (ProcessNoise::init_epoch when the descriptor leaves it open)
     int64_t *dur;         // [n] duration of the NEXT segment (0 = trajectory finished or failed)
     int32_t *status;      // [n] first failing status
     int64_t *acc_n_acc, *acc_n_rej, *acc_n_evals;

@@ -22,6 +22,7 @@ __global__ __launch_bounds__(256) void nyx_predict_init_kernel(PredictArgs a, co
     if (i >= a.n) return;
     for (int k = 0; k < 81; ++k) a.stm[i * 81 + k] = (k % 10 == 0) ? 1.0 : 0.0;  // with_stm(): identity
     a.prev_epoch[i] = epoch0[i];
+    a.init_epoch[i] = epoch0[i];
     a.dur[i] = a.cfg.max_step_ns;  // the loop body always runs once (mod.rs:465-484)
     a.status[i] = 0;
     a.acc_n_acc[i] = 0; a.acc_n_rej[i] = 0; a.acc_n_evals[i] = 0;
@@ -29,7 +30,8 @@ __global__ __launch_bounds__(256) void nyx_predict_init_kernel(PredictArgs a, co
 }
 
 __global__ __launch_bounds__(128) void nyx_time_update_kernel(PredictArgs a) {
-    __shared__ double phi[81], p[81], m[81], dev[9];
+    __shared__ double phi[81], p[81], m[81], dev[9], snc[3];
+    __shared__ int snc_q;
     const int64_t i = blockIdx.x;
     const int t = threadIdx.x;
     if (a.dur[i] == 0) return;  // finished or failed earlier: nothing was propagated for this trajectory
@@ -49,6 +51,54 @@ __global__ __launch_bounds__(128) void nyx_time_update_kernel(PredictArgs a) {
     const int32_t u = a.hist.n_updates[i];
     if (t < 81) { phi[t] = a.stm[i * 81 + t]; p[t] = a.covar[i * 81 + t]; }
     if (t < 9) dev[t] = a.state_dev ? a.state_dev[i * 9 + t] : 0.0;
+    if (t == 0) {
+        // the process noise that applies: last applicable entry (filtering.rs:64-80), its diagonal at this epoch
+        // (ProcessNoise::to_matrix, snc.rs:165-205: exponential decay since init_epoch) expressed in the state frame
+        // (ProcessNoise::propagate, snc.rs:219-239: new = dcm * snc * dcm^T at the nominal orbit, DIAGONAL kept)
+        int pick = -1;
+        for (int q = a.cfg.n_process_noise - 1; q >= 0; --q) {
+            const nyx_hip_process_noise_t &pn = a.cfg.process_noise[q];
+            if (pn.has_start_time && pn.start_time_ns > epoch) continue;  // snc.rs:168-175
+            if (delta_ns > pn.disable_time_ns) continue;                  // snc.rs:178-186, 248-250
+            pick = q;
+            break;
+        }
+        snc_q = pick;
+        if (pick >= 0) {
+            const nyx_hip_process_noise_t &pn = a.cfg.process_noise[pick];
+            double d[3] = {pn.diag[0], pn.diag[1], pn.diag[2]};
+            if (pn.has_decay) {
+                const int64_t init = pn.init_epoch_ns != INT64_MIN ? pn.init_epoch_ns : a.init_epoch[i];
+                const double total = ns_to_seconds(epoch - init);
+                for (int k = 0; k < 3; ++k) d[k] = d[k] * exp(-pn.decay_s[k] * total);
+            }
+            if (pn.local_frame != NYX_HIP_FRAME_INERTIAL) {
+                // dcm_to_inertial(local_frame) of the nominal orbit (anise, absent: classical definitions).  Columns:
+                // RIC = [r^, c^ x r^, c^], VNC = [v^, n^, v^ x n^] with c^ = n^ = (r x v)^
+                const double r[3] = {a.s9[0][i], a.s9[1][i], a.s9[2][i]}, v[3] = {a.s9[3][i], a.s9[4][i], a.s9[5][i]};
+                double h[3] = {r[1] * v[2] - r[2] * v[1], r[2] * v[0] - r[0] * v[2], r[0] * v[1] - r[1] * v[0]};
+                const double hn = sqrt(h[0] * h[0] + h[1] * h[1] + h[2] * h[2]);
+                for (int k = 0; k < 3; ++k) h[k] = h[k] / hn;
+                double e0[3], e1[3], e2[3];
+                if (pn.local_frame == NYX_HIP_FRAME_RIC) {
+                    const double rn = sqrt(r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+                    for (int k = 0; k < 3; ++k) { e0[k] = r[k] / rn; e2[k] = h[k]; }
+                    e1[0] = e2[1] * e0[2] - e2[2] * e0[1]; e1[1] = e2[2] * e0[0] - e2[0] * e0[2]; e1[2] = e2[0] * e0[1] - e2[1] * e0[0];
+                } else {
+                    const double vn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+                    for (int k = 0; k < 3; ++k) { e0[k] = v[k] / vn; e1[k] = h[k]; }
+                    e2[0] = e0[1] * e1[2] - e0[2] * e1[1]; e2[1] = e0[2] * e1[0] - e0[0] * e1[2]; e2[2] = e0[0] * e1[1] - e0[1] * e1[0];
+                }
+                double nd[3];
+                for (int k = 0; k < 3; ++k) {  // (dcm * snc) * dcm^T, entry (k, k); dcm[k][j] = e_j[k]
+                    const double c0 = e0[k], c1 = e1[k], c2 = e2[k];
+                    nd[k] = ((c0 * d[0]) * c0 + (c1 * d[1]) * c1) + (c2 * d[2]) * c2;
+                }
+                for (int k = 0; k < 3; ++k) d[k] = nd[k];
+            }
+            for (int k = 0; k < 3; ++k) snc[k] = d[k];
+        }
+    }
     __syncthreads();
     const int r = t % 9, c = t / 9;  // column-major: element (r, c) at c * 9 + r
     if (t < 81) {
@@ -62,18 +112,11 @@ __global__ __launch_bounds__(128) void nyx_time_update_kernel(PredictArgs a) {
     if (t < 81) {
         double acc = m[r] * phi[c];  // (stm * covar) * stm^T: sum_k M[r,k] * Phi[c,k]
         for (int k = 1; k < 9; ++k) acc = acc + m[k * 9 + r] * phi[k * 9 + c];
-        // process noise: last applicable entry (filtering.rs:64-80)
-        for (int q = a.cfg.n_process_noise - 1; q >= 0; --q) {
-            const nyx_hip_process_noise_t &pn = a.cfg.process_noise[q];
-            if (pn.has_start_time && pn.start_time_ns > epoch) continue;  // snc.rs:168-175
-            if (delta_ns > pn.disable_time_ns) continue;                  // snc.rs:178-186, 248-250
-            if (r < 6 && c < 6 && r % 3 == c % 3) {
-                const double dt = ns_to_seconds(delta_ns);
-                const double half_dt2 = (dt * dt) / 2.0;  // delta_t.powi(2) / 2.0
-                const double g_r = r < 3 ? half_dt2 : dt, g_c = c < 3 ? half_dt2 : dt;
-                acc = acc + (g_r * pn.diag[r % 3]) * g_c;  // (Gamma * Q) * Gamma^T, single non-zero term
-            }
-            break;
+        if (snc_q >= 0 && r < 6 && c < 6 && r % 3 == c % 3) {
+            const double dt = ns_to_seconds(delta_ns);
+            const double half_dt2 = (dt * dt) / 2.0;  // delta_t.powi(2) / 2.0
+            const double g_r = r < 3 ? half_dt2 : dt, g_c = c < 3 ? half_dt2 : dt;
+            acc = acc + (g_r * snc[r % 3]) * g_c;  // (Gamma * Q) * Gamma^T, single non-zero term
         }
         a.covar[i * 81 + t] = acc;
         if (keep && a.hist.covar) a.hist.covar[slot * 81 + t] = acc;

@@ -5,8 +5,8 @@ Mirror of `KalmanODProcess::predict_until / predict_for` (nyx-core/src/od/proces
 many estimates: every 1-step segment, its time update and the STM reset run on the device
 (`nyx_hip_predict_until`); the host only stages the inputs and collects the estimates.
 
-Not mirrored (host-side OD machinery, out of scope): measurement updates, smoothing, residual rejection,
-process-noise decay and local-frame (RIC/VNC) rotation of the noise (ProcessNoise::with_decay, local_frame).
+Not mirrored (host-side OD machinery, out of scope): measurement updates, smoothing, residual rejection.  Process-noise
+decay and the local-frame (RIC / VNC) definition of the noise (ProcessNoise::with_decay, local_frame) are on the device.
 """
 from __future__ import annotations
 
@@ -29,6 +29,17 @@ class ProcessNoise3D:
     diag: Sequence[float]
     disable_time_ns: int
     start_time_ns: Optional[int] = None
+    local_frame: Optional[str] = None          # None (inertial), "RIC" or "VNC" (snc.rs:46-47, 219-239)
+    decay_s: Optional[Sequence[float]] = None  # with_decay (snc.rs:145-160)
+    init_epoch_ns: Optional[int] = None        # None = each estimate's own initial epoch (kalman/initializers.rs:75-101)
+
+    @classmethod
+    def with_decay(cls, values: Sequence[float], disable_time_ns: int, decay_constants_s: Sequence[float], local_frame: Optional[str] = None):
+        """snc.rs:145-160."""
+        assert len(decay_constants_s) == 3, "Not enough decay constants for the size of the SNC matrix"
+        me = cls.from_diagonal(values, disable_time_ns)
+        me.decay_s, me.local_frame = [float(v) for v in decay_constants_s], local_frame
+        return me
 
     @classmethod
     def from_diagonal(cls, values: Sequence[float], disable_time_ns: int):
@@ -90,6 +101,14 @@ def build_predict(max_step_ns: int, end_epoch_ns: int, process_noise: Sequence[P
         pc.process_noise[k].disable_time_ns = int(pn.disable_time_ns)
         pc.process_noise[k].has_start_time = 0 if pn.start_time_ns is None else 1
         pc.process_noise[k].start_time_ns = 0 if pn.start_time_ns is None else int(pn.start_time_ns)
+        lf = {None: _abi.FRAME_INERTIAL, "RIC": _abi.FRAME_RIC, "VNC": _abi.FRAME_VNC}.get(pn.local_frame, -1)
+        if lf < 0:
+            raise NotImplementedError(f"process noise in the {pn.local_frame} frame is not on the device path")
+        pc.process_noise[k].local_frame = lf
+        pc.process_noise[k].has_decay = 0 if pn.decay_s is None else 1
+        for j in range(3):
+            pc.process_noise[k].decay_s[j] = 0.0 if pn.decay_s is None else float(pn.decay_s[j])
+        pc.process_noise[k].init_epoch_ns = -(1 << 63) if pn.init_epoch_ns is None else int(pn.init_epoch_ns)
     return pc
 
 

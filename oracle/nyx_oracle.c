@@ -1796,6 +1796,7 @@ int32_t nyx_oracle_predict_until(const nyx_hip_config_t *cfg, const nyx_hip_stat
         double dev[9];
         for (int k = 0; k < 9; ++k) dev[k] = est->state_dev ? est->state_dev[9 * i + k] : 0.0;
         int64_t prev_epoch = s->epoch_ns;
+        const int64_t init_epoch = s->epoch_ns; /* ProcessNoise::init_epoch = the initial estimate's epoch (kalman/initializers.rs:75) */
         int32_t n_up = 0;
         int st = NYX_HIP_OK;
         for (;;) {
@@ -1810,13 +1811,41 @@ int32_t nyx_oracle_predict_until(const nyx_hip_config_t *cfg, const nyx_hip_stat
                 const nyx_hip_process_noise_t *pn = &pc->process_noise[q];
                 if (pn->has_start_time && pn->start_time_ns > s->epoch_ns) continue;
                 if (delta_ns > pn->disable_time_ns) continue;
+                /* ProcessNoise::to_matrix (snc.rs:165-205): the diagonal at this epoch; ::propagate (:219-239): expressed in the
+                 * state frame through dcm_to_inertial(local_frame) at the nominal orbit (anise, absent: RIC = [r^, c^ x r^, c^],
+                 * VNC = [v^, n^, v^ x n^]), only the diagonal of dcm * snc * dcm^T kept */
+                double d[3] = {pn->diag[0], pn->diag[1], pn->diag[2]};
+                if (pn->has_decay) {
+                    const int64_t init = pn->init_epoch_ns != INT64_MIN ? pn->init_epoch_ns : init_epoch;
+                    const double total = nyx_oracle_ns_to_seconds(s->epoch_ns - init);
+                    for (int k = 0; k < 3; ++k) d[k] = d[k] * exp(-pn->decay_s[k] * total);
+                }
+                if (pn->local_frame != NYX_HIP_FRAME_INERTIAL) {
+                    const double *r = s->y, *v = s->y + 3;
+                    double h[3] = {r[1] * v[2] - r[2] * v[1], r[2] * v[0] - r[0] * v[2], r[0] * v[1] - r[1] * v[0]};
+                    const double hn = norm3(h);
+                    for (int k = 0; k < 3; ++k) h[k] = h[k] / hn;
+                    double e0[3], e1[3], e2[3];
+                    if (pn->local_frame == NYX_HIP_FRAME_RIC) {
+                        const double rn = norm3(r);
+                        for (int k = 0; k < 3; ++k) { e0[k] = r[k] / rn; e2[k] = h[k]; }
+                        e1[0] = e2[1] * e0[2] - e2[2] * e0[1]; e1[1] = e2[2] * e0[0] - e2[0] * e0[2]; e1[2] = e2[0] * e0[1] - e2[1] * e0[0];
+                    } else {
+                        const double vn = norm3(v);
+                        for (int k = 0; k < 3; ++k) { e0[k] = v[k] / vn; e1[k] = h[k]; }
+                        e2[0] = e0[1] * e1[2] - e0[2] * e1[1]; e2[1] = e0[2] * e1[0] - e0[0] * e1[2]; e2[2] = e0[0] * e1[1] - e0[1] * e1[0];
+                    }
+                    double nd[3];
+                    for (int k = 0; k < 3; ++k) nd[k] = ((e0[k] * d[0]) * e0[k] + (e1[k] * d[1]) * e1[k]) + (e2[k] * d[2]) * e2[k];
+                    for (int k = 0; k < 3; ++k) d[k] = nd[k];
+                }
                 const double dt = nyx_oracle_ns_to_seconds(delta_ns);
                 const double half_dt2 = (dt * dt) / 2.0;
                 for (int c = 0; c < 6; ++c)
                     for (int r = 0; r < 6; ++r)
                         if (r % 3 == c % 3) {
                             const double g_r = r < 3 ? half_dt2 : dt, g_c = c < 3 ? half_dt2 : dt;
-                            cb[c * 9 + r] = cb[c * 9 + r] + (g_r * pn->diag[r % 3]) * g_c;
+                            cb[c * 9 + r] = cb[c * 9 + r] + (g_r * d[r % 3]) * g_c;
                         }
                 break;
             }

@@ -76,6 +76,37 @@ def test_config4_geo_covariance_map_vs_oracle():
     ctx.close()
 
 
+@pytest.mark.parametrize("frame", [None, "RIC", "VNC"])
+def test_process_noise_decay_and_local_frame_vs_oracle(frame):
+    """ProcessNoise::with_decay and local_frame (od/snc.rs:145-160, 193-197, 219-239) on the device against the oracle:
+    same arithmetic order, so the noise contribution agrees to the last bits of Phi P Phi^T."""
+    prop, almanac, central = leo_full_setup(degree=8)
+    compiled = prop.compile(almanac, central, stm=True)
+    ctx = nx.GpuContext(compiled)
+    n = 40
+    b = dispersed_leo_batch(n, seed=9)
+    b.epoch_ns[: n // 2] += 17 * S                       # per-trajectory initial epochs: each has its own decay clock
+    p0 = init_covar(n, seed=2)
+    pns = [nx.ProcessNoise3D.from_diagonal([1e-13] * 3, 10 * 60 * S),
+           nx.ProcessNoise3D.with_decay([1e-12, 4e-12, 9e-12], 10 * 60 * S, [5e-3, 1e-2, 0.0], local_frame=frame)]
+    pns[1].start_time_ns = EPOCH0_NS + 100 * S          # the constant one applies first, the decaying one afterwards
+    end = EPOCH0_NS + 6 * 60 * S
+    got = nx.predict_until(ctx, b, p0, end, 60 * S, process_noise=pns, history=6)
+    ref = oracle_lib.predict_until(compiled, b, p0, end, 60 * S, process_noise=pns, history=6)
+    none = nx.predict_until(ctx, b, p0, end, 60 * S, history=6)
+    assert (got.stats.status == 0).all() and (ref.n_updates == 6).all()
+    np.testing.assert_array_equal(got.n_updates, ref.n_updates)
+    e_p = rel_err(got.covar_history, ref.covar_history)
+    # the noise term on its own (P with noise - P without) is a small difference of large numbers: compare it at the
+    # precision that leaves, and make sure it is there at all
+    q_got, q_ref = got.covar_history[0] - none.covar_history[0], ref.covar_history[0] - none.covar_history[0]
+    assert np.abs(q_ref[:, 3, 3]).min() > 0.0
+    print(f"decay + {frame}: Pbar {e_p:.2e}")
+    assert e_p < 1e-9
+    np.testing.assert_allclose(q_got[:, 3:6, 3:6], q_ref[:, 3:6, 3:6], rtol=1e-3, atol=1e-16)
+    ctx.close()
+
+
 def test_ragged_epochs_failures_and_capacity():
     prop, almanac, central = leo_full_setup(degree=4)
     compiled = prop.compile(almanac, central, stm=True)

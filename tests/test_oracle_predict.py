@@ -116,6 +116,54 @@ def test_process_noise_selection_and_gamma():
     assert v.diag == [1e-6 / 600.0, 2e-6 / 600.0, 3e-6 / 600.0]
 
 
+def local_dcm(rv, frame):
+    r, v = rv[:3], rv[3:6]
+    h = np.cross(r, v); h = h / np.linalg.norm(h)
+    if frame == "RIC":
+        e0 = r / np.linalg.norm(r); e2 = h; e1 = np.cross(e2, e0)
+    else:
+        e0 = v / np.linalg.norm(v); e1 = h; e2 = np.cross(e0, e1)
+    return np.stack([e0, e1, e2], axis=1)
+
+
+@pytest.mark.parametrize("frame", ["RIC", "VNC"])
+def test_process_noise_decay_and_local_frame(frame):
+    # snc.rs:145-160, 193-197 (decay since the initial estimate's epoch) and :219-239 (local frame: dcm * snc * dcm^T at the
+    # nominal orbit with only the DIAGONAL kept, as the reference does) against numpy
+    compiled, batch = two_body_rk4(n=2)
+    p0 = np.repeat(INIT_COVAR[None], 2, axis=0)
+    end = EPOCH0_NS + 90 * S
+    base = oracle_lib.predict_until(compiled, batch, p0, end, 30 * S, history=3)
+    q, decay = [1e-12, 4e-12, 9e-12], [1e-2, 2e-2, 0.0]
+    pn = nx.ProcessNoise3D.with_decay(q, 2 * 60 * S, decay, local_frame=frame)
+    got = oracle_lib.predict_until(compiled, batch, p0, end, 30 * S, process_noise=[pn], history=3)
+    np.testing.assert_array_equal(got.stm, base.stm)
+    # the nominal states at the three updates: plain propagation of the same batch
+    for i in range(2):
+        p = p0[i].copy()
+        for u in range(3):
+            t = 30.0 * (u + 1)
+            nominal = oracle_lib.propagate(compiled, batch, int(t) * S)[0].rv()[i]
+            d = np.array(q) * np.exp(-np.array(decay) * t)
+            dcm = local_dcm(nominal, frame)
+            d_in = np.diag(dcm @ np.diag(d) @ dcm.T)
+            phi = got.stm[u, i]
+            p = phi @ p @ phi.T + gamma_q(30.0, d_in)
+            np.testing.assert_allclose(got.covar_history[u, i], p, rtol=1e-10, atol=1e-24)
+    # an explicit init_epoch shifts the decay clock (ProcessNoise::init_epoch)
+    import dataclasses
+    shifted = dataclasses.replace(pn, init_epoch_ns=EPOCH0_NS - 100 * S, local_frame=None)
+    plain = dataclasses.replace(pn, local_frame=None)
+    a = oracle_lib.predict_until(compiled, batch, p0, EPOCH0_NS + 30 * S, 30 * S, process_noise=[shifted], history=1)
+    b = oracle_lib.predict_until(compiled, batch, p0, EPOCH0_NS + 30 * S, 30 * S, process_noise=[plain], history=1)
+    da = np.diag(a.covar_history[0, 0] - base.covar_history[0, 0])[3:6]
+    db = np.diag(b.covar_history[0, 0] - base.covar_history[0, 0])[3:6]
+    np.testing.assert_allclose(da[:2] / db[:2], np.exp(-np.array(decay[:2]) * 100.0), rtol=1e-6)
+    # a frame the device path does not carry is refused by the host mirror
+    with pytest.raises(NotImplementedError):
+        oracle_lib.predict_until(compiled, batch, p0, end, 30 * S, process_noise=[dataclasses.replace(pn, local_frame="RCN")])
+
+
 def test_product_of_segment_stms_tracks_the_long_stm():
     # sanity of the segment/reset scheme: prod(Phi_seg) ~ Phi of one uninterrupted propagation (first-order scheme:
     # agreement to the integration accuracy of Phi, not to round-off)
