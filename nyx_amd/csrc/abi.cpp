@@ -76,6 +76,7 @@ struct nyx_hip_ctx {
     int device = 0;
     DevCfg host_cfg;
     DevCfg *d_cfg = nullptr;
+    int ed_reuse_fit = 0;  // fields of stage-0 epoch data an unchained pipelined loop may carry between attempts (LDS room)
     HarmEntry *d_htab = nullptr;
     ColHdr *d_cols = nullptr;
     double *d_records = nullptr;
@@ -468,6 +469,11 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
     // roles of this workgroup shape and their serial duties (merged roles when there are fewer than three waves)
     double hc[DEV_MAX_WAVES] = {0};
     assign_roles(ctx, n_waves, want_fanout(ctx, quad), hc);
+    // speculative stage 0 (role_loop): the pipelined plain kernel with ONE almanac wave and an even stage count (the last window
+    // then leaves the buffers of stage parity 0 free for the epoch data of t + h)
+    dc.spec = (dc.pipe && !(dc.flags & NYX_HIP_FLAG_STM) && dc.stages % 2 == 0 && dc.n_alm == 1 && dc.has_grav &&
+               !(std::getenv("NYX_HIP_SPEC") && std::atoi(std::getenv("NYX_HIP_SPEC")) == 0)) ? 1 : 0;
+    dc.ed_reuse = dc.spec ? 0 : ctx->ed_reuse_fit;  // (chained attempts need no copy of the stage-0 epoch data: a rejected lane keeps its k_0)
     if (!dc.has_grav || nc == 0) return;
     // with enough column workers the integrator keeps its window free: its serial phases A / C gate every other wave
     if (n_waves >= 8 && !std::getenv("NYX_HIP_ROLE_HANDICAP")) hc[0] = 1e9;
@@ -573,6 +579,18 @@ extern "C" int32_t nyx_hip_debug_weights(nyx_hip_ctx *ctx, double *out) {
     for (int w = 0; w < DEV_MAX_WAVES; ++w) out[w] = it != ctx->weights.end() ? it->second[w] : 0.0;  // (speed weights; the duties follow in the table)
     const auto sp = ctx->weight_spread.find(ctx->last_key);
     out[DEV_MAX_WAVES] = sp != ctx->weight_spread.end() ? sp->second : -1.0;
+    return NYX_HIP_RC_OK;
+}
+
+// Shape of the last launch's workgroups (tools): waves, pipelined loop, carried epoch-data fields, chained attempts, ephemeris
+// records in LDS, their size in doubles, almanac waves, LDS bytes of the plain kernel.
+extern "C" int32_t nyx_hip_debug_layout(nyx_hip_ctx *ctx, int32_t *out) {
+    if (!ctx || !out) return NYX_HIP_RC_BAD_ARG;
+    CTX_LOCK(ctx);
+    const DevCfg &dc = ctx->host_cfg;
+    out[0] = dc.n_waves; out[1] = dc.pipe; out[2] = dc.ed_reuse; out[3] = dc.spec; out[4] = dc.rec_in_lds; out[5] = dc.rec_doubles;
+    out[6] = dc.n_alm;
+    out[7] = (int32_t)nyx_kernel_lds_bytes(DEV_MAX_WAVES, dc.rec_in_lds ? dc.rec_doubles : 0, 0, dc.ed_reuse);
     return NYX_HIP_RC_OK;
 }
 
@@ -826,6 +844,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
         const int nf = 9 + 3 * dc.n_slots;
         if (nyx_kernel_lds_bytes(DEV_MAX_WAVES, dc.rec_in_lds ? dc.rec_doubles : 0, 0, nf) <= 160 * 1024) dc.ed_reuse = nf;
     }
+    ctx->ed_reuse_fit = dc.ed_reuse;
     dc.coop_frac = 0.30;  // measured optimum with two owners per helper (10 000 trajectories, 70x70): 0.28-0.33 is flat
     if (const char *e = std::getenv("NYX_HIP_COOP_FRAC")) dc.coop_frac = std::min(0.9, std::max(0.05, std::atof(e)));
     {
@@ -973,17 +992,18 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
         // records fit in LDS next to this layout's buffers (the quad layout is smaller than the D3 one)
         const bool stm_l = (ctx->host_cfg.flags & NYX_HIP_FLAG_STM) != 0;
         const int kind = stm_l ? (pick_quad(ctx, in->n) ? 2 : 1) : 0;
-        const int rd = ctx->host_cfg.rec_doubles;
-        const int want_rec = ((size_t)rd * sizeof(double) <= 24 * 1024 &&
-                              nyx_kernel_lds_bytes(DEV_MAX_WAVES, rd, kind, kind == 0 ? ctx->host_cfg.ed_reuse : 0) <= 160 * 1024) ? 1 : 0;
-        bool dirty = want_rec != ctx->host_cfg.rec_in_lds;
-        ctx->host_cfg.rec_in_lds = want_rec;
+        bool dirty = false;
         if (nw != ctx->host_cfg.n_waves || (kind == 2) != ctx->sched_quad || ctx->sched_dirty) {
             ctx->sched_quad = kind == 2;
             build_schedule(ctx, nw, kind == 2);
             ctx->sched_dirty = false;
             dirty = true;
         }
+        const int rd = ctx->host_cfg.rec_doubles;  // (after the schedule: chained attempts give the carried epoch data's LDS back)
+        const int want_rec = ((size_t)rd * sizeof(double) <= 24 * 1024 &&
+                              nyx_kernel_lds_bytes(DEV_MAX_WAVES, rd, kind, kind == 0 ? ctx->host_cfg.ed_reuse : 0) <= 160 * 1024) ? 1 : 0;
+        dirty = dirty || want_rec != ctx->host_cfg.rec_in_lds;
+        ctx->host_cfg.rec_in_lds = want_rec;
         if (dirty) HIP_TRY(hipMemcpyAsync(ctx->d_cfg, &ctx->host_cfg, sizeof(DevCfg), hipMemcpyHostToDevice, stream));
     }
     DevBatch bt;

@@ -101,7 +101,8 @@ struct DevCfg {
 
     /* --- roles of the waves (see DEV_ROLE_*) --- */
     int32_t role_kind[DEV_MAX_WAVES], role_mask[DEV_MAX_WAVES], role_slot[DEV_MAX_WAVES]; /* role_slot: index of an almanac wave's status rows */
-    int32_t n_alm, _pad5;
+    int32_t n_alm;
+    int32_t spec; /* speculative stage 0 of the next attempt (pipelined loop, see role_loop) */
 
     /* --- column schedules: wave w walks n_ranges[w] contiguous column ranges --- */
     int32_t n_waves;

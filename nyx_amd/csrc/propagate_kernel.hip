@@ -1743,6 +1743,23 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     // prologue only has to compare epochs - whatever the step logic did - and falls back to computing.
     const int reuse_nf = (!STM && ALMANAC && !INTEG && need_almanac && cfg->n_alm == 1) ? cfg->ed_reuse : 0;  // (one almanac wave only: the epoch tags have one writer)
     if (reuse_nf > 0) { L.ed0_ep[lane] = INT64_MIN; L.spec_ep[lane] = INT64_MIN; }
+    // Speculative stage 0.  The attempt boundary is the one place where the pipelined loop still drains: phase C of the last stage,
+    // error estimate, step control and phase A of stage 0 run with fifteen waves idle (~25 k cycles of ~510 k per RK89 attempt).
+    // But stage 0 of the NEXT attempt sits at y + h sum b_i k_i if this attempt is accepted - a POSITION that needs the stage
+    // velocities only, i.e. is complete inside the last window like the position of any next stage - and if the attempt is
+    // rejected its k_0 is the one this attempt already holds (same epoch, same state: the reference recomputes it, to the same
+    // bits).  So the integrator publishes that position in the last window (the almanac wave already evaluates the epoch data of
+    // t + h there), the column waves go from the last stage straight into it, step control runs beside them, and per lane the
+    // result is kept (accepted) or dropped in favour of the old k_0 (rejected).  No barrier at the attempt boundary any more:
+    // ctl[5] = attempts published (the almanac wave waits for the new epoch and step), ctl[3] counts folds over the whole launch.
+    // Same arithmetic in the same order: bit-identical to NYX_HIP_SPEC=0.  Host-enabled (cfg->spec): plain kernel, pipelined,
+    // one almanac wave, even stage count (the last window then leaves the parity-0 buffers free).  It replaces the epoch data
+    // carried between attempts (no copy of the stage-0 data is needed: nothing is evaluated at a rejected attempt's start) and
+    // its LDS.  The exit is seen one (wasted) window late.
+    const bool spec = pipe && !STM && cfg->spec != 0;
+    bool spec_now = false;  // stage 0 of the attempt being started was published in the previous attempt's last window
+    bool keep_k0 = false;   // (integrator, per lane) the previous attempt was rejected: k_0 stands
+    int att = 0;            // attempts started by this workgroup
     double nx_pos[3] = {0.0, 0.0, 0.0}, nx_s = 0.0, nx_t = 0.0, nx_u = 0.0, nx_kfac = 0.0;
     double m_cur[9], m_nx[9];
 #pragma unroll
@@ -1751,46 +1768,53 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     unsigned long long dbg_answers = 0, dbg_fallbacks = 0, dbg_fb_seq = 0;  // (NYX_HIP_PROFILE: row 16 of the profile)
     bool shared_cur = false, shared_nx = false;  // did the workers of this / the next stage leave columns to a helper?
 
+    // start of a step: final-step test on integer epochs (instance.rs:149-186), then epoch and step published to the other waves
+    auto begin_attempt = [&](ColdState &c) {
+        if (!c.done && c.fresh) {
+            if ((!c.backprop && c.epoch + c.step_size > c.stop) || (c.backprop && c.epoch + c.step_size <= c.stop)) {
+                if (c.stop == c.epoch) {
+                    c.done = true;
+                } else {
+                    c.prev_step = c.step_size;
+                    c.prev_kind = c.fixed;
+                    c.step_size = c.stop - c.epoch;
+                    c.fixed = true;
+                    c.is_final = true;
+                }
+            }
+            c.attempts = 1;
+            c.h = ns_to_seconds(c.step_size);
+            c.fresh = false;
+        }
+        if (!c.done && c.massless) { c.status = NYX_HIP_ERR_MASSLESS; c.done = true; }
+        L.step[lane] = __longlong_as_double(c.epoch);
+        L.step[DEV_LANES + lane] = c.h;
+        if (!__any(!c.done)) {
+            if (lane == 0) L.ctl[0] = 1;
+        }
+    };
+    double h_next = 0.0;  // (chained attempts: the step of the attempt step control has just opened)
+
     for (;;) {  // one iteration = one RK attempt for every live lane (derive(), instance.rs:368-414)
-        double h = 0.0;
-        if (INTEG) {
-            // start of a step: final-step test on integer epochs (instance.rs:149-186)
+        double h = h_next;
+        if (INTEG && !spec_now) {
             ColdState c;
             cold_load(L.cs, lane, c);
-            if (!c.done && c.fresh) {
-                if ((!c.backprop && c.epoch + c.step_size > c.stop) || (c.backprop && c.epoch + c.step_size <= c.stop)) {
-                    if (c.stop == c.epoch) {
-                        c.done = true;
-                    } else {
-                        c.prev_step = c.step_size;
-                        c.prev_kind = c.fixed;
-                        c.step_size = c.stop - c.epoch;
-                        c.fixed = true;
-                        c.is_final = true;
-                    }
-                }
-                c.attempts = 1;
-                c.h = ns_to_seconds(c.step_size);
-                c.fresh = false;
-            }
-            if (!c.done && c.massless) { c.status = NYX_HIP_ERR_MASSLESS; c.done = true; }
+            begin_attempt(c);
             cold_store(L.cs, lane, c);
             h = c.h;
             if (STM) {
 #pragma unroll
                 for (int q = 0; q < (QUAD ? 6 : 12); ++q) L.sacc[q * DEV_LANES + lane] = 0.0;
             }
-            L.step[lane] = __longlong_as_double(c.epoch);
-            L.step[DEV_LANES + lane] = h;
-            if (!__any(!c.done)) {
-                if (lane == 0) L.ctl[0] = 1;
-            }
         }
+        if (!spec_now) {
         __syncthreads();  // B0: attempt published (or exit requested)
         if (((volatile int *)L.ctl)[0]) break;
+        }
 
         // prologue: epoch data of stage 0
-        if (ALMANAC && need_almanac) {
+        if (!spec_now && ALMANAC && need_almanac) {
             const int64_t ep = __double_as_longlong(L.step[lane]);
             bool compute = true;
             if (reuse_nf > 0) {
@@ -1812,8 +1836,12 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 L.ed0_ep[lane] = ep;
             }
         }
+        if (!spec_now) {
         if (INTEG && lane == 0) { L.ctl[2] = 0; L.ctl[3] = 0; L.ctl[4] = 0; }
         __syncthreads();  // Bp
+        }
+        const int fold_base = spec ? att * stages : 0;  // ctl[3] counts the folds of the whole launch when the attempts are chained
+        bool leave = false;
 
         int st_att = NYX_HIP_OK;
         double wpre[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -1826,8 +1854,16 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 // ---- Phase A: stage state  y + h * sum_j a_ij k_j   (instance.rs:376-394)
                 double *const ysb = (pipe && (i & 1)) ? L.ys2 : L.ys;
                 double *const inbb = (pipe && (i & 1)) ? L.inb2 : L.inb;
-                if (pipe && i > 0) {
+                if (pipe && (i > 0 || spec_now)) {
                     // position and inputs of this stage were published in the previous window: only the velocity is left
+                    if (i == 0) {
+                        // speculative stage 0: the state step control has just stored (accepted lanes: its position IS the published
+                        // one, bit for bit; rejected lanes: the result of this stage is dropped, k_0 stands)
+#pragma unroll
+                        for (int e = 0; e < 6; ++e) ys[e] = CS_Y(e);
+#pragma unroll
+                        for (int e = 3; e < 6; ++e) ysb[e * DEV_LANES + lane] = ys[e];
+                    } else {
                     const double a_last = A_ROW(i, i - 1);
 #pragma unroll
                     for (int e = 0; e < 3; ++e) ys[e] = nx_pos[e];
@@ -1837,12 +1873,13 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                         ys[e] = CS_Y(e) + h * wi;
                         ysb[e * DEV_LANES + lane] = ys[e];
                     }
+                    }
                     if (has_drag) {  // the perturbation wave is already in this stage's window; drag is the one term that wants the velocity
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                         if (lane == 0) ((volatile int *)L.ctl)[4] = i + 1;
                     }
                     // (the almanac wave finished this stage's data before the barrier this wave has just passed)
-                    if (need_almanac) {
+                    if (need_almanac && !(i == 0 && keep_k0)) {  // (a rejected lane's stage 0 is not evaluated: its epoch data at t + h does not count)
                         for (int a = 0; a < n_alm; ++a) {
                             const int es = L.edst[(2 * a + (i & 1)) * DEV_LANES + lane];
                             if (es) st_att = es;
@@ -1918,34 +1955,39 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 }
             }
             PROF_ADD(0);
-            if (!pipe || i == 0) {
+            if (!pipe || (i == 0 && !spec_now)) {
                 PROF_T0();
-                __syncthreads();  // B1: stage state and harmonics inputs published (pipelined: stage 0 only)
+                __syncthreads();  // B1: stage state and harmonics inputs published (pipelined: stage 0 only, and not when it was published speculatively)
                 PROF_ADD(6);
             }
             const int64_t ptw_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;
 
             // ---- window --------------------------------------------------------------------------
-            if (INTEG && !STM && coop_on && has_grav && (!pipe || i == 0)) {
+            if (INTEG && !STM && coop_on && has_grav && (!pipe || (i == 0 && !spec_now))) {
                 seq_cur = ++coop_seq;
                 coop_post(cbox, bt.coop_posted + coop_widx, lane, seq_cur, L.inb);
             }
             const bool last_stage = i + 1 == stages;
-            if (ALMANAC && need_almanac && (!last_stage || reuse_nf > 0)) {
+            if (ALMANAC && need_almanac && (!last_stage || reuse_nf > 0 || spec)) {
                 // epoch-only data of the NEXT stage; in the last window (carried epoch data, even stage count: parity 0 again)
                 // that is stage 0 of the next attempt should this one be accepted: epoch + seconds_to_ns(h), instance.rs:401
+                if (spec_now && i == 0) {  // epoch and step of this attempt: step control ran beside the start of this window
+                    int spin = 0;
+                    while (((volatile int *)L.ctl)[5] != att && ++spin < 4000000) __builtin_amdgcn_s_sleep(4);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                }
                 const double c_next = last_stage ? 1.0 : C_COEF(i + 1);
                 const int64_t ep = __double_as_longlong(L.step[lane]) + seconds_to_ns(c_next * L.step[DEV_LANES + lane]);
                 double *edn = L.ed + ((i + 1) & 1) * ED_FIELDS * DEV_LANES;
-                if (last_stage) L.spec_ep[lane] = ep;
+                if (last_stage && reuse_nf > 0) L.spec_ep[lane] = ep;
                 int st = NYX_HIP_OK;
                 if (!dbg_skip_serial || i == 0)  // (timing switch: reuse the data of stages 0/1)
                 {
-                    volatile int *const fl = (pipe && !last_stage && (amask & DEV_ROLE_DCM)) ? (volatile int *)L.ctl + 2 : nullptr;
+                    volatile int *const fl = (pipe && (!last_stage || spec) && (amask & DEV_ROLE_DCM)) ? (volatile int *)L.ctl + 2 : nullptr;
                     st = rec_in_lds ? epoch_data(cfg, (const double *)L.rec, ep, edn, lane, amask, fl, i + 1) : epoch_data(cfg, records, ep, edn, lane, amask, fl, i + 1);
                 }
                 my_edst[((i + 1) & 1) * DEV_LANES + lane] = st;
-                if (pipe && !last_stage && (amask & DEV_ROLE_DCM)) {  // tell the integrator wave (which publishes the inputs of stage i+1 inside this window)
+                if (pipe && (!last_stage || spec) && (amask & DEV_ROLE_DCM)) {  // tell the integrator wave (which publishes the inputs of stage i+1 inside this window)
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     if (lane == 0) ((volatile int *)L.ctl)[2] = i + 1;
                 }
@@ -1975,7 +2017,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     }
                 }
                 if (has_drag && do_srp) {
-                    if (pipe && i > 0) {  // velocity of this stage: written by phase A, which runs beside this window
+                    if (pipe && (i > 0 || spec_now)) {  // velocity of this stage: written by phase A, which runs beside this window
                         int spin = 0;
                         while (((volatile int *)L.ctl)[4] != i + 1 && ++spin < 4000000) __builtin_amdgcn_s_sleep(4);
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -2011,14 +2053,31 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                         }
                     }
                 }
-                if (pipe && i + 1 < stages) {
+                if (pipe && (i + 1 < stages || spec)) {
                     // ---- position and recursion inputs of stage i+1, published inside the window of stage i.
                     // k_i[0..2] is this stage's velocity, so  y + h (wpre + a_{i+1,i} k_i)  is complete for the position
+                    if (i + 1 < stages) {
                     const double a_nl = A_ROW(i + 1, i);
 #pragma unroll
                     for (int e = 0; e < 3; ++e) {
                         const double wi = wpre[e] + a_nl * ys[3 + e];
                         nx_pos[e] = CS_Y(e) + h * wi;
+                    }
+                    } else {
+                        // last window: stage 0 of the next attempt, should this one be accepted - the position step control will form
+                        // (same operations in the same order: next[e] = y[e]; next[e] += (h b_j) k_j[e], j ascending)
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) nx_pos[e] = CS_Y(e);
+                        for (int j = 0; j < i; ++j) {
+                            const double cb = h * B_COEF(j);
+#pragma unroll
+                            for (int e = 0; e < 3; ++e) nx_pos[e] += cb * KB(j, e);
+                        }
+                        {
+                            const double cb = h * B_COEF(i);
+#pragma unroll
+                            for (int e = 0; e < 3; ++e) nx_pos[e] += cb * ys[3 + e];
+                        }
                     }
                     double *const ysn = ((i + 1) & 1) ? L.ys2 : L.ys;
                     double *const inbn = ((i + 1) & 1) ? L.inb2 : L.inb;
@@ -2115,9 +2174,9 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                                            inbw[4 * DEV_LANES + lane]);
                 px = pr.x; py = pr.y; pz = pr.z; pw = pr.w;
                 if (!INTEG) {
-                    if (pipe && i > 0) {  // the integrator folds the partials of stage i-1 at the start of this window
+                    if (pipe && (i > 0 || spec_now)) {  // the integrator folds the partials of stage i-1 at the start of this window
                         int spin = 0;
-                        while (((volatile int *)L.ctl)[3] < i && ++spin < 4000000) __builtin_amdgcn_s_sleep(1);
+                        while (((volatile int *)L.ctl)[3] < fold_base + i && ++spin < 4000000) __builtin_amdgcn_s_sleep(1);
                     }
                     double *pp = L.part + wave * 4 * DEV_LANES;
                     pp[0 * DEV_LANES + lane] = px; pp[1 * DEV_LANES + lane] = py;
@@ -2145,6 +2204,10 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 __syncthreads();  // B2: partials / perturbations / next epoch data published
                 PROF_ADD(6);
             }
+            if (spec_now && i == 0 && ((volatile int *)L.ctl)[0]) {  // every lane had finished: the exit, one window late
+                leave = true;
+                break;
+            }
             const int64_t ptc_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;
 
             if (INTEG) {
@@ -2162,7 +2225,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     }
                     if (pipe) {  // the partial sums of stage i are in registers: the workers may overwrite their slots
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        if (lane == 0) ((volatile int *)L.ctl)[3] = i + 1;
+                        if (lane == 0) ((volatile int *)L.ctl)[3] = fold_base + i + 1;
                     }
                     px += coop_x; py += coop_y; pz += coop_z; pw += coop_w;  // + the helper's columns (0 when working alone)
                     if (coop_drop) {  // (between B2 and the next B1: no worker is reading ctl[1])
@@ -2255,15 +2318,17 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
 #pragma unroll
                     for (int q = 0; q < 3; ++q) L.sacc[(9 + q) * DEV_LANES + lane] += b_i * cv[q];
                 }
-                if (!(STM && QUAD)) {
+                if (!(STM && QUAD) && !(spec_now && i == 0 && keep_k0)) {
                     KB(i, 0) = ys[3]; KB(i, 1) = ys[4]; KB(i, 2) = ys[5];
                     KB(i, 3) = acc[0]; KB(i, 4) = acc[1]; KB(i, 5) = acc[2];
                 }
             }
             if (prof_on) prof_acc[3] += (int64_t)__builtin_readcyclecounter() - ptc_;
         }
+        if (leave) break;
 
         const int64_t pts_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;
+        keep_k0 = false;
         if (INTEG) {
             ColdState c;
             cold_load(L.cs, lane, c);
@@ -2284,8 +2349,8 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 }
             }
             const double h_used = h;
+            bool accept = false, ev_hit = false;
             if (!c.done) {
-                bool accept = false;
                 if (st_att != NYX_HIP_OK) {
                     c.status = st_att;
                     c.done = true;
@@ -2317,6 +2382,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                         c.n_rej += 1;
                         const double prop = 0.9 * h * pow(cfg->tol / c.det_error, cfg->inv_order_m1);
                         h = (prop < cfg->min_step_s) ? cfg->min_step_s : prop;
+                        keep_k0 = true;
                     }
                 }
                 if (accept) {
@@ -2329,7 +2395,6 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     c.det_attempts = c.attempts;
                     // stop condition: checked after every step but the final fixed one; the triggering state is returned,
                     // not published (instance.rs:243-252)
-                    bool ev_hit = false;
                     if (bt.ev_on && valid && !c.is_final)  // (quad layout: the four lanes read and write the same words with the same values)
                         ev_hit = event_step(bt.ev, bt.ev_mu, c.epoch, bt.ev_prev + gid, bt.ev_count + gid, y[0], y[1],
                                             y[2], y[3], y[4], y[5]);
@@ -2337,22 +2402,16 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                         if (wr) bt.ev_found[gid] = 1;
                         c.done = true;
                     }
-                    if (bt.traj_cap > 0 && wr && !ev_hit) {  // chan.send(self.state) after every accepted step, final one included
-                        if (c.n_acc < bt.traj_cap) {
-                            const int64_t at = c.n_acc * bt.n + gid;
-                            bt.t_epoch[at] = c.epoch;
-#pragma unroll
-                            for (int e = 0; e < 6; ++e) bt.t_state[e][at] = y[e];
-                        }
-                        bt.t_len[gid] = (int32_t)(c.n_acc + 1);
-                    }
-                    if (STM && valid) {
-                        double sumb = 0.0;
-                        for (int q = 0; q < stages; ++q) sumb += B_COEF(q);
-                        const bool bad = QUAD ? stm_update_q(bt.o_stm + gid * 81, h_used, L.sacc, lane, ql, sumb)
-                                              : stm_update(bt.o_stm + gid * 81, h_used, L.sacc, lane, sumb);
-                        if (bad) { c.status = NYX_HIP_ERR_NAN; c.done = true; }
-                    }
+                }
+                bool stm_bad = false;
+                if (accept && STM && valid) {
+                    double sumb = 0.0;
+                    for (int q = 0; q < stages; ++q) sumb += B_COEF(q);
+                    stm_bad = QUAD ? stm_update_q(bt.o_stm + gid * 81, h_used, L.sacc, lane, ql, sumb)
+                                   : stm_update(bt.o_stm + gid * 81, h_used, L.sacc, lane, sumb);
+                }
+                if (accept) {
+                    if (stm_bad) { c.status = NYX_HIP_ERR_NAN; c.done = true; }
                     if (y[8] < 0.0) { c.status = NYX_HIP_ERR_FUEL_EXHAUSTED; c.done = true; }
                     if (c.is_final) {
                         c.step_size = c.prev_step;
@@ -2365,9 +2424,29 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 }
             }
             c.h = h;
+            // what is left of an accepted step only writes results: with chained attempts the next one is opened first (all lanes
+            // together: the exit test is a wave vote), the other waves are waiting for its epoch and step
+            const int64_t acc_n = c.n_acc, acc_epoch = c.epoch;
+            if (spec) {
+                begin_attempt(c);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                if (lane == 0) ((volatile int *)L.ctl)[5] = att + 1;  // the almanac wave waits for this word before it reads the new epoch and step
+                h_next = c.h;
+            }
+            if (accept && bt.traj_cap > 0 && wr && !ev_hit) {  // chan.send(self.state) after every accepted step, final one included
+                if (acc_n < bt.traj_cap) {
+                    const int64_t at = acc_n * bt.n + gid;
+                    bt.t_epoch[at] = acc_epoch;
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) bt.t_state[e][at] = y[e];
+                }
+                bt.t_len[gid] = (int32_t)(acc_n + 1);
+            }
             cold_store(L.cs, lane, c);
         }
         if (prof_on) prof_acc[4] += (int64_t)__builtin_readcyclecounter() - pts_;
+        spec_now = spec;
+        ++att;
     }
     if (prof_on && lane == 0) {
         prof_acc[5] = (int64_t)__builtin_readcyclecounter() - prof_start;

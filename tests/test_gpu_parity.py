@@ -515,16 +515,18 @@ def test_pipelined_stage_loop_is_bit_identical(monkeypatch, n, drag):
         b.cd[:] = 2.2
     dur = 45 * 60 * nx.NS_PER_S
     res = {}
-    for pipe, reuse in (("1", "1"), ("0", "0"), ("1", "0"), ("0", "1")):
+    # (1, 1, 1) is the default: pipelined, epoch data carried, stage 0 of the next attempt started speculatively in the last window
+    for pipe, reuse, spec in (("1", "1", "1"), ("0", "0", "0"), ("1", "0", "0"), ("0", "1", "0"), ("1", "1", "0")):
         monkeypatch.setenv("NYX_HIP_PIPE", pipe)
         monkeypatch.setenv("NYX_HIP_ED_REUSE", reuse)
-        ctx = nx.GpuContext(compiled)   # (both switches are read when the context is built)
+        monkeypatch.setenv("NYX_HIP_SPEC", spec)
+        ctx = nx.GpuContext(compiled)   # (the switches are read when the context is built)
         out, st = ctx.propagate(b, dur)
         assert (st.status == 0).all()
         assert (ctx.last_coop_helpers() > 0) == (n >= 512)   # cooperative mode needs at least 8 owners
-        res[(pipe, reuse)] = (out.rv().copy(), out.epoch_ns.copy(), st.n_evals.copy(), st.n_rejected.copy())
+        res[(pipe, reuse, spec)] = (out.rv().copy(), out.epoch_ns.copy(), st.n_evals.copy(), st.n_rejected.copy())
         ctx.close()
-    ref = res[("0", "0")]
+    ref = res[("0", "0", "0")]
     for key, got in res.items():
         for a, r in zip(got, ref):
-            np.testing.assert_array_equal(a, r, err_msg=f"pipe, reuse = {key}")
+            np.testing.assert_array_equal(a, r, err_msg=f"pipe, reuse, spec = {key}")

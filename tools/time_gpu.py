@@ -33,8 +33,12 @@ ms = ctx.last_kernel_ms()
 ev = int(st.n_evals.sum())
 print(f"n={n} hours={hours} deg={degree} waves={waves or 'auto'}: kernel {ms:.1f} ms (wall {wall*1e3:.1f}), evals {ev} -> {ev/ms*1e3:.3e} evals/s, "
       f"{n/ms*1e3*(24/hours):.1f} traj-days/s equiv, acc {st.n_accepted.sum()} rej {st.n_rejected.sum()} status!=0: {(st.status!=0).sum()}")
+import ctypes as C
+lay = (C.c_int32 * 8)()
+ctx._lib.nyx_hip_debug_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+if ctx._lib.nyx_hip_debug_layout(ctx._h, lay) == 0:
+    print("  layout: waves %d pipelined %d carried epoch fields %d chained attempts %d records in LDS %d (%d doubles) almanac waves %d LDS %d B" % tuple(lay))
 if os.environ.get("NYX_HIP_PROFILE"):
-    import ctypes as C
     buf = (C.c_int64 * 136)()
     ctx._lib.nyx_hip_debug_profile.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     if ctx._lib.nyx_hip_debug_profile(ctx._h, buf) == 0:
