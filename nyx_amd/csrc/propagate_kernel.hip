@@ -2529,6 +2529,7 @@ DEVFN void propagate_body(const DevBatch &bt, const DevCfg *cfg_g, const HarmEnt
     }
     if (threadIdx.x == 0) {
         L.ctl[0] = 0;
+        L.ctl[5] = 0;  // chained attempts: attempts published (LDS comes as the previous workgroup left it)
         // ctl[1]: 1 while this workgroup shares its columns with the helpers
         L.ctl[1] = (!STM && bt.coop_helpers > 0 && cfg->has_grav) ? 1 : 0;
     }
