@@ -185,31 +185,40 @@ def cpu_baseline(shard, compiled, n_per_gpu, hours):
     import oracle_lib
     threads, phys = host_threads()
     probe = shard.slice(0, min(threads, shard.n))
-    probe_h = min(0.25, hours)
+    probe_h = min(0.5, hours)
     t0 = time.time()
     oracle_lib.propagate(compiled, probe, int(probe_h * 3600) * nx.NS_PER_S, n_threads=threads)
     per_hour = (time.time() - t0) / probe_h  # wall seconds per hour of propagation of one round (`threads` trajectories)
     budget_s = 25.0
     samp_h = hours
-    if per_hour * hours > budget_s:      # a full-length round does not fit: time the first `samp_h` hours instead
-        samp_h = max(probe_h, min(hours, float(int(budget_s / per_hour * 4) / 4.0)))
-    # as many rounds of `threads` trajectories as fit the budget (the short probe underestimates a long round: at most two
-    # of those), never more than the shard holds
-    per_round = max(per_hour * samp_h, 1e-3)
-    rounds = max(1, min(int(budget_s / per_round), 2 if per_round > 4.0 else 1 << 30, max(1, shard.n // threads)))
-    n = min(threads * rounds, shard.n)
-    sample = shard.slice(0, n)   # the HEAD of this rank's shard: the states the device propagated, not a re-draw
+    if per_hour * hours > 0.6 * budget_s:  # a full-length round does not fit: time the first `samp_h` hours instead
+        samp_h = max(probe_h, min(hours, float(int(0.6 * budget_s / per_hour * 4) / 4.0)))
+    # first round: `threads` trajectories, the HEAD of this rank's shard (the states the device propagated, not a re-draw); the
+    # short probe underestimates a long round, so what follows is sized by the round itself: one more launch with as many rounds
+    # as the rest of the budget holds
+    n1 = min(threads, shard.n)
+    sample = shard.slice(0, n1)
     t0 = time.time()
     out, st = oracle_lib.propagate(compiled, sample, int(samp_h * 3600) * nx.NS_PER_S, n_threads=threads)
     dt = time.time() - t0
     assert (st.status == 0).all()
+    n, evals = n1, float(st.n_evals.sum())
+    more = min(int((budget_s - dt) / max(dt, 1e-3)), (shard.n - n1) // max(threads, 1))
+    if more >= 1:
+        extra = shard.slice(n1, n1 + more * threads)
+        t0 = time.time()
+        _, st2 = oracle_lib.propagate(compiled, extra, int(samp_h * 3600) * nx.NS_PER_S, n_threads=threads)
+        dt += time.time() - t0
+        assert (st2.status == 0).all()
+        n += extra.n
+        evals += float(st2.n_evals.sum())
     frac = samp_h / hours
     what = f"full {hours:g} h propagation each" if frac == 1.0 else \
         f"the first {samp_h:g} h of the {hours:g} h propagation each (rate scaled by {frac:.4g}: the orbit is periodic, the cost per hour constant)"
     return {"value": n / dt * frac, "unit": "trajectories/s", "cores": threads, "physical_cores": phys, "kind": "port",
             "sample": f"{n} of the {n_per_gpu} dispersed states, {what}, {threads} pthreads = hardware threads on {phys} physical cores "
-                      f"(rayon par_iter analogue), {dt:.1f} s wall, {int(st.n_evals.sum())} force evaluations",
-            "evals_per_s": float(st.n_evals.sum()) / dt}, sample, out, samp_h
+                      f"(rayon par_iter analogue), {dt:.1f} s wall, {int(evals)} force evaluations",
+            "evals_per_s": evals / dt}, sample, out, samp_h
 
 
 def measured_traffic(cfg_id, n, hours, degree):
