@@ -321,7 +321,12 @@ int32_t nyx_hip_propagate_batch_with_traj_device(nyx_hip_ctx *ctx, const nyx_hip
 enum nyx_hip_interp_status {
     NYX_HIP_INTERP_OK = 0,
     NYX_HIP_INTERP_NO_DATA = 1, /* TrajError::NoInterpolationData: empty trajectory or epoch outside [first, last] */
-    NYX_HIP_INTERP_MATH = 2     /* InterpolationError::InterpMath (two abscissas closer than f64::EPSILON seconds) */
+    NYX_HIP_INTERP_MATH = 2,    /* InterpolationError::InterpMath (two abscissas closer than f64::EPSILON seconds) */
+    NYX_HIP_INTERP_ILL_CONDITIONED = 3 /* nyx_hip_traj_at only, a WARNING: the sample is what the reference's Hermite fit yields
+                                          (it returns Ok), but its window holds two states closer than 1e-4 of the window's mean
+                                          spacing - typically the exact-length final step of a propagation, a few ms after an
+                                          accepted step of minutes - and the 13-point fit through such a pair is off by up to
+                                          kilometres.  Counted in out->len like an OK sample. */
 };
 
 /* `Traj::at` for every trajectory at `m` shared epochs (host arrays).  Sample q of trajectory i lands at [q * n + i] of

@@ -26,7 +26,12 @@ RC_OK, RC_BAD_ARG, RC_NO_DEVICE, RC_HIP_ERROR, RC_UNSUPPORTED = range(5)
 STATUS_NAMES = ["Ok", "PropMathError(NaN)", "MasslessSpacecraft", "FuelExhausted", "EphemerisOutOfRange", "Unsupported",
                 "NthEventError", "EventSearchFailed"]
 # enum nyx_hip_interp_status
-INTERP_OK, INTERP_NO_DATA, INTERP_MATH = range(3)
+INTERP_OK, INTERP_NO_DATA, INTERP_MATH, INTERP_ILL_CONDITIONED = range(4)
+
+
+def interp_failed(status):
+    """True where a `traj_at` sample was not produced (ILL_CONDITIONED is a warning on a produced sample)."""
+    return (status != INTERP_OK) & (status != INTERP_ILL_CONDITIONED)
 # flags
 FLAG_STM = 0x1
 FLAG_STM_TEXTBOOK = 0x2

@@ -138,7 +138,10 @@ DEVFN bool hrmint_axis(const double (&XS)[SAMPLES], int ns, double x_eval, const
 }
 
 // `Traj::at` for the trajectory of this lane.
-DEVFN int traj_at(const nyx_hip_traj_t &src, const View &v, int64_t epoch_ns, double s6[6]) {
+// `ill` (optional): set when the window of an interpolated sample holds two states closer than 1e-4 of its mean spacing (see
+// NYX_HIP_INTERP_ILL_CONDITIONED); the sample itself is the reference's either way.
+DEVFN int traj_at(const nyx_hip_traj_t &src, const View &v, int64_t epoch_ns, double s6[6], bool *ill = nullptr) {
+    if (ill) *ill = false;
     const double qnan = __builtin_nan("");
     for (int c = 0; c < 6; ++c) s6[c] = qnan;
     int st = NYX_HIP_INTERP_OK;
@@ -179,6 +182,13 @@ DEVFN int traj_at(const nyx_hip_traj_t &src, const View &v, int64_t epoch_ns, do
 #pragma unroll
         for (int k = 0; k < SAMPLES; ++k) XS[k] = k < ns ? ns_to_seconds(v.epoch[v.at(first_idx + k)]) : 0.0;
         const double x_eval = ns_to_seconds(epoch_ns);
+        if (ill && ns > 1) {
+            double dmin = fabs(XS[1] - XS[0]);
+#pragma unroll
+            for (int k = 2; k < SAMPLES; ++k)
+                if (k < ns) dmin = fmin(dmin, fabs(XS[k] - XS[k - 1]));
+            *ill = dmin < 1e-4 * (fabs(XS[ns - 1] - XS[0]) / (double)(ns - 1));
+        }
         bool ok = true;
         double fx = qnan, fy = qnan, fz = qnan, dx = qnan, dy = qnan, dz = qnan;
 #pragma unroll 1
@@ -247,7 +257,9 @@ __global__ __launch_bounds__(LANES) void nyx_traj_eval_kernel(TrajEvalArgs a) {
         const bool mine = live && q < q_end;
         const int64_t epoch = a.mode == TRAJ_MODE_EVERY ? first + q * a.step_ns : a.query[q < a.m ? q : a.m - 1];
         double s6[6];
-        const int st = traj_at(a.src, v, epoch, s6);
+        bool ill = false;
+        int st = traj_at(a.src, v, epoch, s6, a.mode == TRAJ_MODE_AT ? &ill : nullptr);
+        if (st == NYX_HIP_INTERP_OK && ill) st = NYX_HIP_INTERP_ILL_CONDITIONED;
         if (!mine) continue;
         const int64_t at = q * a.n + i;
         if (a.mode == TRAJ_MODE_EVERY) {
@@ -256,7 +268,7 @@ __global__ __launch_bounds__(LANES) void nyx_traj_eval_kernel(TrajEvalArgs a) {
         } else {
             store_sample(a.dst, at, epoch, s6);
             a.status[at] = st;
-            n_ok += st == NYX_HIP_INTERP_OK;
+            n_ok += st == NYX_HIP_INTERP_OK || st == NYX_HIP_INTERP_ILL_CONDITIONED;
         }
     }
     if (a.mode == TRAJ_MODE_AT && live && n_ok) atomicAdd(&a.dst.len[i], n_ok);

@@ -310,7 +310,7 @@ class Results:
             one.epoch_ns[: len(ep), 0] = tb.epoch_ns[: len(ep), i]
             one.state[:, : len(ep), 0] = tb.state[:, : len(ep), i]
             states, status = self._traj_ctx.traj_at(one, q)
-            bad = np.nonzero(status[:, 0] != _abi.INTERP_OK)[0]
+            bad = np.nonzero(_abi.interp_failed(status[:, 0]))[0]
             return states[: (bad[0] if len(bad) else len(q)), 0]
 
         return self._report(param, states_of_run, value_if_run_failed)

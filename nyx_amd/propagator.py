@@ -899,7 +899,7 @@ class Traj:
     def at(self, epoch_ns: int) -> np.ndarray:
         """traj.rs:82-127: the state [x, y, z, vx, vy, vz] at `epoch_ns`; raises TrajError outside the trajectory."""
         states, status = self._ctx.traj_at(self._single(), [int(epoch_ns)])
-        if status[0, 0] != _abi.INTERP_OK:
+        if _abi.interp_failed(status[0, 0]):
             raise TrajError(int(status[0, 0]), int(epoch_ns))
         return states[0, 0]
 
@@ -927,7 +927,7 @@ class Traj:
             return np.zeros(0, dtype=np.int64), np.zeros((0, 6))
         q = lo + int(step_ns) * np.arange((hi - lo) // int(step_ns) + 1, dtype=np.int64)
         states, status = self._ctx.traj_at(self._single(), q)
-        bad = np.nonzero(status[:, 0] != _abi.INTERP_OK)[0]
+        bad = np.nonzero(_abi.interp_failed(status[:, 0]))[0]
         n = int(bad[0]) if len(bad) else len(q)
         return q[:n], states[:n, 0]
 
@@ -964,7 +964,7 @@ class Traj:
         if len(q) == 0:
             return Traj.from_arrays(self._ctx, q, np.zeros((0, 6)))
         states, status = self._ctx.traj_at(self._single(), q)
-        bad = np.nonzero(status[:, 0] != _abi.INTERP_OK)[0]
+        bad = np.nonzero(_abi.interp_failed(status[:, 0]))[0]
         if len(bad):
             raise TrajError(int(status[bad[0], 0]), int(q[bad[0]]))
         return Traj.from_arrays(self._ctx, q, states[:, 0])

@@ -1631,6 +1631,34 @@ int32_t nyx_oracle_traj_at(const nyx_hip_traj_t *traj, int64_t n, int64_t i, int
     return NYX_HIP_INTERP_OK;
 }
 
+/* The conditioning warning of nyx_hip_traj_at (NYX_HIP_INTERP_ILL_CONDITIONED, include/nyx_hip.h): 1 when `epoch_ns` is interpolated
+ * from a window that holds two states closer than 1e-4 of the window's mean spacing.  Not part of the reference (which returns the
+ * fitted state without comment); the window is the one nyx_oracle_traj_at uses (traj.rs:100-115). */
+int32_t nyx_oracle_traj_window_ill(const nyx_hip_traj_t *traj, int64_t n, int64_t i, int64_t epoch_ns) {
+    const traj_view_t v = traj_view(traj, n, i);
+    if (v.len == 0 || traj->epoch_ns[view_at(&v, 0)] > epoch_ns || traj->epoch_ns[view_at(&v, v.len - 1)] < epoch_ns) return 0;
+    int64_t lo = 0, hi = v.len;
+    while (lo < hi) {
+        const int64_t mid = lo + (hi - lo) / 2;
+        const int64_t e = traj->epoch_ns[view_at(&v, mid)];
+        if (e == epoch_ns) return 0;
+        if (e < epoch_ns) lo = mid + 1; else hi = mid;
+    }
+    const int64_t idx = lo;
+    if (idx == 0 || idx >= v.len) return 0;
+    const int64_t num_left = INTERPOLATION_SAMPLES / 2;
+    int64_t first_idx = idx > num_left ? idx - num_left : 0;
+    const int64_t last_idx = v.len < first_idx + INTERPOLATION_SAMPLES ? v.len : first_idx + INTERPOLATION_SAMPLES;
+    if (last_idx == v.len) first_idx = last_idx > 2 * num_left ? last_idx - 2 * num_left : 0;
+    const int32_t ns = (int32_t)(last_idx - first_idx);
+    if (ns < 2) return 0;
+    double xs[INTERPOLATION_SAMPLES];
+    for (int k = 0; k < ns; ++k) xs[k] = nyx_oracle_ns_to_seconds(traj->epoch_ns[view_at(&v, first_idx + k)]);
+    double dmin = fabs(xs[1] - xs[0]);
+    for (int k = 2; k < ns; ++k) dmin = fmin(dmin, fabs(xs[k] - xs[k - 1]));
+    return dmin < 1e-4 * (fabs(xs[ns - 1] - xs[0]) / (double)(ns - 1)) ? 1 : 0;
+}
+
 /* Traj::every (traj.rs:148-162) through TrajIterator (traj_it.rs:33-62); TimeSeries::inclusive yields first + k*step
  * while k*step <= last - first. */
 int32_t nyx_oracle_traj_every(const nyx_hip_traj_t *traj, int64_t n, int64_t step_ns, nyx_hip_traj_t *out) {

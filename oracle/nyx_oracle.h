@@ -63,6 +63,7 @@ double nyx_oracle_error_estimate(int32_t error_ctrl, int32_t nv, const double *e
 int32_t nyx_oracle_hermite_eval(const double *xs, const double *ys, const double *ydots, int32_t n, double x_eval,
                                 double *f, double *df);
 int32_t nyx_oracle_traj_at(const nyx_hip_traj_t *traj, int64_t n, int64_t i, int64_t epoch_ns, double *state6);
+int32_t nyx_oracle_traj_window_ill(const nyx_hip_traj_t *traj, int64_t n, int64_t i, int64_t epoch_ns);
 int32_t nyx_oracle_traj_every(const nyx_hip_traj_t *traj, int64_t n, int64_t step_ns, nyx_hip_traj_t *out);
 
 /* PropInstance::until_nth_event (propagators/event.rs:88-211): oracle twin of nyx_hip_propagate_until_event. */

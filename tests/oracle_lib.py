@@ -65,6 +65,8 @@ def load():
     lib.nyx_oracle_hermite_eval.restype = C.c_int32
     lib.nyx_oracle_traj_at.argtypes = [C.POINTER(_abi.Traj), C.c_int64, C.c_int64, C.c_int64, _abi.c_double_p]
     lib.nyx_oracle_traj_at.restype = C.c_int32
+    lib.nyx_oracle_traj_window_ill.argtypes = [C.POINTER(_abi.Traj), C.c_int64, C.c_int64, C.c_int64]
+    lib.nyx_oracle_traj_window_ill.restype = C.c_int32
     lib.nyx_oracle_traj_every.argtypes = [C.POINTER(_abi.Traj), C.c_int64, C.c_int64, C.POINTER(_abi.Traj)]
     lib.nyx_oracle_traj_every.restype = C.c_int32
     _LIB = lib
@@ -132,6 +134,8 @@ def traj_at(traj, epochs_ns):
     for q, e in enumerate(epochs_ns):
         for i in range(traj.n):
             status[q, i] = lib.nyx_oracle_traj_at(C.byref(ctr), traj.n, i, int(e), s6.ctypes.data_as(_abi.c_double_p))
+            if status[q, i] == _abi.INTERP_OK and lib.nyx_oracle_traj_window_ill(C.byref(ctr), traj.n, i, int(e)):
+                status[q, i] = _abi.INTERP_ILL_CONDITIONED   # (the C-ABI's warning on a produced sample)
             out[q, i] = s6
     return out, status
 
