@@ -226,6 +226,16 @@ typedef struct nyx_hip_config {
     double speed_of_light_km_s; /* anise::constants::SPEED_OF_LIGHT_KM_S (cosmic/mod.rs:179-180) */
 
     const nyx_hip_solid_tides_t *tides; /* NULL => none (accel_models.solid_tides, config.rs:116-118) */
+
+    /* opts.integration_frame (propagators/options.rs:60; instance.rs:117-142, 211-220).  When the states of a batch are centred on
+     * ANOTHER body than the integration centre (same orientation), name it here: bodies[state_frame_body], whose chain is that
+     * body w.r.t. the integration centre.  nyx_hip_propagate_batch[_device] and nyx_hip_propagate_until_epoch then translate every
+     * state into the integration frame at its start epoch (position AND velocity of the chain, no aberration: what
+     * almanac.transform_to(orbit, frame, None) does between two frames of one orientation), propagate, and translate the final
+     * state back at its final epoch.  0 (the integration centre itself) or a body without a chain: no swap.  The entry points
+     * that record trajectories, search events or map covariances refuse a swap (NYX_HIP_RC_UNSUPPORTED). */
+    int32_t state_frame_body;
+    int32_t _pad_cfg;
 } nyx_hip_config_t;
 
 /* flags */

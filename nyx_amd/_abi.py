@@ -155,6 +155,8 @@ class Config(C.Structure):
         ("drag", C.POINTER(Drag)),
         ("speed_of_light_km_s", C.c_double),
         ("tides", C.POINTER(SolidTidesC)),
+        ("state_frame_body", C.c_int32),   # opts.integration_frame: the body the states of a batch are centred on (0: no swap)
+        ("_pad_cfg", C.c_int32),
     ]
 
 

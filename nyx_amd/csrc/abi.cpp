@@ -26,6 +26,9 @@ extern "C" hipError_t nyx_launch_predict_init(const PredictArgs *a, const int64_
 extern "C" hipError_t nyx_launch_time_update(const PredictArgs *a, hipStream_t stream);
 extern "C" hipError_t nyx_launch_event_search(const EventSearchArgs *args, hipStream_t stream);
 extern "C" hipError_t nyx_launch_traj_eval(const TrajEvalArgs *args, hipStream_t stream);
+extern "C" hipError_t nyx_launch_frame_shift(const DevCfg *cfg, const double *records, const int32_t *chain_seg, const double *chain_sign,
+                                             int n_chain, int64_t n, const int64_t *epoch_ns, double *x, double *y, double *z, double *vx,
+                                             double *vy, double *vz, double dir, int32_t *status, hipStream_t stream);
 extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg, const HarmEntry *htab,
                                            const ColHdr *cols, const double *records, int n_waves, int rec_lds_doubles,
                                            int reuse_fields, hipStream_t stream, int quad);
@@ -76,6 +79,12 @@ struct nyx_hip_ctx {
     int device = 0;
     DevCfg host_cfg;
     DevCfg *d_cfg = nullptr;
+    // opts.integration_frame: the states of a batch are centred on another body (its chain w.r.t. the integration centre)
+    int swap_n_chain = 0;
+    int32_t swap_seg[4] = {0, 0, 0, 0};
+    double swap_sign[4] = {0.0, 0.0, 0.0, 0.0};
+    double *d_swap = nullptr;  // six rows of swap_cap doubles: the translated copy of a batch's Cartesian state
+    int64_t swap_cap = 0;
     int ed_reuse_fit = 0;  // fields of stage-0 epoch data an unchained pipelined loop may carry between attempts (LDS room)
     HarmEntry *d_htab = nullptr;
     ColHdr *d_cols = nullptr;
@@ -634,6 +643,7 @@ extern "C" void nyx_hip_ctx_destroy(nyx_hip_ctx *ctx) {
     free_arrays(ctx->in);
     free_arrays(ctx->out);
     free_arrays(ctx->cal);
+    (void)hipFree(ctx->d_swap);
     (void)hipFree(ctx->d_coop);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -740,6 +750,17 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
     };
     for (int b = 0; b < cfg->n_bodies; ++b)
         if (cfg->bodies[b].n_chain == 0) dc.central_radius = cfg->bodies[b].mean_radius_km;
+    if (cfg->state_frame_body != 0) {  // opts.integration_frame: the body the states are centred on
+        const int b = cfg->state_frame_body;
+        if (b < 0 || b >= cfg->n_bodies || cfg->bodies[b].n_chain > 4) { delete ctx; nyx_set_error("state_frame_body: not a body of this configuration"); return NYX_HIP_RC_BAD_ARG; }
+        ctx->swap_n_chain = cfg->bodies[b].n_chain;
+        for (int k = 0; k < ctx->swap_n_chain; ++k) {
+            const int sgi = cfg->bodies[b].chain_segment[k];
+            if (sgi < 0 || sgi >= cfg->n_segments) { delete ctx; nyx_set_error("state_frame_body: bad chain segment index"); return NYX_HIP_RC_BAD_ARG; }
+            ctx->swap_seg[k] = sgi;
+            ctx->swap_sign[k] = (double)cfg->bodies[b].chain_sign[k];
+        }
+    }
     for (int k = 0; k < cfg->n_point_masses; ++k) {
         int s = slot_for(cfg->point_mass_body[k]);
         if (s == -2) { delete ctx; nyx_set_error("too many / invalid point-mass bodies"); return NYX_HIP_RC_BAD_ARG; }
@@ -885,7 +906,7 @@ static bool calibration_on(const nyx_hip_ctx *ctx) {
 
 static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t *out, nyx_hip_step_stats_t *st,
                   int64_t duration_ns, int64_t end_epoch_ns, int use_end, hipStream_t stream, bool time_it,
-                  const nyx_hip_traj_t *traj, const int64_t *dur_ns, const DevBatch *ev, bool calibrating);
+                  const nyx_hip_traj_t *traj, const int64_t *dur_ns, const DevBatch *ev, bool calibrating, bool swapped = false);
 
 // Device views of a DevArrays block (outputs + stats).
 static void views_of(DevArrays &d, int64_t n, bool stm, nyx_hip_states_t &so, nyx_hip_step_stats_t &ss) {
@@ -983,8 +1004,40 @@ static int calibrate(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, hipStream_t s
 
 static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t *out, nyx_hip_step_stats_t *st,
                   int64_t duration_ns, int64_t end_epoch_ns, int use_end, hipStream_t stream, bool time_it,
-                  const nyx_hip_traj_t *traj = nullptr, const int64_t *dur_ns = nullptr, const DevBatch *ev = nullptr, bool calibrating = false) {
+                  const nyx_hip_traj_t *traj = nullptr, const int64_t *dur_ns = nullptr, const DevBatch *ev = nullptr, bool calibrating = false,
+                  bool swapped) {
     CTX_LOCK(ctx);
+    if (ctx->swap_n_chain > 0 && !swapped && !calibrating) {
+        // opts.integration_frame (instance.rs:117-142, 211-220): translate a COPY of the Cartesian state into the integration frame
+        // at the start epochs, propagate that, translate the final states back at their own epochs
+        if (traj || dur_ns || ev) {
+            nyx_set_error("integration-frame swap: only the plain propagation entry points take states of another frame");
+            return NYX_HIP_RC_UNSUPPORTED;
+        }
+        if (ctx->launched) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_done, 0));  // (the copy below is shared by the launches of this context)
+        if (ctx->swap_cap < in->n) {
+            (void)hipFree(ctx->d_swap);
+            ctx->d_swap = nullptr; ctx->swap_cap = 0;
+            HIP_TRY(hipMalloc(&ctx->d_swap, (size_t)6 * (size_t)in->n * sizeof(double)));
+            ctx->swap_cap = in->n;
+        }
+        nyx_hip_states_t in2 = *in;
+        double *rows[6];
+        const double *src[6] = {in->x_km, in->y_km, in->z_km, in->vx_km_s, in->vy_km_s, in->vz_km_s};
+        for (int q = 0; q < 6; ++q) {
+            rows[q] = ctx->d_swap + (size_t)q * (size_t)ctx->swap_cap;
+            HIP_TRY(hipMemcpyAsync(rows[q], src[q], (size_t)in->n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        }
+        in2.x_km = rows[0]; in2.y_km = rows[1]; in2.z_km = rows[2]; in2.vx_km_s = rows[3]; in2.vy_km_s = rows[4]; in2.vz_km_s = rows[5];
+        HIP_TRY(nyx_launch_frame_shift(ctx->d_cfg, ctx->d_records, ctx->swap_seg, ctx->swap_sign, ctx->swap_n_chain, in->n, in->epoch_ns,
+                                       rows[0], rows[1], rows[2], rows[3], rows[4], rows[5], +1.0, nullptr, stream));
+        if (int rc = launch(ctx, &in2, out, st, duration_ns, end_epoch_ns, use_end, stream, time_it, nullptr, nullptr, nullptr, false, true)) return rc;
+        // (a start epoch outside the ephemeris leaves a garbage translation: the back-translation at the same table reports it)
+        HIP_TRY(nyx_launch_frame_shift(ctx->d_cfg, ctx->d_records, ctx->swap_seg, ctx->swap_sign, ctx->swap_n_chain, in->n, out->epoch_ns,
+                                       out->x_km, out->y_km, out->z_km, out->vx_km_s, out->vy_km_s, out->vz_km_s, -1.0, st ? st->status : nullptr, stream));
+        HIP_TRY(hipEventRecord(ctx->ev_done, stream));
+        return NYX_HIP_RC_OK;
+    }
     if (ctx->launched) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_done, 0));  // one launch of a context at a time on the device
     const int nw = pick_waves(ctx, in->n);
     {
@@ -1104,7 +1157,7 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
         if (!calibrating && calibration_on(ctx) && ctx->host_cfg.has_grav && nw >= 8 && in->n >= 64 && !traj && !dur_ns && !ev &&
             span >= 100 * ctx->host_cfg.init_step_ns && !ctx->weights.count(key)) {
             if (int rc = calibrate(ctx, in, stream)) return rc;
-            return launch(ctx, in, out, st, duration_ns, end_epoch_ns, use_end, stream, time_it, traj, dur_ns, ev, false);
+            return launch(ctx, in, out, st, duration_ns, end_epoch_ns, use_end, stream, time_it, traj, dur_ns, ev, false, swapped);
         }
     }
     if (std::getenv("NYX_HIP_PROFILE") || calibrating) {

@@ -95,6 +95,71 @@ DEVFN int cheby_eval(const CAS DevSeg &sg, P records, double et_s, double *r3) {
     return st;
 }
 
+// SPK type 2 with the derivative (the integration-frame swap needs the velocity of a chain): value as cheby_eval, derivative by
+// the companion recurrence of SPICE's CHBINT, dW_j = 2 W_{j+1} + 2t dW_{j+1} - dW_{j+2}, scaled by 1 / radius.
+template <typename P>
+DEVFN int cheby_eval_pv(const CAS DevSeg &sg, P records, double et_s, double *r3, double *v3) {
+    const double rel = (et_s - sg.init_et) / sg.interval;
+    int idx = (int)floor(rel);
+    int st = NYX_HIP_OK;
+    if (idx < 0 || idx > sg.n_rec || (idx == sg.n_rec && et_s > sg.end_et)) st = NYX_HIP_ERR_EPHEM_RANGE;
+    idx = idx < 0 ? 0 : (idx >= sg.n_rec ? sg.n_rec - 1 : idx);
+    const int nc = sg.n_coef;
+    P rec = records + sg.offset + idx * sg.stride;
+    const double t = (et_s - rec[0]) / rec[1];
+    const double two_t = 2.0 * t;
+    for (int c = 0; c < 3; ++c) {
+        P cf = rec + 2 + c * nc;
+        double w0 = 0.0, w1 = 0.0, w2, d0 = 0.0, d1 = 0.0, d2;
+        for (int j = nc - 1; j >= 1; --j) {
+            w2 = w1; w1 = w0;
+            w0 = cf[j] + (two_t * w1 - w2);
+            d2 = d1; d1 = d0;
+            d0 = (2.0 * w1 + two_t * d1) - d2;
+        }
+        r3[c] = cf[0] + (t * w0 - w1);
+        v3[c] = ((w0 + t * d0) - d1) / rec[1];
+    }
+    return st;
+}
+
+struct FrameChain {
+    int32_t n_chain, seg[4];
+    double sign[4];
+};
+// opts.integration_frame (instance.rs:117-142, 211-220): x += dir * (state of the chain's body w.r.t. the integration centre at the
+// trajectory's epoch); dir = +1 into the integration frame, -1 back.  One thread per trajectory.
+__global__ __launch_bounds__(256) void nyx_frame_shift_kernel(const DevCfg *cfg_g, const double *records, FrameChain ch, int64_t n,
+                                                              const int64_t *epoch_ns, double *x, double *y, double *z, double *vx,
+                                                              double *vy, double *vz, double dir, int32_t *status) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    CfgPtr cfg = (CfgPtr)cfg_g;
+    const double et = ns_to_seconds(epoch_ns[i]);
+    double b[3] = {0.0, 0.0, 0.0}, bv[3] = {0.0, 0.0, 0.0};
+    int st = NYX_HIP_OK;
+    for (int k = 0; k < ch.n_chain; ++k) {
+        double p[3], v[3];
+        const int s1 = cheby_eval_pv(cfg->seg[ch.seg[k]], records, et, p, v);
+        if (s1) st = s1;
+        for (int c = 0; c < 3; ++c) { b[c] = b[c] + ch.sign[k] * p[c]; bv[c] = bv[c] + ch.sign[k] * v[c]; }
+    }
+    x[i] = x[i] + dir * b[0]; y[i] = y[i] + dir * b[1]; z[i] = z[i] + dir * b[2];
+    vx[i] = vx[i] + dir * bv[0]; vy[i] = vy[i] + dir * bv[1]; vz[i] = vz[i] + dir * bv[2];
+    if (st && status && status[i] == NYX_HIP_OK) status[i] = st;
+}
+extern "C" hipError_t nyx_launch_frame_shift(const DevCfg *cfg, const double *records, const int32_t *chain_seg, const double *chain_sign,
+                                             int n_chain, int64_t n, const int64_t *epoch_ns, double *x, double *y, double *z, double *vx,
+                                             double *vy, double *vz, double dir, int32_t *status, hipStream_t stream) {
+    FrameChain ch;
+    ch.n_chain = n_chain;
+    for (int k = 0; k < 4; ++k) { ch.seg[k] = k < n_chain ? chain_seg[k] : 0; ch.sign[k] = k < n_chain ? chain_sign[k] : 0.0; }
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(nyx_frame_shift_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, cfg, records, ch, n, epoch_ns, x, y, z,
+                       vx, vy, vz, dir, status);
+    return hipGetLastError();
+}
+
 // Body-fixed orientation (nyx_hip_rotation_t, see include/nyx_hip.h): the IAU phase angles with their trigonometric series, or
 // the Chebyshev Euler angles of a binary PCK.  `w_rate` (optional): dW/dt in rad/s (the drag model's velocity transform).
 DEVFN void r3r1r3(double a1, double a2, double a3, double *m) {

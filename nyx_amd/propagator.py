@@ -94,6 +94,7 @@ class IntegratorOptions:
     attempts: int = 50
     fixed_step: bool = False
     error_ctrl: ErrorControl = ErrorControl.RSSCartesianStep
+    integration_frame: Optional["Frame"] = None   # options.rs:60: integrate in this frame, hand the states back in their own
 
     @classmethod
     def with_adaptive_step(cls, min_step: int, max_step: int, tolerance: float, error_ctrl: ErrorControl):
@@ -425,7 +426,7 @@ class CompiledConfig:
 
 
 def compile_config(dynamics: SpacecraftDynamics, method: IntegratorMethod, opts: IntegratorOptions, almanac: Almanac,
-                   central: Frame, stm: bool = False, stm_textbook: bool = False) -> CompiledConfig:
+                   central: Frame, stm: bool = False, stm_textbook: bool = False, state_frame: Optional[Frame] = None) -> CompiledConfig:
     """Flattens (dynamics, method, options, almanac) into ``nyx_hip_config_t`` — the analogue of
     ``PropagatorConfig::build`` (dynamics/sequence/config.rs:145-151) run in reverse."""
     keep: list = []
@@ -482,6 +483,10 @@ def compile_config(dynamics: SpacecraftDynamics, method: IntegratorMethod, opts:
         return body_index[naif_id]
 
     body_of(central.naif_id)
+    # opts.integration_frame (instance.rs:117-142): `central` is the integration frame, the states come centred on `state_frame`
+    cfg.state_frame_body = 0
+    if state_frame is not None and state_frame.naif_id != central.naif_id:
+        cfg.state_frame_body = body_of(state_frame.naif_id)
     pm = [m for m in dynamics.orbital_dyn.accel_models if isinstance(m, PointMasses)]
     gf = [m for m in dynamics.orbital_dyn.accel_models if isinstance(m, GravityFieldData)]
     srp = [m for m in dynamics.force_models if isinstance(m, SolarPressure)]
@@ -1035,21 +1040,28 @@ class Propagator:
         self.opts.set_min_step(step)
         self._ctx_cache.clear()
 
-    def compile(self, almanac: Almanac, central: Frame, stm: bool = False) -> CompiledConfig:
-        return compile_config(self.dynamics, self.method, self.opts, almanac, central, stm=stm)
+    def compile(self, almanac: Almanac, central: Frame, stm: bool = False, state_frame: Optional[Frame] = None) -> CompiledConfig:
+        """`central`: the frame the dynamics integrate in; `state_frame`: the frame the states come in when it is another one
+        (`opts.integration_frame`, instance.rs:117-142: translated in at the start, back at the end)."""
+        return compile_config(self.dynamics, self.method, self.opts, almanac, central, stm=stm, state_frame=state_frame)
 
     def _context(self, almanac: Almanac, central: Frame, stm: bool) -> GpuContext:
         """Cached device context.  The key is a CONTENT fingerprint (dynamics, method, options, the full central frame, the
         almanac's bodies and segment tables): `prop.opts.tolerance = ...`, a mutated almanac or a new one at a recycled
         address all miss the cache instead of silently reusing a stale compiled configuration."""
+        # `central` is the frame of the states; with opts.integration_frame set to another body the dynamics run there
+        state_frame = None
+        integ = self.opts.integration_frame
+        if integ is not None and integ.naif_id != central.naif_id:
+            state_frame, central = central, integ
         h = hashlib.blake2b(digest_size=16)
-        _feed(h, (self.dynamics, int(self.method), self.opts, central, bool(stm), int(self.device)))
+        _feed(h, (self.dynamics, int(self.method), self.opts, central, state_frame, bool(stm), int(self.device)))
         _feed(h, almanac)
         key = h.digest()
         if key not in self._ctx_cache:
             if len(self._ctx_cache) >= 8:   # bounded: drop the oldest context (device tables are a few MB each)
                 self._ctx_cache.pop(next(iter(self._ctx_cache))).close()
-            self._ctx_cache[key] = GpuContext(self.compile(almanac, central, stm), self.device)
+            self._ctx_cache[key] = GpuContext(self.compile(almanac, central, stm, state_frame), self.device)
         return self._ctx_cache[key]
 
     def with_(self, state: Spacecraft, almanac: Almanac) -> PropInstance:

@@ -112,6 +112,54 @@ static int cheby_eval(const nyx_hip_cheby_segment_t *seg, double et_s, double *r
     return NYX_HIP_OK;
 }
 
+/* SPK type 2 with the derivative: the value as cheby_eval, the derivative by the companion recurrence of SPICE's CHBINT
+ * (dW_j = 2 W_{j+1} + 2t dW_{j+1} - dW_{j+2}), scaled by 1 / radius.  anise's `chebyshev_eval` (absent) is a port of CHBINT: unpinned. */
+static int cheby_eval_pv(const nyx_hip_cheby_segment_t *seg, double et_s, double *r3, double *v3) {
+    double rel = (et_s - seg->init_et_s) / seg->interval_s;
+    long idx = (long)floor(rel);
+    if (idx < 0 || idx > seg->n_records) return NYX_HIP_ERR_EPHEM_RANGE;
+    if (idx == seg->n_records) {
+        if (et_s > seg->init_et_s + seg->interval_s * (double)seg->n_records) return NYX_HIP_ERR_EPHEM_RANGE;
+        idx = seg->n_records - 1;
+    }
+    const int nc = seg->n_coeffs;
+    const double *rec = seg->records + (size_t)idx * (size_t)(2 + 3 * nc);
+    const double t = (et_s - rec[0]) / rec[1];
+    const double two_t = 2.0 * t;
+    for (int c = 0; c < 3; ++c) {
+        const double *cf = rec + 2 + c * nc;
+        double w0 = 0.0, w1 = 0.0, w2, d0 = 0.0, d1 = 0.0, d2;
+        for (int j = nc - 1; j >= 1; --j) {
+            w2 = w1; w1 = w0;
+            w0 = cf[j] + (two_t * w1 - w2);
+            d2 = d1; d1 = d0;
+            d0 = (2.0 * w1 + two_t * d1) - d2;
+        }
+        r3[c] = cf[0] + (t * w0 - w1);
+        v3[c] = ((w0 + t * d0) - d1) / rec[1];
+    }
+    return NYX_HIP_OK;
+}
+
+/* opts.integration_frame (instance.rs:117-142, 211-220): almanac.transform_to(orbit, frame, None) between two frames of one
+ * orientation = the state of bodies[b] w.r.t. the integration centre added (dir = +1, into the integration frame) or
+ * subtracted (dir = -1, back). */
+static int frame_shift(const nyx_hip_config_t *cfg, int b, int64_t epoch_ns, double *y6, double dir) {
+    const nyx_hip_body_t *body = &cfg->bodies[b];
+    const double et = nyx_oracle_ns_to_seconds(epoch_ns);
+    double r[3] = {0.0, 0.0, 0.0}, v[3] = {0.0, 0.0, 0.0};
+    int st = NYX_HIP_OK;
+    for (int k = 0; k < body->n_chain; ++k) {
+        double p[3] = {0.0, 0.0, 0.0}, pv[3] = {0.0, 0.0, 0.0};
+        const int s1 = cheby_eval_pv(&cfg->segments[body->chain_segment[k]], et, p, pv);
+        if (s1) st = s1;
+        const double sg = (double)body->chain_sign[k];
+        for (int c = 0; c < 3; ++c) { r[c] = r[c] + sg * p[c]; v[c] = v[c] + sg * pv[c]; }
+    }
+    for (int c = 0; c < 3; ++c) { y6[c] = y6[c] + dir * r[c]; y6[3 + c] = y6[3 + c] + dir * v[c]; }
+    return st;
+}
+
 /* Position of bodies[b] w.r.t. the integration centre = signed sum over its chain. */
 static int body_position(const nyx_hip_config_t *cfg, int b, double et_s, double *r3) {
     const nyx_hip_body_t *body = &cfg->bodies[b];
@@ -1502,8 +1550,15 @@ static void run_one(const job_t *jb, inst_t *s, int64_t i) {
     inst_init(s, jb->p, jb->in, i);
     s->traj = jb->traj;
     if (jb->traj) jb->traj->len[i] = 0;
+    const nyx_hip_config_t *cfg = jb->p->cfg;
+    const int swap = !jb->traj && cfg->state_frame_body > 0 && cfg->state_frame_body < cfg->n_bodies && cfg->bodies[cfg->state_frame_body].n_chain > 0;
+    if (swap) (void)frame_shift(cfg, cfg->state_frame_body, s->epoch_ns, s->y, +1.0);  /* instance.rs:117-142 */
     traj_push(s);
-    const int st = propagate(s, jb->duration_ns);
+    int st = propagate(s, jb->duration_ns);
+    if (swap) {  /* instance.rs:211-220; an epoch outside the ephemeris is reported by this translation */
+        const int s2 = frame_shift(cfg, cfg->state_frame_body, s->epoch_ns, s->y, -1.0);
+        if (s2 && st == NYX_HIP_OK) st = s2;
+    }
     inst_store(s, jb->out, jb->stats, i, st);
 }
 
