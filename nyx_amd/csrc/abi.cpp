@@ -498,10 +498,24 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
         for (int c = 1; c <= nc; ++c) terms += ctx->col_len[c];
         std::vector<int> own, help;
         const int col_waves = DEV_MAX_WAVES - 2;  // a helper's wave 0 claims jobs, its last wave answers
+        // One column per helper wave is the rule for short evaluation periods (70x70: a second column makes the job longer than the
+        // owner can wait, 302 ms against 182 ms).  A large field turns that around: at 150x150 the owner's period is 140 k cycles,
+        // a job of one 150-row column 34 k + the hand-off, and fourteen columns are 18 % of the terms where the helpers could take
+        // half - so when the one-column rule leaves the helpers below HALF of their share, their waves take up to
+        // DEV_MAX_RANGES columns each (config 5: 12.05 s with 14 columns, 11.36 s with 21, 10.31 s with 28).
         int max_cols = col_waves;
-        if (const char *e = std::getenv("NYX_HIP_COOP_COLS")) max_cols = std::min(2 * col_waves, std::max(1, std::atoi(e)));
+        double share = dc.coop_frac;
+        {
+            double first = 0.0;
+            for (int c = 1; c <= std::min(nc, col_waves); ++c) first += ctx->col_len[c];
+            if (first < 0.5 * dc.coop_frac * terms) {
+                max_cols = DEV_MAX_RANGES * col_waves;
+                share = 0.92 * dc.coop_frac;  // (several columns per wave: a job is longer for the same share; 35 / 38 / 42 columns at 150x150: 9.24 / 9.04 / 9.72 s)
+            }
+        }
+        if (const char *e = std::getenv("NYX_HIP_COOP_COLS")) max_cols = std::min(DEV_MAX_RANGES * col_waves, std::max(1, std::atoi(e)));
         for (int c = 1; c <= nc; ++c) {
-            if ((int)help.size() < max_cols && c < nc - 1 && given + 0.5 * ctx->col_len[c] <= dc.coop_frac * terms) {
+            if ((int)help.size() < max_cols && c < nc - 1 && given + 0.5 * ctx->col_len[c] <= share * terms) {
                 help.push_back(c);
                 given += ctx->col_len[c];
             } else {
@@ -514,8 +528,9 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
         DevSched &hs = dc.sched[DEV_SCHED_HELPER];
         for (int w = 0; w < DEV_MAX_WAVES; ++w) hs.n_ranges[w] = 0;
         for (size_t k = 0; k < help.size(); ++k) {
-            // a second round (NYX_HIP_COOP_COLS) is dealt in the opposite direction: every wave's pair has about the same length
-            const int w = (int)k < col_waves ? wave_order[k] : wave_order[2 * col_waves - 1 - (int)k];
+            // further rounds are dealt in alternating directions: every wave's set has about the same length
+            const int round = (int)k / col_waves, pos = (int)k % col_waves;
+            const int w = (round & 1) ? wave_order[col_waves - 1 - pos] : wave_order[pos];
             const int r = hs.n_ranges[w]++;
             hs.range_c0[w][r] = help[k]; hs.range_cnt[w][r] = 1;
         }
@@ -1105,7 +1120,10 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
         const bool stm_ctx = (ctx->host_cfg.flags & NYX_HIP_FLAG_STM) != 0;
         if (want && !stm_ctx && ctx->host_cfg.has_grav && nw == DEV_MAX_WAVES && ctx->host_cfg.coop_ok &&
             base + 8 <= ctx->n_cu) {
-            const int64_t helpers = std::min<int64_t>(n_own, (ctx->n_cu - base) / 8 * 8);
+            // (more helpers than owners: the jobs are claimed, not assigned, so extra helpers shorten the queue of a set)
+            double h_ratio = 1.0;
+            if (const char *e2 = std::getenv("NYX_HIP_COOP_HELPERS")) h_ratio = std::min(3.0, std::max(0.25, std::atof(e2)));
+            const int64_t helpers = std::min<int64_t>((int64_t)((double)n_own * h_ratio), (ctx->n_cu - base) / 8 * 8);
             if (helpers >= 8 && 4 * helpers >= n_own) {
                 // share of the terms the helpers take: owners keep (1 - x), each helper does x * owners / helpers jobs' worth
                 // per evaluation period, plus its hand-off overhead: x ~ 0.95 r / (1 + r) with r = helpers / owners
