@@ -23,7 +23,13 @@ for cfg in cfgs:
     json.dump(line, open(os.path.join(ROOT, "profiles", f"{tag}_cfg{cfg}_bench.json"), "w"), indent=1)
     shutil.copy(os.path.join(src, "kernel_trace_stats.md"), os.path.join(ROOT, "profiles", f"{tag}_cfg{cfg}_kernel_trace_stats.md"))
     per = collections.defaultdict(list)
+    # (gpurun merges every pass of a configuration into the same scratch directory: the newest file of each counter set counts)
+    newest = {}
     for f in glob.glob(src + "/pmc_*/**/*counter_collection.csv", recursive=True):
+        key = f[len(src):].split(os.sep)[1]
+        if key not in newest or os.path.getmtime(f) > os.path.getmtime(newest[key]):
+            newest[key] = f
+    for f in newest.values():
         for r in csv.DictReader(open(f)):
             if "nyx_propagate" in r.get("Kernel_Name", ""):
                 per[r["Counter_Name"]].append(float(r["Counter_Value"]))
