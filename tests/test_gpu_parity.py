@@ -499,6 +499,33 @@ def test_cooperative_mode_matches_solo_and_oracle(monkeypatch):
     ctx.close()
 
 
+def test_chained_attempts_backwards_and_fixed_step(monkeypatch):
+    """The speculative stage 0 of the next attempt with a negative step (back-propagation) and with fixed steps (every attempt
+    accepted, the exact-length final step): bit-identical to the unchained loop, and the round trip returns to the start."""
+    prop, almanac, central = leo_full_setup(degree=70)
+    b = dispersed_leo_batch(192, seed=17)
+    hour = 3600 * nx.NS_PER_S
+    res = {}
+    for spec in ("1", "0"):
+        monkeypatch.setenv("NYX_HIP_SPEC", spec)
+        monkeypatch.setenv("NYX_HIP_WAVE_WEIGHTS", "1,1.3,1.3,1.6,1.6,1.3,1.3,1.3,1.3,0.9,0.9,0.9,0.9,0.5,0.5,0.5")
+        ctx = nx.GpuContext(prop.compile(almanac, central))
+        fwd, st = ctx.propagate(b, hour)
+        back, st2 = ctx.propagate(fwd, -hour)
+        assert (st.status == 0).all() and (st2.status == 0).all() and (back.epoch_ns == b.epoch_ns).all()
+        ctx.close()
+        fprop = nx.Propagator(prop.dynamics, nx.IntegratorMethod.RungeKutta89, nx.IntegratorOptions.with_fixed_step_s(47.0))
+        ctx = nx.GpuContext(fprop.compile(almanac, central))
+        fixed, st3 = ctx.propagate(b, 1000 * nx.NS_PER_S)          # 21 steps of 47 s and a final one of 13 s
+        assert (st3.status == 0).all() and (st3.n_accepted == 22).all() and (st3.n_rejected == 0).all()
+        ctx.close()
+        res[spec] = (fwd.rv().copy(), back.rv().copy(), fixed.rv().copy(), st.n_evals.copy(), st2.n_evals.copy())
+    for a, r in zip(res["1"], res["0"]):
+        np.testing.assert_array_equal(a, r)
+    d = res["1"][1] - b.rv()
+    assert np.linalg.norm(d[:, :3], axis=1).max() < 1e-5 and np.linalg.norm(d[:, 3:], axis=1).max() < 1e-8
+
+
 @pytest.mark.parametrize("n,drag", [(256, None), (2048, None), (512, "exp")])
 def test_pipelined_stage_loop_is_bit_identical(monkeypatch, n, drag):
     """The pipelined stage loop (the next stage's position is published inside the current window), the epoch data carried
