@@ -79,6 +79,30 @@ def test_full_model_events_not_found_and_mixed_outcomes():
     ctx.close()
 
 
+def test_events_and_dense_output_with_chained_attempts(monkeypatch):
+    """70x70: sixteen-wave workgroups, pipelined stage loop, attempts chained (the next attempt's stage 0 starts before step control
+    has counted the crossing).  The stop condition, the dense output and the search see exactly what the unchained loop gives them."""
+    prop, almanac, central = leo_full_setup(degree=70)
+    compiled = prop.compile(almanac, central)
+    b = dispersed_leo_batch(140, seed=23)
+    ev = nx.Event.periapsis()
+    res = {}
+    for spec in ("1", "0"):
+        monkeypatch.setenv("NYX_HIP_SPEC", spec)
+        monkeypatch.setenv("NYX_HIP_WAVE_WEIGHTS", "1,1.3,1.3,1.6,1.6,1.3,1.3,1.3,1.3,0.9,0.9,0.9,0.9,0.5,0.5,0.5")
+        ctx = nx.GpuContext(compiled)
+        out, st, traj, cr = ctx.propagate_until_event(b, 3 * 3600 * S, ev, trigger=1, capacity=300)
+        assert (st.status == 0).all() and (cr == 1).all()
+        fin, st2, tr2 = ctx.propagate_with_traj(b, 3600 * S, capacity=300)
+        assert (st2.status == 0).all()
+        res[spec] = (out.rv().copy(), out.epoch_ns.copy(), traj.len.copy(), traj.state.copy(), fin.rv().copy(), tr2.len.copy(), tr2.epoch_ns.copy())
+        ctx.close()
+    for a, r in zip(res["1"], res["0"]):
+        np.testing.assert_array_equal(a, r)
+    ta = np.array([true_anomaly_deg(res["1"][0][i], central.mu_km3_s2) for i in range(0, 140, 10)])
+    assert np.abs((ta + 180.0) % 360.0 - 180.0).max() < 1e-5
+
+
 def test_front_ends_mirror_the_reference():
     # (no SRP here: a shadow crossing makes the step controller cluster states a few seconds apart, and when such a
     # cluster falls in the 12-state window of the LAST interval - where the event is searched - the reference's
