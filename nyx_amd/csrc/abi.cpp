@@ -291,8 +291,15 @@ static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, con
     for (int w = 0; w < DEV_MAX_WAVES; ++w) hc[w] = hc_model[w];
     for (int w = 0; w < DEV_MAX_WAVES; ++w) sd.n_ranges[w] = 0;
     if (list.empty()) return true;
+    // cost of a column in rows: its length plus what it costs to START one (header, complex power of the range, a cold first batch).
+    // With the short columns of a small field in the quad layout that start is most of a column: 21x21, 1 000 trajectories, sixty
+    // segments: 11.45 ms with 0 rows, 11.1 with 4, 10.83 with 6, 10.95 with 8 (four runs each, +-0.03).  70x70 plain kernel: no effect
+    // up to 6, slower beyond (the measured per-wave weights already carry it there).
+    double col_fix = (ctx->sched_quad && n_waves == DEV_MAX_WAVES) ? 6.0 : 0.0;  // (the quad layout's production shape: sixteen waves)
+    if (const char *e = std::getenv("NYX_HIP_COL_FIX")) col_fix = std::max(0.0, std::atof(e));
+    auto cost = [&](int c) { return (double)ctx->col_len[c] + col_fix; };
     double terms = 0.0;
-    for (int c : list) terms += ctx->col_len[c];
+    for (int c : list) terms += cost(c);
     // Per-wave weights.  The four waves that share a SIMD (w, w+4, w+8, w+12) are arbitrated oldest-first, so with equal
     // shares the oldest finishes early and the youngest runs the tail alone, with nothing to hide its scalar-load latency;
     // role waves carry their duty besides.  The weights are MEASURED: calibrate() runs the workload's own first steps with
@@ -346,9 +353,9 @@ static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, con
             lo = hi + 1;
         } else {
             double load = 0.0;
-            while (lo <= hi && load + 0.5 * ctx->col_len[list[lo]] <= tgt) { load += ctx->col_len[list[lo]]; mine.push_back(list[lo++]); }
+            while (lo <= hi && load + 0.5 * cost(list[lo]) <= tgt) { load += cost(list[lo]); mine.push_back(list[lo++]); }
             std::vector<int> tail;
-            while (lo <= hi && load + 0.5 * ctx->col_len[list[hi]] <= tgt) { load += ctx->col_len[list[hi]]; tail.push_back(list[hi--]); }
+            while (lo <= hi && load + 0.5 * cost(list[hi]) <= tgt) { load += cost(list[hi]); tail.push_back(list[hi--]); }
             mine.insert(mine.end(), tail.rbegin(), tail.rend());
         }
         // contiguous runs of column numbers -> ranges
