@@ -87,6 +87,7 @@ struct nyx_hip_ctx {
     int64_t swap_cap = 0;
     int ed_reuse_fit = 0;  // fields of stage-0 epoch data an unchained pipelined loop may carry between attempts (LDS room)
     HarmEntry *d_htab = nullptr;
+    double *d_hyb = nullptr;  // the same table in the hybrid-feed layout (devcfg.h HYB_*)
     ColHdr *d_cols = nullptr;
     double *d_records = nullptr;
     std::vector<int32_t> col_len;  // rows per column (index = c)
@@ -275,6 +276,40 @@ static void build_harmonics(const nyx_hip_gravity_field_t *g, std::vector<HarmEn
             tab.push_back(e);
         }
     }
+}
+
+// The same table in the hybrid-feed layout (devcfg.h, HYB_*): per column the scalar rows {g, t1, t2} padded to whole batches,
+// then - behind all scalar rows - the vector groups [t3..t6][16 rows] in pairs.  Fills cols[c].hs / .hv.
+static void build_hybrid(const std::vector<HarmEntry> &tab, std::vector<ColHdr> &cols, const std::vector<int32_t> &col_len, int n_cols,
+                         std::vector<double> &hyb) {
+    hyb.clear();
+    for (int c = 1; c <= n_cols; ++c) {
+        const int rows = col_len[c], padded = (rows + HYB_ROWS - 1) / HYB_ROWS * HYB_ROWS;
+        cols[c].hs = (int32_t)hyb.size();
+        for (int r = 0; r < padded; ++r) {
+            const HarmEntry z = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            const HarmEntry &e = r < rows ? tab[(size_t)cols[c].start + r] : z;
+            hyb.push_back(e.g); hyb.push_back(e.t1); hyb.push_back(e.t2);
+        }
+    }
+    hyb.resize((hyb.size() + HYB_ROWS * HYB_KS + 15) / 16 * 16, 0.0);  // a tail batch may be fetched past the last row; 128-byte aligned groups
+    for (int c = 1; c <= n_cols; ++c) {
+        const int rows = col_len[c], groups = (rows + 15) / 16;
+        cols[c].hv = (int32_t)hyb.size();
+        for (int gq = 0; gq < groups; ++gq)
+            for (int j = 0; j < 4; ++j)
+                for (int l = 0; l < 16; ++l) {
+                    const int r = gq * 16 + l;
+                    double v = 0.0;
+                    if (r < rows) {
+                        const HarmEntry &e = tab[(size_t)cols[c].start + r];
+                        v = j == 0 ? e.t3 : j == 1 ? e.t4 : j == 2 ? e.t5 : e.t6;
+                    }
+                    hyb.push_back(v);
+                }
+    }
+    for (int c = n_cols + 1; c < (int)cols.size(); ++c) { cols[c].hs = 0; cols[c].hv = (int32_t)hyb.size(); }  // (prefetched headers)
+    hyb.resize(hyb.size() + 2 * HYB_GROUP, 0.0);  // the last column's walk prefetches one group further
 }
 
 // Column schedule: wave w walks at most two contiguous ranges — long columns from the low-c end,
@@ -661,7 +696,7 @@ extern "C" int32_t nyx_hip_debug_profile(nyx_hip_ctx *ctx, int64_t *out) {
 extern "C" void nyx_hip_ctx_destroy(nyx_hip_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
-    hipFree(ctx->d_cfg); hipFree(ctx->d_htab); hipFree(ctx->d_cols); hipFree(ctx->d_records);
+    hipFree(ctx->d_cfg); hipFree(ctx->d_htab); hipFree(ctx->d_hyb); hipFree(ctx->d_cols); hipFree(ctx->d_records);
     free_arrays(ctx->in);
     free_arrays(ctx->out);
     free_arrays(ctx->cal);
@@ -897,6 +932,17 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
     build_schedule(ctx, 1);
 
     // ---- upload
+    dc.hyb = 0;
+    dc.harm_feed = 0;
+    if (!tab.empty()) {
+        std::vector<double> hyb;
+        build_hybrid(tab, cols, ctx->col_len, dc.n_cols, hyb);
+        HIP_TRY(hipMalloc(&ctx->d_hyb, hyb.size() * sizeof(double)));
+        HIP_TRY(hipMemcpy(ctx->d_hyb, hyb.data(), hyb.size() * sizeof(double), hipMemcpyHostToDevice));
+        dc.hyb = (uint64_t)ctx->d_hyb;
+        dc.harm_feed = 0;  // (measured: the hybrid feed wins in isolation, tools/harm_microbench.hip, not yet inside the kernel - see DESIGN.md)
+        if (const char *e = std::getenv("NYX_HIP_HARM_FEED")) dc.harm_feed = std::atoi(e) != 0 ? 1 : 0;
+    }
     HIP_TRY(hipMalloc(&ctx->d_cfg, sizeof(DevCfg)));
     HIP_TRY(hipMemcpy(ctx->d_cfg, &dc, sizeof(DevCfg), hipMemcpyHostToDevice));
     if (!tab.empty()) {

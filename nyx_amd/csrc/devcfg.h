@@ -111,7 +111,9 @@ struct DevCfg {
     int32_t ed_reuse; /* > 0: stage-0 epoch data is carried between attempts; value = fields kept per lane (9 + 3 * n_slots) */
     DevSched sched[DEV_N_SCHED];
     double coop_frac; /* share of the harmonics terms a helper workgroup takes over (cooperative mode) */
-    int32_t coop_ok, _pad4; /* PRIMARY / HELPER schedules are valid */
+    int32_t coop_ok;  /* PRIMARY / HELPER schedules are valid */
+    int32_t harm_feed; /* 0: every table operand through the scalar data path (HarmEntry stream); 1: hybrid feed (HYB_* below) */
+    uint64_t hyb;     /* device address of the hybrid-feed table (doubles) */
 };
 
 /* Column header (32 B = one s_load_dwordx8): rows of column c start at htab[start]: `nb & 0xffff` batches of HARM_BATCH
@@ -121,8 +123,21 @@ struct ColHdr {
     int32_t start, nb;
     double scale; /* c * sqrt(2) */
     double diag;  /* A[c][c] */
-    double _pad;
+    int32_t hs, hv; /* hybrid feed: offsets (in doubles) of the column's scalar rows and of its first vector group */
 };
+
+/* Hybrid feed of the same table (plain f64 kernel).  The scalar data path delivers ~4 bytes per cycle and CU whatever the
+ * occupancy, and a 56-byte entry feeds nine f64 instructions: 0.64 issue at best (tools/harm_microbench.hip).  So only the
+ * first HYB_KS values of a row (g, t1, t2) travel as scalars - 24 bytes per row, batches of HYB_ROWS rows = three
+ * s_load_dwordx16 - and t3..t6 travel through VECTOR registers: sixteen rows per register pair, lane e of every 16-lane row
+ * holding row e's value, and v_fmac_f64_dpp row_newbcast:e multiplies by it - a wave-uniform operand without the scalar path.
+ *   scalar side : column c = rows x {g, t1, t2} at hyb[hs], padded to a multiple of HYB_ROWS rows (64-byte aligned batches)
+ *   vector side : column c = ceil(rows / 16) groups at hyb[hv]; group = [4 values t3..t6][16 rows] = 64 doubles; the groups of
+ *                 consecutive columns are contiguous (one stream per column range, prefetched one group ahead)
+ * Same operations on the same operands in the same order as the scalar stream: bit-identical sums. */
+#define HYB_KS 3
+#define HYB_ROWS 8
+#define HYB_GROUP 64
 
 /* One (n', c) entry of the harmonics table: 56 B, seven scalar-register pairs; a batch of five is 70 SGPRs.
  * The column recursion of the reference, a_n = u b_n a_{n-1} - c_n a_{n-2} with c_n = b_n / b_{n-1}, is carried on

@@ -39,6 +39,16 @@
 #include "hifitime_dev.h"
 #include "event_dev.h"
 
+// which kernels this translation unit emits (see NYX_KERNEL at the end of the file; propagate_*.hip include this file)
+#ifndef NYX_EMIT
+#define NYX_EMIT 1
+#endif
+#define NYX_EMIT_PLAIN16 1  /* sixteen waves (the north-star shape), helpers */
+#define NYX_EMIT_PLAIN8 2   /* eight waves or fewer */
+#define NYX_EMIT_STM 4      /* D3 duals: at most DEV_MAX_WAVES_STM waves (dual-number harmonics need ~4x the registers) */
+#define NYX_EMIT_STMQ16 8   /* quad layout (16 trajectories per workgroup, four lanes per trajectory, D1 duals), sixteen waves */
+#define NYX_EMIT_STMQ8 16   /* quad layout, eight waves or fewer */
+
 #define CAS __attribute__((address_space(4)))
 typedef const CAS DevCfg *CfgPtr;
 typedef const CAS HarmEntry *HarmPtr;
@@ -127,6 +137,7 @@ struct FrameChain {
     int32_t n_chain, seg[4];
     double sign[4];
 };
+#if NYX_EMIT & NYX_EMIT_PLAIN16
 // opts.integration_frame (instance.rs:117-142, 211-220): x += dir * (state of the chain's body w.r.t. the integration centre at the
 // trajectory's epoch); dir = +1 into the integration frame, -1 back.  One thread per trajectory.
 __global__ __launch_bounds__(256) void nyx_frame_shift_kernel(const DevCfg *cfg_g, const double *records, FrameChain ch, int64_t n,
@@ -159,6 +170,7 @@ extern "C" hipError_t nyx_launch_frame_shift(const DevCfg *cfg, const double *re
                        vx, vy, vz, dir, status);
     return hipGetLastError();
 }
+#endif
 
 // Body-fixed orientation (nyx_hip_rotation_t, see include/nyx_hip.h): the IAU phase angles with their trigonometric series, or
 // the Chebyshev Euler angles of a binary PCK.  `w_rate` (optional): dW/dt in rad/s (the drag model's velocity transform).
@@ -775,7 +787,7 @@ DEVFN uint64_t uniform_u64(uint64_t v) {
 DEVFN ColHdr load_hdr(ColPtr cols, int c) {
     const ColHdr CAS &r = cols[c];
     ColHdr h;
-    h.start = r.start; h.nb = r.nb; h.scale = r.scale; h.diag = r.diag; h._pad = 0.0;
+    h.start = r.start; h.nb = r.nb; h.scale = r.scale; h.diag = r.diag; h.hs = r.hs; h.hv = r.hv;
     return h;
 }
 
@@ -860,6 +872,177 @@ DEVFN Partial4T<T> harmonics_core(CfgPtr cfg, HarmPtr htab, ColPtr cols, const i
     return r;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Hybrid feed of the column recursion (devcfg.h HYB_*): {g, t1, t2} of eight rows through three scalar loads behind one
+// wait, t3..t6 of sixteen rows in four VGPR pairs (one coalesced 128-byte load each: lane e of every 16-lane row holds row e)
+// and picked by the DPP row_newbcast of v_fmac_f64.  Per row: 24 scalar bytes instead of 56, the same nine f64 operations on
+// the same operands in the same order (v_fmac_f64 IS fma(src0, src1, dst)): bit-identical to the scalar stream.
+// Hazards the assembler does not see inside inline asm (GCNHazardRecognizer: a VALU write of a VGPR needs two wait states
+// before a DPP read of it, a VALU write of EXEC five): the DPP operand registers are written by VMEM loads only (ordered by
+// the compiler's s_waitcnt vmcnt, which does see the asm operands), and tools/check_dpp_hazards.py scans the code object.
+typedef const __attribute__((address_space(1))) double *HybVPtr;
+typedef const CAS double *HybSPtr;
+struct HybS { v16i q0, q1, q2; };  // eight rows x {g, t1, t2}
+struct HybV { double r[4]; };      // sixteen rows x {t3, t4, t5, t6}
+DEVFN void hyb_sload(HybSPtr e, HybS &b) {
+    asm volatile(
+        "s_load_dwordx16 %0, %3, 0x0\n\t"
+        "s_load_dwordx16 %1, %3, 0x40\n\t"
+        "s_load_dwordx16 %2, %3, 0x80\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&s"(b.q0), "=&s"(b.q1), "=&s"(b.q2)
+        : "s"(e)
+        : "memory");
+}
+#ifndef HYB_TOUCH
+#define HYB_TOUCH 1
+#endif
+// touch the three 64-byte lines of the NEXT batch (results discarded; the rows of consecutive columns are contiguous, so the last
+// batch of a column touches the first one of the next): its loads then hit the scalar cache.  `sink` as in touch_batch().
+DEVFN void hyb_touch(HybSPtr e, int &sink) {
+    asm volatile(
+        "s_load_dword %0, %1, 0xc0\n\t"
+        "s_load_dword %0, %1, 0x100\n\t"
+        "s_load_dword %0, %1, 0x140"
+        : "+&s"(sink)
+        : "s"(e)
+        : "memory");
+}
+DEVFN void hyb_vload(HybVPtr p, HybV &v) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v.r[j] = p[16 * j];
+}
+template <int DW>
+DEVFN double hyb_sval(const HybS &b) {
+    if constexpr (DW < 16) return HB_D(b.q0, DW);
+    else if constexpr (DW < 32) return HB_D(b.q1, DW - 16);
+    else return HB_D(b.q2, DW - 32);
+}
+template <int K>
+DEVFN void fmac_bc(double &acc, double tab, double x) {  // acc += (row K of tab) * x
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(tab), "v"(x), "n"(K));
+}
+struct HybAcc { double a1, a2, s1, s2, s3, s4, s5, s6; };
+template <int E, int LANE0>
+DEVFN void hyb_term(const HybS &b, const HybV &v, const double rho_u, const double rho2, HybAcc &A) {
+    const double an = __builtin_fma(rho_u, A.a1, -((rho2 * hyb_sval<6 * E>(b)) * A.a2));
+    A.s1 = __builtin_fma(an, hyb_sval<6 * E + 2>(b), A.s1);
+    A.s2 = __builtin_fma(an, hyb_sval<6 * E + 4>(b), A.s2);
+    fmac_bc<LANE0 + E>(A.s3, v.r[0], an);
+    fmac_bc<LANE0 + E>(A.s4, v.r[1], an);
+    fmac_bc<LANE0 + E>(A.s5, v.r[2], an);
+    fmac_bc<LANE0 + E>(A.s6, v.r[3], an);
+    A.a2 = A.a1;
+    A.a1 = an;
+}
+// one batch of the scalar side against half a vector group (LANE0 = 0 / 8): all eight rows, or the first `rem` of them
+template <int LANE0>
+DEVFN void hyb_batch(HybSPtr e, const HybV &v, const double rho_u, const double rho2, HybAcc &A, int &sink) {
+    HybS b;
+    hyb_sload(e, b);
+    if (HYB_TOUCH) hyb_touch(e, sink);
+    hyb_term<0, LANE0>(b, v, rho_u, rho2, A); hyb_term<1, LANE0>(b, v, rho_u, rho2, A);
+    hyb_term<2, LANE0>(b, v, rho_u, rho2, A); hyb_term<3, LANE0>(b, v, rho_u, rho2, A);
+    hyb_term<4, LANE0>(b, v, rho_u, rho2, A); hyb_term<5, LANE0>(b, v, rho_u, rho2, A);
+    hyb_term<6, LANE0>(b, v, rho_u, rho2, A); hyb_term<7, LANE0>(b, v, rho_u, rho2, A);
+}
+template <int LANE0>
+DEVFN void hyb_tail(HybSPtr e, const HybV &v, const int rem, const double rho_u, const double rho2, HybAcc &A, int &sink) {
+    HybS b;
+    hyb_sload(e, b);  // (the scalar rows of a column are padded to whole batches)
+    if (HYB_TOUCH) hyb_touch(e, sink);
+    hyb_term<0, LANE0>(b, v, rho_u, rho2, A);
+    if (rem > 1) {
+        hyb_term<1, LANE0>(b, v, rho_u, rho2, A);
+        if (rem > 2) {
+            hyb_term<2, LANE0>(b, v, rho_u, rho2, A);
+            if (rem > 3) {
+                hyb_term<3, LANE0>(b, v, rho_u, rho2, A);
+                if (rem > 4) {
+                    hyb_term<4, LANE0>(b, v, rho_u, rho2, A);
+                    if (rem > 5) {
+                        hyb_term<5, LANE0>(b, v, rho_u, rho2, A);
+                        if (rem > 6) hyb_term<6, LANE0>(b, v, rho_u, rho2, A);
+                    }
+                }
+            }
+        }
+    }
+}
+// up to sixteen rows against one vector group; returns the rows of the column still to do
+DEVFN int hyb_group(HybSPtr &e, const HybV &v, int left, const double rho_u, const double rho2, HybAcc &A, int &sink) {
+    if (left >= HYB_ROWS) {
+        hyb_batch<0>(e, v, rho_u, rho2, A, sink);
+        e += HYB_ROWS * HYB_KS;
+        left -= HYB_ROWS;
+        if (left >= HYB_ROWS) {
+            hyb_batch<8>(e, v, rho_u, rho2, A, sink);
+            e += HYB_ROWS * HYB_KS;
+            return left - HYB_ROWS;
+        }
+        if (left > 0) hyb_tail<8>(e, v, left, rho_u, rho2, A, sink);
+        return 0;
+    }
+    hyb_tail<0>(e, v, left, rho_u, rho2, A, sink);
+    return 0;
+}
+
+DEVFN Partial4 harmonics_core_hyb(CfgPtr cfg, ColPtr cols, const int wave, const int sched, const int lane, double zr, double zi, double rho_u,
+                                  double rho, double inv_rho) {
+    double px = 0.0, py = 0.0, pz = 0.0, pw = 0.0;
+    const double rho2 = rho * rho;
+    const CAS DevSched &sd = cfg->sched[sched];
+    const int nr = sd.n_ranges[wave];
+    const uint64_t hyb_u = cfg->hyb;
+    HybSPtr hs0 = (HybSPtr)hyb_u;
+    HybVPtr hv0 = (HybVPtr)hyb_u + (lane & 15);
+    for (int q = 0; q < nr; ++q) {
+        const int c0 = sd.range_c0[wave][q];
+        const int cnt = sd.range_cnt[wave][q];
+        ColHdr hd = load_hdr(cols, c0);
+        // The vector groups of consecutive columns are contiguous: one stream per range, walked with a prefetch distance of exactly
+        // one group whatever the column lengths - the group after the one being evaluated is always in flight, in the other
+        // register set (`par` = the set that holds the current group; a uniform branch picks the code for it).
+        HybVPtr pv = hv0 + hd.hv;
+        HybV va, vb;
+        hyb_vload(pv, va);
+        int par = 0;
+        double rc, ic;
+        cpow_uniform(zr, zi, c0 - 1, rc, ic);
+        for (int c = c0; c < c0 + cnt; ++c) {
+            const ColHdr hn = load_hdr(cols, c + 1);
+            HybSPtr e = hs0 + hd.hs;
+            int left = (hd.nb & 0xffff) * HARM_BATCH + (hd.nb >> 16);  // rows of the column
+            HybAcc A = {0.0, inv_rho * hd.diag, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            int sink = 0;
+            do {
+                pv += HYB_GROUP;
+                if (par == 0) {
+                    hyb_vload(pv, vb);
+                    left = hyb_group(e, va, left, rho_u, rho2, A, sink);
+                } else {
+                    hyb_vload(pv, va);
+                    left = hyb_group(e, vb, left, rho_u, rho2, A, sink);
+                }
+                par ^= 1;
+            } while (left > 0);
+            if (HYB_TOUCH) touch_done(sink);
+            const double sc = rho * hd.scale;  // rho * c * sqrt(2)
+            px = gfma(sc, gfma(rc, A.s1, gmul(ic, A.s2)), px);
+            py = gfma(sc, gfma(rc, A.s2, -(gmul(ic, A.s1))), py);
+            pz = gfma(rho, gfma(rc, A.s3, gmul(ic, A.s4)), pz);
+            pw = pw - gfma(rc, A.s5, gmul(ic, A.s6));
+            const double t = gmul(rc, zr) - gmul(ic, zi);
+            ic = gmul(rc, zi) + gmul(ic, zr);
+            rc = t;
+            hd = hn;
+        }
+    }
+    Partial4 r = {px, py, pz, pw};
+    return r;
+}
+
 static __device__ __attribute__((noinline)) Partial4 harmonics_partial(uint64_t cfg_u, uint64_t htab_u, uint64_t cols_u, int wave_v,
                                                                      int sched_v, double zr, double zi, double rho_u, double rho,
                                                                      double inv_rho) {
@@ -868,6 +1051,7 @@ static __device__ __attribute__((noinline)) Partial4 harmonics_partial(uint64_t 
     ColPtr cols = (ColPtr)uniform_u64(cols_u);
     const int wave = __builtin_amdgcn_readfirstlane(wave_v);
     const int sched = __builtin_amdgcn_readfirstlane(sched_v);
+    if (cfg->harm_feed) return harmonics_core_hyb(cfg, cols, wave, sched, (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), zr, zi, rho_u, rho, inv_rho);
     return harmonics_core<double>(cfg, htab, cols, wave, sched, zr, zi, rho_u, rho, inv_rho);
 }
 
@@ -1670,7 +1854,12 @@ DEVFN LdsMap carve_lds(char *smem, int n_waves, bool stm, int rec_lds_doubles, i
     return m;
 }
 
-extern "C" size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles, int stm, int reuse_fields) {  // stm: 0 = plain, 1 = D3, 2 = quad layout
+#if !(NYX_EMIT & NYX_EMIT_PLAIN16)
+static
+#else
+extern "C"
+#endif
+size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles, int stm, int reuse_fields) {  // stm: 0 = plain, 1 = D3, 2 = quad layout
     const bool quad = stm == 2;
     size_t d = (size_t)DEV_MAX_STAGES * 6 * (quad ? DEV_LANES / 4 : DEV_LANES) + DEV_MAX_STAGES * DEV_MAX_STAGES + 3 * DEV_MAX_STAGES + 6 * DEV_LANES +
                2 * ED_FIELDS * DEV_LANES + 2 * DEV_LANES + CS_FIELDS * DEV_LANES + (size_t)(quad ? DEV_MAX_WAVES * QSLOT : DEV_MAX_WAVES * 4 * DEV_LANES) + DEV_MAX_ALM * DEV_LANES +
@@ -2612,32 +2801,39 @@ DEVFN void propagate_body(const DevBatch &bt, const DevCfg *cfg_g, const HarmEnt
     }
 }
 
-extern "C" __global__ void __launch_bounds__(DEV_MAX_WAVES *DEV_LANES)
-    nyx_propagate_kernel(DevBatch bt, const DevCfg *cfg_g, const HarmEntry *htab_g, const ColHdr *cols_g,
-                         const double *__restrict__ records) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    propagate_body<false>(bt, cfg_g, htab_g, cols_g, records, smem);
-}
+// One kernel per workgroup SHAPE, each in its own translation unit (NYX_EMIT selects; propagate_*.hip include this file): the
+// register budget follows __launch_bounds__ - 128 VGPRs for sixteen waves, 256 for eight or fewer - so the role code of the
+// small shapes (fan-out workgroups of dynamics without a gravity field, the quad STM layout on eight waves) is compiled without
+// the 128-VGPR cap that sixteen waves per workgroup impose, instead of one instantiation serving every shape.
+#define NYX_KERNEL(NAME, THREADS, ...)                                                                                        \
+    extern "C" __global__ void __launch_bounds__(THREADS)                                                                     \
+        NAME(DevBatch bt, const DevCfg *cfg_g, const HarmEntry *htab_g, const ColHdr *cols_g, const double *__restrict__ records) { \
+        extern __shared__ __attribute__((aligned(16))) char smem[];                                                           \
+        propagate_body<__VA_ARGS__>(bt, cfg_g, htab_g, cols_g, records, smem);                                                \
+    }
+#define NYX_KERNEL_DECL(NAME) \
+    extern "C" __global__ void NAME(DevBatch bt, const DevCfg *cfg_g, const HarmEntry *htab_g, const ColHdr *cols_g, const double *__restrict__ records);
+#if NYX_EMIT & NYX_EMIT_PLAIN16
+NYX_KERNEL(nyx_propagate_kernel, DEV_MAX_WAVES *DEV_LANES, false)
+#endif
+#if NYX_EMIT & NYX_EMIT_PLAIN8
+NYX_KERNEL(nyx_propagate_kernel_w8, 8 * DEV_LANES, false)
+#endif
+#if NYX_EMIT & NYX_EMIT_STM
+NYX_KERNEL(nyx_propagate_kernel_stm, DEV_MAX_WAVES_STM *DEV_LANES, true)
+#endif
+#if NYX_EMIT & NYX_EMIT_STMQ16
+NYX_KERNEL(nyx_propagate_kernel_stmq, DEV_MAX_WAVES *DEV_LANES, true, true)
+#endif
+#if NYX_EMIT & NYX_EMIT_STMQ8
+NYX_KERNEL(nyx_propagate_kernel_stmq_w8, 8 * DEV_LANES, true, true)
+#endif
 
-// STM variant (Spacecraft.stm = Some): 9x9 state-transition matrix alongside the state.  Dual-number harmonics need
-// ~4x the registers, hence at most DEV_MAX_WAVES_STM waves per workgroup (256 VGPRs each).
-extern "C" __global__ void __launch_bounds__(DEV_MAX_WAVES_STM *DEV_LANES)
-    nyx_propagate_kernel_stm(DevBatch bt, const DevCfg *cfg_g, const HarmEntry *htab_g, const ColHdr *cols_g,
-                             const double *__restrict__ records) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    propagate_body<true>(bt, cfg_g, htab_g, cols_g, records, smem);
-}
-
-// STM variant, QUAD LAYOUT (small ensembles): 16 trajectories per workgroup, four lanes per trajectory, each carrying the
-// value and ONE position partial of every dual (D1).  A quarter of the dual registers => the role code fits the
-// 128-VGPR budget of a 16-wave workgroup: column waves to hide the scalar-load latency, and 4x the workgroups.
-extern "C" __global__ void __launch_bounds__(DEV_MAX_WAVES *DEV_LANES)
-    nyx_propagate_kernel_stmq(DevBatch bt, const DevCfg *cfg_g, const HarmEntry *htab_g, const ColHdr *cols_g,
-                              const double *__restrict__ records) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    propagate_body<true, true>(bt, cfg_g, htab_g, cols_g, records, smem);
-}
-
+#if NYX_EMIT & NYX_EMIT_PLAIN16
+NYX_KERNEL_DECL(nyx_propagate_kernel_w8)
+NYX_KERNEL_DECL(nyx_propagate_kernel_stm)
+NYX_KERNEL_DECL(nyx_propagate_kernel_stmq)
+NYX_KERNEL_DECL(nyx_propagate_kernel_stmq_w8)
 extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg, const HarmEntry *htab,
                                            const ColHdr *cols, const double *records, int n_waves, int rec_lds_doubles,
                                            int reuse_fields, hipStream_t stream, int quad) {
@@ -2649,21 +2845,25 @@ extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg
         (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_stm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_stmq, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_w8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_stmq_w8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
     const bool stm = bt.o_stm != nullptr;
     size_t lds = nyx_kernel_lds_bytes(n_waves, rec_lds_doubles, stm ? (quad ? 2 : 1) : 0, stm ? 0 : reuse_fields);
     if (!stm && bt.coop_helpers > 0 && lds < (size_t)HELPER_LDS_BYTES) lds = HELPER_LDS_BYTES;
+    const bool small = n_waves <= 8;  // (helpers are sixteen-wave workgroups: cooperative launches never are)
     if (stm && quad)
-        hipLaunchKernelGGL(nyx_propagate_kernel_stmq, dim3((unsigned)blocks), dim3((unsigned)(n_waves * DEV_LANES)), lds, stream, bt, cfg,
-                           htab, cols, records);
+        hipLaunchKernelGGL(small ? nyx_propagate_kernel_stmq_w8 : nyx_propagate_kernel_stmq, dim3((unsigned)blocks),
+                           dim3((unsigned)(n_waves * DEV_LANES)), lds, stream, bt, cfg, htab, cols, records);
     else if (stm)
         hipLaunchKernelGGL(nyx_propagate_kernel_stm, dim3((unsigned)blocks), dim3((unsigned)(n_waves * DEV_LANES)), lds, stream, bt, cfg,
                            htab, cols, records);
     else {
         const int64_t grid = bt.coop_helpers > 0 ? (int64_t)bt.coop_base + bt.coop_helpers : blocks;
-        hipLaunchKernelGGL(nyx_propagate_kernel, dim3((unsigned)grid), dim3((unsigned)(n_waves * DEV_LANES)), lds, stream, bt, cfg,
-                           htab, cols, records);
+        hipLaunchKernelGGL((small && bt.coop_helpers == 0) ? nyx_propagate_kernel_w8 : nyx_propagate_kernel, dim3((unsigned)grid),
+                           dim3((unsigned)(n_waves * DEV_LANES)), lds, stream, bt, cfg, htab, cols, records);
     }
     return hipGetLastError();
 }
+#endif  // NYX_EMIT & NYX_EMIT_PLAIN16

@@ -1,0 +1,4 @@
+// propagate_w8.hip - one workgroup shape of the propagation kernel in its own translation unit (see NYX_KERNEL in
+// propagate_kernel.hip): its own __launch_bounds__, hence its own register budget; compiled in parallel with the others.
+#define NYX_EMIT 2 /* NYX_EMIT_PLAIN8 */
+#include "propagate_kernel.hip"

@@ -5,7 +5,9 @@
 // column waves of the propagation kernel; nothing is reused in the 16 KB scalar cache between passes (15 other waves went through it).
 // Variants: 0 = five entries per wait + touch of the next batch (the kernel's loop), 1 = the same without the touch, 2 = two windows of
 // three entries, the next one in flight while this one is evaluated, 3 = variant 0 with TWO lane sets per table pass, 4 = variant 2 with
-// two lane sets.
+// two lane sets, 8 = the table through VGPRs, sixteen doubles per register pair (one per lane of a 16-lane row), every operand picked
+// by the DPP row_newbcast of v_fmac_f64 (no scalar data path at all), 16 entries = 7 coalesced 128-byte loads per batch, double-buffered;
+// 9 = variant 8 with two lane sets.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -84,6 +86,114 @@ struct Acc { double a1[L], a2[L], s1[L], s2[L], s3[L], s4[L], s5[L], s6[L], rho_
     }
 #define E48(b0, i0, b1, i1, b2, i2, b3, i3, b4, i4, b5, i5, p3, p4) TERM48(D(b0, i0), D(b1, i1), D(b2, i2), D(b3, i3), D(b4, i4), D(b5, i5), p3, p4)
 
+
+// ---- DPP-fed variant: the table lives in VGPRs, 16 doubles per register pair (lane l of every 16-lane row holds double l of a 128-byte
+// line), and v_fmac_f64_dpp row_newbcast:k multiplies by double k of the row: wave-uniform operands without the scalar data path.
+// a_n = rho_u a_{n-1} + g_n (-rho2 a_{n-2}): mul, fmac(dpp), mul, 6 fmac(dpp) = nine operations per entry, like the scalar form.
+struct V7 { double r[7]; };
+template <int K>
+__device__ __forceinline__ void fmac_bc(double &acc, double tab, double x) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(tab), "v"(x), "n"(K));
+}
+template <int L, int E>
+__device__ __forceinline__ void term_dpp(Acc<L> &A, double (&np1)[L], double (&np2)[L], const V7 &v) {
+    constexpr int f = 7 * E;
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        double an = A.rho_u[l] * A.a1[l];
+        fmac_bc<(f + 0) & 15>(an, v.r[(f + 0) >> 4], np2[l]);
+        fmac_bc<(f + 1) & 15>(A.s1[l], v.r[(f + 1) >> 4], an);
+        fmac_bc<(f + 2) & 15>(A.s2[l], v.r[(f + 2) >> 4], an);
+        fmac_bc<(f + 3) & 15>(A.s3[l], v.r[(f + 3) >> 4], an);
+        fmac_bc<(f + 4) & 15>(A.s4[l], v.r[(f + 4) >> 4], an);
+        fmac_bc<(f + 5) & 15>(A.s5[l], v.r[(f + 5) >> 4], an);
+        fmac_bc<(f + 6) & 15>(A.s6[l], v.r[(f + 6) >> 4], an);
+        np2[l] = np1[l]; np1[l] = A.rho2[l] * an;  // (rho2 holds -rho^2 here)
+        A.a1[l] = an;
+    }
+}
+template <int L>
+__device__ __forceinline__ void terms16_dpp(Acc<L> &A, double (&np1)[L], double (&np2)[L], const V7 &v) {
+    term_dpp<L, 0>(A, np1, np2, v); term_dpp<L, 1>(A, np1, np2, v); term_dpp<L, 2>(A, np1, np2, v); term_dpp<L, 3>(A, np1, np2, v);
+    term_dpp<L, 4>(A, np1, np2, v); term_dpp<L, 5>(A, np1, np2, v); term_dpp<L, 6>(A, np1, np2, v); term_dpp<L, 7>(A, np1, np2, v);
+    term_dpp<L, 8>(A, np1, np2, v); term_dpp<L, 9>(A, np1, np2, v); term_dpp<L, 10>(A, np1, np2, v); term_dpp<L, 11>(A, np1, np2, v);
+    term_dpp<L, 12>(A, np1, np2, v); term_dpp<L, 13>(A, np1, np2, v); term_dpp<L, 14>(A, np1, np2, v); term_dpp<L, 15>(A, np1, np2, v);
+}
+typedef const __attribute__((address_space(1))) double *GTab;
+__device__ __forceinline__ void vload7(GTab p, V7 &v) {
+#pragma unroll
+    for (int j = 0; j < 7; ++j) v.r[j] = p[16 * j];
+}
+
+// ---- hybrid: KS of the seven values of an entry through the scalar path (g first), the other 7 - KS through the DPP broadcast.
+// Scalar side: 8 entries per wait (KS * 64 bytes); vector side: 16 entries per register pair (value j of entry e = lane e of pair j).
+template <int KS> struct SB;  // KS x 16 dwords
+template <> struct SB<3> { v16i q[3]; };
+template <> struct SB<4> { v16i q[4]; };
+template <> struct SB<5> { v16i q[5]; };
+__device__ __forceinline__ void sload(TabPtr e, SB<3> &b) {
+    asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx16 %1, %3, 0x40\n\ts_load_dwordx16 %2, %3, 0x80\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(b.q[0]), "=&s"(b.q[1]), "=&s"(b.q[2]) : "s"(e) : "memory");
+}
+__device__ __forceinline__ void sload(TabPtr e, SB<4> &b) {
+    asm volatile("s_load_dwordx16 %0, %4, 0x0\n\ts_load_dwordx16 %1, %4, 0x40\n\ts_load_dwordx16 %2, %4, 0x80\n\ts_load_dwordx16 %3, %4, 0xc0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(b.q[0]), "=&s"(b.q[1]), "=&s"(b.q[2]), "=&s"(b.q[3]) : "s"(e) : "memory");
+}
+__device__ __forceinline__ void sload(TabPtr e, SB<5> &b) {
+    asm volatile("s_load_dwordx16 %0, %5, 0x0\n\ts_load_dwordx16 %1, %5, 0x40\n\ts_load_dwordx16 %2, %5, 0x80\n\ts_load_dwordx16 %3, %5, 0xc0\n\t"
+                 "s_load_dwordx16 %4, %5, 0x100\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(b.q[0]), "=&s"(b.q[1]), "=&s"(b.q[2]), "=&s"(b.q[3]), "=&s"(b.q[4]) : "s"(e) : "memory");
+}
+template <int KS> struct VD { double r[7 - KS]; };
+template <int KS>
+__device__ __forceinline__ void vloadk(GTab p, VD<KS> &v) {
+#pragma unroll
+    for (int j = 0; j < 7 - KS; ++j) v.r[j] = p[16 * j];
+}
+// scalar value i (0 .. KS-1) of entry E (0..7) of a half batch: dword 2 * (KS * E + i)
+#define SVAL(b, E, i) D((b).q[(2 * (KS * (E) + (i))) >> 4], (2 * (KS * (E) + (i))) & 15)
+template <int L, int KS, int E, int LANE0>
+__device__ __forceinline__ void term_hyb(Acc<L> &A, const SB<KS> &b, const VD<KS> &v) {
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const double an = __builtin_fma(A.rho_u[l], A.a1[l], -((A.rho2[l] * SVAL(b, E, 0)) * A.a2[l]));
+        double *acc[6] = {&A.s1[l], &A.s2[l], &A.s3[l], &A.s4[l], &A.s5[l], &A.s6[l]};
+        if (KS > 1) *acc[0] = __builtin_fma(an, SVAL(b, E, 1 < KS ? 1 : 0), *acc[0]);
+        if (KS > 2) *acc[1] = __builtin_fma(an, SVAL(b, E, 2 < KS ? 2 : 0), *acc[1]);
+        if (KS > 3) *acc[2] = __builtin_fma(an, SVAL(b, E, 3 < KS ? 3 : 0), *acc[2]);
+        if (KS > 4) *acc[3] = __builtin_fma(an, SVAL(b, E, 4 < KS ? 4 : 0), *acc[3]);
+#pragma unroll
+        for (int j = 0; j < 7 - KS; ++j) fmac_bc<LANE0 + E>(*acc[KS - 1 + j], v.r[j], an);
+        A.a2[l] = A.a1[l]; A.a1[l] = an;
+    }
+}
+template <int L, int KS, int LANE0>
+__device__ __forceinline__ void terms8_hyb(Acc<L> &A, const SB<KS> &b, const VD<KS> &v) {
+    term_hyb<L, KS, 0, LANE0>(A, b, v); term_hyb<L, KS, 1, LANE0>(A, b, v); term_hyb<L, KS, 2, LANE0>(A, b, v); term_hyb<L, KS, 3, LANE0>(A, b, v);
+    term_hyb<L, KS, 4, LANE0>(A, b, v); term_hyb<L, KS, 5, LANE0>(A, b, v); term_hyb<L, KS, 6, LANE0>(A, b, v); term_hyb<L, KS, 7, LANE0>(A, b, v);
+}
+template <int L, int KS>
+__device__ __forceinline__ void hybrid_pass(Acc<L> &A, uint64_t base, int lane, int entries_per_wave) {
+    // scalar part: KS * 8 bytes per entry at `base`; vector part: (7 - KS) * 8 bytes per entry behind it (same wave's share of the table)
+    TabPtr e = (TabPtr)base;
+    GTab pv = (GTab)(base + (uint64_t)entries_per_wave * KS * 8) + (lane & 15);
+    VD<KS> va, vb;
+    vloadk<KS>(pv, va);
+    const int nbt = entries_per_wave / 16;
+    for (int b = 0; b + 1 < nbt; b += 2, pv += 2 * 16 * (7 - KS)) {
+        vloadk<KS>(pv + 16 * (7 - KS), vb);
+        { SB<KS> w; sload(e, w); terms8_hyb<L, KS, 0>(A, w, va); e += 8 * KS; }
+        { SB<KS> w; sload(e, w); terms8_hyb<L, KS, 8>(A, w, va); e += 8 * KS; }
+        vloadk<KS>(pv + 2 * 16 * (7 - KS), va);
+        { SB<KS> w; sload(e, w); terms8_hyb<L, KS, 0>(A, w, vb); e += 8 * KS; }
+        { SB<KS> w; sload(e, w); terms8_hyb<L, KS, 8>(A, w, vb); e += 8 * KS; }
+    }
+    if (nbt & 1) {
+        { SB<KS> w; sload(e, w); terms8_hyb<L, KS, 0>(A, w, va); e += 8 * KS; }
+        { SB<KS> w; sload(e, w); terms8_hyb<L, KS, 8>(A, w, va); e += 8 * KS; }
+    }
+}
+
 // entries: multiples of 180 so that every variant evaluates the same rows
 template <int VARIANT, int L>
 __global__ __launch_bounds__(1024) void bench(const double *tab_g, int entries_per_wave, int passes, double *out) {
@@ -91,13 +201,29 @@ __global__ __launch_bounds__(1024) void bench(const double *tab_g, int entries_p
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     Acc<L> A;
     for (int l = 0; l < L; ++l) {
-        A.rho_u[l] = 0.3 + 1e-3 * lane + 0.01 * l; A.rho2[l] = 0.81; A.a1[l] = 0.0; A.a2[l] = 1.0 + 1e-3 * lane;
+        A.rho_u[l] = 0.3 + 1e-3 * lane + 0.01 * l; A.rho2[l] = (VARIANT == 8 || VARIANT == 9) ? -0.81 : 0.81; A.a1[l] = 0.0; A.a2[l] = 1.0 + 1e-3 * lane;
         A.s1[l] = A.s2[l] = A.s3[l] = A.s4[l] = A.s5[l] = A.s6[l] = 0.0;
     }
     const uint64_t base = (uint64_t)tab_g + (VARIANT == 7 ? 0 : (uint64_t)(wave & 15) * (uint64_t)entries_per_wave * 56);
     for (int p = 0; p < passes; ++p) {
         TabPtr e = (TabPtr)base;
-        if (VARIANT == 5 || VARIANT == 6) {  // 48-byte entries, six per wait (the same number of BYTES per wave as the others: 7/6 of the rows)
+        if (VARIANT >= 10) {
+            hybrid_pass<L, VARIANT == 10 || VARIANT == 13 ? 4 : VARIANT == 11 ? 5 : 3>(A, base, lane, entries_per_wave);
+        } else if (VARIANT == 8 || VARIANT == 9) {
+            GTab pl = (GTab)base + (lane & 15);
+            double np1[L], np2[L];
+            for (int l = 0; l < L; ++l) { np1[l] = A.rho2[l] * A.a1[l]; np2[l] = A.rho2[l] * A.a2[l]; }
+            V7 va, vb;
+            vload7(pl, va);
+            const int nbt = entries_per_wave / 16;  // whole batches of 16 entries (112 doubles = 7 lines of 128 bytes)
+            for (int b = 0; b + 1 < nbt; b += 2, pl += 224) {
+                vload7(pl + 112, vb);
+                terms16_dpp<L>(A, np1, np2, va);
+                vload7(pl + 224, va);  // (padded table: the last one reads past the wave's share)
+                terms16_dpp<L>(A, np1, np2, vb);
+            }
+            if (nbt & 1) terms16_dpp<L>(A, np1, np2, va);
+        } else if (VARIANT == 5 || VARIANT == 6) {  // 48-byte entries, six per wait (the same number of BYTES per wave as the others: 7/6 of the rows)
             double c3 = 1e-4, c4 = -1e-4;    // (t3, t4) of the last row of the previous batch: scalar registers
             for (int b = 0; b < entries_per_wave * 7 / 36; ++b, e += 36) {
                 B6 w;
@@ -157,7 +283,7 @@ static void run(const char *name, const double *tab, double *out, int waves, int
     float ms = 0;
     CHECK(hipEventElapsedTime(&ms, t0, t1));
     const double clk = 2.4e9, cyc = ms * 1e-3 * clk;
-    const double ent = (double)entries * passes;                      // entries per wave
+    const double ent = (double)(VARIANT >= 8 ? entries / 16 * 16 : entries) * passes;  // entries per wave
     const double rows = VARIANT == 5 || VARIANT == 6 ? 7.0 / 6.0 : 1.0, ops = VARIANT == 5 || VARIANT == 6 ? 10.0 : 9.0;
     const double valu = ent * rows * ops * 4.0 * L * (waves / 4.0);   // VALU cycles a SIMD must issue
     double chk = 0.0;
@@ -192,6 +318,12 @@ int main() {
         run<5, 1>("48-byte entries, 6 per wait", tab, out, waves, blocks, entries, passes);
         run<6, 2>("48-byte entries, 2 sets", tab, out, waves, blocks, entries, passes);
         run<7, 1>("scalar-cache HITS (5 + touch)", tab, out, waves, blocks, entries, passes);
+        run<8, 1>("DPP row_newbcast, 16 per batch", tab, out, waves, blocks, entries, passes);
+        run<9, 2>("DPP row_newbcast, 2 sets", tab, out, waves, blocks, entries, passes);
+        run<12, 1>("hybrid 3 scalar + 4 DPP", tab, out, waves, blocks, entries, passes);
+        run<10, 1>("hybrid 4 scalar + 3 DPP", tab, out, waves, blocks, entries, passes);
+        run<11, 1>("hybrid 5 scalar + 2 DPP", tab, out, waves, blocks, entries, passes);
+        run<13, 2>("hybrid 4 + 3, 2 sets", tab, out, waves, blocks, entries, passes);
     }
     // one workgroup only: the table path with no other CU on the L2
     run<0, 1>("ONE workgroup: 5 + touch", tab, out, 16, 1, entries, passes);
