@@ -248,6 +248,7 @@ static void build_harmonics(const nyx_hip_gravity_field_t *g, std::vector<HarmEn
         const int nb = rows / HARM_BATCH, rem = rows % HARM_BATCH;  // full batches, then `rem` rows one at a time
         cols[c].start = (int32_t)tab.size();
         cols[c].nb = nb | (rem << 16);
+        cols[c].rows = rows;
         cols[c].scale = (double)c * SQ2;
         cols[c].diag = diag[c];
         col_len[c] = rows;
@@ -278,38 +279,25 @@ static void build_harmonics(const nyx_hip_gravity_field_t *g, std::vector<HarmEn
     }
 }
 
-// The same table in the hybrid-feed layout (devcfg.h, HYB_*): per column the scalar rows {g, t1, t2} padded to whole batches,
-// then - behind all scalar rows - the vector groups [t3..t6][16 rows] in pairs.  Fills cols[c].hs / .hv.
-static void build_hybrid(const std::vector<HarmEntry> &tab, std::vector<ColHdr> &cols, const std::vector<int32_t> &col_len, int n_cols,
-                         std::vector<double> &hyb) {
+// The same table as ONE stream for the hybrid feed (devcfg.h, HYB_*): stream row r = entry r of `tab` (the columns' rows back to
+// back).  Scalar side: {g, t1, t2}, 24 bytes per row; vector side, behind it: groups of sixteen rows, [t3..t6][16].
+static void build_hybrid(const std::vector<HarmEntry> &tab, std::vector<double> &hyb, int64_t &vec_off) {
+    // whole groups, plus two more: the walk fetches one batch / one group past its last row
+    const size_t n = tab.size(), padded = (n + 15) / 16 * 16 + 2 * 16;
+    const HarmEntry z = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     hyb.clear();
-    for (int c = 1; c <= n_cols; ++c) {
-        const int rows = col_len[c], padded = (rows + HYB_ROWS - 1) / HYB_ROWS * HYB_ROWS;
-        cols[c].hs = (int32_t)hyb.size();
-        for (int r = 0; r < padded; ++r) {
-            const HarmEntry z = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            const HarmEntry &e = r < rows ? tab[(size_t)cols[c].start + r] : z;
-            hyb.push_back(e.g); hyb.push_back(e.t1); hyb.push_back(e.t2);
-        }
+    for (size_t r = 0; r < padded; ++r) {
+        const HarmEntry &e = r < n ? tab[r] : z;
+        hyb.push_back(e.g); hyb.push_back(e.t1); hyb.push_back(e.t2);
     }
-    hyb.resize((hyb.size() + HYB_ROWS * HYB_KS + 15) / 16 * 16, 0.0);  // a tail batch may be fetched past the last row; 128-byte aligned groups
-    for (int c = 1; c <= n_cols; ++c) {
-        const int rows = col_len[c], groups = (rows + 15) / 16;
-        cols[c].hv = (int32_t)hyb.size();
-        for (int gq = 0; gq < groups; ++gq)
-            for (int j = 0; j < 4; ++j)
-                for (int l = 0; l < 16; ++l) {
-                    const int r = gq * 16 + l;
-                    double v = 0.0;
-                    if (r < rows) {
-                        const HarmEntry &e = tab[(size_t)cols[c].start + r];
-                        v = j == 0 ? e.t3 : j == 1 ? e.t4 : j == 2 ? e.t5 : e.t6;
-                    }
-                    hyb.push_back(v);
-                }
-    }
-    for (int c = n_cols + 1; c < (int)cols.size(); ++c) { cols[c].hs = 0; cols[c].hv = (int32_t)hyb.size(); }  // (prefetched headers)
-    hyb.resize(hyb.size() + 2 * HYB_GROUP, 0.0);  // the last column's walk prefetches one group further
+    vec_off = (int64_t)hyb.size();  // 3 * padded doubles = a multiple of 48: the vector side starts 128-byte aligned
+    for (size_t g = 0; g < padded / 16; ++g)
+        for (int j = 0; j < 4; ++j)
+            for (int l = 0; l < 16; ++l) {
+                const size_t r = g * 16 + l;
+                const HarmEntry &e = r < n ? tab[r] : z;
+                hyb.push_back(j == 0 ? e.t3 : j == 1 ? e.t4 : j == 2 ? e.t5 : e.t6);
+            }
 }
 
 // Column schedule: wave w walks at most two contiguous ranges — long columns from the low-c end,
@@ -936,11 +924,15 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
     dc.harm_feed = 0;
     if (!tab.empty()) {
         std::vector<double> hyb;
-        build_hybrid(tab, cols, ctx->col_len, dc.n_cols, hyb);
+        int64_t vec_off = 0;
+        build_hybrid(tab, hyb, vec_off);
         HIP_TRY(hipMalloc(&ctx->d_hyb, hyb.size() * sizeof(double)));
         HIP_TRY(hipMemcpy(ctx->d_hyb, hyb.data(), hyb.size() * sizeof(double), hipMemcpyHostToDevice));
         dc.hyb = (uint64_t)ctx->d_hyb;
-        dc.harm_feed = 0;  // (measured: the hybrid feed wins in isolation, tools/harm_microbench.hip, not yet inside the kernel - see DESIGN.md)
+        dc.hyb_v = (uint64_t)(ctx->d_hyb + vec_off);
+        // measured (same box, calibrated): 150x150 cooperative 373 -> 334 ms per 6 250 x 3 h (1.12x); 70x70 alone 1.02-1.11x;
+        // 70x70 cooperative (one column per helper wave and job: the walk's start-up weighs more) 0-2 % slower
+        dc.harm_feed = dc.n_cols > 96 ? 1 : 0;
         if (const char *e = std::getenv("NYX_HIP_HARM_FEED")) dc.harm_feed = std::atoi(e) != 0 ? 1 : 0;
     }
     HIP_TRY(hipMalloc(&ctx->d_cfg, sizeof(DevCfg)));

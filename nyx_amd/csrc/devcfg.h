@@ -113,7 +113,8 @@ struct DevCfg {
     double coop_frac; /* share of the harmonics terms a helper workgroup takes over (cooperative mode) */
     int32_t coop_ok;  /* PRIMARY / HELPER schedules are valid */
     int32_t harm_feed; /* 0: every table operand through the scalar data path (HarmEntry stream); 1: hybrid feed (HYB_* below) */
-    uint64_t hyb;     /* device address of the hybrid-feed table (doubles) */
+    uint64_t hyb;     /* device address of the hybrid-feed stream: scalar side (24 bytes per stream row) */
+    uint64_t hyb_v;   /* its vector side (groups of sixteen stream rows, [t3..t6][16]) */
 };
 
 /* Column header (32 B = one s_load_dwordx8): rows of column c start at htab[start]: `nb & 0xffff` batches of HARM_BATCH
@@ -123,7 +124,7 @@ struct ColHdr {
     int32_t start, nb;
     double scale; /* c * sqrt(2) */
     double diag;  /* A[c][c] */
-    int32_t hs, hv; /* hybrid feed: offsets (in doubles) of the column's scalar rows and of its first vector group */
+    int32_t rows, _pad; /* rows of the column (what `nb` encodes in batches of HARM_BATCH) */
 };
 
 /* Hybrid feed of the same table (plain f64 kernel).  The scalar data path delivers ~4 bytes per cycle and CU whatever the
@@ -131,9 +132,11 @@ struct ColHdr {
  * first HYB_KS values of a row (g, t1, t2) travel as scalars - 24 bytes per row, batches of HYB_ROWS rows = three
  * s_load_dwordx16 - and t3..t6 travel through VECTOR registers: sixteen rows per register pair, lane e of every 16-lane row
  * holding row e's value, and v_fmac_f64_dpp row_newbcast:e multiplies by it - a wave-uniform operand without the scalar path.
- *   scalar side : column c = rows x {g, t1, t2} at hyb[hs], padded to a multiple of HYB_ROWS rows (64-byte aligned batches)
- *   vector side : column c = ceil(rows / 16) groups at hyb[hv]; group = [4 values t3..t6][16 rows] = 64 doubles; the groups of
- *                 consecutive columns are contiguous (one stream per column range, prefetched one group ahead)
+ * The table is ONE stream of rows, the columns' rows back to back (stream row r = entry r of the HarmEntry table).  A wave walks a
+ * range of consecutive columns as a contiguous piece of that stream - no tail batches, no per-column pipeline drain, a fixed
+ * prefetch distance - and finds the column boundaries by counting rows (headers: ColHdr, one column ahead).
+ *   scalar side : 24 bytes per stream row, batches of eight stream rows (64-byte aligned)
+ *   vector side : groups of sixteen stream rows, [4 values t3..t6][16 rows] = 64 doubles
  * Same operations on the same operands in the same order as the scalar stream: bit-identical sums. */
 #define HYB_KS 3
 #define HYB_ROWS 8

@@ -56,6 +56,11 @@ typedef const CAS ColHdr *ColPtr;
 
 #define DEVFN static __device__ __forceinline__
 typedef const __attribute__((address_space(3))) double *LdsCPtr;
+// The control words of a workgroup (LdsMap.ctl) through an LDS-qualified pointer: a volatile access through a GENERIC pointer
+// is left alone by the address-space inference and becomes a flat_load ... sc0 sc1 behind s_waitcnt vmcnt(0) - which also waits
+// for every scratch reload in flight - where ds_read_b32 is meant.
+typedef volatile __attribute__((address_space(3))) int *LdsFlagPtr;
+#define LCTL ((LdsFlagPtr)L.ctl)
 
 DEVFN double norm3(double x, double y, double z) { return sqrt(x * x + y * y + z * z); }
 DEVFN double cube(double x) { return x * (x * x); }  // f64::powi(3)
@@ -246,7 +251,7 @@ template <typename P>
 // needs only that to form the next stage's recursion inputs, the body positions are for the next window.
 // `amask`: the share of this almanac wave when the duty is dealt over several (role fan-out, DEV_ROLE_DCM = the DCM, bit s =
 // body slot s); every wave writes only its own rows of `slot`.
-DEVFN int epoch_data(CfgPtr cfg, P records, int64_t epoch_ns, double *slot, int lane, int amask, volatile int *dcm_flag = nullptr, int dcm_val = 0) {
+DEVFN int epoch_data(CfgPtr cfg, P records, int64_t epoch_ns, double *slot, int lane, int amask, LdsFlagPtr dcm_flag = nullptr, int dcm_val = 0) {
     const double et = ns_to_seconds(epoch_ns);
     int status = NYX_HIP_OK;
     if ((amask & DEV_ROLE_DCM) && (cfg->has_grav || cfg->has_drag || cfg->has_tides)) {  // (ctx_create requires these body-fixed frames to coincide)
@@ -787,7 +792,7 @@ DEVFN uint64_t uniform_u64(uint64_t v) {
 DEVFN ColHdr load_hdr(ColPtr cols, int c) {
     const ColHdr CAS &r = cols[c];
     ColHdr h;
-    h.start = r.start; h.nb = r.nb; h.scale = r.scale; h.diag = r.diag; h.hs = r.hs; h.hv = r.hv;
+    h.start = r.start; h.nb = r.nb; h.scale = r.scale; h.diag = r.diag; h.rows = r.rows; h._pad = 0;
     return h;
 }
 
@@ -878,166 +883,42 @@ DEVFN Partial4T<T> harmonics_core(CfgPtr cfg, HarmPtr htab, ColPtr cols, const i
 // wait, t3..t6 of sixteen rows in four VGPR pairs (one coalesced 128-byte load each: lane e of every 16-lane row holds row e)
 // and picked by the DPP row_newbcast of v_fmac_f64.  Per row: 24 scalar bytes instead of 56, the same nine f64 operations on
 // the same operands in the same order (v_fmac_f64 IS fma(src0, src1, dst)): bit-identical to the scalar stream.
-// Hazards the assembler does not see inside inline asm (GCNHazardRecognizer: a VALU write of a VGPR needs two wait states
-// before a DPP read of it, a VALU write of EXEC five): the DPP operand registers are written by VMEM loads only (ordered by
-// the compiler's s_waitcnt vmcnt, which does see the asm operands), and tools/check_dpp_hazards.py scans the code object.
-typedef const __attribute__((address_space(1))) double *HybVPtr;
-typedef const CAS double *HybSPtr;
-struct HybS { v16i q0, q1, q2; };  // eight rows x {g, t1, t2}
-struct HybV { double r[4]; };      // sixteen rows x {t3, t4, t5, t6}
-DEVFN void hyb_sload(HybSPtr e, HybS &b) {
-    asm volatile(
-        "s_load_dwordx16 %0, %3, 0x0\n\t"
-        "s_load_dwordx16 %1, %3, 0x40\n\t"
-        "s_load_dwordx16 %2, %3, 0x80\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&s"(b.q0), "=&s"(b.q1), "=&s"(b.q2)
-        : "s"(e)
-        : "memory");
-}
-#ifndef HYB_TOUCH
-#define HYB_TOUCH 1
-#endif
-// touch the three 64-byte lines of the NEXT batch (results discarded; the rows of consecutive columns are contiguous, so the last
-// batch of a column touches the first one of the next): its loads then hit the scalar cache.  `sink` as in touch_batch().
-DEVFN void hyb_touch(HybSPtr e, int &sink) {
-    asm volatile(
-        "s_load_dword %0, %1, 0xc0\n\t"
-        "s_load_dword %0, %1, 0x100\n\t"
-        "s_load_dword %0, %1, 0x140"
-        : "+&s"(sink)
-        : "s"(e)
-        : "memory");
-}
-DEVFN void hyb_vload(HybVPtr p, HybV &v) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v.r[j] = p[16 * j];
-}
-template <int DW>
-DEVFN double hyb_sval(const HybS &b) {
-    if constexpr (DW < 16) return HB_D(b.q0, DW);
-    else if constexpr (DW < 32) return HB_D(b.q1, DW - 16);
-    else return HB_D(b.q2, DW - 32);
-}
-template <int K>
-DEVFN void fmac_bc(double &acc, double tab, double x) {  // acc += (row K of tab) * x
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(tab), "v"(x), "n"(K));
-}
-struct HybAcc { double a1, a2, s1, s2, s3, s4, s5, s6; };
-template <int E, int LANE0>
-DEVFN void hyb_term(const HybS &b, const HybV &v, const double rho_u, const double rho2, HybAcc &A) {
-    const double an = __builtin_fma(rho_u, A.a1, -((rho2 * hyb_sval<6 * E>(b)) * A.a2));
-    A.s1 = __builtin_fma(an, hyb_sval<6 * E + 2>(b), A.s1);
-    A.s2 = __builtin_fma(an, hyb_sval<6 * E + 4>(b), A.s2);
-    fmac_bc<LANE0 + E>(A.s3, v.r[0], an);
-    fmac_bc<LANE0 + E>(A.s4, v.r[1], an);
-    fmac_bc<LANE0 + E>(A.s5, v.r[2], an);
-    fmac_bc<LANE0 + E>(A.s6, v.r[3], an);
-    A.a2 = A.a1;
-    A.a1 = an;
-}
-// one batch of the scalar side against half a vector group (LANE0 = 0 / 8): all eight rows, or the first `rem` of them
-template <int LANE0>
-DEVFN void hyb_batch(HybSPtr e, const HybV &v, const double rho_u, const double rho2, HybAcc &A, int &sink) {
-    HybS b;
-    hyb_sload(e, b);
-    if (HYB_TOUCH) hyb_touch(e, sink);
-    hyb_term<0, LANE0>(b, v, rho_u, rho2, A); hyb_term<1, LANE0>(b, v, rho_u, rho2, A);
-    hyb_term<2, LANE0>(b, v, rho_u, rho2, A); hyb_term<3, LANE0>(b, v, rho_u, rho2, A);
-    hyb_term<4, LANE0>(b, v, rho_u, rho2, A); hyb_term<5, LANE0>(b, v, rho_u, rho2, A);
-    hyb_term<6, LANE0>(b, v, rho_u, rho2, A); hyb_term<7, LANE0>(b, v, rho_u, rho2, A);
-}
-template <int LANE0>
-DEVFN void hyb_tail(HybSPtr e, const HybV &v, const int rem, const double rho_u, const double rho2, HybAcc &A, int &sink) {
-    HybS b;
-    hyb_sload(e, b);  // (the scalar rows of a column are padded to whole batches)
-    if (HYB_TOUCH) hyb_touch(e, sink);
-    hyb_term<0, LANE0>(b, v, rho_u, rho2, A);
-    if (rem > 1) {
-        hyb_term<1, LANE0>(b, v, rho_u, rho2, A);
-        if (rem > 2) {
-            hyb_term<2, LANE0>(b, v, rho_u, rho2, A);
-            if (rem > 3) {
-                hyb_term<3, LANE0>(b, v, rho_u, rho2, A);
-                if (rem > 4) {
-                    hyb_term<4, LANE0>(b, v, rho_u, rho2, A);
-                    if (rem > 5) {
-                        hyb_term<5, LANE0>(b, v, rho_u, rho2, A);
-                        if (rem > 6) hyb_term<6, LANE0>(b, v, rho_u, rho2, A);
-                    }
-                }
-            }
-        }
-    }
-}
-// up to sixteen rows against one vector group; returns the rows of the column still to do
-DEVFN int hyb_group(HybSPtr &e, const HybV &v, int left, const double rho_u, const double rho2, HybAcc &A, int &sink) {
-    if (left >= HYB_ROWS) {
-        hyb_batch<0>(e, v, rho_u, rho2, A, sink);
-        e += HYB_ROWS * HYB_KS;
-        left -= HYB_ROWS;
-        if (left >= HYB_ROWS) {
-            hyb_batch<8>(e, v, rho_u, rho2, A, sink);
-            e += HYB_ROWS * HYB_KS;
-            return left - HYB_ROWS;
-        }
-        if (left > 0) hyb_tail<8>(e, v, left, rho_u, rho2, A, sink);
-        return 0;
-    }
-    hyb_tail<0>(e, v, left, rho_u, rho2, A, sink);
-    return 0;
-}
+// Hazards (GCNHazardRecognizer does not look inside inline asm): a VALU write of a VGPR needs two wait states before a DPP
+// read of it, a VALU write of EXEC five - the DPP operand registers are written by VMEM loads only, EXEC is never written;
+// tools/check_dpp_hazards.py scans the code object.
+#include "harm_stream_asm.h"
 
-DEVFN Partial4 harmonics_core_hyb(CfgPtr cfg, ColPtr cols, const int wave, const int sched, const int lane, double zr, double zi, double rho_u,
-                                  double rho, double inv_rho) {
+// The column shares of one wave (schedule `sched`) over the hybrid stream: per range of consecutive columns ONE pass of the
+// generated loop (tools/gen_harm_stream.py -> harm_stream_asm.h).  Out of line like harmonics_partial, and on its own (the
+// scalar loop must not carry this one's registers: with both in one function the callers' save / restore cost 6 % of the run).
+static __device__ __attribute__((noinline)) Partial4 harmonics_stream(uint64_t cfg_u, uint64_t cols_u, int wave_v, int sched_v, double zr,
+                                                                    double zi, double rho_u, double rho, double inv_rho) {
+    CfgPtr cfg = (CfgPtr)uniform_u64(cfg_u);
+    ColPtr cols = (ColPtr)uniform_u64(cols_u);
+    const int wave = __builtin_amdgcn_readfirstlane(wave_v);
+    const int sched = __builtin_amdgcn_readfirstlane(sched_v);
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
     double px = 0.0, py = 0.0, pz = 0.0, pw = 0.0;
     const double rho2 = rho * rho;
     const CAS DevSched &sd = cfg->sched[sched];
     const int nr = sd.n_ranges[wave];
-    const uint64_t hyb_u = cfg->hyb;
-    HybSPtr hs0 = (HybSPtr)hyb_u;
-    HybVPtr hv0 = (HybVPtr)hyb_u + (lane & 15);
+    const uint64_t hs0 = cfg->hyb, hv0 = cfg->hyb_v;
+    const int voff = (lane & 15) * 8;
     for (int q = 0; q < nr; ++q) {
         const int c0 = sd.range_c0[wave][q];
-        const int cnt = sd.range_cnt[wave][q];
-        ColHdr hd = load_hdr(cols, c0);
-        // The vector groups of consecutive columns are contiguous: one stream per range, walked with a prefetch distance of exactly
-        // one group whatever the column lengths - the group after the one being evaluated is always in flight, in the other
-        // register set (`par` = the set that holds the current group; a uniform branch picks the code for it).
-        HybVPtr pv = hv0 + hd.hv;
-        HybV va, vb;
-        hyb_vload(pv, va);
-        int par = 0;
+        int cols_left = sd.range_cnt[wave][q];
+        const int srow = cols[c0].start;  // stream row of the range's first row (= its index in the entry table)
+        // start at the batch that holds it; the rows in front of it (the previous column's last ones) run through the recursion
+        // with a zero state - every sum stays an exact zero - and are dropped when the first column is started
+        const uint64_t e = hs0 + (uint64_t)(srow & ~7) * (HYB_KS * 8);
+        const uint64_t vp = hv0 + (uint64_t)(srow >> 4) * (HYB_GROUP * 8);
+        const uint64_t hp = (uint64_t)cols + (uint64_t)c0 * sizeof(ColHdr);
         double rc, ic;
         cpow_uniform(zr, zi, c0 - 1, rc, ic);
-        for (int c = c0; c < c0 + cnt; ++c) {
-            const ColHdr hn = load_hdr(cols, c + 1);
-            HybSPtr e = hs0 + hd.hs;
-            int left = (hd.nb & 0xffff) * HARM_BATCH + (hd.nb >> 16);  // rows of the column
-            HybAcc A = {0.0, inv_rho * hd.diag, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            int sink = 0;
-            do {
-                pv += HYB_GROUP;
-                if (par == 0) {
-                    hyb_vload(pv, vb);
-                    left = hyb_group(e, va, left, rho_u, rho2, A, sink);
-                } else {
-                    hyb_vload(pv, va);
-                    left = hyb_group(e, vb, left, rho_u, rho2, A, sink);
-                }
-                par ^= 1;
-            } while (left > 0);
-            if (HYB_TOUCH) touch_done(sink);
-            const double sc = rho * hd.scale;  // rho * c * sqrt(2)
-            px = gfma(sc, gfma(rc, A.s1, gmul(ic, A.s2)), px);
-            py = gfma(sc, gfma(rc, A.s2, -(gmul(ic, A.s1))), py);
-            pz = gfma(rho, gfma(rc, A.s3, gmul(ic, A.s4)), pz);
-            pw = pw - gfma(rc, A.s5, gmul(ic, A.s6));
-            const double t = gmul(rc, zr) - gmul(ic, zi);
-            ic = gmul(rc, zi) + gmul(ic, zr);
-            rc = t;
-            hd = hn;
-        }
+        int left = srow & 7, first = 1, sink;
+        const int low_half = (srow & 8) == 0 ? 1 : 0;
+        HARM_STREAM_ASM(e, vp, hp, voff, left, cols_left, first, low_half, sink, rho_u, rho2, rho, inv_rho, zr, zi, px, py, pz, pw, rc, ic);
+        (void)sink;
     }
     Partial4 r = {px, py, pz, pw};
     return r;
@@ -1051,7 +932,6 @@ static __device__ __attribute__((noinline)) Partial4 harmonics_partial(uint64_t 
     ColPtr cols = (ColPtr)uniform_u64(cols_u);
     const int wave = __builtin_amdgcn_readfirstlane(wave_v);
     const int sched = __builtin_amdgcn_readfirstlane(sched_v);
-    if (cfg->harm_feed) return harmonics_core_hyb(cfg, cols, wave, sched, (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), zr, zi, rho_u, rho, inv_rho);
     return harmonics_core<double>(cfg, htab, cols, wave, sched, zr, zi, rho_u, rho, inv_rho);
 }
 
@@ -1082,7 +962,7 @@ static __device__ __attribute__((noinline)) void harmonics_partial_dual(uint64_t
 #define QSLOT (4 * DEV_LANES + 4 * (DEV_LANES / 4))
 typedef __attribute__((address_space(3))) double *LdsPtr;
 static __device__ __attribute__((noinline)) void harmonics_partial_d1(uint64_t cfg_u, uint64_t htab_u, uint64_t cols_u, int wave_v,
-                                                                    LdsCPtr inbQ, LdsPtr outQ, int lane, volatile int *gate, int need_v) {
+                                                                    LdsCPtr inbQ, LdsPtr outQ, int lane, LdsFlagPtr gate, int need_v) {
     CfgPtr cfg = (CfgPtr)uniform_u64(cfg_u);
     HarmPtr htab = (HarmPtr)uniform_u64(htab_u);
     ColPtr cols = (ColPtr)uniform_u64(cols_u);
@@ -1192,7 +1072,8 @@ static __device__ __attribute__((noinline)) Partial4 coop_fallback(uint64_t cfg_
                  v3 = inb[3 * DEV_LANES + lane], v4 = inb[4 * DEV_LANES + lane];
     Partial4 o = {0.0, 0.0, 0.0, 0.0};
     for (int hw = 0; hw < DEV_MAX_WAVES; ++hw) {
-        const Partial4 p = harmonics_partial(cfg_u, htab_u, cols_u, hw, DEV_SCHED_HELPER, v0, v1, v2, v3, v4);
+        const Partial4 p = ((CfgPtr)uniform_u64(cfg_u))->harm_feed ? harmonics_stream(cfg_u, cols_u, hw, DEV_SCHED_HELPER, v0, v1, v2, v3, v4)
+                                                                     : harmonics_partial(cfg_u, htab_u, cols_u, hw, DEV_SCHED_HELPER, v0, v1, v2, v3, v4);
         o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
     }
     return o;
@@ -1215,7 +1096,7 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
     double *part = (double *)smem;                                 // [2][16][4][64]
     double *inl = part + 2 * DEV_MAX_WAVES * 4 * DEV_LANES;        // [2][5][64]
     int *ctl = (int *)(inl + 2 * 5 * DEV_LANES);
-    volatile int *ready = ctl, *answered = ctl + 2, *jown = ctl + 4, *jseq = ctl + 6;
+    const LdsFlagPtr ready = (LdsFlagPtr)ctl, answered = (LdsFlagPtr)ctl + 2, jown = (LdsFlagPtr)ctl + 4, jseq = (LdsFlagPtr)ctl + 6;
     int *cnt = ctl + 8;
     const int answer_wave = (int)(blockDim.x / DEV_LANES) - 1;
     const int n_col_waves = answer_wave - 1;
@@ -1317,7 +1198,8 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
             const double *il = inl + s * 5 * DEV_LANES;
             const double v0 = il[0 * DEV_LANES + lane], v1 = il[1 * DEV_LANES + lane], v2 = il[2 * DEV_LANES + lane],
                          v3 = il[3 * DEV_LANES + lane], v4 = il[4 * DEV_LANES + lane];
-            const Partial4 pr = harmonics_partial((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, DEV_SCHED_HELPER, v0, v1, v2, v3, v4);
+            const Partial4 pr = cfg->harm_feed ? harmonics_stream((uint64_t)cfg, (uint64_t)cols, wave, DEV_SCHED_HELPER, v0, v1, v2, v3, v4)
+                                               : harmonics_partial((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, DEV_SCHED_HELPER, v0, v1, v2, v3, v4);
             double *pp = ps + wave * 4 * DEV_LANES;
             pp[0 * DEV_LANES + lane] = pr.x; pp[1 * DEV_LANES + lane] = pr.y; pp[2 * DEV_LANES + lane] = pr.z; pp[3 * DEV_LANES + lane] = pr.w;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1635,7 +1517,7 @@ DEVFN bool stm_update_q(double *phi, double h, const double *sacc, int lane, int
 // (LDS pointers are passed as such: through generic pointers every access pays an address-space test)
 static __device__ __attribute__((noinline)) void phase_c_quad(LdsCPtr pertD, LdsCPtr partD, LdsCPtr qpre,
                                                             LdsCPtr ysl, LdsPtr sacc, LdsPtr kb, int kb_str, double b_i, int nw_v,
-                                                            int flags_v, int lane, int ql, volatile int *gate, int gate_val_v,
+                                                            int flags_v, int lane, int ql, LdsFlagPtr gate, int gate_val_v,
                                                             int64_t *pslot = nullptr) {
     const int64_t pc0 = pslot ? (int64_t)__builtin_readcyclecounter() : 0;
     const int nw = __builtin_amdgcn_readfirstlane(nw_v);
@@ -1879,7 +1761,7 @@ size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles, int stm, int reuse_fie
 
 // One role (or a merged set of roles) of the workgroup.  Every instantiation executes the SAME sequence of
 // workgroup barriers; only the work between them differs, so that each role keeps just its own state live.
-template <bool INTEG, bool ALMANAC, bool PERT, bool STM, bool QUAD = false>
+template <bool INTEG, bool ALMANAC, bool PERT, bool STM, bool QUAD = false, bool PIPE = false>
 DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPtr htab, ColPtr cols,
                      const double *__restrict__ records, const LdsMap &L, const int lane, const int wave, const int nw) {
     double *const kbuf = L.kbuf;
@@ -1976,7 +1858,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     // cooperative mode (see above): the integrator owns the conversation with the helper
     CoopBox *const cbox = bt.coop_box + blockIdx.x;
     const int coop_widx = bt.coop_sets > 0 ? ((int)blockIdx.x % bt.coop_sets) * COOP_SET + (int)blockIdx.x / bt.coop_sets : 0;
-    bool coop_on = !STM && ((volatile int *)L.ctl)[1] != 0;
+    bool coop_on = !STM && LCTL[1] != 0;
     const bool coop_started = coop_on;
     uint32_t coop_seq = 0;
     bool coop_drop = false;  // fallback taken: the workers go back to DEV_SCHED_SOLO from the next evaluation on
@@ -1989,7 +1871,10 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     // has written, ctl[3] = number of stages whose partial sums the integrator has folded (a worker does not overwrite
     // its slot before that), ctl[4] = last stage whose velocity is published (drag is the one position-AND-velocity term
     // of the perturbation wave).  Same arithmetic in the same order as the plain loop: bit-identical results.
-    const bool pipe = (!STM || QUAD) && !(INTEG && (ALMANAC || PERT)) && cfg->pipe != 0 && has_grav;
+    // (a template parameter: the two stage loops share this function, and compiled together each carries the other's live ranges;
+    //  propagate_body() picks the instantiation from cfg->pipe)
+    static_assert(!PIPE || ((!STM || QUAD) && !(INTEG && (ALMANAC || PERT))), "the pipelined stage loop needs the integrator in a wave of its own");
+    constexpr bool pipe = PIPE;
     // Epoch data carried between attempts (almanac wave, host-enabled when the stage count is even and LDS has room).
     // Stage 0 of the next attempt sits at t + h if this attempt is accepted and at t again if it is rejected: the first
     // is computed by the almanac wave in the LAST window (where it has no next stage to prepare; buffer 0 is free by
@@ -2064,7 +1949,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
         }
         if (!spec_now) {
         __syncthreads();  // B0: attempt published (or exit requested)
-        if (((volatile int *)L.ctl)[0]) break;
+        if (LCTL[0]) break;
         }
 
         // prologue: epoch data of stage 0
@@ -2130,7 +2015,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     }
                     if (has_drag) {  // the perturbation wave is already in this stage's window; drag is the one term that wants the velocity
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                        if (lane == 0) ((volatile int *)L.ctl)[4] = i + 1;
+                        if (lane == 0) LCTL[4] = i + 1;
                     }
                     // (the almanac wave finished this stage's data before the barrier this wave has just passed)
                     if (need_almanac && !(i == 0 && keep_k0)) {  // (a rejected lane's stage 0 is not evaluated: its epoch data at t + h does not count)
@@ -2227,7 +2112,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 // that is stage 0 of the next attempt should this one be accepted: epoch + seconds_to_ns(h), instance.rs:401
                 if (spec_now && i == 0) {  // epoch and step of this attempt: step control ran beside the start of this window
                     int spin = 0;
-                    while (((volatile int *)L.ctl)[5] != att && ++spin < 4000000) __builtin_amdgcn_s_sleep(4);
+                    while (LCTL[5] != att && ++spin < 4000000) __builtin_amdgcn_s_sleep(4);
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 }
                 const double c_next = last_stage ? 1.0 : C_COEF(i + 1);
@@ -2237,13 +2122,13 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 int st = NYX_HIP_OK;
                 if (!dbg_skip_serial || i == 0)  // (timing switch: reuse the data of stages 0/1)
                 {
-                    volatile int *const fl = (pipe && (!last_stage || spec) && (amask & DEV_ROLE_DCM)) ? (volatile int *)L.ctl + 2 : nullptr;
+                    const LdsFlagPtr fl = (pipe && (!last_stage || spec) && (amask & DEV_ROLE_DCM)) ? LCTL + 2 : nullptr;
                     st = rec_in_lds ? epoch_data(cfg, (const double *)L.rec, ep, edn, lane, amask, fl, i + 1) : epoch_data(cfg, records, ep, edn, lane, amask, fl, i + 1);
                 }
                 my_edst[((i + 1) & 1) * DEV_LANES + lane] = st;
                 if (pipe && (!last_stage || spec) && (amask & DEV_ROLE_DCM)) {  // tell the integrator wave (which publishes the inputs of stage i+1 inside this window)
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    if (lane == 0) ((volatile int *)L.ctl)[2] = i + 1;
+                    if (lane == 0) LCTL[2] = i + 1;
                 }
             }
             if (PERT && (has_pm || has_srp || has_drag || has_tides)) {
@@ -2273,7 +2158,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 if (has_drag && do_srp) {
                     if (pipe && (i > 0 || spec_now)) {  // velocity of this stage: written by phase A, which runs beside this window
                         int spin = 0;
-                        while (((volatile int *)L.ctl)[4] != i + 1 && ++spin < 4000000) __builtin_amdgcn_s_sleep(4);
+                        while (LCTL[4] != i + 1 && ++spin < 4000000) __builtin_amdgcn_s_sleep(4);
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     }
                     const double vv[3] = {ysp[3 * DEV_LANES + lane], ysp[4 * DEV_LANES + lane], ysp[5 * DEV_LANES + lane]};
@@ -2340,7 +2225,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     if (need_almanac) {  // the almanac wave writes the DCM of stage i+1 first thing in this window
                         // (bounded: a protocol error must end as a failed run, never as a hung GPU)
                         int spin = 0;
-                        while (((volatile int *)L.ctl)[2] != i + 1 && ++spin < 4000000) __builtin_amdgcn_s_sleep(4);
+                        while (LCTL[2] != i + 1 && ++spin < 4000000) __builtin_amdgcn_s_sleep(4);
                         if (spin >= 4000000) st_att = NYX_HIP_ERR_NAN;
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                     }
@@ -2413,24 +2298,26 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             if (STM && QUAD) {
                 if (has_grav && cfg->sched[DEV_SCHED_SOLO].n_ranges[wave] > 0)  // (a wave without columns keeps the zeros of its slot)
                     harmonics_partial_d1((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, (LdsCPtr)((pipe && (i & 1)) ? L.inb2 : L.inbD),
-                                         (LdsPtr)(L.partD + wave * QSLOT), lane, (volatile int *)L.ctl + 3, pipe ? i : 0);
+                                         (LdsPtr)(L.partD + wave * QSLOT), lane, LCTL + 3, pipe ? i : 0);
             } else if (STM && has_grav)
                 harmonics_partial_dual((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, L.inbD, L.partD + wave * 16 * DEV_LANES, lane);
             if (!STM && has_grav && !dbg_skip_harm) {
                 // (ctl[1] is written before the barrier that precedes this read: B1 for stage 0, B2 of the previous stage otherwise;
                 //  the integrator wave itself carries no columns in a pipelined workgroup and uses whatever it just wrote)
-                const int sched = ((volatile int *)L.ctl)[1] ? DEV_SCHED_PRIMARY : DEV_SCHED_SOLO;
+                const int sched = LCTL[1] ? DEV_SCHED_PRIMARY : DEV_SCHED_SOLO;
                 const double *const inbw = (pipe && (i & 1)) ? L.inb2 : L.inb;
                 Partial4 pr = {0.0, 0.0, 0.0, 0.0};
-                if (!(pipe && INTEG))
-                    pr = harmonics_partial((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, sched, inbw[0 * DEV_LANES + lane],
-                                           inbw[1 * DEV_LANES + lane], inbw[2 * DEV_LANES + lane], inbw[3 * DEV_LANES + lane],
-                                           inbw[4 * DEV_LANES + lane]);
+                if (!(pipe && INTEG)) {
+                    const double v0 = inbw[0 * DEV_LANES + lane], v1 = inbw[1 * DEV_LANES + lane], v2 = inbw[2 * DEV_LANES + lane],
+                                 v3 = inbw[3 * DEV_LANES + lane], v4 = inbw[4 * DEV_LANES + lane];
+                    pr = cfg->harm_feed ? harmonics_stream((uint64_t)cfg, (uint64_t)cols, wave, sched, v0, v1, v2, v3, v4)
+                                        : harmonics_partial((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, sched, v0, v1, v2, v3, v4);
+                }
                 px = pr.x; py = pr.y; pz = pr.z; pw = pr.w;
                 if (!INTEG) {
                     if (pipe && (i > 0 || spec_now)) {  // the integrator folds the partials of stage i-1 at the start of this window
                         int spin = 0;
-                        while (((volatile int *)L.ctl)[3] < fold_base + i && ++spin < 4000000) __builtin_amdgcn_s_sleep(1);
+                        while (LCTL[3] < fold_base + i && ++spin < 4000000) __builtin_amdgcn_s_sleep(1);
                     }
                     double *pp = L.part + wave * 4 * DEV_LANES;
                     pp[0 * DEV_LANES + lane] = px; pp[1 * DEV_LANES + lane] = py;
@@ -2458,7 +2345,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 __syncthreads();  // B2: partials / perturbations / next epoch data published
                 PROF_ADD(6);
             }
-            if (spec_now && i == 0 && ((volatile int *)L.ctl)[0]) {  // every lane had finished: the exit, one window late
+            if (spec_now && i == 0 && LCTL[0]) {  // every lane had finished: the exit, one window late
                 leave = true;
                 break;
             }
@@ -2479,7 +2366,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     }
                     if (pipe) {  // the partial sums of stage i are in registers: the workers may overwrite their slots
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        if (lane == 0) ((volatile int *)L.ctl)[3] = fold_base + i + 1;
+                        if (lane == 0) LCTL[3] = fold_base + i + 1;
                     }
                     px += coop_x; py += coop_y; pz += coop_z; pw += coop_w;  // + the helper's columns (0 when working alone)
                     if (coop_drop) {  // (between B2 and the next B1: no worker is reading ctl[1])
@@ -2505,7 +2392,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                                  (LdsCPtr)((pipe && (i & 1)) ? L.ys2 : L.ys), (LdsPtr)L.sacc,
                                  (LdsPtr)(kbuf + (i * 6) * KB_STR + kb_li), KB_STR, B_COEF(i), nw,
                                  ((has_pm || has_tides) ? PC_HAS_PM : 0) | (has_grav ? PC_HAS_GRAV : 0) | (has_srp ? PC_HAS_SRP : 0), lane, ql,
-                                 (volatile int *)L.ctl + 3, pipe ? i + 1 : 0, prof_on ? bt.prof + 16 * 8 : nullptr);
+                                 LCTL + 3, pipe ? i + 1 : 0, prof_on ? bt.prof + 16 * 8 : nullptr);
                 } else if (STM) {
                     // dual path (dual_eom, spacecraft.rs:312-363): f(x) and A = df/dx; the derivative written to k_i is
                     // the dual path's real part, as in the reference's STM branch (spacecraft.rs:208-224)
@@ -2684,7 +2571,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             if (spec) {
                 begin_attempt(c);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                if (lane == 0) ((volatile int *)L.ctl)[5] = att + 1;  // the almanac wave waits for this word before it reads the new epoch and step
+                if (lane == 0) LCTL[5] = att + 1;  // the almanac wave waits for this word before it reads the new epoch and step
                 h_next = c.h;
             }
             if (accept && bt.traj_cap > 0 && wr && !ev_hit) {  // chan.send(self.state) after every accepted step, final one included
@@ -2739,7 +2626,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     }
 }
 
-template <bool STM, bool QUAD = false>
+template <bool STM, bool QUAD = false, bool W16 = true>  // W16: sixteen-wave workgroups (the only shape with a pipelined stage loop)
 DEVFN void propagate_body(const DevBatch &bt, const DevCfg *cfg_g, const HarmEntry *htab_g, const ColHdr *cols_g,
                           const double *__restrict__ records, char *smem) {
     const int lane = threadIdx.x & (DEV_LANES - 1);
@@ -2791,6 +2678,18 @@ DEVFN void propagate_body(const DevBatch &bt, const DevCfg *cfg_g, const HarmEnt
 
 
     // ---- role dispatch (wave-uniform): the host deals the duties (cfg->role_kind / role_mask, see build_schedule)
+    if constexpr ((!STM || QUAD) && W16) {
+        if (cfg->pipe != 0 && cfg->has_grav != 0 && cfg->role_kind[wave] != DEV_ROLE_ALL) {  // pipelined stage loop (uniform)
+            switch (cfg->role_kind[wave]) {
+            case DEV_ROLE_INTEG: role_loop<true, false, false, STM, QUAD, true>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw); break;
+            case DEV_ROLE_ALMANAC: role_loop<false, true, false, STM, QUAD, true>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw); break;
+            case DEV_ROLE_PERT: role_loop<false, false, true, STM, QUAD, true>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw); break;
+            case DEV_ROLE_ALMANAC_PERT: role_loop<false, true, true, STM, QUAD, true>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw); break;
+            default: role_loop<false, false, false, STM, QUAD, true>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw); break;
+            }
+            return;
+        }
+    }
     switch (cfg->role_kind[wave]) {
     case DEV_ROLE_ALL: role_loop<true, true, true, STM, QUAD>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw); break;
     case DEV_ROLE_INTEG: role_loop<true, false, false, STM, QUAD>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw); break;
@@ -2817,7 +2716,7 @@ DEVFN void propagate_body(const DevBatch &bt, const DevCfg *cfg_g, const HarmEnt
 NYX_KERNEL(nyx_propagate_kernel, DEV_MAX_WAVES *DEV_LANES, false)
 #endif
 #if NYX_EMIT & NYX_EMIT_PLAIN8
-NYX_KERNEL(nyx_propagate_kernel_w8, 8 * DEV_LANES, false)
+NYX_KERNEL(nyx_propagate_kernel_w8, 8 * DEV_LANES, false, false, false)
 #endif
 #if NYX_EMIT & NYX_EMIT_STM
 NYX_KERNEL(nyx_propagate_kernel_stm, DEV_MAX_WAVES_STM *DEV_LANES, true)
@@ -2826,7 +2725,7 @@ NYX_KERNEL(nyx_propagate_kernel_stm, DEV_MAX_WAVES_STM *DEV_LANES, true)
 NYX_KERNEL(nyx_propagate_kernel_stmq, DEV_MAX_WAVES *DEV_LANES, true, true)
 #endif
 #if NYX_EMIT & NYX_EMIT_STMQ8
-NYX_KERNEL(nyx_propagate_kernel_stmq_w8, 8 * DEV_LANES, true, true)
+NYX_KERNEL(nyx_propagate_kernel_stmq_w8, 8 * DEV_LANES, true, true, false)
 #endif
 
 #if NYX_EMIT & NYX_EMIT_PLAIN16

@@ -58,10 +58,11 @@ __global__ __launch_bounds__(1024) void k(const double *in, double *out, long lo
     if (lane == 0) cyc[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = c1 - c0;
 }
 
+static int g_blocks = 256;
 template <int MODE>
 static void run(const char *name, int nops, const double *in, double *out, long long *cyc) {
-    for (int waves : {4, 8, 16}) {
-        const int iters = 20000, blocks = 256;
+    for (int waves : {4, 16}) {
+        const int iters = 200000, blocks = g_blocks;
         hipEvent_t e0, e1;
         CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
         k<MODE><<<blocks, waves * 64>>>(in, out, cyc, 100);
@@ -75,12 +76,13 @@ static void run(const char *name, int nops, const double *in, double *out, long 
         long long h[16];
         CHECK(hipMemcpy(h, cyc, sizeof(long long) * waves, hipMemcpyDeviceToHost));
         // wall cycles at 2.4 GHz per op and SIMD: ms * 2.4e6 / (iters * nops * waves/4)
-        printf("%-34s waves/SIMD %d: %.2f SIMD cycles per op (events, 2.4 GHz), wave-0 counter %lld per iteration\n", name, waves / 4,
+        printf("[%3d workgroups] %-30s waves/SIMD %d: %.2f SIMD cycles per op (events, 2.4 GHz), wave-0 counter %lld per iteration\n", blocks, name, waves / 4,
                ms * 2.4e6 / ((double)iters * nops * (waves / 4)), h[0] / iters);
     }
 }
 
-int main() {
+int main(int argc, char **argv) {
+    if (argc > 1) g_blocks = atoi(argv[1]);
     double h[256];
     for (int i = 0; i < 256; ++i) h[i] = 1e-3 * (i + 1);
     double *in, *out; long long *cyc;
