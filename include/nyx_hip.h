@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define NYX_HIP_ABI_VERSION 3
+#define NYX_HIP_ABI_VERSION 4
 
 /* ---- IntegratorMethod: nyx-core/src/propagators/rk_methods/mod.rs:65-79 ---- */
 enum nyx_hip_method {
@@ -200,6 +200,50 @@ typedef struct nyx_hip_solid_tides {
     int32_t _pad;
 } nyx_hip_solid_tides_t;
 
+/* ---- Execution tuning (ABI v4).  Everything that used to be a process environment variable: a host behind the C-ABI cannot
+ * reason about the environment, and several of these change the ORDER in which the harmonics are summed, i.e. the last bits
+ * of the result.  config.tuning = NULL selects the defaults (every field "auto").
+ *
+ * Reproducibility contract.  `schedule` fixes how the harmonics columns are dealt over the waves of a workgroup, hence the
+ * summation order:
+ *   NYX_HIP_SCHED_MODEL (default)  a cost model keyed on the workgroup shape and the force model only: the same config gives
+ *                                  the same bits in every context, process, rank and on every box.  No hidden launches.
+ *   NYX_HIP_SCHED_CALIBRATED       the first launch of every workgroup shape runs up to four short launches of the workload's
+ *                                  own first steps (it SYNCHRONISES the stream and copies a few hundred bytes back: not
+ *                                  graph-capturable) and deals the columns by the measured cycle counts: a few percent
+ *                                  faster, and context-dependent in the last bits (~0.05 mm after 45 min).
+ *   NYX_HIP_SCHED_EXPLICIT         wave_weights[] / role_duties[] as given.
+ * `deterministic` = 1 additionally makes every trajectory's bits independent of the BATCH it is launched in (batch size,
+ * position in the batch, rank-sharding): the cooperative mode - whose column split follows the ratio of idle CUs to
+ * workgroups - is switched off.  The reference is reproducible per (seed, index) in exactly this sense
+ * (mc/montecarlo.rs:208-224, 290-295).  Cost: none for ensembles that fill the chip (>= 64 trajectories x CUs), the
+ * cooperative gain (~1.27x at 10 000 trajectories on 256 CUs) below that. */
+enum nyx_hip_schedule { NYX_HIP_SCHED_MODEL = 0, NYX_HIP_SCHED_CALIBRATED = 1, NYX_HIP_SCHED_EXPLICIT = 2 };
+typedef struct nyx_hip_tuning {
+    int32_t schedule;          /* enum nyx_hip_schedule */
+    int32_t deterministic;     /* 1: bits per trajectory independent of the batch (cooperative mode off) */
+    int32_t cooperative;       /* -1 auto (on when the launch has fewer workgroups than CUs), 0 off, 1 on */
+    int32_t pipelined;         /* -1 auto, 0 two-barrier stage loop, 1 pipelined stage loop (sixteen-wave workgroups) */
+    int32_t chained_attempts;  /* -1 auto, 0 off, 1 speculative stage 0 of the next attempt */
+    int32_t epoch_data_reuse;  /* -1 auto, 0 off (only read when the attempts are not chained) */
+    int32_t role_fanout;       /* -1 auto, 0 off, 1 almanac / perturbation duties dealt over several waves */
+    int32_t merge_roles;       /* 0 / 1: almanac and perturbation duties share one wave */
+    int32_t stm_quad;          /* -1 by ensemble size, 0 64 trajectories x 3-partial duals, 1 quad layout */
+    int32_t harmonics_feed;    /* -1 auto, 0 scalar stream, 1 hybrid scalar + DPP stream */
+    int32_t coop_max_columns;  /* 0 auto: columns a helper workgroup may take */
+    int32_t coop_mute;         /* test switch: helpers never answer (exercises the owner's fallback) */
+    int32_t profile;           /* 1: in-kernel cycle accounting of workgroup 0 (nyx_hip_debug_profile) */
+    int32_t debug_flags;       /* timing-only switches (0x100 skip the serial role work, 0x200 skip the harmonics): WRONG RESULTS */
+    double coop_fraction;      /* 0 auto: share of the harmonics terms a helper takes */
+    double coop_helper_ratio;  /* 0 auto: helper workgroups per trajectory-owning workgroup */
+    double column_start_cost;  /* < 0 auto: rows a column's start is charged in the schedule */
+    double role_duties[3];     /* all 0: model.  Integrator, almanac, perturbation duty in harmonics-term units */
+    double age_weights[4];     /* NYX_HIP_SCHED_EXPLICIT, all 0: unused.  One speed weight per SIMD age class */
+    double wave_weights[16];   /* NYX_HIP_SCHED_EXPLICIT: per-wave speed weights (all 0: age_weights) */
+} nyx_hip_tuning_t;
+/* all "auto" */
+#define NYX_HIP_TUNING_DEFAULT {0, 0, -1, -1, -1, -1, -1, 0, -1, -1, 0, 0, 0, 0, 0.0, 0.0, -1.0, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}, {0.0}}
+
 /* PropagatorConfig{dynamics, method, options}: dynamics/sequence/config.rs:96-169.
  * Model order is the reference's `Dynamics::build` order: two-body, point
  * masses, gravity field, solid tides; then SRP, drag. */
@@ -236,6 +280,7 @@ typedef struct nyx_hip_config {
      * that record trajectories, search events or map covariances refuse a swap (NYX_HIP_RC_UNSUPPORTED). */
     int32_t state_frame_body;
     int32_t _pad_cfg;
+    const nyx_hip_tuning_t *tuning; /* NULL => NYX_HIP_TUNING_DEFAULT (ABI v4) */
 } nyx_hip_config_t;
 
 /* flags */
@@ -466,9 +511,13 @@ int32_t nyx_hip_predict_until(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, cons
  * 64-trajectory workgroup (0 = pick automatically from n). */
 int32_t nyx_hip_ctx_set_column_waves(nyx_hip_ctx *ctx, int32_t waves);
 
+/* Changes the launch-time part of the tuning between launches (cooperative mode, determinism, schedule kind and explicit weights,
+ * helper ratio / share, profiling); the create-time part (stage loop, role layout, table feed) must equal the context's. */
+int32_t nyx_hip_ctx_set_tuning(nyx_hip_ctx *ctx, const nyx_hip_tuning_t *tuning);
+
 /* Number of helper workgroups of the last propagate launch on this ctx (0 = every workgroup worked alone).  Cooperative
- * mode is chosen automatically when the 64-trajectory workgroups leave CUs idle (propagate_kernel.hip); NYX_HIP_COOP=0
- * in the environment disables it. */
+ * mode is chosen automatically when the 64-trajectory workgroups leave CUs idle (propagate_kernel.hip);
+ * tuning.cooperative = 0 or tuning.deterministic = 1 disables it. */
 int32_t nyx_hip_last_coop_helpers(nyx_hip_ctx *ctx);
 
 /* Elapsed device time (ms) of the kernels launched by the last propagate call on

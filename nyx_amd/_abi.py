@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_CHAIN = 4
 MAX_BODIES = 8
 MAX_SEGMENTS = 16
@@ -138,6 +138,38 @@ class SolidTidesC(C.Structure):
     ]
 
 
+SCHED_MODEL, SCHED_CALIBRATED, SCHED_EXPLICIT = 0, 1, 2
+
+
+class Tuning(C.Structure):
+    """``nyx_hip_tuning_t`` (ABI v4): every execution switch of the library; defaults = all "auto" (``Tuning()``).
+    ``schedule``: SCHED_MODEL (default, process-independent), SCHED_CALIBRATED (measured at the first launch) or
+    SCHED_EXPLICIT (``wave_weights``); ``deterministic=1``: bits per trajectory independent of the batch."""
+    _fields_ = [
+        ("schedule", C.c_int32), ("deterministic", C.c_int32), ("cooperative", C.c_int32), ("pipelined", C.c_int32),
+        ("chained_attempts", C.c_int32), ("epoch_data_reuse", C.c_int32), ("role_fanout", C.c_int32), ("merge_roles", C.c_int32),
+        ("stm_quad", C.c_int32), ("harmonics_feed", C.c_int32), ("coop_max_columns", C.c_int32), ("coop_mute", C.c_int32),
+        ("profile", C.c_int32), ("debug_flags", C.c_int32),
+        ("coop_fraction", C.c_double), ("coop_helper_ratio", C.c_double), ("column_start_cost", C.c_double),
+        ("role_duties", C.c_double * 3), ("age_weights", C.c_double * 4), ("wave_weights", C.c_double * 16),
+    ]
+
+    def __init__(self, **kw):
+        super().__init__()
+        self.cooperative = self.pipelined = self.chained_attempts = self.epoch_data_reuse = self.role_fanout = -1
+        self.stm_quad = self.harmonics_feed = -1
+        self.column_start_cost = -1.0
+        for k, v in kw.items():
+            if k in ("role_duties", "age_weights", "wave_weights"):
+                arr = getattr(self, k)
+                for i, x in enumerate(v):
+                    arr[i] = float(x)
+            else:
+                if not hasattr(self, k):
+                    raise AttributeError(f"nyx_hip_tuning_t has no field {k!r}")
+                setattr(self, k, v)
+
+
 class Config(C.Structure):
     _fields_ = [
         ("abi_version", C.c_uint32),
@@ -157,6 +189,7 @@ class Config(C.Structure):
         ("tides", C.POINTER(SolidTidesC)),
         ("state_frame_body", C.c_int32),   # opts.integration_frame: the body the states of a batch are centred on (0: no swap)
         ("_pad_cfg", C.c_int32),
+        ("tuning", C.POINTER(Tuning)),     # NULL => defaults (ABI v4)
     ]
 
 
@@ -320,6 +353,18 @@ class StateBatch:
         o.step_ns[:] = self.step_ns[lo:hi]
         return o
 
+    def take(self, index) -> "StateBatch":
+        """The trajectories `index` (an integer array), in that order."""
+        index = np.asarray(index, dtype=np.int64)
+        o = StateBatch(len(index), self.stm is not None)
+        o.epoch_ns[:] = self.epoch_ns[index]
+        for f in F64_FIELDS:
+            getattr(o, f)[:] = getattr(self, f)[index]
+        if self.stm is not None:
+            o.stm[:] = self.stm[index]
+        o.step_ns[:] = self.step_ns[index]
+        return o
+
     def as_c(self) -> States:
         s = States()
         s.n = self.n
@@ -375,7 +420,7 @@ EXPORTS = [
     "nyx_hip_last_kernel_ms", "nyx_hip_last_error", "nyx_hip_load_cof", "nyx_hip_load_shadr", "nyx_hip_free",
     "nyx_hip_propagate_batch_with_traj", "nyx_hip_propagate_batch_with_traj_device",
     "nyx_hip_traj_at", "nyx_hip_traj_every", "nyx_hip_traj_at_device", "nyx_hip_traj_every_device",
-    "nyx_hip_predict_until", "nyx_hip_propagate_until_event", "nyx_hip_last_coop_helpers",
+    "nyx_hip_predict_until", "nyx_hip_propagate_until_event", "nyx_hip_last_coop_helpers", "nyx_hip_ctx_set_tuning",
 ]
 
 
@@ -436,6 +481,8 @@ def load_library():
     lib.nyx_hip_load_shadr.restype = C.c_int32
     lib.nyx_hip_free.argtypes = [C.c_void_p]
     lib.nyx_hip_free.restype = None
+    lib.nyx_hip_ctx_set_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
+    lib.nyx_hip_ctx_set_tuning.restype = C.c_int32
     lib.nyx_hip_abi_sizeof.argtypes = [C.c_int32]
     lib.nyx_hip_abi_sizeof.restype = C.c_int64
     _LIB = lib

@@ -77,6 +77,7 @@ struct DevArrays {  // one SoA batch resident on the device: ONE device block, O
 
 struct nyx_hip_ctx {
     int device = 0;
+    nyx_hip_tuning_t tune = NYX_HIP_TUNING_DEFAULT;  // config.tuning, resolved (see resolve_tuning)
     DevCfg host_cfg;
     DevCfg *d_cfg = nullptr;
     // opts.integration_frame: the states of a batch are centred on another body (its chain w.r.t. the integration centre)
@@ -100,7 +101,6 @@ struct nyx_hip_ctx {
     typedef std::tuple<int, int, int, int> WKey;
     std::map<WKey, std::array<double, 2 * DEV_MAX_WAVES>> weights;  // [0..16): speed weights, [16..32): measured duties (harmonics-term units)
     std::map<WKey, double> weight_spread;  // (max - min) / mean of the per-wave windows after calibration
-    int calibrate_mode = 1;                // 0 = structural default weights only (deterministic across processes), 1 = calibrate
     WKey last_key = WKey(0, 0, 0, 0);      // shape of the last launch
     DevArrays cal;                         // scratch outputs of the calibration launches
     int forced_quad = -1;  // STM layout: -1 = by ensemble size, 0 = 64 trajectories x D3 per workgroup, 1 = quad layout (16 x 4 lanes, D1)
@@ -178,6 +178,7 @@ extern "C" int64_t nyx_hip_abi_sizeof(int32_t which) {
     case 12: return sizeof(nyx_hip_predict_t);
     case 13: return sizeof(nyx_hip_predict_history_t);
     case 14: return sizeof(nyx_hip_process_noise_t);
+    case 15: return sizeof(nyx_hip_tuning_t);
     default: return -1;
     }
 }
@@ -205,6 +206,46 @@ static double ns_to_seconds_host(int64_t ns) {  // Duration::to_seconds for |ns|
     int64_t q = ns / 1000000000LL, r = ns % 1000000000LL;
     return (double)q + (double)r * 1e-9;
 }
+
+// config.tuning -> the context's copy.  The process environment is consulted ONLY when NYX_HIP_TUNING_ENV is set (the A/B
+// tools of this repository: tools/*.py, tools/*.sh): a library behind a C-ABI takes its switches through its config struct.
+static nyx_hip_tuning_t resolve_tuning(const nyx_hip_tuning_t *t) {
+    nyx_hip_tuning_t r = NYX_HIP_TUNING_DEFAULT;
+    if (t) r = *t;
+    if (!std::getenv("NYX_HIP_TUNING_ENV")) return r;
+    auto geti = [](const char *name, int32_t &dst) { if (const char *e = std::getenv(name)) dst = (int32_t)std::strtol(e, nullptr, 0); };
+    auto getd = [](const char *name, double &dst) { if (const char *e = std::getenv(name)) dst = std::atof(e); };
+    int32_t cal = -1;
+    geti("NYX_HIP_CALIBRATE", cal);
+    if (cal == 1) r.schedule = NYX_HIP_SCHED_CALIBRATED;
+    if (cal == 0) r.schedule = NYX_HIP_SCHED_MODEL;
+    geti("NYX_HIP_DETERMINISTIC", r.deterministic);
+    geti("NYX_HIP_COOP", r.cooperative);
+    geti("NYX_HIP_PIPE", r.pipelined);
+    geti("NYX_HIP_SPEC", r.chained_attempts);
+    geti("NYX_HIP_ED_REUSE", r.epoch_data_reuse);
+    geti("NYX_HIP_FANOUT", r.role_fanout);
+    if (std::getenv("NYX_HIP_MERGE_ROLES")) r.merge_roles = 1;
+    geti("NYX_HIP_STM_QUAD", r.stm_quad);
+    geti("NYX_HIP_HARM_FEED", r.harmonics_feed);
+    geti("NYX_HIP_COOP_COLS", r.coop_max_columns);
+    if (std::getenv("NYX_HIP_COOP_MUTE")) r.coop_mute = 1;
+    if (std::getenv("NYX_HIP_PROFILE")) r.profile = 1;
+    geti("NYX_HIP_DEBUG", r.debug_flags);
+    getd("NYX_HIP_COOP_FRAC", r.coop_fraction);
+    getd("NYX_HIP_COOP_HELPERS", r.coop_helper_ratio);
+    getd("NYX_HIP_COL_FIX", r.column_start_cost);
+    if (const char *e = std::getenv("NYX_HIP_ROLE_HANDICAP")) (void)std::sscanf(e, "%lf,%lf,%lf", &r.role_duties[0], &r.role_duties[1], &r.role_duties[2]);
+    if (const char *e = std::getenv("NYX_HIP_AGE_WEIGHTS"))
+        if (std::sscanf(e, "%lf,%lf,%lf,%lf", &r.age_weights[0], &r.age_weights[1], &r.age_weights[2], &r.age_weights[3]) == 4) r.schedule = NYX_HIP_SCHED_EXPLICIT;
+    if (const char *e = std::getenv("NYX_HIP_WAVE_WEIGHTS")) {
+        const char *q = e;
+        for (int w = 0; w < 16 && *q; ++w) { r.wave_weights[w] = std::strtod(q, (char **)&q); if (*q == ',') ++q; }
+        r.schedule = NYX_HIP_SCHED_EXPLICIT;
+    }
+    return r;
+}
+static bool any_nonzero(const double *v, int n) { for (int k = 0; k < n; ++k) if (v[k] != 0.0) return true; return false; }
 
 // GravityField::new (reference dynamics/gravity_field.rs:52-132) re-expressed as the per-column
 // entry table the kernel streams (see HarmEntry in devcfg.h).
@@ -319,7 +360,7 @@ static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, con
     // segments: 11.45 ms with 0 rows, 11.1 with 4, 10.83 with 6, 10.95 with 8 (four runs each, +-0.03).  70x70 plain kernel: no effect
     // up to 6, slower beyond (the measured per-wave weights already carry it there).
     double col_fix = (ctx->sched_quad && n_waves == DEV_MAX_WAVES) ? 6.0 : 0.0;  // (the quad layout's production shape: sixteen waves)
-    if (const char *e = std::getenv("NYX_HIP_COL_FIX")) col_fix = std::max(0.0, std::atof(e));
+    if (ctx->tune.column_start_cost >= 0.0) col_fix = ctx->tune.column_start_cost;
     auto cost = [&](int c) { return (double)ctx->col_len[c] + col_fix; };
     double terms = 0.0;
     for (int c : list) terms += cost(c);
@@ -333,23 +374,26 @@ static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, con
         const nyx_hip_ctx::WKey key(n_waves, (ctx->host_cfg.pipe && (!(ctx->host_cfg.flags & NYX_HIP_FLAG_STM) || ctx->sched_quad)) ? 1 : 0, ctx->sched_quad ? 1 : 0,
                                     all_columns ? -1 : (int)(ctx->host_cfg.coop_frac * 10.0 + 0.5));
         const auto it = ctx->weights.find(key);
-        static const double age[4] = {1.3, 1.2, 0.9, 0.6};
+        // The cost model of NYX_HIP_SCHED_MODEL: the speed of a wave is a property of its place in the workgroup (the four waves of a
+        // SIMD are arbitrated oldest first; role waves and their SIMD-mates run differently) and of the workgroup's shape, not of
+        // the force model.  Measured once with the calibration below on the BASELINE workloads (tools/dump_weights.py, two contexts
+        // each, agreement ~2 %) and frozen here, so that the default schedule - hence the summation order, hence every bit of the
+        // result - is the same in every context, process and rank.
+        static const double model_coop[16] = {1.70, 1.66, 1.48, 2.14, 2.08, 1.70, 1.65, 1.67, 1.45, 0.97, 1.05, 1.02, 0.70, 0.53, 0.56, 0.55};
+        static const double model_solo[16] = {1.41, 1.41, 1.26, 1.61, 1.59, 1.29, 1.375, 1.23, 1.06, 0.98, 0.98, 0.98, 0.77, 0.69, 0.70, 0.70};
+        static const double model_quad[16] = {0.70, 0.70, 0.70, 0.70, 1.26, 2.03, 1.78, 1.59, 1.58, 1.68, 0.96, 1.02, 0.875, 0.93, 0.86, 0.91};
+        const double *model = ctx->sched_quad ? model_quad : (all_columns ? model_solo : model_coop);
         for (int w = 0; w < DEV_MAX_WAVES; ++w)
-            per_wave[w] = it != ctx->weights.end() ? it->second[w] : (n_waves == 16 ? age[w / 4] : 1.0);
+            per_wave[w] = it != ctx->weights.end() ? it->second[w] : (n_waves == 16 ? model[w] : 1.0);
         if (it != ctx->weights.end())  // measured duties replace the model's (the integrator keeps its window free: hc_model[0])
             for (int w = 0; w < n_waves; ++w)
                 if (hc_model[w] < 1e8) hc[w] = it->second[DEV_MAX_WAVES + w];
     }
-    if (const char *e = std::getenv("NYX_HIP_AGE_WEIGHTS")) {  // coarse knob: one weight per age class
-        double aw[4] = {1.0, 1.0, 1.0, 1.0};
-        if (std::sscanf(e, "%lf,%lf,%lf,%lf", &aw[0], &aw[1], &aw[2], &aw[3]) == 4 && n_waves == 16)
-            for (int w = 0; w < DEV_MAX_WAVES; ++w) per_wave[w] = aw[w / 4];
-    }
-    if (const char *e = std::getenv("NYX_HIP_WAVE_WEIGHTS")) {  // tuning: 16 comma-separated weights (tools/tune_wave_weights.py)
-        const char *p = e;
-        for (int w = 0; w < DEV_MAX_WAVES && *p; ++w) {
-            per_wave[w] = std::strtod(p, (char **)&p);
-            if (*p == ',') ++p;
+    if (ctx->tune.schedule == NYX_HIP_SCHED_EXPLICIT) {  // explicit weights: per wave, or one per SIMD age class
+        const bool per = any_nonzero(ctx->tune.wave_weights, 16), age_on = any_nonzero(ctx->tune.age_weights, 4);
+        for (int w = 0; w < DEV_MAX_WAVES; ++w) {
+            if (per) per_wave[w] = ctx->tune.wave_weights[w];
+            else if (age_on && n_waves == 16) per_wave[w] = ctx->tune.age_weights[w / 4];
         }
     }
     auto wgt = [&](int w) { return per_wave[w]; };
@@ -408,7 +452,7 @@ static int fanout_almanac_units(const DevCfg &dc, int *unit_mask, double *unit_c
     return n;
 }
 static bool want_fanout(const nyx_hip_ctx *ctx, bool quad) {
-    if (const char *e = std::getenv("NYX_HIP_FANOUT")) return std::atoi(e) != 0;
+    if (ctx->tune.role_fanout >= 0) return ctx->tune.role_fanout != 0;
     return quad || !ctx->host_cfg.has_grav;
 }
 static int fanout_role_waves(const nyx_hip_ctx *ctx, int *n_alm_out = nullptr, int *n_pert_out = nullptr) {
@@ -500,22 +544,19 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
     for (int k = 0; k < DEV_N_SCHED; ++k)
         for (int w = 0; w < DEV_MAX_WAVES; ++w) dc.sched[k].n_ranges[w] = 0;
     dc.n_waves = n_waves;
-    dc.merge_roles = (std::getenv("NYX_HIP_MERGE_ROLES") && n_waves >= 8) ? 1 : 0;
-    {
-        const char *e = std::getenv("NYX_HIP_PIPE");
-        dc.pipe = (n_waves == DEV_MAX_WAVES && !dc.merge_roles && (e ? std::atoi(e) != 0 : true)) ? 1 : 0;
-    }
+    dc.merge_roles = (ctx->tune.merge_roles && n_waves >= 8) ? 1 : 0;
+    dc.pipe = (n_waves == DEV_MAX_WAVES && !dc.merge_roles && ctx->tune.pipelined != 0) ? 1 : 0;
     // roles of this workgroup shape and their serial duties (merged roles when there are fewer than three waves)
     double hc[DEV_MAX_WAVES] = {0};
     assign_roles(ctx, n_waves, want_fanout(ctx, quad), hc);
     // speculative stage 0 (role_loop): the pipelined plain kernel with ONE almanac wave and an even stage count (the last window
     // then leaves the buffers of stage parity 0 free for the epoch data of t + h)
     dc.spec = (dc.pipe && !(dc.flags & NYX_HIP_FLAG_STM) && dc.stages % 2 == 0 && dc.n_alm == 1 && dc.has_grav &&
-               !(std::getenv("NYX_HIP_SPEC") && std::atoi(std::getenv("NYX_HIP_SPEC")) == 0)) ? 1 : 0;
+               ctx->tune.chained_attempts != 0) ? 1 : 0;
     dc.ed_reuse = dc.spec ? 0 : ctx->ed_reuse_fit;  // (chained attempts need no copy of the stage-0 epoch data: a rejected lane keeps its k_0)
     if (!dc.has_grav || nc == 0) return;
     // with enough column workers the integrator keeps its window free: its serial phases A / C gate every other wave
-    if (n_waves >= 8 && !std::getenv("NYX_HIP_ROLE_HANDICAP")) hc[0] = 1e9;
+    if (n_waves >= 8 && !any_nonzero(ctx->tune.role_duties, 3)) hc[0] = 1e9;
     std::vector<int> all;
     for (int c = 1; c <= nc; ++c) all.push_back(c);
     (void)fill_schedule(ctx, dc.sched[DEV_SCHED_SOLO], n_waves, all, hc, true);
@@ -543,7 +584,7 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
                 share = 0.92 * dc.coop_frac;  // (several columns per wave: a job is longer for the same share; 35 / 38 / 42 columns at 150x150: 9.24 / 9.04 / 9.72 s)
             }
         }
-        if (const char *e = std::getenv("NYX_HIP_COOP_COLS")) max_cols = std::min(DEV_MAX_RANGES * col_waves, std::max(1, std::atoi(e)));
+        if (ctx->tune.coop_max_columns > 0) max_cols = std::min(DEV_MAX_RANGES * col_waves, (int)ctx->tune.coop_max_columns);
         for (int c = 1; c <= nc; ++c) {
             if ((int)help.size() < max_cols && c < nc - 1 && given + 0.5 * ctx->col_len[c] <= share * terms) {
                 help.push_back(c);
@@ -581,7 +622,7 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
 static bool pick_quad(const nyx_hip_ctx *ctx, int64_t n) {
     if (!(ctx->host_cfg.flags & NYX_HIP_FLAG_STM)) return false;
     if (ctx->forced_quad >= 0) return ctx->forced_quad != 0;
-    if (const char *e = std::getenv("NYX_HIP_STM_QUAD")) return std::atoi(e) != 0;
+    if (ctx->tune.stm_quad >= 0) return ctx->tune.stm_quad != 0;
     const int64_t cus = ctx->n_cu > 0 ? ctx->n_cu : 256;
     return (n + 15) / 16 <= 2 * cus;
 }
@@ -648,11 +689,41 @@ extern "C" int32_t nyx_hip_debug_layout(nyx_hip_ctx *ctx, int32_t *out) {
     return NYX_HIP_RC_OK;
 }
 
-// Calibration of the column weights: 1 = on the device, once per workgroup shape (default), 0 = structural weights only.
+// Calibration of the column weights: 1 = on the device, once per workgroup shape, 0 = the model's weights (tuning.schedule).
 extern "C" int32_t nyx_hip_debug_set_calibration(nyx_hip_ctx *ctx, int32_t mode) {
     if (!ctx || mode < 0 || mode > 1) return NYX_HIP_RC_BAD_ARG;
     CTX_LOCK(ctx);
-    ctx->calibrate_mode = mode;
+    ctx->tune.schedule = mode ? NYX_HIP_SCHED_CALIBRATED : NYX_HIP_SCHED_MODEL;
+    return NYX_HIP_RC_OK;
+}
+
+// The launch-time part of the tuning (cooperative mode, determinism, schedule kind and explicit weights, helper ratio / share /
+// mute, profiling) may be changed between launches; the create-time part (stage loop, role layout, feed) is fixed with the context.
+extern "C" int32_t nyx_hip_ctx_set_tuning(nyx_hip_ctx *ctx, const nyx_hip_tuning_t *t) {
+    if (!ctx) return NYX_HIP_RC_BAD_ARG;
+    CTX_LOCK(ctx);
+    const nyx_hip_tuning_t n = resolve_tuning(t), &o = ctx->tune;
+    if (n.pipelined != o.pipelined || n.chained_attempts != o.chained_attempts || n.epoch_data_reuse != o.epoch_data_reuse ||
+        n.role_fanout != o.role_fanout || n.merge_roles != o.merge_roles || n.harmonics_feed != o.harmonics_feed ||
+        n.debug_flags != o.debug_flags || std::memcmp(n.role_duties, o.role_duties, sizeof n.role_duties) != 0) {
+        nyx_set_error("nyx_hip_ctx_set_tuning: stage loop, role layout, feed and debug switches are fixed at nyx_hip_ctx_create");
+        return NYX_HIP_RC_BAD_ARG;
+    }
+    ctx->tune = n;
+    ctx->weights.clear();
+    ctx->weight_spread.clear();
+    ctx->sched_dirty = true;
+    return NYX_HIP_RC_OK;
+}
+
+// Speed weights [0..16), duties [16..32) and the window spread [32] of the last launch's workgroup shape (tools).
+extern "C" int32_t nyx_hip_debug_schedule_weights(nyx_hip_ctx *ctx, double *out) {
+    if (!ctx || !out) return NYX_HIP_RC_BAD_ARG;
+    CTX_LOCK(ctx);
+    const auto it = ctx->weights.find(ctx->last_key);
+    for (int w = 0; w < 2 * DEV_MAX_WAVES; ++w) out[w] = it != ctx->weights.end() ? it->second[w] : 0.0;
+    const auto sp = ctx->weight_spread.find(ctx->last_key);
+    out[2 * DEV_MAX_WAVES] = sp != ctx->weight_spread.end() ? sp->second : -1.0;
     return NYX_HIP_RC_OK;
 }
 
@@ -755,12 +826,13 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
 
     nyx_hip_ctx *ctx = new nyx_hip_ctx();
     ctx->device = device;
+    ctx->tune = resolve_tuning(cfg->tuning);
     DevCfg &dc = ctx->host_cfg;
     std::memset(&dc, 0, sizeof dc);
     const NyxTableau &tb = NYX_TABLEAUX[o.method];
     dc.stages = tb.stages; dc.order = tb.order;
     dc.fixed_step = o.fixed_step; dc.error_ctrl = o.error_ctrl; dc.attempts = o.attempts; dc.flags = (int32_t)cfg->flags;
-    if (const char *e = std::getenv("NYX_HIP_DEBUG")) dc.flags |= (int32_t)std::strtol(e, nullptr, 0) & 0xff00;  // timing-only switches
+    dc.flags |= ctx->tune.debug_flags & 0xff00;  // timing-only switches
     dc.tol = o.tolerance;
     dc.init_step_ns = o.init_step_ns; dc.min_step_ns = o.min_step_ns; dc.max_step_ns = o.max_step_ns;
     dc.min_step_s = ns_to_seconds_host(o.min_step_ns);
@@ -889,14 +961,14 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
     {
         int nseg_eval = 0;
         for (int s = 0; s < dc.n_slots; ++s) nseg_eval += dc.slot[s].n_chain;
-        ctx->role_handicap[0] = 15.0;
-        ctx->role_handicap[1] = 12.0 * nseg_eval + (dc.has_grav ? 18.0 : 0.0);
-        ctx->role_handicap[2] = 6.0 * dc.n_pm + (dc.has_srp ? 6.0 + 6.0 * dc.n_shadow : 0.0) + (dc.has_drag ? 10.0 : 0.0) +
-                                (dc.has_tides ? 14.0 + 8.0 * dc.t_n : 0.0);
-        if (const char *e = std::getenv("NYX_HIP_ROLE_HANDICAP")) {
-            double h0, h1, h2;
-            if (std::sscanf(e, "%lf,%lf,%lf", &h0, &h1, &h2) == 3) { ctx->role_handicap[0] = h0; ctx->role_handicap[1] = h1; ctx->role_handicap[2] = h2; }
-        }
+        // (refitted in round 3 to the duties the calibration measures on the BASELINE workloads: 70x70 + Sun / Moon + SRP gives
+        //  integrator 66, almanac 140, perturbations 52 harmonics-term units - the first formulas were 2.2x too low)
+        ctx->role_handicap[0] = 60.0;
+        ctx->role_handicap[1] = 26.0 * nseg_eval + (dc.has_grav ? 38.0 : 0.0);
+        ctx->role_handicap[2] = 13.0 * dc.n_pm + (dc.has_srp ? 13.0 + 13.0 * dc.n_shadow : 0.0) + (dc.has_drag ? 22.0 : 0.0) +
+                                (dc.has_tides ? 30.0 + 17.0 * dc.t_n : 0.0);
+        if (any_nonzero(ctx->tune.role_duties, 3))
+            for (int k = 0; k < 3; ++k) ctx->role_handicap[k] = ctx->tune.role_duties[k];
     }
     records.resize(records.size() + 16, 0.0);  // padding for the 16-wide coefficient window
     dc.rec_doubles = (int32_t)records.size();
@@ -906,13 +978,13 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
     // stage-0 epoch data carried between attempts (see role_loop): needs an even stage count (the last stage's window
     // then leaves buffer 0 free) and 9 + 3 * n_slots doubles + 20 bytes of LDS per lane
     dc.ed_reuse = 0;
-    if (!(cfg->flags & NYX_HIP_FLAG_STM) && dc.stages % 2 == 0 && !(std::getenv("NYX_HIP_ED_REUSE") && std::atoi(std::getenv("NYX_HIP_ED_REUSE")) == 0)) {
+    if (!(cfg->flags & NYX_HIP_FLAG_STM) && dc.stages % 2 == 0 && ctx->tune.epoch_data_reuse != 0) {
         const int nf = 9 + 3 * dc.n_slots;
         if (nyx_kernel_lds_bytes(DEV_MAX_WAVES, dc.rec_in_lds ? dc.rec_doubles : 0, 0, nf) <= 160 * 1024) dc.ed_reuse = nf;
     }
     ctx->ed_reuse_fit = dc.ed_reuse;
     dc.coop_frac = 0.30;  // measured optimum with two owners per helper (10 000 trajectories, 70x70): 0.28-0.33 is flat
-    if (const char *e = std::getenv("NYX_HIP_COOP_FRAC")) dc.coop_frac = std::min(0.9, std::max(0.05, std::atof(e)));
+    if (ctx->tune.coop_fraction > 0.0) dc.coop_frac = std::min(0.9, std::max(0.05, ctx->tune.coop_fraction));
     {
         hipDeviceProp_t prop;
         ctx->n_cu = (hipGetDeviceProperties(&prop, device) == hipSuccess) ? prop.multiProcessorCount : 0;
@@ -933,7 +1005,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
         // measured (same box, calibrated): 150x150 cooperative 373 -> 334 ms per 6 250 x 3 h (1.12x); 70x70 alone 1.02-1.11x;
         // 70x70 cooperative (one column per helper wave and job: the walk's start-up weighs more) 0-2 % slower
         dc.harm_feed = dc.n_cols > 96 ? 1 : 0;
-        if (const char *e = std::getenv("NYX_HIP_HARM_FEED")) dc.harm_feed = std::atoi(e) != 0 ? 1 : 0;
+        if (ctx->tune.harmonics_feed >= 0) dc.harm_feed = ctx->tune.harmonics_feed != 0 ? 1 : 0;
     }
     HIP_TRY(hipMalloc(&ctx->d_cfg, sizeof(DevCfg)));
     HIP_TRY(hipMemcpy(ctx->d_cfg, &dc, sizeof(DevCfg), hipMemcpyHostToDevice));
@@ -957,12 +1029,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
 // propagate
 // ---------------------------------------------------------------------------------------------
 
-static bool calibration_on(const nyx_hip_ctx *ctx) {
-    if (std::getenv("NYX_HIP_WAVE_WEIGHTS") || std::getenv("NYX_HIP_AGE_WEIGHTS")) return false;  // explicit weights win
-
-    if (const char *e = std::getenv("NYX_HIP_CALIBRATE")) return std::atoi(e) != 0;
-    return ctx->calibrate_mode != 0;
-}
+static bool calibration_on(const nyx_hip_ctx *ctx) { return ctx->tune.schedule == NYX_HIP_SCHED_CALIBRATED; }
 
 static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t *out, nyx_hip_step_stats_t *st,
                   int64_t duration_ns, int64_t end_epoch_ns, int use_end, hipStream_t stream, bool time_it,
@@ -988,7 +1055,7 @@ static void views_of(DevArrays &d, int64_t n, bool stm, nyx_hip_states_t &so, ny
 // water-filling then gets the speed weight cbar / c[w] and the handicap duty[w] / c[w] (in entries), which makes
 // duty + columns equal across the waves; iterated with damping because the shares interact through the shared SIMDs.
 // Rounded to 1/64 and kept for the life of the context: launches of one context are deterministic.
-static int calibrate(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, hipStream_t stream) {
+static int calibrate(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, hipStream_t stream, bool backward = false) {
     const bool stm = (ctx->host_cfg.flags & NYX_HIP_FLAG_STM) != 0;
     const int64_t n = in->n;
     if (int rc = ensure_arrays(ctx->cal, n, true)) return rc;
@@ -1001,7 +1068,8 @@ static int calibrate(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, hipStream_t s
     nyx_hip_states_t so;
     nyx_hip_step_stats_t ss;
     views_of(ctx->cal, n, stm, so, ss);
-    const int64_t dur = (stm ? 4 : 30) * ctx->host_cfg.init_step_ns;
+    const int64_t dur = (backward ? -1 : 1) * (stm ? 4 : 30) * ctx->host_cfg.init_step_ns;  // the direction of the real request: the ephemerides may end either way
+    std::vector<int32_t> cal_status((size_t)n);
     std::array<double, 2 * DEV_MAX_WAVES> w;
     bool have = false;
     nyx_hip_ctx::WKey key(0, 0, 0, 0);
@@ -1012,6 +1080,12 @@ static int calibrate(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, hipStream_t s
         if (int rc = launch(ctx, in, &so, &ss, dur, 0, 0, stream, false, nullptr, nullptr, nullptr, true)) return rc;
         HIP_TRY(hipStreamSynchronize(stream));
         HIP_TRY(hipMemcpy(prof.data(), ctx->d_prof, prof.size() * sizeof(int64_t), hipMemcpyDeviceToHost));
+        if (ss.status) {  // lanes that died early produce garbage cycle counts: keep the model's weights then
+            HIP_TRY(hipMemcpy(cal_status.data(), ss.status, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+            bool bad = false;
+            for (int64_t q = 0; q < n && !bad; ++q) bad = cal_status[(size_t)q] != NYX_HIP_OK;
+            if (bad) { have = false; ctx->weights.erase(ctx->last_key); ctx->sched_dirty = true; break; }
+        }
         key = ctx->last_key;
         const int nw = std::get<0>(key);
         const DevSched &sd = ctx->host_cfg.sched[std::get<3>(key) >= 0 ? DEV_SCHED_PRIMARY : DEV_SCHED_SOLO];
@@ -1158,8 +1232,8 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
     // agree modulo 8 (round-robin XCD dispatch: same L2); every owner needs a helper for the split to pay off.
     ctx->last_coop_helpers = 0;
     {
-        const char *e = std::getenv("NYX_HIP_COOP");
-        const bool want = e ? std::atoi(e) != 0 : true;  // on by default; NYX_HIP_COOP=0 forces one workgroup per 64 trajectories to work alone
+        // on by default; tuning.cooperative = 0 (or .deterministic: the split follows the batch size) makes every workgroup work alone
+        const bool want = ctx->tune.cooperative != 0 && !ctx->tune.deterministic;
         const int64_t n_own = (in->n + DEV_LANES - 1) / DEV_LANES;
         const int64_t base = (n_own + 7) / 8 * 8;
         const bool stm_ctx = (ctx->host_cfg.flags & NYX_HIP_FLAG_STM) != 0;
@@ -1167,12 +1241,12 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
             base + 8 <= ctx->n_cu) {
             // (more helpers than owners: the jobs are claimed, not assigned, so extra helpers shorten the queue of a set)
             double h_ratio = 1.0;
-            if (const char *e2 = std::getenv("NYX_HIP_COOP_HELPERS")) h_ratio = std::min(3.0, std::max(0.25, std::atof(e2)));
+            if (ctx->tune.coop_helper_ratio > 0.0) h_ratio = std::min(3.0, std::max(0.25, ctx->tune.coop_helper_ratio));
             const int64_t helpers = std::min<int64_t>((int64_t)((double)n_own * h_ratio), (ctx->n_cu - base) / 8 * 8);
             if (helpers >= 8 && 4 * helpers >= n_own) {
                 // share of the terms the helpers take: owners keep (1 - x), each helper does x * owners / helpers jobs' worth
                 // per evaluation period, plus its hand-off overhead: x ~ 0.95 r / (1 + r) with r = helpers / owners
-                if (!std::getenv("NYX_HIP_COOP_FRAC")) {
+                if (!(ctx->tune.coop_fraction > 0.0)) {
                     const double r = (double)helpers / (double)n_own;
                     const double x = std::min(0.55, std::max(0.10, 0.95 * r / (1.0 + r)));
                     if (std::fabs(x - ctx->host_cfg.coop_frac) > 0.01) {
@@ -1204,7 +1278,7 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
                     uint32_t *words = (uint32_t *)(ctx->d_coop + ctx->coop_cap);
                     bt.coop_posted = words; bt.coop_claimed = words + (ctx->coop_cap + 64); bt.coop_finished = words + 2 * (ctx->coop_cap + 64);
                     bt.coop_sets = (int32_t)((n_own + 15) / 16);
-                    bt.coop_mute = std::getenv("NYX_HIP_COOP_MUTE") ? 1 : 0;
+                    bt.coop_mute = ctx->tune.coop_mute ? 1 : 0;
                     ctx->last_coop_helpers = (int)helpers;
                 }
             }
@@ -1219,11 +1293,11 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
         const int64_t span = use_end ? INT64_MAX : (duration_ns < 0 ? -duration_ns : duration_ns);
         if (!calibrating && calibration_on(ctx) && ctx->host_cfg.has_grav && nw >= 8 && in->n >= 64 && !traj && !dur_ns && !ev &&
             span >= 100 * ctx->host_cfg.init_step_ns && !ctx->weights.count(key)) {
-            if (int rc = calibrate(ctx, in, stream)) return rc;
+            if (int rc = calibrate(ctx, in, stream, !use_end && duration_ns < 0)) return rc;
             return launch(ctx, in, out, st, duration_ns, end_epoch_ns, use_end, stream, time_it, traj, dur_ns, ev, false, swapped);
         }
     }
-    if (std::getenv("NYX_HIP_PROFILE") || calibrating) {
+    if (ctx->tune.profile || calibrating) {
         if (!ctx->d_prof) HIP_TRY(hipMalloc(&ctx->d_prof, 17 * 8 * sizeof(int64_t)));
         HIP_TRY(hipMemsetAsync(ctx->d_prof, 0, 17 * 8 * sizeof(int64_t), stream));
         bt.prof = ctx->d_prof;
@@ -1706,7 +1780,7 @@ extern "C" int32_t nyx_hip_predict_until(nyx_hip_ctx *ctx, const nyx_hip_states_
         // the column weights of their workgroup shape once per context, on the staged states (identity STM set above)
         const int nw_c = pick_waves(ctx, n);
         const bool quad_c = pick_quad(ctx, n);
-        const bool pipe_c = quad_c && nw_c == DEV_MAX_WAVES && !(std::getenv("NYX_HIP_PIPE") && std::atoi(std::getenv("NYX_HIP_PIPE")) == 0);
+        const bool pipe_c = quad_c && nw_c == DEV_MAX_WAVES && ctx->tune.pipelined != 0;
         const nyx_hip_ctx::WKey key(nw_c, pipe_c ? 1 : 0, quad_c ? 1 : 0, -1);
         if (calibration_on(ctx) && ctx->host_cfg.has_grav && nw_c >= 8 && n >= 16 && !ctx->weights.count(key)) {
             if (int rc = calibrate(ctx, &sg.din, stream)) return rc;

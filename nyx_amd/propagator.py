@@ -638,14 +638,27 @@ def unpack_spacecraft(batch: _abi.StateBatch, template: Sequence[Spacecraft]) ->
 class GpuContext:
     """RAII wrapper of ``nyx_hip_ctx`` (immutable after creation => shareable like `Arc<Propagator>`)."""
 
-    def __init__(self, compiled: CompiledConfig, device: int = 0):
+    def __init__(self, compiled: CompiledConfig, device: int = 0, tuning: Optional[_abi.Tuning] = None):
         self._lib = _abi.load_library()
         self.compiled = compiled
+        self.tuning = tuning
         h = C.c_void_p()
-        rc = self._lib.nyx_hip_ctx_create(C.byref(compiled.cfg), device, C.byref(h))
+        cfg = compiled.cfg
+        if tuning is not None:  # (a private copy of the descriptor: the compiled config may be shared by several contexts)
+            cfg = _abi.Config()
+            C.memmove(C.byref(cfg), C.byref(compiled.cfg), C.sizeof(_abi.Config))
+            cfg.tuning = C.pointer(tuning)
+        rc = self._lib.nyx_hip_ctx_create(C.byref(cfg), device, C.byref(h))
         if rc != 0:
             raise RuntimeError(f"nyx_hip_ctx_create failed (rc={rc}): {_abi.last_error()}")
         self._h = h
+
+    def set_tuning(self, tuning: Optional[_abi.Tuning]):
+        """Launch-time part of the tuning for the following launches (``nyx_hip_ctx_set_tuning``)."""
+        rc = self._lib.nyx_hip_ctx_set_tuning(self._h, C.byref(tuning) if tuning is not None else None)
+        if rc != 0:
+            raise RuntimeError(f"nyx_hip_ctx_set_tuning failed (rc={rc}): {_abi.last_error()}")
+        self.tuning = tuning
 
     def close(self):
         if getattr(self, "_h", None):

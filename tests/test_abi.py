@@ -18,7 +18,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     lib = _abi.load_library()
     header = open(os.path.join(ROOT, "include", "nyx_hip.h")).read()
     declared = set(re.findall(r"^(?:int32_t|void|double|const char \*)\s*(nyx_hip_[a-z_0-9]+)\(", header, flags=re.M))
-    assert len(declared) == 21
+    assert len(declared) == 22
     assert declared >= set(_abi.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in nyx_hip.h but not exported"
@@ -28,7 +28,7 @@ def test_struct_layouts_match_the_header():
     lib = _abi.load_library()
     mirror = [_abi.IntegOpts, _abi.ChebySegment, _abi.Body, _abi.Rotation, _abi.GravityField, _abi.Srp, _abi.Drag,
               _abi.Config, _abi.States, _abi.StepStats, _abi.Traj, _abi.SolidTidesC, _abi.Predict, _abi.PredictHistory,
-              _abi.ProcessNoiseC]
+              _abi.ProcessNoiseC, _abi.Tuning]
     for which, cls in enumerate(mirror):
         assert lib.nyx_hip_abi_sizeof(which) == C.sizeof(cls), cls.__name__
 

@@ -79,7 +79,7 @@ def test_full_model_events_not_found_and_mixed_outcomes():
     ctx.close()
 
 
-def test_events_and_dense_output_with_chained_attempts(monkeypatch):
+def test_events_and_dense_output_with_chained_attempts():
     """70x70: sixteen-wave workgroups, pipelined stage loop, attempts chained (the next attempt's stage 0 starts before step control
     has counted the crossing).  The stop condition, the dense output and the search see exactly what the unchained loop gives them."""
     prop, almanac, central = leo_full_setup(degree=70)
@@ -88,9 +88,9 @@ def test_events_and_dense_output_with_chained_attempts(monkeypatch):
     ev = nx.Event.periapsis()
     res = {}
     for spec in ("1", "0"):
-        monkeypatch.setenv("NYX_HIP_SPEC", spec)
-        monkeypatch.setenv("NYX_HIP_WAVE_WEIGHTS", "1,1.3,1.3,1.6,1.6,1.3,1.3,1.3,1.3,0.9,0.9,0.9,0.9,0.5,0.5,0.5")
-        ctx = nx.GpuContext(compiled)
+        tun = nx.Tuning(chained_attempts=int(spec), schedule=nx.SCHED_EXPLICIT,
+                        wave_weights=[1, 1.3, 1.3, 1.6, 1.6, 1.3, 1.3, 1.3, 1.3, 0.9, 0.9, 0.9, 0.9, 0.5, 0.5, 0.5])
+        ctx = nx.GpuContext(compiled, tuning=tun)
         out, st, traj, cr = ctx.propagate_until_event(b, 3 * 3600 * S, ev, trigger=1, capacity=300)
         assert (st.status == 0).all() and (cr == 1).all()
         fin, st2, tr2 = ctx.propagate_with_traj(b, 3600 * S, capacity=300)

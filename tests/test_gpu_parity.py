@@ -23,6 +23,10 @@ def gpu_run(prop, almanac, central, batch, duration_ns, waves=0):
     return out, st, ms
 
 
+# one fixed column split for the tests that compare two stage loops bit for bit (nyx_hip_tuning_t.wave_weights)
+FIXED_WEIGHTS = [1, 1.3, 1.3, 1.6, 1.6, 1.3, 1.3, 1.3, 1.3, 0.9, 0.9, 0.9, 0.9, 0.5, 0.5, 0.5]
+
+
 @pytest.mark.parametrize("name", ["RungeKutta4", "Verner56", "DormandPrince45", "DormandPrince78", "RungeKutta89"])
 def test_golden_fixed_step_bit_exact(name):
     # reference: tests/propagation/propagators.rs:306-472 — the GPU path reproduces the asserted 6-vectors exactly
@@ -296,7 +300,7 @@ def test_config5_lunar_150x150_vs_oracle(method):
     ctx.close()
 
 
-def test_full_size_properties_config2(monkeypatch):
+def test_full_size_properties_config2():
     """BASELINE size (10 000 x 70x70, 3 h slice): index stability under re-batching, determinism, and the two-body
     energy drift bound when the perturbations are switched off."""
     prop, almanac, central = leo_full_setup(degree=70)
@@ -314,11 +318,10 @@ def test_full_size_properties_config2(monkeypatch):
     part, _ = ctx.propagate(b.slice(lo, hi), dur)
     dr, dv = pos_vel_errors(part, out.slice(lo, hi))
     assert dr.max() < 1e-6 and dv.max() < 1e-9
-    monkeypatch.setenv("NYX_HIP_COOP", "0")
+    ctx.set_tuning(nx.Tuning(deterministic=1))   # (nyx_hip_tuning_t.deterministic: every workgroup works alone)
     solo, _ = ctx.propagate(b, dur)
     part, _ = ctx.propagate(b.slice(lo, hi), dur)
     np.testing.assert_array_equal(part.rv(), solo.rv()[lo:hi])
-    monkeypatch.delenv("NYX_HIP_COOP")
     ctx.close()
     # two-body only, full day, full ensemble: specific orbital energy conserved to ~1e-12 relative
     from scenarios import GOLDEN as G, two_body_setup
@@ -457,7 +460,7 @@ def test_solid_tides_stm_and_frame_rule():
         nx.GpuContext(prop.compile(almanac, central))
 
 
-def test_cooperative_mode_matches_solo_and_oracle(monkeypatch):
+def test_cooperative_mode_matches_solo_and_oracle():
     """10 000 trajectories leave 99 of the 256 CUs idle: helper workgroups take over a share of the harmonics columns
     (propagate_kernel.hip, cooperative mode).  Same physics: against the solo launch the states agree to the level of a
     different summation order, against the oracle within the parity bar; and the exchange is deterministic."""
@@ -466,11 +469,11 @@ def test_cooperative_mode_matches_solo_and_oracle(monkeypatch):
     ctx = nx.GpuContext(compiled)
     b = dispersed_leo_batch(10_000, seed=0)
     dur = 2 * 3600 * nx.NS_PER_S
-    monkeypatch.setenv("NYX_HIP_COOP", "0")
+    ctx.set_tuning(nx.Tuning(cooperative=0))
     solo, sst = ctx.propagate(b, dur)
     assert ctx.last_coop_helpers() == 0
     solo_ms = ctx.last_kernel_ms()
-    monkeypatch.setenv("NYX_HIP_COOP", "1")
+    ctx.set_tuning(None)
     coop, cst = ctx.propagate(b, dur)
     assert ctx.last_coop_helpers() == 96          # ceil(10000/64) = 157 owners, base 160, 96 helpers on the idle CUs
     coop_ms = ctx.last_kernel_ms()
@@ -489,9 +492,9 @@ def test_cooperative_mode_matches_solo_and_oracle(monkeypatch):
     assert coop_ms < solo_ms                                          # and it is what it is for
     # helpers that never answer (as if they had not become resident): every owner times out once (2 ms), evaluates the
     # helper's columns itself for that evaluation and finishes alone - same physics, no hang
-    monkeypatch.setenv("NYX_HIP_COOP_MUTE", "1")
+    ctx.set_tuning(nx.Tuning(coop_mute=1))
     mute, mst = ctx.propagate(b, dur)
-    monkeypatch.delenv("NYX_HIP_COOP_MUTE")
+    ctx.set_tuning(None)
     assert ctx.last_coop_helpers() == 96 and (mst.status == 0).all()
     dr, dv = pos_vel_errors(mute, solo)
     print(f"muted helpers: kernel {ctx.last_kernel_ms():.1f} ms, max dr vs solo {dr.max()*1e3:.2e} m")
@@ -499,7 +502,7 @@ def test_cooperative_mode_matches_solo_and_oracle(monkeypatch):
     ctx.close()
 
 
-def test_chained_attempts_backwards_and_fixed_step(monkeypatch):
+def test_chained_attempts_backwards_and_fixed_step():
     """The speculative stage 0 of the next attempt with a negative step (back-propagation) and with fixed steps (every attempt
     accepted, the exact-length final step): bit-identical to the unchained loop, and the round trip returns to the start."""
     prop, almanac, central = leo_full_setup(degree=70)
@@ -507,15 +510,14 @@ def test_chained_attempts_backwards_and_fixed_step(monkeypatch):
     hour = 3600 * nx.NS_PER_S
     res = {}
     for spec in ("1", "0"):
-        monkeypatch.setenv("NYX_HIP_SPEC", spec)
-        monkeypatch.setenv("NYX_HIP_WAVE_WEIGHTS", "1,1.3,1.3,1.6,1.6,1.3,1.3,1.3,1.3,0.9,0.9,0.9,0.9,0.5,0.5,0.5")
-        ctx = nx.GpuContext(prop.compile(almanac, central))
+        tun = nx.Tuning(chained_attempts=int(spec), schedule=nx.SCHED_EXPLICIT, wave_weights=FIXED_WEIGHTS)
+        ctx = nx.GpuContext(prop.compile(almanac, central), tuning=tun)
         fwd, st = ctx.propagate(b, hour)
         back, st2 = ctx.propagate(fwd, -hour)
         assert (st.status == 0).all() and (st2.status == 0).all() and (back.epoch_ns == b.epoch_ns).all()
         ctx.close()
         fprop = nx.Propagator(prop.dynamics, nx.IntegratorMethod.RungeKutta89, nx.IntegratorOptions.with_fixed_step_s(47.0))
-        ctx = nx.GpuContext(fprop.compile(almanac, central))
+        ctx = nx.GpuContext(fprop.compile(almanac, central), tuning=tun)
         fixed, st3 = ctx.propagate(b, 1000 * nx.NS_PER_S)          # 21 steps of 47 s and a final one of 13 s
         assert (st3.status == 0).all() and (st3.n_accepted == 22).all() and (st3.n_rejected == 0).all()
         ctx.close()
@@ -527,13 +529,12 @@ def test_chained_attempts_backwards_and_fixed_step(monkeypatch):
 
 
 @pytest.mark.parametrize("n,drag", [(256, None), (2048, None), (512, "exp")])
-def test_pipelined_stage_loop_is_bit_identical(monkeypatch, n, drag):
+def test_pipelined_stage_loop_is_bit_identical(n, drag):
     """The pipelined stage loop (the next stage's position is published inside the current window), the epoch data carried
     between attempts and the plain two-barrier loop do the same arithmetic in the same order: bit-identical states and step
     counts once both walk the same column schedule (by default the two loops use differently calibrated per-wave weights,
     i.e. a different summation order of the harmonics partial sums).  256 trajectories run alone, 512 (with drag) and
     2 048 in cooperative mode (one helper per owner: same column split in both loops)."""
-    monkeypatch.setenv("NYX_HIP_WAVE_WEIGHTS", "1,1.3,1.3,1.6,1.6,1.3,1.3,1.3,1.3,0.9,0.9,0.9,0.9,0.5,0.5,0.5")
     prop, almanac, central = leo_full_setup(degree=70, drag=drag) if drag else leo_full_setup(degree=70)
     compiled = prop.compile(almanac, central)
     b = dispersed_leo_batch(n, seed=11)
@@ -544,10 +545,9 @@ def test_pipelined_stage_loop_is_bit_identical(monkeypatch, n, drag):
     res = {}
     # (1, 1, 1) is the default: pipelined, epoch data carried, stage 0 of the next attempt started speculatively in the last window
     for pipe, reuse, spec in (("1", "1", "1"), ("0", "0", "0"), ("1", "0", "0"), ("0", "1", "0"), ("1", "1", "0")):
-        monkeypatch.setenv("NYX_HIP_PIPE", pipe)
-        monkeypatch.setenv("NYX_HIP_ED_REUSE", reuse)
-        monkeypatch.setenv("NYX_HIP_SPEC", spec)
-        ctx = nx.GpuContext(compiled)   # (the switches are read when the context is built)
+        tun = nx.Tuning(pipelined=int(pipe), epoch_data_reuse=int(reuse), chained_attempts=int(spec), schedule=nx.SCHED_EXPLICIT,
+                        wave_weights=FIXED_WEIGHTS)
+        ctx = nx.GpuContext(compiled, tuning=tun)   # (these switches are fixed when the context is built)
         out, st = ctx.propagate(b, dur)
         assert (st.status == 0).all()
         assert (ctx.last_coop_helpers() > 0) == (n >= 512)   # cooperative mode needs at least 8 owners

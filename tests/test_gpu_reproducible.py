@@ -1,0 +1,74 @@
+"""Reproducibility contract of nyx_hip_tuning_t (include/nyx_hip.h, ABI v4).  The reference's Monte Carlo is reproducible per
+(seed, index) whatever the batch (mc/montecarlo.rs:208-224, 290-295: every run is seeded and propagated on its own).  Here:
+default schedule = a cost model => the same bits in every context; deterministic = 1 => the same bits whatever the batch."""
+import numpy as np
+import pytest
+
+import nyx_amd as nx
+from scenarios import dispersed_leo_batch, leo_full_setup, pos_vel_errors
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_fresh_contexts_give_identical_bits():
+    prop, almanac, central = leo_full_setup(degree=70)
+    compiled = prop.compile(almanac, central)
+    b = dispersed_leo_batch(10_000, seed=5)
+    dur = 40 * 60 * nx.NS_PER_S
+    outs = []
+    for _ in range(2):
+        ctx = nx.GpuContext(compiled)          # default tuning: NYX_HIP_SCHED_MODEL, cooperative mode on (96 helpers)
+        out, st = ctx.propagate(b, dur)
+        assert (st.status == 0).all() and ctx.last_coop_helpers() == 96
+        outs.append((out.rv().copy(), st.n_evals.copy()))
+        ctx.close()
+    np.testing.assert_array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+
+def test_deterministic_mode_is_independent_of_the_batch():
+    """Rank shards (ragged), a permuted batch and a single trajectory propagated alone all reproduce the full batch bit for bit."""
+    prop, almanac, central = leo_full_setup(degree=70)
+    compiled = prop.compile(almanac, central)
+    n = 3000
+    b = dispersed_leo_batch(n, seed=9)
+    dur = 40 * 60 * nx.NS_PER_S
+    ctx = nx.GpuContext(compiled, tuning=nx.Tuning(deterministic=1))
+    full, st = ctx.propagate(b, dur)
+    assert (st.status == 0).all() and ctx.last_coop_helpers() == 0
+    for rank in range(3):                      # contiguous index shards of a 3-rank job
+        lo, hi = nx.shard_bounds(n, rank, 3)
+        part, _ = ctx.propagate(b.slice(lo, hi), dur)
+        np.testing.assert_array_equal(part.rv(), full.rv()[lo:hi])
+    other = nx.GpuContext(compiled, tuning=nx.Tuning(deterministic=1))   # another context, another batch composition
+    perm = np.random.default_rng(0).permutation(n)
+    shuffled, _ = other.propagate(b.take(perm), dur)
+    np.testing.assert_array_equal(shuffled.rv(), full.rv()[perm])
+    one, _ = other.propagate(b.slice(1234, 1235), dur)
+    np.testing.assert_array_equal(one.rv(), full.rv()[1234:1235])
+    # ... and the cooperative default differs from it only by the summation order of the harmonics
+    coop_ctx = nx.GpuContext(compiled)
+    coop, _ = coop_ctx.propagate(b, dur)
+    assert coop_ctx.last_coop_helpers() > 0
+    dr, dv = pos_vel_errors(coop, full)
+    assert dr.max() < 1e-6 and dv.max() < 1e-9
+    for c in (ctx, other, coop_ctx):
+        c.close()
+
+
+def test_calibrated_schedule_is_opt_in_and_agrees():
+    prop, almanac, central = leo_full_setup(degree=70)
+    compiled = prop.compile(almanac, central)
+    b = dispersed_leo_batch(4096, seed=2)
+    dur = 2 * 3600 * nx.NS_PER_S
+    model = nx.GpuContext(compiled)
+    ref, _ = model.propagate(b, dur)
+    cal = nx.GpuContext(compiled, tuning=nx.Tuning(schedule=nx.SCHED_CALIBRATED))
+    out, st = cal.propagate(b, dur)
+    assert (st.status == 0).all()
+    again, _ = cal.propagate(b, dur)
+    np.testing.assert_array_equal(out.rv(), again.rv())   # a context stays deterministic once its schedule is measured
+    dr, dv = pos_vel_errors(out, ref)
+    assert dr.max() < 1e-6 and dv.max() < 1e-9
+    model.close()
+    cal.close()

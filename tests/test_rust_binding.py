@@ -25,7 +25,7 @@ def test_every_entry_point_and_struct_is_bound():
     lib = _abi.load_library()
     order = ["nyx_hip_integ_opts_t", "nyx_hip_cheby_segment_t", "nyx_hip_body_t", "nyx_hip_rotation_t", "nyx_hip_gravity_field_t",
              "nyx_hip_srp_t", "nyx_hip_drag_t", "nyx_hip_config_t", "nyx_hip_states_t", "nyx_hip_step_stats_t", "nyx_hip_traj_t",
-             "nyx_hip_solid_tides_t", "nyx_hip_predict_t", "nyx_hip_predict_history_t", "nyx_hip_process_noise_t"]
+             "nyx_hip_solid_tides_t", "nyx_hip_predict_t", "nyx_hip_predict_history_t", "nyx_hip_process_noise_t", "nyx_hip_tuning_t"]
     for which, name in enumerate(order):
         assert lib.nyx_hip_abi_sizeof(which) == sizes[name][0], name
     assert lib.nyx_hip_abi_sizeof(len(order)) in (-1, sizes.get("nyx_hip_event_t", (0,))[0], sizes.get("nyx_hip_estimates_t", (0,))[0])

@@ -14,6 +14,7 @@ import numpy as np  # noqa: E402
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 os.environ["NYX_HIP_COOP"] = sys.argv[2] if len(sys.argv) > 2 else "1"
 os.environ["NYX_HIP_PROFILE"] = "1"
+os.environ.setdefault("NYX_HIP_TUNING_ENV", "1")  # the A/B switches of these tools travel through the environment
 import nyx_amd as nx  # noqa: E402
 from scenarios import dispersed_leo_batch, leo_full_setup  # noqa: E402
 
