@@ -511,6 +511,15 @@ int32_t nyx_hip_predict_until(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, cons
  * 64-trajectory workgroup (0 = pick automatically from n). */
 int32_t nyx_hip_ctx_set_column_waves(nyx_hip_ctx *ctx, int32_t waves);
 
+/* One batch over SEVERAL contexts - the devices of one node driven by one process (what replaces the rayon par_iter of
+ * mc/montecarlo.rs:233-253 when the host is not rank-sharded).  Host arrays.  Shard k of n_ctx is the contiguous index range
+ * [k n / n_ctx, (k + 1) n / n_ctx); every context (created by the caller with the same config, one per device:
+ * nyx_hip_device_count()) propagates its shard from its own host thread, so copies and kernels of the devices overlap; results
+ * land in place (index-stable), a failing shard's return code and message are reported.  traj may be NULL.  With
+ * tuning.deterministic = 1 the result is bit for bit the single-context one. */
+int32_t nyx_hip_propagate_batch_sharded(nyx_hip_ctx *const *ctxs, int32_t n_ctx, const nyx_hip_states_t *in, int64_t duration_ns,
+                                        nyx_hip_states_t *out, nyx_hip_step_stats_t *stats, nyx_hip_traj_t *traj);
+
 /* Changes the launch-time part of the tuning between launches (cooperative mode, determinism, schedule kind and explicit weights,
  * helper ratio / share, profiling); the create-time part (stage loop, role layout, table feed) must equal the context's. */
 int32_t nyx_hip_ctx_set_tuning(nyx_hip_ctx *ctx, const nyx_hip_tuning_t *tuning);

@@ -199,6 +199,48 @@ class GpuPropagator {
     int64_t init_step_;
 };
 
+// The same propagator on SEVERAL devices of one node, driven by one process: one context per device, a batch is cut into
+// contiguous index shards, the devices work concurrently (nyx_hip_propagate_batch_sharded).  `devices` empty => every device
+// nyx_hip_device_count() reports; a device may be named twice (two contexts on it: how the 1-GPU tests exercise this).
+class MultiGpuPropagator {
+  public:
+    explicit MultiGpuPropagator(const nyx_hip_config_t &cfg, std::vector<int> devices = {}) {
+        if (devices.empty())
+            for (int d = 0; d < nyx_hip_device_count(); ++d) devices.push_back(d);
+        if (devices.empty()) throw std::runtime_error("no HIP device");
+        for (int d : devices) {
+            nyx_hip_ctx *c = nullptr;
+            if (nyx_hip_ctx_create(&cfg, d, &c) != NYX_HIP_RC_OK) {
+                const std::string msg = nyx_hip_last_error();
+                for (nyx_hip_ctx *q : ctxs_) nyx_hip_ctx_destroy(q);
+                throw std::runtime_error(msg);
+            }
+            ctxs_.push_back(c);
+        }
+    }
+    ~MultiGpuPropagator() { for (nyx_hip_ctx *c : ctxs_) nyx_hip_ctx_destroy(c); }
+    MultiGpuPropagator(const MultiGpuPropagator &) = delete;
+    MultiGpuPropagator &operator=(const MultiGpuPropagator &) = delete;
+    int devices() const { return (int)ctxs_.size(); }
+
+    void many_for_duration(StateBatch &in, int64_t duration_ns, StateBatch &out, RunStats &stats) {
+        nyx_hip_states_t vi = in.view(), vo = out.view();
+        nyx_hip_step_stats_t vs = stats.view();
+        if (nyx_hip_propagate_batch_sharded(ctxs_.data(), (int32_t)ctxs_.size(), &vi, duration_ns, &vo, &vs, nullptr) != NYX_HIP_RC_OK)
+            throw std::runtime_error(nyx_hip_last_error());
+    }
+    void many_for_duration_with_traj(StateBatch &in, int64_t duration_ns, StateBatch &out, RunStats &stats, TrajBatch &traj) {
+        nyx_hip_states_t vi = in.view(), vo = out.view();
+        nyx_hip_step_stats_t vs = stats.view();
+        nyx_hip_traj_t vt = traj.view();
+        if (nyx_hip_propagate_batch_sharded(ctxs_.data(), (int32_t)ctxs_.size(), &vi, duration_ns, &vo, &vs, &vt) != NYX_HIP_RC_OK)
+            throw std::runtime_error(nyx_hip_last_error());
+    }
+
+  private:
+    std::vector<nyx_hip_ctx *> ctxs_;
+};
+
 inline TrajBatch TrajBatch::at(GpuPropagator &prop, const std::vector<int64_t> &epochs_ns, std::vector<int32_t> &status) {
     const int64_t m = (int64_t)epochs_ns.size();
     TrajBatch out(n_, m > 0 ? m : 1);

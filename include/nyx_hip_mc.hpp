@@ -198,19 +198,32 @@ class MonteCarlo {  // montecarlo.rs:44-75
         return out;
     }
 
-    // montecarlo.rs:189-273: every run is until_epoch_with_traj; `capacity` accepted steps per run are recorded
-    Results resume_run_until_epoch(GpuPropagator &prop, size_t skip, int64_t end_epoch_ns, size_t num_runs, int64_t capacity = 4096) const {
+    // montecarlo.rs:189-273: every run is until_epoch_with_traj.  `capacity` = accepted steps recorded per run, a first guess:
+    // the kernel stops STORING at the capacity but keeps counting (traj.len), so a run that needed more is seen and the batch is
+    // re-run with what the longest run needs - no caller ever sees a clipped trajectory (a 3-day low-LEO run takes > 4 096 steps).
+    // P = GpuPropagator (one device) or MultiGpuPropagator (the devices of the node, contiguous index shards).
+    template <typename P>
+    Results resume_run_until_epoch(P &prop, size_t skip, int64_t end_epoch_ns, size_t num_runs, int64_t capacity = 4096) const {
         const auto states = generate_states(skip, num_runs);
-        StateBatch in((int64_t)states.size()), out((int64_t)states.size());
+        const int64_t n = (int64_t)states.size();
+        StateBatch in(n), out(n);
         for (size_t k = 0; k < states.size(); ++k) in.set((int64_t)k, states[k].second);
-        RunStats st((int64_t)states.size());
-        Results res{{}, scenario_, TrajBatch((int64_t)states.size(), capacity)};
-        prop.many_for_duration_with_traj(in, end_epoch_ns - random_state_.template_state().epoch_ns, out, st, res.traj);
-        for (size_t k = 0; k < states.size(); ++k)
-            res.runs.push_back(Run{states[k].first, states[k].second, st.status[k], out.get((int64_t)k)});
-        return res;
+        RunStats st(n);
+        const int64_t duration = end_epoch_ns - random_state_.template_state().epoch_ns;
+        int64_t cap = capacity > 0 ? capacity : 1;
+        for (;;) {
+            Results res{{}, scenario_, TrajBatch(n, cap)};
+            prop.many_for_duration_with_traj(in, duration, out, st, res.traj);
+            int64_t need = 0;
+            for (int64_t i = 0; i < n; ++i) need = res.traj.len(i) > need ? res.traj.len(i) : need;
+            if (need > cap) { cap = need; continue; }
+            for (size_t k = 0; k < states.size(); ++k)
+                res.runs.push_back(Run{states[k].first, states[k].second, st.status[k], out.get((int64_t)k)});
+            return res;
+        }
     }
-    Results run_until_epoch(GpuPropagator &prop, int64_t end_epoch_ns, size_t num_runs, int64_t capacity = 4096) const {
+    template <typename P>
+    Results run_until_epoch(P &prop, int64_t end_epoch_ns, size_t num_runs, int64_t capacity = 4096) const {
         return resume_run_until_epoch(prop, 0, end_epoch_ns, num_runs, capacity);
     }
 

@@ -12,6 +12,8 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -28,7 +30,7 @@ extern "C" hipError_t nyx_launch_event_search(const EventSearchArgs *args, hipSt
 extern "C" hipError_t nyx_launch_traj_eval(const TrajEvalArgs *args, hipStream_t stream);
 extern "C" hipError_t nyx_launch_frame_shift(const DevCfg *cfg, const double *records, const int32_t *chain_seg, const double *chain_sign,
                                              int n_chain, int64_t n, const int64_t *epoch_ns, double *x, double *y, double *z, double *vx,
-                                             double *vy, double *vz, double dir, int32_t *status, hipStream_t stream);
+                                             double *vy, double *vz, double dir, int32_t *status, const int32_t *prior, hipStream_t stream);
 extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg, const HarmEntry *htab,
                                            const ColHdr *cols, const double *records, int n_waves, int rec_lds_doubles,
                                            int reuse_fields, hipStream_t stream, int quad);
@@ -1152,7 +1154,7 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
         if (ctx->swap_cap < in->n) {
             (void)hipFree(ctx->d_swap);
             ctx->d_swap = nullptr; ctx->swap_cap = 0;
-            HIP_TRY(hipMalloc(&ctx->d_swap, (size_t)6 * (size_t)in->n * sizeof(double)));
+            HIP_TRY(hipMalloc(&ctx->d_swap, (size_t)7 * (size_t)in->n * sizeof(double)));  // (row 6: the forward shift's status words)
             ctx->swap_cap = in->n;
         }
         nyx_hip_states_t in2 = *in;
@@ -1163,12 +1165,16 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
             HIP_TRY(hipMemcpyAsync(rows[q], src[q], (size_t)in->n * sizeof(double), hipMemcpyDeviceToDevice, stream));
         }
         in2.x_km = rows[0]; in2.y_km = rows[1]; in2.z_km = rows[2]; in2.vx_km_s = rows[3]; in2.vy_km_s = rows[4]; in2.vz_km_s = rows[5];
+        // a start epoch outside the swap body's ephemeris gives a clamped, i.e. WRONG, translation: its status is kept aside and
+        // merged into the run's status by the back-translation (the propagation launch rewrites the status array in between)
+        int32_t *fwd_status = (int32_t *)(ctx->d_swap + (size_t)6 * (size_t)ctx->swap_cap);
+        HIP_TRY(hipMemsetAsync(fwd_status, 0, (size_t)in->n * sizeof(int32_t), stream));
         HIP_TRY(nyx_launch_frame_shift(ctx->d_cfg, ctx->d_records, ctx->swap_seg, ctx->swap_sign, ctx->swap_n_chain, in->n, in->epoch_ns,
-                                       rows[0], rows[1], rows[2], rows[3], rows[4], rows[5], +1.0, nullptr, stream));
+                                       rows[0], rows[1], rows[2], rows[3], rows[4], rows[5], +1.0, fwd_status, nullptr, stream));
         if (int rc = launch(ctx, &in2, out, st, duration_ns, end_epoch_ns, use_end, stream, time_it, nullptr, nullptr, nullptr, false, true)) return rc;
-        // (a start epoch outside the ephemeris leaves a garbage translation: the back-translation at the same table reports it)
         HIP_TRY(nyx_launch_frame_shift(ctx->d_cfg, ctx->d_records, ctx->swap_seg, ctx->swap_sign, ctx->swap_n_chain, in->n, out->epoch_ns,
-                                       out->x_km, out->y_km, out->z_km, out->vx_km_s, out->vy_km_s, out->vz_km_s, -1.0, st ? st->status : nullptr, stream));
+                                       out->x_km, out->y_km, out->z_km, out->vx_km_s, out->vy_km_s, out->vz_km_s, -1.0, st ? st->status : nullptr,
+                                       fwd_status, stream));
         HIP_TRY(hipEventRecord(ctx->ev_done, stream));
         return NYX_HIP_RC_OK;
     }
@@ -1483,6 +1489,89 @@ extern "C" int32_t nyx_hip_propagate_batch_with_traj(nyx_hip_ctx *ctx, const nyx
 extern "C" int32_t nyx_hip_propagate_until_epoch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t end_epoch_ns,
                                                  nyx_hip_states_t *out, nyx_hip_step_stats_t *stats) {
     return host_propagate(ctx, in, 0, end_epoch_ns, 1, out, stats);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One batch over several contexts = several devices of one node, from ONE process (what replaces the rayon par_iter of
+// mc/montecarlo.rs:233-253 when the host is not sharded by rank): contiguous index shards (shard k of m holds
+// [k n / m, (k + 1) n / m), the rule of nyx_amd.shard_bounds), one host thread per context so that the staging copies
+// and the kernels of the devices overlap, results written in place at the shard's offset - the "gather" is free because the
+// arrays are structure-of-arrays.  With a trajectory the shards record into private buffers (the step-major layout has the
+// batch size as its stride) and are scattered afterwards.  Trajectories are independent: no device-to-device traffic at all.
+// ---------------------------------------------------------------------------------------------
+static nyx_hip_states_t states_at(const nyx_hip_states_t &s, int64_t lo, int64_t n) {
+    nyx_hip_states_t v = s;
+    v.n = n;
+    auto off = [&](auto *p) { return p ? p + lo : p; };
+    v.epoch_ns = off(s.epoch_ns);
+    v.x_km = off(s.x_km); v.y_km = off(s.y_km); v.z_km = off(s.z_km);
+    v.vx_km_s = off(s.vx_km_s); v.vy_km_s = off(s.vy_km_s); v.vz_km_s = off(s.vz_km_s);
+    v.cr = off(s.cr); v.cd = off(s.cd); v.prop_mass_kg = off(s.prop_mass_kg); v.dry_mass_kg = off(s.dry_mass_kg);
+    v.extra_mass_kg = off(s.extra_mass_kg); v.srp_area_m2 = off(s.srp_area_m2); v.drag_area_m2 = off(s.drag_area_m2);
+    v.stm = s.stm ? s.stm + lo * 81 : nullptr;
+    v.step_ns = off(s.step_ns);
+    return v;
+}
+static nyx_hip_step_stats_t stats_at(const nyx_hip_step_stats_t &s, int64_t lo) {
+    nyx_hip_step_stats_t v = s;
+    auto off = [&](auto *p) { return p ? p + lo : p; };
+    v.status = off(s.status); v.last_step_ns = off(s.last_step_ns); v.last_error = off(s.last_error);
+    v.last_attempts = off(s.last_attempts); v.n_accepted = off(s.n_accepted); v.n_rejected = off(s.n_rejected); v.n_evals = off(s.n_evals);
+    return v;
+}
+
+extern "C" int32_t nyx_hip_propagate_batch_sharded(nyx_hip_ctx *const *ctxs, int32_t n_ctx, const nyx_hip_states_t *in, int64_t duration_ns,
+                                                   nyx_hip_states_t *out, nyx_hip_step_stats_t *stats, nyx_hip_traj_t *traj) {
+    if (!ctxs || n_ctx < 1 || !in || !out) { nyx_set_error("sharded: null argument or no context"); return NYX_HIP_RC_BAD_ARG; }
+    for (int32_t k = 0; k < n_ctx; ++k)
+        if (!ctxs[k]) { nyx_set_error("sharded: null context %d", k); return NYX_HIP_RC_BAD_ARG; }
+    if (out->n != in->n) { nyx_set_error("sharded: out->n != in->n"); return NYX_HIP_RC_BAD_ARG; }
+    if (traj && traj->capacity < 1) { nyx_set_error("traj with capacity >= 1 required"); return NYX_HIP_RC_BAD_ARG; }
+    const int64_t n = in->n, cap = traj ? traj->capacity : 0;
+    std::vector<int32_t> rcs((size_t)n_ctx, NYX_HIP_RC_OK);
+    std::vector<std::string> errs((size_t)n_ctx);
+    struct ShardTraj { std::vector<int64_t> ep; std::vector<double> f[6]; std::vector<int32_t> len; };
+    std::vector<ShardTraj> st((size_t)n_ctx);
+    std::vector<std::thread> threads;
+    for (int32_t k = 0; k < n_ctx; ++k) {
+        const int64_t lo = n * k / n_ctx, hi = n * (k + 1) / n_ctx;
+        if (hi == lo) continue;
+        threads.emplace_back([&, k, lo, hi]() {
+            const nyx_hip_states_t vi = states_at(*in, lo, hi - lo);
+            nyx_hip_states_t vo = states_at(*out, lo, hi - lo);
+            nyx_hip_step_stats_t vs{};
+            if (stats) vs = stats_at(*stats, lo);
+            int32_t rc;
+            if (traj) {
+                ShardTraj &t = st[(size_t)k];
+                const size_t cells = (size_t)((hi - lo) * cap);
+                t.ep.resize(cells); t.len.assign((size_t)(hi - lo), 0);
+                for (auto &f : t.f) f.resize(cells);
+                nyx_hip_traj_t vt{cap, t.ep.data(), t.f[0].data(), t.f[1].data(), t.f[2].data(), t.f[3].data(), t.f[4].data(), t.f[5].data(), t.len.data()};
+                rc = nyx_hip_propagate_batch_with_traj(ctxs[k], &vi, duration_ns, &vo, stats ? &vs : nullptr, &vt);
+            } else {
+                rc = nyx_hip_propagate_batch(ctxs[k], &vi, duration_ns, &vo, stats ? &vs : nullptr);
+            }
+            rcs[(size_t)k] = rc;
+            if (rc != NYX_HIP_RC_OK) errs[(size_t)k] = nyx_hip_last_error();  // (the message is thread-local)
+        });
+    }
+    for (auto &t : threads) t.join();
+    for (int32_t k = 0; k < n_ctx; ++k)
+        if (rcs[(size_t)k] != NYX_HIP_RC_OK) { nyx_set_error("shard %d: %s", k, errs[(size_t)k].c_str()); return rcs[(size_t)k]; }
+    if (traj) {  // scatter the shards' step-major blocks (stride = shard size) into the batch's (stride = n)
+        for (int32_t k = 0; k < n_ctx; ++k) {
+            const int64_t lo = n * k / n_ctx, hi = n * (k + 1) / n_ctx, m = hi - lo;
+            const ShardTraj &t = st[(size_t)k];
+            for (int64_t i = 0; i < m; ++i) traj->len[lo + i] = t.len[(size_t)i];
+            for (int64_t s2 = 0; s2 < cap; ++s2) {
+                std::memcpy(traj->epoch_ns + s2 * n + lo, t.ep.data() + s2 * m, (size_t)m * sizeof(int64_t));
+                double *dst[6] = {traj->x_km, traj->y_km, traj->z_km, traj->vx_km_s, traj->vy_km_s, traj->vz_km_s};
+                for (int c = 0; c < 6; ++c) std::memcpy(dst[c] + s2 * n + lo, t.f[c].data() + s2 * m, (size_t)m * sizeof(double));
+            }
+        }
+    }
+    return NYX_HIP_RC_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -147,7 +147,7 @@ struct FrameChain {
 // trajectory's epoch); dir = +1 into the integration frame, -1 back.  One thread per trajectory.
 __global__ __launch_bounds__(256) void nyx_frame_shift_kernel(const DevCfg *cfg_g, const double *records, FrameChain ch, int64_t n,
                                                               const int64_t *epoch_ns, double *x, double *y, double *z, double *vx,
-                                                              double *vy, double *vz, double dir, int32_t *status) {
+                                                              double *vy, double *vz, double dir, int32_t *status, const int32_t *prior) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     CfgPtr cfg = (CfgPtr)cfg_g;
@@ -162,17 +162,18 @@ __global__ __launch_bounds__(256) void nyx_frame_shift_kernel(const DevCfg *cfg_
     }
     x[i] = x[i] + dir * b[0]; y[i] = y[i] + dir * b[1]; z[i] = z[i] + dir * b[2];
     vx[i] = vx[i] + dir * bv[0]; vy[i] = vy[i] + dir * bv[1]; vz[i] = vz[i] + dir * bv[2];
+    if (prior && prior[i] != NYX_HIP_OK) st = prior[i];  // (the translation INTO the integration frame had failed already)
     if (st && status && status[i] == NYX_HIP_OK) status[i] = st;
 }
 extern "C" hipError_t nyx_launch_frame_shift(const DevCfg *cfg, const double *records, const int32_t *chain_seg, const double *chain_sign,
                                              int n_chain, int64_t n, const int64_t *epoch_ns, double *x, double *y, double *z, double *vx,
-                                             double *vy, double *vz, double dir, int32_t *status, hipStream_t stream) {
+                                             double *vy, double *vz, double dir, int32_t *status, const int32_t *prior, hipStream_t stream) {
     FrameChain ch;
     ch.n_chain = n_chain;
     for (int k = 0; k < 4; ++k) { ch.seg[k] = k < n_chain ? chain_seg[k] : 0; ch.sign[k] = k < n_chain ? chain_sign[k] : 0.0; }
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(nyx_frame_shift_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, cfg, records, ch, n, epoch_ns, x, y, z,
-                       vx, vy, vz, dir, status);
+                       vx, vy, vz, dir, status, prior);
     return hipGetLastError();
 }
 #endif

@@ -231,20 +231,29 @@ class Results:
         return self.runs if self._local is None else self.runs[self._local[0]:self._local[1]]
 
     def mean_and_covariance(self):
-        """Ensemble mean and (unbiased) covariance of the final 9-vectors [r, v, Cr, Cd, prop mass] of the successful runs.
+        """Ensemble mean and (unbiased) covariance of the final 9-vectors [r, v, Cr, Cd, prop mass] of the successful runs
+        (NINE components since round 2: Cr, Cd and the propellant mass are dispersed and integrated like r and v; rounds before
+        returned the 6-vector only).  No successful run at all: NaNs.
         On a sharded ensemble each rank sums ITS runs only and one all-reduce (RCCL / gloo) of the 1 + 9 + 45 moments
         [count, sum(x - x0), upper triangle of sum((x - x0)(x - x0)^T)] completes them; x0 = the final state of the
         first successful run (every rank holds the gathered final states), which keeps the sums well conditioned.
         Returns (mean[9], cov[9, 9])."""
         d = STATE_DIM
-        ok = self.ok_runs()
-        x0 = _vec9(ok[0].result.state) if ok else np.zeros(d)
-        xs = np.array([_vec9(r.result.state) for r in self._local_runs() if isinstance(r.result, PropResult)]).reshape(-1, d) - x0
         iu = np.triu_indices(d)
-        mom = np.concatenate([[float(len(xs))], xs.sum(axis=0), (xs.T @ xs)[iu]])
+        err, mom, x0 = None, np.zeros(1 + d + len(iu[0])), np.zeros(d)
+        try:
+            ok = self.ok_runs()
+            x0 = _vec9(ok[0].result.state) if ok else np.zeros(d)
+            xs = np.array([_vec9(r.result.state) for r in self._local_runs() if isinstance(r.result, PropResult)]).reshape(-1, d) - x0
+            mom = np.concatenate([[float(len(xs))], xs.sum(axis=0), (xs.T @ xs)[iu]])
+        except Exception as e:  # noqa: BLE001 - re-raised on every rank below
+            err = e
+        self._sync_errors(err)
         if self._dist is not None and self._dist.get_world_size() > 1:
             mom = all_reduce_sum(self._dist, mom)
         n, sx = mom[0], mom[1:1 + d]
+        if n < 1:   # no successful run anywhere: nothing to average
+            return np.full(d, np.nan), np.full((d, d), np.nan)
         sxx = np.zeros((d, d))
         sxx[iu] = mom[1 + d:]
         sxx = sxx + np.triu(sxx, 1).T
@@ -258,22 +267,41 @@ class Results:
         return state_value(param, rv, self.mu_km3_s2, cr=s.cr, cd=s.cd, dry_mass_kg=s.dry_mass_kg, prop_mass_kg=s.prop_mass_kg,
                            extra_mass_kg=getattr(s, "extra_mass_kg", 0.0))
 
-    def _report(self, param: StateParameter, states_of_run, value_if_run_failed: Optional[float]) -> List[float]:
+    def _sync_errors(self, err: Optional[BaseException]) -> None:
+        """Sharded ensemble: a rank that fails BEFORE a collective would leave the others waiting in it for ever.  Every rank
+        therefore reduces an error flag first and all of them raise - the failing rank its own exception, the others a
+        RuntimeError naming the situation."""
+        if self._dist is not None and self._dist.get_world_size() > 1:
+            failed = all_reduce_sum(self._dist, np.array([1.0 if err is not None else 0.0]))[0]
+            if err is None and failed > 0:
+                raise RuntimeError("another rank failed while preparing this collective report; aborted on every rank")
+        if err is not None:
+            raise err
+
+    def _report(self, param: StateParameter, states_of_run, value_if_run_failed: Optional[float], prepare=None) -> List[float]:
         """One flat list, run after run.  Sharded ensemble: every rank reports the runs it propagated (it holds their
-        trajectories) and the pieces are gathered in rank order = index order (contiguous shards): a collective call."""
+        trajectories) and the pieces are gathered in rank order = index order (contiguous shards): a collective call.
+        `prepare` (optional) runs first, inside the guarded section, and returns `states_of_run`."""
         report: List[float] = []
-        for run in self._local_runs():
-            if not isinstance(run.result, PropResult):
-                if value_if_run_failed is not None:
-                    report.append(float(value_if_run_failed))
-                continue
-            rv = states_of_run(run)
-            try:
-                report.extend(self._value(param, run, rv).ravel().tolist())
-            except StateError:
-                # (the reference pushes the substitute once per state that cannot be evaluated)
-                if value_if_run_failed is not None:
-                    report.extend([float(value_if_run_failed)] * len(rv))
+        err = None
+        try:
+            if prepare is not None:
+                states_of_run = prepare()
+            for run in self._local_runs():
+                if not isinstance(run.result, PropResult):
+                    if value_if_run_failed is not None:
+                        report.append(float(value_if_run_failed))
+                    continue
+                rv = states_of_run(run)
+                try:
+                    report.extend(self._value(param, run, rv).ravel().tolist())
+                except StateError:
+                    # (the reference pushes the substitute once per state that cannot be evaluated)
+                    if value_if_run_failed is not None:
+                        report.extend([float(value_if_run_failed)] * len(rv))
+        except Exception as e:  # noqa: BLE001 - re-raised on every rank by _sync_errors
+            err = e
+        self._sync_errors(err)
         if self._dist is not None and self._dist.get_world_size() > 1:
             report = all_gather_lists(self._dist, report)
         return report
@@ -284,21 +312,23 @@ class Results:
 
     def every_value_of(self, param: StateParameter, step_ns: int, value_if_run_failed: Optional[float] = None) -> List[float]:
         """results.rs:127-160: `param` of every run from the start to the end of its trajectory every `step_ns`."""
-        self._need_traj()
-        tb = self._traj_batch
-        last = np.array([tb.epoch_ns[max(min(int(tb.len[i]), tb.capacity) - 1, 0), i] for i in range(tb.n)])
-        count = int(np.max(np.abs(last - tb.epoch_ns[0]) // abs(int(step_ns)))) + 1 if tb.n else 1
-        res = self._traj_ctx.traj_every(tb, int(step_ns), count) if tb.n else None   # (each rank resamples ITS shard on its device)
-        return self._report(param, lambda run: res.trajectory(self._traj_rows[run.index])[1], value_if_run_failed)
+        def prepare():
+            self._need_traj()
+            tb = self._traj_batch
+            last = np.array([tb.epoch_ns[max(min(int(tb.len[i]), tb.capacity) - 1, 0), i] for i in range(tb.n)])
+            count = int(np.max(np.abs(last - tb.epoch_ns[0]) // abs(int(step_ns)))) + 1 if tb.n else 1
+            res = self._traj_ctx.traj_every(tb, int(step_ns), count) if tb.n else None   # (each rank resamples ITS shard on its device)
+            return lambda run: res.trajectory(self._traj_rows[run.index])[1]
+
+        return self._report(param, None, value_if_run_failed, prepare=prepare)
 
     def every_value_of_between(self, param: StateParameter, step_ns: int, start_ns: int, end_ns: int,
                                value_if_run_failed: Optional[float] = None) -> List[float]:
         """results.rs:89-125: as above between max(start, first epoch) and min(end, last epoch) of each run
         (`Traj::every_between`, traj.rs:153-162; the series stops at the first epoch that cannot be interpolated)."""
-        self._need_traj()
-        tb = self._traj_batch
-
         def states_of_run(run):
+            self._need_traj()
+            tb = self._traj_batch
             i = self._traj_rows[run.index]
             ep, _ = tb.trajectory(i)
             lo, hi = max(int(start_ns), int(ep.min())), min(int(end_ns), int(ep.max()))
@@ -317,13 +347,13 @@ class Results:
 
     def first_values_of(self, param: StateParameter, value_if_run_failed: Optional[float] = None) -> List[float]:
         """results.rs:162-190."""
-        self._need_traj()
-        return self._report(param, lambda run: np.asarray(run.result.traj.first())[None, :], value_if_run_failed)
+        return self._report(param, None, value_if_run_failed,
+                            prepare=lambda: (self._need_traj(), lambda run: np.asarray(run.result.traj.first())[None, :])[1])
 
     def last_values_of(self, param: StateParameter, value_if_run_failed: Optional[float] = None) -> List[float]:
         """results.rs:192-220."""
-        self._need_traj()
-        return self._report(param, lambda run: np.asarray(run.result.traj.last())[None, :], value_if_run_failed)
+        return self._report(param, None, value_if_run_failed,
+                            prepare=lambda: (self._need_traj(), lambda run: np.asarray(run.result.traj.last())[None, :])[1])
 
     def dispersion_values_of(self, param: StateParameter) -> List[float]:
         """results.rs:222-239: the applied dispersion of `param` for every run; StateError if it was not dispersed."""

@@ -486,6 +486,10 @@ def compile_config(dynamics: SpacecraftDynamics, method: IntegratorMethod, opts:
     # opts.integration_frame (instance.rs:117-142): `central` is the integration frame, the states come centred on `state_frame`
     cfg.state_frame_body = 0
     if state_frame is not None and state_frame.naif_id != central.naif_id:
+        # the device swap is a pure translation (two frames of one orientation): a rotated pair needs almanac.transform_to's
+        # rotation as well, which this path does not do - refused rather than silently treated as a translation
+        if (state_frame.rotation is None) != (central.rotation is None) or (state_frame.rotation is not None and state_frame.rotation != central.rotation):
+            raise NotImplementedError("opts.integration_frame: the state frame and the integration frame must have the same orientation")
         cfg.state_frame_body = body_of(state_frame.naif_id)
     pm = [m for m in dynamics.orbital_dyn.accel_models if isinstance(m, PointMasses)]
     gf = [m for m in dynamics.orbital_dyn.accel_models if isinstance(m, GravityFieldData)]
@@ -633,6 +637,20 @@ def unpack_spacecraft(batch: _abi.StateBatch, template: Sequence[Spacecraft]) ->
             s.stm = batch.stm[i].reshape(9, 9).T.copy()
         out.append(s)
     return out
+
+
+def propagate_sharded(contexts, batch: "_abi.StateBatch", duration_ns: int):
+    """``nyx_hip_propagate_batch_sharded``: one batch over several contexts (one per device of the node, driven by this process):
+    contiguous index shards, concurrent devices, results in place.  Returns (out, stats)."""
+    lib = _abi.load_library()
+    out = batch.copy()
+    stats = _abi.StatsBatch(batch.n)
+    cin, cout, cst = batch.as_c(), out.as_c(), stats.as_c()
+    arr = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    rc = lib.nyx_hip_propagate_batch_sharded(arr, len(contexts), C.byref(cin), int(duration_ns), C.byref(cout), C.byref(cst), None)
+    if rc != 0:
+        raise RuntimeError(f"nyx_hip_propagate_batch_sharded failed (rc={rc}): {_abi.last_error()}")
+    return out, stats
 
 
 class GpuContext:
@@ -988,12 +1006,35 @@ class Traj:
         return Traj.from_arrays(self._ctx, q, states[:, 0])
 
 
+_ARRAY_DIGESTS: dict = {}
+
+
+def _array_digest(a: np.ndarray) -> bytes:
+    """Digest of an array's content.  The ephemeris records and Stokes coefficients are megabytes and are hashed for every
+    `Propagator.with_()`: the digest of a large array is memoised under its buffer (address, shape, strides, type) and revalidated
+    with a strided sample of 256 elements - an in-place edit that leaves all of them untouched would be missed, a rebuilt table
+    (the way these are produced) is not."""
+    if a.nbytes <= 4096:
+        return hashlib.blake2b(np.ascontiguousarray(a).tobytes(), digest_size=16).digest()
+    flat = a.reshape(-1)
+    sample = np.ascontiguousarray(flat[:: max(1, flat.size // 256)]).tobytes()
+    key = (a.__array_interface__["data"][0], a.shape, a.strides, a.dtype.str)
+    hit = _ARRAY_DIGESTS.get(key)
+    if hit is not None and hit[0] == sample:
+        return hit[1]
+    d = hashlib.blake2b(np.ascontiguousarray(a).tobytes(), digest_size=16).digest()
+    if len(_ARRAY_DIGESTS) > 256:
+        _ARRAY_DIGESTS.clear()
+    _ARRAY_DIGESTS[key] = (sample, d)
+    return d
+
+
 def _feed(h, obj) -> None:
     """Content fingerprint of a model tree (dataclasses, containers, numpy arrays, scalars): what the context cache is
     keyed on, so that ANY change of the dynamics, the options, the frame or the almanac's tables builds a new context."""
     if isinstance(obj, np.ndarray):
         h.update(str((obj.dtype.str, obj.shape)).encode())
-        h.update(np.ascontiguousarray(obj).tobytes())
+        h.update(_array_digest(obj))
     elif dataclasses.is_dataclass(obj) and not isinstance(obj, type):
         h.update(type(obj).__name__.encode())
         for f in dataclasses.fields(obj):
@@ -1072,8 +1113,9 @@ class Propagator:
         _feed(h, almanac)
         key = h.digest()
         if key not in self._ctx_cache:
-            if len(self._ctx_cache) >= 8:   # bounded: drop the oldest context (device tables are a few MB each)
-                self._ctx_cache.pop(next(iter(self._ctx_cache))).close()
+            if len(self._ctx_cache) >= 8:   # bounded: forget the oldest context (device tables are a few MB each).  NOT closed here:
+                # PropInstance and Traj objects may still hold it; GpuContext.__del__ destroys it with its last user
+                self._ctx_cache.pop(next(iter(self._ctx_cache)))
             self._ctx_cache[key] = GpuContext(self.compile(almanac, central, stm, state_frame), self.device)
         return self._ctx_cache[key]
 

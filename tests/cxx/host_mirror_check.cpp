@@ -105,5 +105,21 @@ int main() {
         mc_ok = mc_ok && run.status == NYX_HIP_OK && run.state.epoch_ns == 1800LL * 1000000000LL &&
                 res.traj.state(res.traj.len((int64_t)run.index) - 1, (int64_t)run.index, 0) == run.state.rv[0];
     std::printf("MonteCarlo::run_until_epoch: %s\n", mc_ok ? "ok" : "FAILED");
-    return resample_ok && event_ok && mc_ok ? 0 : 1;
+
+    // The same Monte Carlo over SEVERAL contexts (nyx_hip_propagate_batch_sharded; here two contexts on device 0, on a node one per
+    // device): contiguous index shards, run concurrently, must equal the single-context result bit for bit; the first guess of
+    // the trajectory capacity (4) is far too small on purpose: the batch is re-run with what the longest run needs.
+    nyx::MultiGpuPropagator multi(cfg, {0, 0});
+    nyx::Results sharded = mc.run_until_epoch(multi, 1800LL * 1000000000LL, 8, 4);
+    bool multi_ok = sharded.runs.size() == 8 && multi.devices() == 2 && sharded.traj.capacity() >= sharded.traj.len(0);
+    for (size_t k = 0; k < sharded.runs.size() && multi_ok; ++k) {
+        const auto &a = sharded.runs[k], &b = res.runs[k];
+        for (int c = 0; c < 6; ++c) multi_ok = multi_ok && a.state.rv[c] == b.state.rv[c];
+        multi_ok = multi_ok && a.status == NYX_HIP_OK && sharded.traj.len((int64_t)k) == res.traj.len((int64_t)k);
+        for (int32_t q = 0; q < res.traj.len((int64_t)k) && multi_ok; ++q)
+            multi_ok = sharded.traj.epoch_ns(q, (int64_t)k) == res.traj.epoch_ns(q, (int64_t)k) &&
+                       sharded.traj.state(q, (int64_t)k, 3) == res.traj.state(q, (int64_t)k, 3);
+    }
+    std::printf("MultiGpuPropagator (2 contexts, capacity regrown to %d): %s\n", (int)sharded.traj.capacity(), multi_ok ? "ok" : "FAILED");
+    return resample_ok && event_ok && mc_ok && multi_ok ? 0 : 1;
 }

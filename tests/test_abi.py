@@ -18,7 +18,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     lib = _abi.load_library()
     header = open(os.path.join(ROOT, "include", "nyx_hip.h")).read()
     declared = set(re.findall(r"^(?:int32_t|void|double|const char \*)\s*(nyx_hip_[a-z_0-9]+)\(", header, flags=re.M))
-    assert len(declared) == 22
+    assert len(declared) == 23
     assert declared >= set(_abi.EXPORTS)
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in nyx_hip.h but not exported"
@@ -105,6 +105,7 @@ def test_cxx_host_mirror_golden_on_gpu(tmp_path):
     import subprocess
     r = subprocess.run([_build_cxx_check(tmp_path)], capture_output=True, text=True)
     assert r.returncode == 0 and "max |delta|" in r.stdout, r.stdout + r.stderr
+    assert "MultiGpuPropagator (2 contexts" in r.stdout and "FAILED" not in r.stdout, r.stdout
 
 
 def _create_rc(cc):

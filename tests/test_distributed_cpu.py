@@ -159,3 +159,35 @@ def test_single_process_moments_match_numpy():
     x = res.final_rv()
     np.testing.assert_allclose(mean[:6], x.mean(axis=0), rtol=1e-13)
     np.testing.assert_allclose(cov[:6, :6], np.cov(x, rowvar=False), rtol=1e-9, atol=1e-12)
+
+
+def _worker_fail(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    prop, almanac, mc = _build_with_traj(3)
+    res = mc.resume_run_until_epoch(prop, almanac, 0, EPOCH0_NS + 600 * nx.NS_PER_S, 6, dist=dist)
+    if rank == 1:   # this rank loses its trajectories: its part of the report cannot be made
+        res._traj_batch = None
+    outcome = "no error"
+    try:
+        res.every_value_of(nx.StateParameter.X, 300 * nx.NS_PER_S)
+    except ValueError as e:
+        outcome = "ValueError: " + str(e)
+    except RuntimeError as e:
+        outcome = "RuntimeError: " + str(e)
+    # ... and the process group is still usable: nobody is stuck inside a half-entered collective
+    mean, _ = res.mean_and_covariance()
+    with open(os.path.join(out_dir, f"f{rank}.txt"), "w") as f:
+        f.write(outcome + "\n" + repr(float(mean[0])))
+    dist.destroy_process_group()
+
+
+def test_a_failing_rank_aborts_the_collective_on_every_rank(tmp_path):
+    """a rank that raises before a gathered report must not leave the others waiting in the collective."""
+    port = _free_port()
+    mp.spawn(_worker_fail, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    f0, f1 = open(tmp_path / "f0.txt").read().split("\n"), open(tmp_path / "f1.txt").read().split("\n")
+    assert f0[0].startswith("RuntimeError: another rank failed")
+    assert f1[0].startswith("ValueError: these results carry no trajectories")
+    assert f0[1] == f1[1]

@@ -72,3 +72,23 @@ def test_calibrated_schedule_is_opt_in_and_agrees():
     assert dr.max() < 1e-6 and dv.max() < 1e-9
     model.close()
     cal.close()
+
+
+def test_sharded_entry_point_equals_the_single_context_run():
+    """nyx_hip_propagate_batch_sharded (the multi-device driver of the C-ABI) with three contexts on device 0 - on a node: one per
+    device - against one context, deterministic tuning: bit for bit, ragged shards included."""
+    prop, almanac, central = leo_full_setup(degree=21)
+    compiled = prop.compile(almanac, central)
+    b = dispersed_leo_batch(1000, seed=4)
+    dur = 30 * 60 * nx.NS_PER_S
+    tun = nx.Tuning(deterministic=1)
+    one = nx.GpuContext(compiled, tuning=tun)
+    ref, rst = one.propagate(b, dur)
+    ctxs = [nx.GpuContext(compiled, tuning=tun) for _ in range(3)]
+    out, st = nx.propagate_sharded(ctxs, b, dur)
+    assert (st.status == 0).all()
+    np.testing.assert_array_equal(out.rv(), ref.rv())
+    np.testing.assert_array_equal(out.epoch_ns, ref.epoch_ns)
+    np.testing.assert_array_equal(st.n_evals, rst.n_evals)
+    for c in ctxs + [one]:
+        c.close()

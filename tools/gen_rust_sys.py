@@ -63,17 +63,20 @@ def parse(text):
         a = " ".join(m.group(3).split())
         if a != "void":
             for arg in a.split(","):
-                am = re.match(r"\s*(const\s+)?(struct\s+)?(\w+)\s*((?:\*\s*)*)(\w+)\s*$", arg)
-                args.append(dict(const=bool(am.group(1)), base=am.group(3), ptr=am.group(4).count("*"), name=am.group(5)))
+                am = re.match(r"\s*(const\s+)?(struct\s+)?(\w+)\s*((?:\*\s*(?:const\s*)?)*)(\w+)\s*$", arg)
+                # `T *const *p`: the const AFTER a star qualifies the pointer of that level (seen from the next level out)
+                lv_const = [bool(x) for x in re.findall(r"\*\s*(const)?", am.group(4))]
+                args.append(dict(const=bool(am.group(1)), base=am.group(3), ptr=am.group(4).count("*"), name=am.group(5), lv_const=lv_const))
         funcs.append((m.group(2), " ".join(m.group(1).split()), args))
     return defines, enums, structs, opaque, funcs
 
 
-def rust_type(base, const, ptr, known):
+def rust_type(base, const, ptr, known, lv_const=None):
     t = PRIM[base][0] if base in PRIM else base
     for k in range(ptr):
-        # `const T *` is a pointer to const; further levels (T **) are out-parameters
-        t = ("*const " if (const and k == 0) else "*mut ") + t
+        # `const T *` is a pointer to const; further levels (T **) are out-parameters unless the level below is `*const`
+        pointee_const = (const and k == 0) or (k > 0 and lv_const and lv_const[k - 1])
+        t = ("*const " if pointee_const else "*mut ") + t
     return t
 
 
@@ -134,7 +137,7 @@ def generate():
         L.append(f"pub enum {alias} {{}}   // opaque")
     L += ["", '#[link(name = "nyx_hip")]', 'extern "C" {']
     for fname, ret, args in funcs:
-        a = ", ".join(f"{x['name'] if x['name'] not in ('in', 'type') else x['name'] + '_'}: {rust_type(x['base'], x['const'], x['ptr'], None)}" for x in args)
+        a = ", ".join(f"{x['name'] if x['name'] not in ('in', 'type') else x['name'] + '_'}: {rust_type(x['base'], x['const'], x['ptr'], None, x.get('lv_const'))}" for x in args)
         r = {"int32_t": " -> i32", "int64_t": " -> i64", "double": " -> f64", "void": "", "const char *": " -> *const c_char"}[ret]
         line = f"    pub fn {fname}({a}){r};"
         while len(line) > 120:
