@@ -178,10 +178,15 @@ def host_threads():
         return logical, logical
 
 
+CPU_BASELINE_MIN_WALL_S = 12.0   # the timed CPU wall of every configuration: >= 10 s, so that thread start-up and scheduling noise are < 1 %
+
+
 def cpu_baseline(shard, compiled, n_per_gpu, hours):
-    """The oracle (CPU restatement of the reference, kind = "port") timed on this box's host on a bounded sample of the
-    SAME workload: one pthread per hardware thread over trajectories (rayon par_iter analogue), full-length trajectories
-    when a round of them fits the ~25 s budget, otherwise the head of the propagation (stated in `sample`)."""
+    """The oracle (CPU restatement of the reference, kind = "port") timed on this box's host on a bounded sample of the SAME
+    workload: one pthread per hardware thread over trajectories (rayon par_iter analogue).  Rounds of `threads` trajectories -
+    the head of this rank's shard first (the states the device propagated, not a re-draw), cycling through the shard when it
+    is exhausted - are propagated until the timed wall reaches CPU_BASELINE_MIN_WALL_S; full-length trajectories when one round
+    fits the budget, otherwise the head of the propagation (stated in `sample`, the rate scaled by the fraction)."""
     import oracle_lib
     threads, phys = host_threads()
     probe = shard.slice(0, min(threads, shard.n))
@@ -189,36 +194,89 @@ def cpu_baseline(shard, compiled, n_per_gpu, hours):
     t0 = time.time()
     oracle_lib.propagate(compiled, probe, int(probe_h * 3600) * nx.NS_PER_S, n_threads=threads)
     per_hour = (time.time() - t0) / probe_h  # wall seconds per hour of propagation of one round (`threads` trajectories)
-    budget_s = 25.0
     samp_h = hours
-    if per_hour * hours > 0.6 * budget_s:  # a full-length round does not fit: time the first `samp_h` hours instead
-        samp_h = max(probe_h, min(hours, float(int(0.6 * budget_s / per_hour * 4) / 4.0)))
-    # first round: `threads` trajectories, the HEAD of this rank's shard (the states the device propagated, not a re-draw); the
-    # short probe underestimates a long round, so what follows is sized by the round itself: one more launch with as many rounds
-    # as the rest of the budget holds
+    if per_hour * hours > 1.5 * CPU_BASELINE_MIN_WALL_S:  # a full-length round is too long: time the first `samp_h` hours instead
+        samp_h = max(probe_h, min(hours, float(int(1.2 * CPU_BASELINE_MIN_WALL_S / per_hour * 4) / 4.0)))
+    span = int(samp_h * 3600) * nx.NS_PER_S
     n1 = min(threads, shard.n)
-    sample = shard.slice(0, n1)
-    t0 = time.time()
-    out, st = oracle_lib.propagate(compiled, sample, int(samp_h * 3600) * nx.NS_PER_S, n_threads=threads)
-    dt = time.time() - t0
-    assert (st.status == 0).all()
-    n, evals = n1, float(st.n_evals.sum())
-    more = min(int((budget_s - dt) / max(dt, 1e-3)), (shard.n - n1) // max(threads, 1))
-    if more >= 1:
-        extra = shard.slice(n1, n1 + more * threads)
+    dt, n, evals, rounds, lo = 0.0, 0, 0.0, 0, 0
+    sample = out = None
+    while dt < CPU_BASELINE_MIN_WALL_S and rounds < 400:
+        if lo + n1 > shard.n:
+            lo = 0   # (the shard is exhausted: the same states again - the cost does not depend on who propagates them)
+        chunk = shard.slice(lo, lo + n1)
         t0 = time.time()
-        _, st2 = oracle_lib.propagate(compiled, extra, int(samp_h * 3600) * nx.NS_PER_S, n_threads=threads)
+        o, st = oracle_lib.propagate(compiled, chunk, span, n_threads=threads)
         dt += time.time() - t0
-        assert (st2.status == 0).all()
-        n += extra.n
-        evals += float(st2.n_evals.sum())
+        assert (st.status == 0).all()
+        if sample is None:
+            sample, out = chunk, o
+        n += chunk.n
+        evals += float(st.n_evals.sum())
+        rounds += 1
+        lo += n1
     frac = samp_h / hours
     what = f"full {hours:g} h propagation each" if frac == 1.0 else \
         f"the first {samp_h:g} h of the {hours:g} h propagation each (rate scaled by {frac:.4g}: the orbit is periodic, the cost per hour constant)"
     return {"value": n / dt * frac, "unit": "trajectories/s", "cores": threads, "physical_cores": phys, "kind": "port",
-            "sample": f"{n} of the {n_per_gpu} dispersed states, {what}, {threads} pthreads = hardware threads on {phys} physical cores "
-                      f"(rayon par_iter analogue), {dt:.1f} s wall, {int(evals)} force evaluations",
-            "evals_per_s": evals / dt}, sample, out, samp_h
+            "sample": f"{n} propagations ({rounds} rounds of {n1} of the {n_per_gpu} dispersed states), {what}, {threads} pthreads = hardware threads "
+                      f"on {phys} physical cores (rayon par_iter analogue), {dt:.1f} s wall, {int(evals)} force evaluations",
+            "wall_s": dt, "evals_per_s": evals / dt}, sample, out, samp_h
+
+
+def cpu_baseline_predict(shard, compiled, p0, end_ns, n_per_gpu, hours):
+    """Config 4: the oracle's predict_until twin over independent estimates.  One OD process is sequential, but the workload
+    is 1 000 independent ones, which the reference would par_iter: every hardware thread maps its own chunk of 16 estimates
+    again and again (the C call releases the GIL; its arguments are prepared once per thread) until the timed wall reaches
+    CPU_BASELINE_MIN_WALL_S; the one-thread rate is kept beside it."""
+    import threading
+    import oracle_lib
+    from nyx_amd import od
+    threads, phys = host_threads()
+    step = 60 * nx.NS_PER_S
+    chunk = 16
+    lib = oracle_lib.load()
+    t1 = time.time()
+    oracle_lib.predict_until(compiled, shard.slice(0, chunk), p0[:chunk], end_ns, step)
+    one_chunk_s = time.time() - t1
+    reps = max(2, int(np.ceil(CPU_BASELINE_MIN_WALL_S / max(one_chunk_s, 1e-3))))
+    gate = threading.Barrier(threads + 1)
+    done = [0] * threads
+
+    def worker(k):
+        lo = (k * chunk) % max(shard.n - chunk, 1)
+        held = {}
+
+        def capture(*args):   # (keeps the ctypes arguments - and through `keep` everything they point to - alive for the timed loop)
+            held["args"] = args
+            return 0
+        keep = od.predict_until(None, shard.slice(lo, lo + chunk), p0[lo:lo + chunk], end_ns, step, _call=capture)
+        gate.wait()
+        for _ in range(reps):
+            rc = lib.nyx_oracle_predict_until(C.byref(compiled.cfg), *held["args"])   # (the covariances keep being mapped on: same cost)
+            assert rc == 0
+            done[k] += chunk
+        del keep
+
+    ts = [threading.Thread(target=worker, args=(k,)) for k in range(threads)]
+    for t in ts:
+        t.start()
+    gate.wait()
+    t1 = time.time()
+    for t in ts:
+        t.join()
+    dt = time.time() - t1
+    total = sum(done)
+    # one thread, for reference: the first 256 estimates
+    ns = min(shard.n, 256)
+    t1 = time.time()
+    ref = oracle_lib.predict_until(compiled, shard.slice(0, ns), p0[:ns], end_ns, step)
+    dt1 = time.time() - t1
+    return {"value": total / dt, "unit": "trajectories/s", "cores": threads, "physical_cores": phys, "kind": "port", "wall_s": dt,
+            "one_thread": {"value": ns / dt1, "unit": "trajectories/s", "wall_s": dt1},
+            "sample": f"{total} covariance mappings ({threads} host threads x {reps} passes over a chunk of {chunk} of the {n_per_gpu} GEO states), all "
+                      f"{int(round(hours * 60))} one-minute time updates each, the oracle's predict_until twin (independent estimates mapped in "
+                      f"parallel, as a par_iter over OD processes would), {dt:.1f} s wall on {phys} physical cores"}, ref, ns
 
 
 def measured_traffic(cfg_id, n, hours, degree):
@@ -349,7 +407,9 @@ def main():
         alg_gbps = n * BYTES_PER_TRAJ / (k_ms * 1e-3) / 1e9
         traffic, traffic_src = measured_traffic(args.config, n, hours, w["degree"])
         # CU occupancy of the launch: trajectory-owning workgroups (64 trajectories each) + cooperative-mode helpers
-        owners = (n + 63) // 64
+        # (the STM kernel's quad layout - chosen when ceil(n / 16) <= 2 x CUs - has 16 trajectories per workgroup)
+        per_wg = 16 if (w["stm"] and (n + 15) // 16 <= 2 * N_CU) else 64
+        owners = (n + per_wg - 1) // per_wg
         helpers = ctx.last_coop_helpers() if not w["stm"] else 0
         line = {
             "metric": w["metric"],
@@ -358,11 +418,12 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": w["label"](n, hours), "baseline_config": args.config,
                        "trajectories_per_gpu": n, "column_waves": args.waves or "auto",
+                       "tuning": "nyx_hip_tuning_t defaults: NYX_HIP_SCHED_MODEL (process-independent column schedule), cooperative mode auto",
                        "sharding": "contiguous index shards, no data-path collective; one RCCL all-gather of final states per step"},
             "force_evals_per_s": n_evals * world / (elapsed / args.steps),
             "force_evals_per_launch": n_evals, "accepted_steps": n_acc, "rejected_attempts": n_rej,
             "kernel_ms": k_ms,
-            "occupancy": {"workgroups": owners + helpers, "owner_workgroups": owners, "helper_workgroups": helpers, "cus": N_CU,
+            "occupancy": {"workgroups": owners + helpers, "owner_workgroups": owners, "helper_workgroups": helpers, "trajectories_per_workgroup": per_wg, "cus": N_CU,
                           "cu_fraction": min(1.0, (owners + helpers) / N_CU)},
             "roofline": {"bound": "valu_fp64", "achieved": achieved_tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved_tf / FP64_VECTOR_PEAK_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
@@ -430,22 +491,13 @@ def main():
                 cb["parity_on_sample"] = {"max_dr_m": float(np.linalg.norm(d[:, :3], axis=1).max() * 1e3),
                                           "max_dv_mm_s": float(np.linalg.norm(d[:, 3:], axis=1).max() * 1e6)}
             else:
-                import oracle_lib
-                threads, phys = host_threads()
-                ns = min(n, 256)
-                sb = shard.slice(0, ns)
-                t1 = time.time()
-                ref = oracle_lib.predict_until(compiled, sb, p0[:ns], end_ns, 60 * nx.NS_PER_S)
-                dt = time.time() - t1
+                cb, ref, ns = cpu_baseline_predict(shard, compiled, p0, end_ns, n, hours)
                 got = last["res"]
                 scale = np.maximum(np.abs(ref.covar), 1e-6 * np.abs(ref.covar).max(axis=(-2, -1), keepdims=True))
                 d = got.states.rv()[:ns] - ref.states.rv()
-                cb = {"value": ns / dt, "unit": "trajectories/s", "cores": 1, "physical_cores": phys, "kind": "port",
-                      "sample": f"{ns} of the {n} GEO states, all {int(round(hours * 60))} one-minute time updates each, the oracle's predict_until "
-                                f"twin on ONE thread (the reference's OD process is sequential per estimate), {dt:.1f} s wall",
-                      "parity_on_sample": {"max_dr_m": float(np.linalg.norm(d[:, :3], axis=1).max() * 1e3),
-                                           "max_dv_mm_s": float(np.linalg.norm(d[:, 3:], axis=1).max() * 1e6),
-                                           "max_rel_covar": float((np.abs(got.covar[:ns] - ref.covar) / scale).max())}}
+                cb["parity_on_sample"] = {"max_dr_m": float(np.linalg.norm(d[:, :3], axis=1).max() * 1e3),
+                                          "max_dv_mm_s": float(np.linalg.norm(d[:, 3:], axis=1).max() * 1e6),
+                                          "max_rel_covar": float((np.abs(got.covar[:ns] - ref.covar) / scale).max())}
             line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)
     if world > 1:

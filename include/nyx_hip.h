@@ -104,7 +104,7 @@ typedef struct nyx_hip_cheby_segment {
 } nyx_hip_cheby_segment_t;
 /* The device Clenshaw loop walks a fixed window: segments with more coefficients per component are refused by
  * nyx_hip_ctx_create (NYX_HIP_RC_UNSUPPORTED), never truncated.  DE440s uses 11-13. */
-#define NYX_HIP_MAX_CHEBY_COEFFS 16
+#define NYX_HIP_MAX_CHEBY_COEFFS 32
 
 #define NYX_HIP_MAX_CHAIN 4
 #define NYX_HIP_MAX_BODIES 8

@@ -814,7 +814,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
         if (sg.n_coeffs < 1 || sg.n_records < 1 || !(sg.interval_s > 0.0) || !sg.records) {
             nyx_set_error("segment %d: n_coeffs >= 1, n_records >= 1, interval_s > 0 and records are required", i); return NYX_HIP_RC_BAD_ARG;
         }
-        if (sg.n_coeffs > NYX_HIP_MAX_CHEBY_COEFFS) {  // the device Clenshaw loop walks a fixed 16-wide window (cheby_eval)
+        if (sg.n_coeffs > NYX_HIP_MAX_CHEBY_COEFFS) {  // (cheby_eval: a 16-wide register window, a rolled loop up to this limit)
             nyx_set_error("segment %d: %d Chebyshev coefficients per component, the device path evaluates at most %d", i, sg.n_coeffs, NYX_HIP_MAX_CHEBY_COEFFS);
             return NYX_HIP_RC_UNSUPPORTED;
         }

@@ -77,7 +77,7 @@ DEVFN double clamp02(double x) { return x < 0.0 ? 0.0 : (x > 2.0 ? 2.0 : x); }
 // SPK type 2 evaluation (Clenshaw); record index is per lane, metadata is uniform.  `records` is the
 // LDS copy of the segment table when it fits (cfg->rec_in_lds), else the global array.  The 16-wide
 // coefficient window is loaded before the recurrence starts (the table is padded by 16 doubles), so the
-// loads are independent of the serial w0/w1/w2 chain.
+// loads are independent of the serial w0/w1/w2 chain.  Segments with more than CHEB_MAXC coefficients take a rolled loop.
 #define CHEB_MAXC 16
 template <typename P>
 DEVFN int cheby_eval(const CAS DevSeg &sg, P records, double et_s, double *r3) {
@@ -90,6 +90,21 @@ DEVFN int cheby_eval(const CAS DevSeg &sg, P records, double et_s, double *r3) {
     P rec = records + sg.offset + idx * sg.stride;
     const double t = (et_s - rec[0]) / rec[1];
     const double two_t = 2.0 * t;
+    if (nc > CHEB_MAXC) {  // (uniform) up to NYX_HIP_MAX_CHEBY_COEFFS: the tail beyond the 16-wide register window is walked first,
+        // coefficient by coefficient from the table - the same recurrence in the same order (DE440's Mercury / Sun segments, binary PCKs)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            P cf = rec + 2 + c * nc;
+            double w0 = 0.0, w1 = 0.0, w2;
+            for (int j = nc - 1; j >= 1; --j) {
+                w2 = w1;
+                w1 = w0;
+                w0 = cf[j] + (two_t * w1 - w2);
+            }
+            r3[c] = cf[0] + (t * w0 - w1);
+        }
+        return st;
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         P cf = rec + 2 + c * nc;

@@ -132,8 +132,8 @@ def test_ctx_create_refuses_what_the_device_code_cannot_represent():
         al.add_body(nx.MOON, ephem.MU_MOON, ephem.R_MOON, [(s, +1)])
         return al
 
-    rc, msg = _create_rc(prop.compile(almanac_with(17), central))
-    assert rc == _abi.RC_UNSUPPORTED and "17 Chebyshev coefficients" in msg
+    rc, msg = _create_rc(prop.compile(almanac_with(33), central))
+    assert rc == _abi.RC_UNSUPPORTED and "33 Chebyshev coefficients" in msg
     cc = prop.compile(almanac_with(13), central)
     cc.cfg.segments[0].interval_s = 0.0
     assert _create_rc(cc)[0] == _abi.RC_BAD_ARG
@@ -144,14 +144,17 @@ def test_ctx_create_refuses_what_the_device_code_cannot_represent():
     cc.cfg.bodies[1].n_chain = 5
     rc, msg = _create_rc(cc)
     assert rc == _abi.RC_BAD_ARG and "n_chain" in msg
-    # a valid 16-coefficient segment gets past validation (and then stops at "no device" on this box)
-    rc, msg = _create_rc(prop.compile(almanac_with(16), central))
-    assert rc in (0, _abi.RC_NO_DEVICE), msg
+    # valid 16- and 32-coefficient segments get past validation (and then stop at "no device" on this box)
+    for nc in (16, 32):
+        rc, msg = _create_rc(prop.compile(almanac_with(nc), central))
+        assert rc in (0, _abi.RC_NO_DEVICE), msg
 
 
 @pytest.mark.gpu
-def test_sixteen_coefficient_segments_device_vs_oracle():
-    """The widest segment the device evaluates (NYX_HIP_MAX_CHEBY_COEFFS): every coefficient must enter the Clenshaw sum."""
+@pytest.mark.parametrize("ncoef", [16, 26, 32])
+def test_wide_coefficient_segments_device_vs_oracle(ncoef):
+    """The widest segment of the register window (16) and of the rolled path (up to NYX_HIP_MAX_CHEBY_COEFFS = 32, what DE440's
+    inner-planet segments and the binary PCKs carry): every coefficient must enter the Clenshaw sum."""
     import oracle_lib
     from nyx_amd import ephem
     from scenarios import EPOCH0_NS, dispersed_leo_batch, pos_vel_errors
@@ -159,9 +162,9 @@ def test_sixteen_coefficient_segments_device_vs_oracle():
     et0 = nx.to_seconds(EPOCH0_NS)
     al = nx.Almanac()
     s_sun = al.add_segment(ephem.fit_segment(ephem.sun_geocentric, et0 - 2 * day, 16 * day, 2, 16))
-    moon = ephem.fit_segment(ephem.moon_geocentric, et0 - 2 * day, 8 * day, 3, 16)
+    moon = ephem.fit_segment(ephem.moon_geocentric, et0 - 2 * day, 8 * day, 3, ncoef)
     for c in range(3):
-        moon.records[:, 2 + 16 * c + 15] = 500.0   # a LARGE 16th coefficient (synthetic table): dropping it moves the Moon by up to 500 km
+        moon.records[:, 2 + ncoef * c + ncoef - 1] = 500.0   # a LARGE last coefficient (synthetic table): dropping it moves the Moon by up to 500 km
     s_moon = al.add_segment(moon)
     al.add_body(nx.EARTH, ephem.MU_EARTH, ephem.R_EARTH, [])
     al.add_body(nx.SUN, ephem.MU_SUN, ephem.R_SUN, [(s_sun, +1)])
@@ -178,6 +181,6 @@ def test_sixteen_coefficient_segments_device_vs_oracle():
     assert dr.max() < 1e-6 and dv.max() < 1e-9, (dr.max(), dv.max())
     # ... and it matters at the level of this comparison: without it the oracle itself lands > 1 mm elsewhere
     for c in range(3):
-        al.segments[s_moon].records[:, 2 + 16 * c + 15] = 0.0
+        al.segments[s_moon].records[:, 2 + ncoef * c + ncoef - 1] = 0.0
     ref0, _ = oracle_lib.propagate(prop.compile(al, central), b, dur, n_threads=os.cpu_count() or 1)
     assert pos_vel_errors(ref0, ref)[0].max() > 1e-6

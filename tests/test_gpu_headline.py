@@ -73,6 +73,13 @@ def test_config5_llo_150x150():
     device_vs_oracle_sample(prop, almanac, central, sc.lunar_batch(6_250, seed=0), 6 * 3600 * S, 256, "config 5")
 
 
+def test_config5_llo_150x150_full_three_days():
+    """configs[4] at its FULL length: 6 250 low-lunar-orbit states x 150x150 + Earth/Sun, DP78 default options, 72 h (~9 s of
+    device time), every state of a 32-trajectory sample within 1 m / 1 mm/s of the oracle (~4 min of CPU on 32 threads)."""
+    prop, almanac, central = sc.lunar_setup(degree=150)
+    device_vs_oracle_sample(prop, almanac, central, sc.lunar_batch(6_250, seed=0), 72 * 3600 * S, 32, "config 5, 72 h")
+
+
 def test_config4_geo_1k_sixty_updates():
     """configs[3]: 1 000 GEO states, 21x21 + Sun/Moon + SRP(Cr), STM, sixty 1-minute time updates; Phi-mapped covariance
     and nominal state vs the oracle's predict_until twin on a spread sample."""

@@ -79,3 +79,16 @@ def test_euler_chebyshev_orientation(drag, stm):
     # leaving the coverage of the orientation data: per-trajectory status, like an ephemeris gap
     out2, st2, _, rst2 = both(prop, almanac, sc.earth_frame(ephem.MU_EARTH), b, 2 * 86400 * S, stm=stm)
     assert (st2.status == _abi.ERR_EPHEM_RANGE).all() and (rst2.status == _abi.ERR_EPHEM_RANGE).all()
+
+
+def test_spin_sense_sub_synchronous_orbit_drifts_east():
+    """The sense of the Earth's spin in the device's rotation_dcm (what the harmonics pins of orbitaldyn.rs do not catch)."""
+    from spin_cases import check_spin_sense
+
+    def until_event(compiled, b, max_ns, ev):
+        ctx = nx.GpuContext(compiled)
+        out, st, _, _ = ctx.propagate_until_event(b, max_ns, ev, trigger=1, capacity=2048)
+        ctx.close()
+        return out, st
+
+    check_spin_sense(until_event)

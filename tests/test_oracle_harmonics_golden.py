@@ -35,6 +35,36 @@ def test_j2_monte():
     print("J2 vs Monte %.3e km %.3e km/s; vs GMAT %.3e km %.3e km/s" % (err_r, err_v, gr, gv))
 
 
+def _monte_error(shift_s=0.0, pole=None):
+    prop, almanac, central, g = j2_case()
+    if pole is not None:
+        f = prop.dynamics.orbital_dyn.accel_models[0]
+        r = nx.IAU_EARTH_ROTATION
+        f.frame = nx.Frame(f.frame.naif_id, f.frame.mu_km3_s2, f.frame.mean_equatorial_radius_km,
+                           nx.Rotation((pole[0], r.ra_deg[1], 0.0), (pole[1], r.dec_deg[1], 0.0), r.w_deg))
+    b = initial_batch()
+    b.epoch_ns[:] += int(round(shift_s * 1e9))
+    out, _ = oracle_lib.propagate(prop.compile(almanac, central), b, DAY_NS)
+    return rss_errors(out.rv()[0], g["state_monte"])[0]
+
+
+def test_what_the_j2_margin_depends_on():
+    """The J2 pin passes at 19.59 m of the reference's 20 m.  It is NOT at the mercy of the epoch model: a zonal field is
+    axially symmetric, so the prime meridian W(t) does not enter - the TDB-TT term dropped in the fixture (< 2 ms) moves the
+    result by < 1e-7 m, confusing TAI with TT (32.184 s) by 0.2 mm, a whole hour by 2 cm.  What it DOES depend on is the
+    direction of the pole: the two-angle IAU polynomial puts it on the J2000 z axis at this epoch (to 4e-4 arcsec), Monte's
+    and GMAT's Earth-fixed frames include nutation (~8 arcsec of pole offset on 2000-01-01), and 8 arcsec of tilt move the
+    result by 3 ... 100 m depending on its azimuth.  The modelling term behind the 19.6 m is therefore the pole model, shared
+    with the reference (whose own tolerance for this very comparison is 20 m), not time."""
+    base = _monte_error()
+    assert abs(base - 0.019588) < 2e-5
+    for shift in (2e-3, -32.184, 3600.0):
+        assert abs(_monte_error(shift_s=shift) - base) < 3e-5, shift          # < 3 cm for an HOUR of epoch error
+    tilt = 8.0 / 3600.0
+    moved = [abs(_monte_error(pole=(az, 90.0 - tilt)) - base) for az in (133.84, -133.84, 46.16, -46.16)]
+    assert min(moved) > 1e-3 and max(moved) > 0.05                            # metres to a hundred metres for 8 arcsec of pole
+
+
 @pytest.mark.parametrize("with_stm", [False, True])
 def test_jgm3_70x70_gmat(with_stm):
     # with_stm=True is what the test NAMED _partials would exercise (in this snapshot it does not call with_stm());

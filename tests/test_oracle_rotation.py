@@ -111,3 +111,13 @@ def test_descriptor_validation():
     with pytest.raises(ValueError):
         bad = nx.Rotation(nut_prec_angles_deg=[(0.0, 1.0)] * 17)
         field_with(bad)[0].compile(nx.Almanac(), central)
+
+
+def test_spin_sense_sub_synchronous_orbit_drifts_east():
+    from spin_cases import check_spin_sense
+
+    def until_event(compiled, b, max_ns, ev):
+        out, st, _, _ = oracle_lib.propagate_until_event(compiled, b, max_ns, ev, trigger=1, capacity=2048)
+        return out, st
+
+    check_spin_sense(until_event)
