@@ -124,6 +124,38 @@ struct nyx_hip_ctx {
 };
 #define CTX_LOCK(ctx) std::lock_guard<std::recursive_mutex> lock_((ctx)->mu)
 
+// Cooperative-mode mailboxes live in UNCACHED device memory (hipExtMallocWithFlags), and that kind of allocation must not be
+// churned: in round 3 the ~17th allocate / free cycle of one in a process handed back memory on which the owner <-> helper
+// exchange no longer worked (a cooperative launch that never finished, reproducibly, only after ~90 other tests).  The blocks
+// are therefore pooled per process and device: a context borrows one at its first cooperative launch and returns it when it
+// is destroyed; a block is never freed before the process ends.
+struct MailboxBlock { int device; void *ptr; int64_t cap; };
+static std::mutex g_mailbox_mu;
+static std::vector<MailboxBlock> g_mailbox_free;
+static void *mailbox_acquire(int device, int64_t want_cap, int64_t *cap_out) {
+    {
+        std::lock_guard<std::mutex> lk(g_mailbox_mu);
+        for (size_t k = 0; k < g_mailbox_free.size(); ++k)
+            if (g_mailbox_free[k].device == device && g_mailbox_free[k].cap >= want_cap) {
+                void *p = g_mailbox_free[k].ptr;
+                *cap_out = g_mailbox_free[k].cap;
+                g_mailbox_free.erase(g_mailbox_free.begin() + (long)k);
+                return p;
+            }
+    }
+    const int64_t cap = (want_cap + 255) / 256 * 256;
+    const size_t bytes = (size_t)cap * sizeof(CoopBox) + 3 * (size_t)(cap + 64) * sizeof(uint32_t);  // sets of 16: <= cap + 16 words
+    void *p = nullptr;
+    if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    *cap_out = cap;
+    return p;
+}
+static void mailbox_release(int device, void *ptr, int64_t cap) {
+    if (!ptr) return;
+    std::lock_guard<std::mutex> lk(g_mailbox_mu);
+    g_mailbox_free.push_back(MailboxBlock{device, ptr, cap});
+}
+
 static void free_arrays(DevArrays &a) {
     (void)hipFree(a.dblock);
     (void)hipHostFree(a.hblock);
@@ -139,6 +171,7 @@ static int ensure_arrays(DevArrays &a, int64_t n, bool stats) {
     const size_t n64 = 15 + (stats ? 5 : 0);  // epoch, step, 13 f64 (+ last_step, n_acc, n_rej, n_evals, last_error)
     a.bytes = n64 * slot + (stats ? 2 * (size_t)cap * 4 : 0);
     HIP_TRY(hipMalloc((void **)&a.dblock, a.bytes));
+    HIP_TRY(hipMemset(a.dblock, 0, a.bytes));  // (never hand the kernel recycled device memory it might read before writing)
     HIP_TRY(hipHostMalloc((void **)&a.hblock, a.bytes, hipHostMallocDefault));
     char *p = a.dblock;
     a.epoch = (int64_t *)p; p += slot;
@@ -762,7 +795,7 @@ extern "C" void nyx_hip_ctx_destroy(nyx_hip_ctx *ctx) {
     free_arrays(ctx->out);
     free_arrays(ctx->cal);
     (void)hipFree(ctx->d_swap);
-    (void)hipFree(ctx->d_coop);
+    mailbox_release(ctx->device, ctx->d_coop, ctx->coop_cap);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     if (ctx->ev_done) hipEventDestroy(ctx->ev_done);
@@ -1261,22 +1294,19 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
                         HIP_TRY(hipMemcpyAsync(ctx->d_cfg, &ctx->host_cfg, sizeof(DevCfg), hipMemcpyHostToDevice, stream));
                     }
                 }
-                const int64_t want_cap = std::max<int64_t>(n_own, 256);
-                const size_t cap_bytes = (size_t)want_cap * sizeof(CoopBox) + 3 * (size_t)(want_cap + 64) * sizeof(uint32_t);  // sets of 16: <= cap + 16 words
                 bool have_boxes = ctx->coop_cap >= n_own;
                 if (!have_boxes) {
-                    (void)hipFree(ctx->d_coop);
+                    mailbox_release(ctx->device, ctx->d_coop, ctx->coop_cap);
                     ctx->d_coop = nullptr;
                     ctx->coop_cap = 0;
                     // uncached device memory: the mailboxes are coherent across the XCDs' L2s without any cache
                     // write-back / invalidate in the kernel (those would also flush the harmonics table out of L2)
-                    if (hipExtMallocWithFlags((void **)&ctx->d_coop, cap_bytes, hipDeviceMallocUncached) == hipSuccess) {
-                        ctx->coop_cap = std::max<int64_t>(n_own, 256);
+                    int64_t got = 0;
+                    ctx->d_coop = (CoopBox *)mailbox_acquire(ctx->device, std::max<int64_t>(n_own, 256), &got);
+                    if (ctx->d_coop) {
+                        ctx->coop_cap = got;
                         have_boxes = true;
-                    } else {
-                        ctx->d_coop = nullptr;  // no such memory here: every workgroup works alone
-                        (void)hipGetLastError();
-                    }
+                    }  // (else: no such memory here, every workgroup works alone)
                 }
                 if (have_boxes && ctx->host_cfg.coop_ok) {
                     HIP_TRY(hipMemsetAsync(ctx->d_coop, 0, (size_t)ctx->coop_cap * sizeof(CoopBox) + 3 * (size_t)(ctx->coop_cap + 64) * sizeof(uint32_t), stream));
@@ -1438,8 +1468,11 @@ static int host_propagate(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t 
     if (out->n < n) { nyx_set_error("out batch smaller than in batch"); return NYX_HIP_RC_BAD_ARG; }
     CTX_LOCK(ctx);
     HIP_TRY(hipSetDevice(ctx->device));
+    const bool trace = (ctx->tune.debug_flags & 0x400) != 0;  // (tuning.debug_flags 0x400: milestones of the host path on stderr)
+    if (trace) std::fprintf(stderr, "[nyx_hip] host_propagate n=%lld: staging\n", (long long)n);
     Staged sg;
     if (int rc = stage_batch(ctx, in, out, sg)) return rc;
+    if (trace) std::fprintf(stderr, "[nyx_hip] staged, launching\n");
 
     nyx_hip_traj_t dtraj;
     std::memset(&dtraj, 0, sizeof dtraj);
@@ -1458,7 +1491,9 @@ static int host_propagate(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t 
         if (traj_block) (void)hipFree(traj_block);
         return rc;
     }
+    if (trace) std::fprintf(stderr, "[nyx_hip] launched (%d helpers, %d waves), synchronising\n", ctx->last_coop_helpers, ctx->host_cfg.n_waves);
     HIP_TRY(hipDeviceSynchronize());
+    if (trace) std::fprintf(stderr, "[nyx_hip] kernel done\n");
     if (traj_block) {
         const size_t slots = (size_t)traj->capacity * (size_t)n;
         HIP_TRY(hipMemcpy(traj->len, dtraj.len, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));

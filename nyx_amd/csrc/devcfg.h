@@ -185,6 +185,7 @@ struct DevBatch { /* device pointers of one launch */
     int32_t *ev_found; /* [n] 1 when the propagation stopped on the event */
     /* cooperative mode: workgroups [0, ceil(n/64)) own trajectories, [coop_base, coop_base + coop_helpers) help */
     int32_t coop_helpers, coop_base;
+    int32_t lds_bytes, _pad_lds; /* dynamic LDS of the launch: zeroed by every workgroup before use (see propagate_body) */
     int32_t coop_mute, coop_sets; /* coop_sets: owners are dealt into this many sets of <= 16, each watched by its own helpers */ /* test switch (NYX_HIP_COOP_MUTE): helpers exit at once, as if they had never become resident */
     struct CoopBox *coop_box; /* one mailbox per trajectory-owning workgroup, zeroed before the launch */
     uint32_t *coop_posted, *coop_claimed, *coop_finished; /* [owners] packed scan words, zeroed before the launch */

@@ -2648,6 +2648,11 @@ DEVFN void propagate_body(const DevBatch &bt, const DevCfg *cfg_g, const HarmEnt
     const int lane = threadIdx.x & (DEV_LANES - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int nw = (int)(blockDim.x >> 6);
+    // LDS comes as the previous workgroup on this CU left it.  Everything below is written before it is read by design, but a run
+    // whose outcome could depend on what ran on the CU before (round 3: a cooperative launch that never finished, only after ~90
+    // other tests in the same process) is not something to leave to design: every workgroup starts from zeroed LDS (20 k stores).
+    for (int q = (int)threadIdx.x; q < bt.lds_bytes / 8; q += (int)blockDim.x) ((double *)smem)[q] = 0.0;
+    __syncthreads();
     const LdsMap L = carve_lds(smem, nw, STM, cfg_g->rec_in_lds ? cfg_g->rec_doubles : 0, STM ? 0 : cfg_g->ed_reuse, QUAD);
     double *const kbuf = L.kbuf;
     double *const tabl = L.tabl;
@@ -2767,17 +2772,19 @@ extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg
     const bool stm = bt.o_stm != nullptr;
     size_t lds = nyx_kernel_lds_bytes(n_waves, rec_lds_doubles, stm ? (quad ? 2 : 1) : 0, stm ? 0 : reuse_fields);
     if (!stm && bt.coop_helpers > 0 && lds < (size_t)HELPER_LDS_BYTES) lds = HELPER_LDS_BYTES;
+    DevBatch btl = bt;
+    btl.lds_bytes = (int32_t)lds;
     const bool small = n_waves <= 8;  // (helpers are sixteen-wave workgroups: cooperative launches never are)
     if (stm && quad)
         hipLaunchKernelGGL(small ? nyx_propagate_kernel_stmq_w8 : nyx_propagate_kernel_stmq, dim3((unsigned)blocks),
-                           dim3((unsigned)(n_waves * DEV_LANES)), lds, stream, bt, cfg, htab, cols, records);
+                           dim3((unsigned)(n_waves * DEV_LANES)), lds, stream, btl, cfg, htab, cols, records);
     else if (stm)
-        hipLaunchKernelGGL(nyx_propagate_kernel_stm, dim3((unsigned)blocks), dim3((unsigned)(n_waves * DEV_LANES)), lds, stream, bt, cfg,
+        hipLaunchKernelGGL(nyx_propagate_kernel_stm, dim3((unsigned)blocks), dim3((unsigned)(n_waves * DEV_LANES)), lds, stream, btl, cfg,
                            htab, cols, records);
     else {
         const int64_t grid = bt.coop_helpers > 0 ? (int64_t)bt.coop_base + bt.coop_helpers : blocks;
         hipLaunchKernelGGL((small && bt.coop_helpers == 0) ? nyx_propagate_kernel_w8 : nyx_propagate_kernel, dim3((unsigned)grid),
-                           dim3((unsigned)(n_waves * DEV_LANES)), lds, stream, bt, cfg, htab, cols, records);
+                           dim3((unsigned)(n_waves * DEV_LANES)), lds, stream, btl, cfg, htab, cols, records);
     }
     return hipGetLastError();
 }
