@@ -20,7 +20,7 @@ for cfg in cfgs:
     if not os.path.isdir(src):
         continue
     line = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
-    json.dump(line, open(os.path.join(ROOT, "profiles", f"{tag}_cfg{cfg}_bench.json"), "w"), indent=1)
+    bench_out = os.path.join(ROOT, "profiles", f"{tag}_cfg{cfg}_bench.json")
     shutil.copy(os.path.join(src, "kernel_trace_stats.md"), os.path.join(ROOT, "profiles", f"{tag}_cfg{cfg}_kernel_trace_stats.md"))
     per = collections.defaultdict(list)
     # (gpurun merges every pass of a configuration into the same scratch directory: the newest file of each counter set counts)
@@ -74,4 +74,10 @@ for cfg in cfgs:
                "fetch_size_bytes_raw": fetch_b * launches, "write_size_bytes": write_b * launches,
                "note": "2 x FETCH_SIZE + WRITE_SIZE of the timed step (gfx950 correction of MI355X_MICROARCH.md), rocprofv3 --pmc, separate passes",
                "workload": w}, open(os.path.join(ROOT, "profiles", f"{tag}_cfg{cfg}_hbm_traffic.json"), "w"), indent=1)
+    # the bench line was printed before the counter passes of this round existed: give it THIS round's traffic (same command, same build)
+    line["roofline"]["traffic"] = traffic * launches
+    line["roofline"]["traffic_source"] = f"profiles/{tag}_cfg{cfg}_hbm_traffic.json"
+    line["roofline"]["hbm"]["achieved"] = traffic * launches / (line["kernel_ms"] * 1e-3) / 1e9
+    line["roofline"]["hbm"]["frac"] = line["roofline"]["hbm"]["achieved"] / line["roofline"]["hbm"]["peak"]
+    json.dump(line, open(bench_out, "w"), indent=1)
     print(f"config {cfg}: value {line['value']:.1f} {line['unit']}, kernel {line['kernel_ms']:.2f} ms, frac {line['roofline']['frac']:.4f}, traffic {traffic * launches / 1e6:.4g} MB")
