@@ -1,20 +1,23 @@
-// gravity_io.cpp — host-side loaders of spherical-harmonics coefficient files, part of the
-// propagation path's boundary ("parsers run on host, tables go to GPU").
+// gravity_io.cpp — host-side loaders of spherical-harmonics coefficient files, part of the propagation path's boundary
+// ("parsers run on host, tables go to GPU").
 //
-// Behaviour follows GravityFieldData::from_cof / ::load of the reference
-// (nyx-core/src/io/gravity.rs:150-367, 370-501) including its quirks:
-//   * only lines starting with 'R' are data in a .cof; fields are whitespace separated;
-//   * C and S are glued together when S is negative ("1.0e-06-2.0e-07"): detected by counting '-';
-//   * reading stops at the first line whose degree exceeds the request;
-//   * coefficients with order > request are skipped but still counted for the reported max order;
-//   * the reported degree/order are the maxima SEEN, not the request (io/gravity.rs:330-366).
-// Output layout differs from the reference's dense DMatrix: packed lower-triangular,
-// idx(n, m) = n (n + 1) / 2 + m, which is what the device tables are built from.
+// Two text formats, one table.  Each format is a RECORD READER that turns one line into (degree, order, C, S) or says
+// "not a data line"; a common driver applies the selection rules that GravityFieldData::from_cof / ::load observe
+// (nyx-core/src/io/gravity.rs:150-367, 370-501) and that callers of the reference rely on:
+//   * the file is ordered by degree: reading stops at the first record beyond the requested degree;
+//   * records beyond the requested ORDER are not stored but still count for the reported maximum order;
+//   * the reported degree / order are the maxima SEEN, not the request (io/gravity.rs:330-366).
+// GMAT .cof: data lines start with 'R' (RECOEF n m C [S] ...); when S is negative the two numbers are written without a
+// blank ("2.43e-06-1.40e-06") - split here at the end of the first NUMBER, which a float scanner finds by itself.
+// SHADR: first line is a header; fields separated by blanks and / or commas; Fortran 'D' exponents.
+// Output: packed lower-triangular arrays, idx(n, m) = n (n + 1) / 2 + m, which is what the device tables are built from
+// (the reference keeps dense (N+1) x (N+1) matrices).
 
 #include "../../include/nyx_hip.h"
 
 #include <zlib.h>
 
+#include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -25,11 +28,111 @@ void nyx_set_error(const char *fmt, ...);  // abi.cpp
 
 namespace {
 
-bool read_all(const char *path, bool gunzipped, std::string &out) {
+struct Record {
+    long degree = 0, order = 0;
+    double c = 0.0, s = 0.0;
+};
+enum class Line { Data, Skip, Malformed };
+
+// A cursor over the blank- (and, for SHADR, comma-) separated fields of one line; no copies of the line are made.
+class Fields {
+  public:
+    Fields(const char *begin, const char *end, bool commas) : p_(begin), end_(end), commas_(commas) {}
+    bool next(std::string &field) {
+        while (p_ < end_ && sep(*p_)) ++p_;
+        const char *q = p_;
+        while (q < end_ && !sep(*q)) ++q;
+        if (q == p_) return false;
+        field.assign(p_, q);
+        p_ = q;
+        return true;
+    }
+
+  private:
+    bool sep(char ch) const { return std::isspace((unsigned char)ch) || (commas_ && ch == ','); }
+    const char *p_, *end_;
+    bool commas_;
+};
+
+bool to_index(const std::string &s, long &v) {  // digits only, as usize::from_str accepts them in these files
+    if (s.empty()) return false;
+    for (char ch : s)
+        if (!std::isdigit((unsigned char)ch)) return false;
+    v = std::strtol(s.c_str(), nullptr, 10);
+    return true;
+}
+
+// One or two numbers out of a field: "1.0e-06" or the glued "1.0e-06-2.0e-07".  Returns how many were read (0 = malformed).
+int scan_numbers(const std::string &s, double &first, double &second) {
+    const char *p = s.c_str();
+    char *end = nullptr;
+    first = std::strtod(p, &end);
+    if (end == p) return 0;
+    if (*end == '\0') return 1;
+    const char *q = end;
+    second = std::strtod(q, &end);
+    return (end != q && *end == '\0') ? 2 : 0;
+}
+
+struct Problem {
+    const char *what = nullptr;  // "degree", "order", "C_nm/S_nm", "S_nm", or a field number for SHADR
+    std::string text;
+};
+
+// RECOEF n m C [S] [sigmas ...]
+Line read_cof(const char *b, const char *e, bool want_s, Record &r, Problem &pb) {
+    if (b == e || *b != 'R') return Line::Skip;  // comment, header, POTFIELD, END
+    Fields f(b, e, false);
+    std::string tag, fn, fm, fc, fs;
+    f.next(tag);
+    if (!f.next(fn)) return Line::Data;  // (a bare tag: all zeros, like the reference's item loop that never reaches a field)
+    if (!to_index(fn, r.degree)) { pb = {"degree", fn}; return Line::Malformed; }
+    if (!f.next(fm)) return Line::Data;
+    if (!to_index(fm, r.order)) { pb = {"order", fm}; return Line::Malformed; }
+    if (!f.next(fc)) return Line::Data;
+    double c = 0.0, s = 0.0;
+    const int got = scan_numbers(fc, c, s);
+    if (got == 0 || (!want_s && got == 2)) { pb = {"C_nm/S_nm", fc}; return Line::Malformed; }
+    r.c = c;
+    if (got == 2) {
+        r.s = s;       // glued pair: the next field, if any, is a sigma
+        return Line::Data;
+    }
+    if (f.next(fs)) {
+        double extra;
+        if (scan_numbers(fs, s, extra) != 1) { pb = {"S_nm", fs}; return Line::Malformed; }
+        r.s = want_s ? s : 0.0;
+    }
+    return Line::Data;
+}
+
+// n, m, C, S [, sigmas]  with blanks and / or commas, 'D' exponents
+Line read_shadr(const char *b, const char *e, bool, Record &r, Problem &pb) {
+    Fields f(b, e, true);
+    std::string fld;
+    static const char *const names[4] = {"field 0", "field 1", "field 2", "field 3"};
+    if (!f.next(fld)) return Line::Skip;  // blank line
+    for (int k = 0; k < 4; ++k) {
+        if (k > 0 && !f.next(fld)) break;
+        bool ok;
+        if (k < 2) {
+            ok = to_index(fld, k == 0 ? r.degree : r.order);
+        } else {
+            for (char &ch : fld)
+                if (ch == 'D' || ch == 'd') ch = 'E';
+            double extra;
+            ok = scan_numbers(fld, k == 2 ? r.c : r.s, extra) == 1;
+        }
+        if (!ok) { pb = {names[k], fld}; return Line::Malformed; }
+    }
+    return Line::Data;
+}
+
+bool slurp(const char *path, bool gunzipped, std::string &out) {
+    char buf[1 << 16];
     if (gunzipped) {
         gzFile f = gzopen(path, "rb");
         if (!f) return false;
-        char buf[1 << 16];
         int n;
         while ((n = gzread(f, buf, sizeof buf)) > 0) out.append(buf, (size_t)n);
         gzclose(f);
@@ -37,82 +140,65 @@ bool read_all(const char *path, bool gunzipped, std::string &out) {
     }
     FILE *f = std::fopen(path, "rb");
     if (!f) return false;
-    char buf[1 << 16];
     size_t n;
     while ((n = std::fread(buf, 1, sizeof buf, f)) > 0) out.append(buf, n);
     std::fclose(f);
     return true;
 }
 
-void split_ws(const std::string &line, std::vector<std::string> &items) {
-    items.clear();
-    size_t i = 0;
-    while (i < line.size()) {
-        while (i < line.size() && std::isspace((unsigned char)line[i])) ++i;
-        size_t j = i;
-        while (j < line.size() && !std::isspace((unsigned char)line[j])) ++j;
-        if (j > i) items.emplace_back(line, i, j - i);
-        i = j;
+typedef Line (*Reader)(const char *, const char *, bool, Record &, Problem &);
+
+int load_table(const char *who, const char *path, int32_t degree, int32_t order, int32_t gunzipped, int skip_lines, Reader reader,
+               int32_t *out_degree, int32_t *out_order, double **c_nm, double **s_nm) {
+    if (!path || degree < 0 || order < 0 || !out_degree || !out_order || !c_nm || !s_nm) {
+        nyx_set_error("%s: bad argument", who);
+        return NYX_HIP_RC_BAD_ARG;
     }
-}
-
-bool parse_usize(const std::string &s, long &v) {
-    if (s.empty()) return false;
-    for (char ch : s)
-        if (ch < '0' || ch > '9') return false;  // usize::from_str: digits only (a leading '+' is accepted by Rust, not seen in files)
-    v = std::strtol(s.c_str(), nullptr, 10);
-    return true;
-}
-
-bool parse_f64(const std::string &s, double &v) {
-    if (s.empty()) return false;
-    char *end = nullptr;
-    v = std::strtod(s.c_str(), &end);
-    return end && *end == '\0';
-}
-
-std::vector<std::string> split_char(const std::string &s, char ch) {
-    std::vector<std::string> parts;
-    size_t start = 0;
-    for (;;) {
-        size_t p = s.find(ch, start);
-        if (p == std::string::npos) {
-            parts.emplace_back(s, start);
-            break;
+    std::string text;
+    if (!slurp(path, gunzipped != 0, text)) {
+        nyx_set_error("File not found or unreadable: %s", path);
+        return NYX_HIP_RC_BAD_ARG;
+    }
+    const size_t n_coef = (size_t)(degree + 1) * (size_t)(degree + 2) / 2;
+    std::vector<double> c(n_coef, 0.0), s(n_coef, 0.0);
+    long seen_degree = 0, seen_order = 0, lno = 0;
+    const char *p = text.data(), *const end = p + text.size();
+    for (; p <= end; ++lno) {
+        const char *nl = (const char *)std::memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        const char *b = p;
+        p = nl ? nl + 1 : end + 1;
+        if (lno < skip_lines) continue;
+        Record r;
+        Problem pb;
+        const Line kind = reader(b, le, degree != 0, r, pb);
+        if (kind == Line::Skip) continue;
+        if (kind == Line::Malformed) {
+            nyx_set_error("Harmonics file: could not parse %s `%s` on line %ld", pb.what, pb.text.c_str(), lno);
+            return NYX_HIP_RC_BAD_ARG;
         }
-        parts.emplace_back(s, start, p - start);
-        start = p + 1;
+        if (r.degree > degree) break;
+        if (r.order <= order && r.order <= r.degree) {
+            const size_t i = (size_t)r.degree * (size_t)(r.degree + 1) / 2 + (size_t)r.order;
+            c[i] = r.c;
+            s[i] = r.s;
+        }
+        if (r.order > seen_order) seen_order = r.order;
+        if (r.degree > seen_degree) seen_degree = r.degree;
     }
-    return parts;
-}
-
-struct Packed {
-    int degree;
-    std::vector<double> c, s;
-    explicit Packed(int d) : degree(d), c((size_t)(d + 1) * (d + 2) / 2, 0.0), s(c.size(), 0.0) {}
-    void set(long n, long m, double cv, double sv) {
-        if (m > n) return;  // never present in a well-formed file; the dense reference matrix would hold it unused
-        size_t i = (size_t)n * (n + 1) / 2 + (size_t)m;
-        c[i] = cv;
-        s[i] = sv;
-    }
-};
-
-int finish(Packed &pk, long max_degree, long max_order, int32_t *out_degree, int32_t *out_order, double **c_nm, double **s_nm) {
-    size_t bytes = pk.c.size() * sizeof(double);
-    double *pc = (double *)std::malloc(bytes), *ps = (double *)std::malloc(bytes);
+    double *pc = (double *)std::malloc(n_coef * sizeof(double)), *ps = (double *)std::malloc(n_coef * sizeof(double));
     if (!pc || !ps) {
         std::free(pc);
         std::free(ps);
         nyx_set_error("out of memory");
         return NYX_HIP_RC_BAD_ARG;
     }
-    std::memcpy(pc, pk.c.data(), bytes);
-    std::memcpy(ps, pk.s.data(), bytes);
+    std::memcpy(pc, c.data(), n_coef * sizeof(double));
+    std::memcpy(ps, s.data(), n_coef * sizeof(double));
     *c_nm = pc;
     *s_nm = ps;
-    *out_degree = (int32_t)max_degree;
-    *out_order = (int32_t)max_order;
+    *out_degree = (int32_t)seen_degree;
+    *out_order = (int32_t)seen_order;
     return NYX_HIP_RC_OK;
 }
 
@@ -120,132 +206,12 @@ int finish(Packed &pk, long max_degree, long max_order, int32_t *out_degree, int
 
 extern "C" int32_t nyx_hip_load_cof(const char *path, int32_t degree, int32_t order, int32_t gunzipped, int32_t *out_degree,
                                     int32_t *out_order, double **c_nm, double **s_nm) {
-    if (!path || degree < 0 || order < 0 || !out_degree || !out_order || !c_nm || !s_nm) {
-        nyx_set_error("nyx_hip_load_cof: bad argument");
-        return NYX_HIP_RC_BAD_ARG;
-    }
-    std::string data;
-    if (!read_all(path, gunzipped != 0, data)) {
-        nyx_set_error("File not found or unreadable: %s", path);
-        return NYX_HIP_RC_BAD_ARG;
-    }
-    Packed pk(degree);
-    long max_order = 0, max_degree = 0;
-    std::vector<std::string> items;
-    size_t pos = 0;
-    long lno = 0;
-    while (pos <= data.size()) {
-        size_t nl = data.find('\n', pos);
-        std::string line = data.substr(pos, nl == std::string::npos ? std::string::npos : nl - pos);
-        pos = (nl == std::string::npos) ? data.size() + 1 : nl + 1;
-        const long this_lno = lno++;
-        if (line.empty() || line[0] != 'R') continue;  // comment, header or "END"
-        long cur_degree = 0, cur_order = 0;
-        double cv = 0.0, sv = 0.0;
-        split_ws(line, items);
-        for (size_t ino = 0; ino < items.size(); ++ino) {
-            const std::string &item = items[ino];
-            if (ino == 0) continue;
-            if (ino == 1) {
-                if (!parse_usize(item, cur_degree)) {
-                    nyx_set_error("Harmonics file: could not parse degree `%s` on line %ld", item.c_str(), this_lno);
-                    return NYX_HIP_RC_BAD_ARG;
-                }
-            } else if (ino == 2) {
-                if (!parse_usize(item, cur_order)) {
-                    nyx_set_error("Harmonics file: could not parse order `%s` on line %ld", item.c_str(), this_lno);
-                    return NYX_HIP_RC_BAD_ARG;
-                }
-            } else if (ino == 3) {
-                bool ok = true;
-                if (degree == 0) {
-                    sv = 0.0;
-                    ok = parse_f64(item, cv);
-                } else {
-                    long minus = 0;
-                    for (char ch : item) minus += (ch == '-');
-                    if ((minus == 3 && item[0] != '-') || minus == 4) {
-                        std::vector<std::string> parts = split_char(item, '-');
-                        if (parts.size() == 5) {  // both negative
-                            ok = parse_f64("-" + parts[1] + "-" + parts[2], cv) && parse_f64("-" + parts[3] + "-" + parts[4], sv);
-                        } else if (parts.size() >= 4) {  // C positive, S negative
-                            ok = parse_f64(parts[0] + "-" + parts[1], cv) && parse_f64("-" + parts[2] + "-" + parts[3], sv);
-                        } else {
-                            ok = false;
-                        }
-                    } else {
-                        ok = parse_f64(item, cv);
-                    }
-                }
-                if (!ok) {
-                    nyx_set_error("Harmonics file: could not parse C_nm/S_nm `%s` on line %ld", item.c_str(), this_lno);
-                    return NYX_HIP_RC_BAD_ARG;
-                }
-            } else if (ino == 4) {
-                if (!parse_f64(item, sv)) {
-                    nyx_set_error("Harmonics file: could not parse S_nm `%s` on line %ld", item.c_str(), this_lno);
-                    return NYX_HIP_RC_BAD_ARG;
-                }
-            } else {
-                break;  // covariances are not stored
-            }
-        }
-        if (cur_degree > degree) break;  // file is ordered by degree
-        if (cur_order <= order) pk.set(cur_degree, cur_order, cv, sv);
-        if (cur_order > max_order) max_order = cur_order;
-        if (cur_degree > max_degree) max_degree = cur_degree;
-    }
-    return finish(pk, max_degree, max_order, out_degree, out_order, c_nm, s_nm);
+    return load_table("nyx_hip_load_cof", path, degree, order, gunzipped, 0, read_cof, out_degree, out_order, c_nm, s_nm);
 }
 
 extern "C" int32_t nyx_hip_load_shadr(const char *path, int32_t degree, int32_t order, int32_t gunzipped, int32_t *out_degree,
                                       int32_t *out_order, double **c_nm, double **s_nm) {
-    if (!path || degree < 0 || order < 0 || !out_degree || !out_order || !c_nm || !s_nm) {
-        nyx_set_error("nyx_hip_load_shadr: bad argument");
-        return NYX_HIP_RC_BAD_ARG;
-    }
-    std::string data;
-    if (!read_all(path, gunzipped != 0, data)) {
-        nyx_set_error("File not found or unreadable: %s", path);
-        return NYX_HIP_RC_BAD_ARG;
-    }
-    Packed pk(degree);
-    long max_order = 0, max_degree = 0;
-    std::vector<std::string> items;
-    size_t pos = 0;
-    long lno = 0;
-    while (pos <= data.size()) {
-        size_t nl = data.find('\n', pos);
-        std::string line = data.substr(pos, nl == std::string::npos ? std::string::npos : nl - pos);
-        pos = (nl == std::string::npos) ? data.size() + 1 : nl + 1;
-        const long this_lno = lno++;
-        if (this_lno == 0) continue;  // SHADR header line
-        for (char &ch : line)
-            if (ch == ',') ch = ' ';
-        long cur_degree = 0, cur_order = 0;
-        double cv = 0.0, sv = 0.0;
-        split_ws(line, items);
-        for (size_t ino = 0; ino < items.size() && ino < 4; ++ino) {
-            std::string item = items[ino];
-            bool ok = true;
-            if (ino == 0) ok = parse_usize(item, cur_degree);
-            else if (ino == 1) ok = parse_usize(item, cur_order);
-            else {
-                for (char &ch : item)
-                    if (ch == 'D') ch = 'E';
-                ok = parse_f64(item, ino == 2 ? cv : sv);
-            }
-            if (!ok) {
-                nyx_set_error("Harmonics file: could not parse field %zu `%s` on line %ld", ino, item.c_str(), this_lno);
-                return NYX_HIP_RC_BAD_ARG;
-            }
-        }
-        if (cur_degree > degree) break;
-        if (cur_order <= order) pk.set(cur_degree, cur_order, cv, sv);
-        if (cur_order > max_order) max_order = cur_order;
-        if (cur_degree > max_degree) max_degree = cur_degree;
-    }
-    return finish(pk, max_degree, max_order, out_degree, out_order, c_nm, s_nm);
+    return load_table("nyx_hip_load_shadr", path, degree, order, gunzipped, 1, read_shadr, out_degree, out_order, c_nm, s_nm);
 }
 
 extern "C" void nyx_hip_free(void *p) { std::free(p); }
