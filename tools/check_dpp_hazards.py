@@ -14,14 +14,22 @@ BUNDLER = "/opt/rocm/lib/llvm/bin/clang-offload-bundler"
 
 
 def disassemble(lib):
+    """Disassembly of every gfx950 code object of the library (one offload bundle per translation unit)."""
+    text = []
     with tempfile.TemporaryDirectory() as td:
-        co = os.path.join(td, "k.co")
-        # the fat binary sits in .hip_fatbin; unbundle the gfx950 code object
         fat = os.path.join(td, "fat.bin")
         subprocess.run(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat], check=True)
-        subprocess.run([BUNDLER, "--unbundle", "--type=o", f"--input={fat}", f"--output={co}",
-                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], check=True)
-        return subprocess.run([OBJDUMP, "-d", "--mcpu=gfx950", co], check=True, capture_output=True, text=True).stdout
+        data = open(fat, "rb").read()
+        starts = [m.start() for m in re.finditer(b"__CLANG_OFFLOAD_BUNDLE__", data)]
+        for k, st in enumerate(starts):
+            piece, co = os.path.join(td, f"b{k}.bin"), os.path.join(td, f"k{k}.co")
+            open(piece, "wb").write(data[st:(starts[k + 1] if k + 1 < len(starts) else len(data))])
+            r = subprocess.run([BUNDLER, "--unbundle", "--type=o", f"--input={piece}", f"--output={co}",
+                                "--targets=hipv4-amdgcn-amd-amdhsa--gfx950"], capture_output=True)
+            if r.returncode or not os.path.exists(co) or os.path.getsize(co) == 0:
+                continue
+            text.append(subprocess.run([OBJDUMP, "-d", "--mcpu=gfx950", co], check=True, capture_output=True, text=True).stdout)
+    return "\n".join(text)
 
 
 def vregs(tok):
