@@ -480,9 +480,34 @@ static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, con
 // pieces.  They are dealt over several waves - the DCM and the body slots over up to DEV_MAX_ALM almanac waves (longest
 // first), point masses (+ tides) and SRP (+ drag) over two perturbation waves - each writing its own LDS rows, so the
 // arithmetic and its order do not change.  Costs in harmonics-term units, as `role_handicap`.
+// Units of the almanac duty: the DCM, then either the DISTINCT ephemeris segments of all chains (segment mode: Earth -> EMB sits on
+// every chain of an Earth-centred run and is evaluated once; the readers sum the chains, ed_bp() in the kernel) when their vectors
+// fit the body rows of the epoch data - 4 with a DCM, 7 without - or the body slots.
+static int distinct_segments(const DevCfg &dc, int *useg_seg = nullptr) {
+    int n = 0, list[DEV_MAX_SEG];
+    for (int s = 0; s < dc.n_slots; ++s)
+        for (int k = 0; k < dc.slot[s].n_chain; ++k) {
+            bool seen = false;
+            for (int q = 0; q < n; ++q) seen = seen || list[q] == dc.slot[s].seg[k];
+            if (!seen && n < DEV_MAX_SEG) list[n++] = dc.slot[s].seg[k];
+        }
+    if (useg_seg) for (int q = 0; q < n; ++q) useg_seg[q] = list[q];
+    return n;
+}
+static bool segment_units_fit(const DevCfg &dc) {
+    const bool dcm = dc.has_grav || dc.has_drag || dc.has_tides;
+    const int nu = distinct_segments(dc);
+    return nu >= 2 && nu <= (dcm ? DEV_MAX_SLOTS : DEV_MAX_SLOTS + 3);
+}
 static int fanout_almanac_units(const DevCfg &dc, int *unit_mask, double *unit_cost) {
     int n = 0;
     if (dc.has_grav || dc.has_drag || dc.has_tides) { unit_mask[n] = DEV_ROLE_DCM; unit_cost[n] = 18.0; ++n; }
+    if (segment_units_fit(dc)) {
+        int us[DEV_MAX_SEG];
+        const int nu = distinct_segments(dc, us);
+        for (int u = 0; u < nu; ++u) { unit_mask[n] = 1 << u; unit_cost[n] = 3.0 + 0.75 * dc.seg[us[u]].n_coef; ++n; }
+        return n;
+    }
     for (int s = 0; s < dc.n_slots; ++s) { unit_mask[n] = 1 << s; unit_cost[n] = 12.0 * dc.slot[s].n_chain; ++n; }
     return n;
 }
@@ -492,7 +517,7 @@ static bool want_fanout(const nyx_hip_ctx *ctx, bool quad) {
 }
 static int fanout_role_waves(const nyx_hip_ctx *ctx, int *n_alm_out = nullptr, int *n_pert_out = nullptr) {
     const DevCfg &dc = ctx->host_cfg;
-    int um[8]; double uc[8];
+    int um[10]; double uc[10];
     const int units = fanout_almanac_units(dc, um, uc);
     const int n_alm = std::min(DEV_MAX_ALM, std::max(units, 0));
     const int n_pert = ((dc.n_pm > 0 || dc.has_tides) ? 1 : 0) + ((dc.has_srp || dc.has_drag) ? 1 : 0);
@@ -508,6 +533,7 @@ static void assign_roles(nyx_hip_ctx *ctx, int n_waves, bool fanout, double *hc)
     const int all_pert = (DEV_PERT_PM | DEV_PERT_SRP) << 16;
     for (int w = 0; w < DEV_MAX_WAVES; ++w) { dc.role_kind[w] = DEV_ROLE_COLUMNS; dc.role_mask[w] = 0; dc.role_slot[w] = 0; hc[w] = 0.0; }
     dc.n_alm = 1;
+    dc.seg_mode = 0;
     const double *rh = ctx->role_handicap;
     if (n_waves == 1) { dc.role_kind[0] = DEV_ROLE_ALL; dc.role_mask[0] = all_alm | all_pert; hc[0] = rh[0] + rh[1] + rh[2]; return; }
     dc.role_kind[0] = DEV_ROLE_INTEG; hc[0] = rh[0];
@@ -519,13 +545,13 @@ static void assign_roles(nyx_hip_ctx *ctx, int n_waves, bool fanout, double *hc)
         struct Duty { int kind, mask, slot; double cost; };
         std::vector<Duty> duties;
         {
-            int um[8]; double uc[8];
+            int um[10]; double uc[10];
             const int units = fanout_almanac_units(dc, um, uc);
-            int order[8];
+            int order[10];
             for (int k = 0; k < units; ++k) order[k] = k;
             std::sort(order, order + units, [&](int a, int b) { return uc[a] > uc[b]; });
-            double load[DEV_MAX_ALM] = {0.0, 0.0, 0.0};
-            int amask[DEV_MAX_ALM] = {0, 0, 0};
+            double load[DEV_MAX_ALM] = {0.0};
+            int amask[DEV_MAX_ALM] = {0};
             for (int k = 0; k < units; ++k) {
                 int best = 0;
                 for (int a = 1; a < n_alm; ++a) if (load[a] < load[best]) best = a;
@@ -565,7 +591,18 @@ static void assign_roles(nyx_hip_ctx *ctx, int n_waves, bool fanout, double *hc)
             simd_load[best_w % 4] += d.cost;
             dc.role_kind[best_w] = d.kind; dc.role_mask[best_w] = d.mask; dc.role_slot[best_w] = d.slot; hc[best_w] = d.cost;
         }
-        if (placed_all) return;
+        if (placed_all) {
+            if (segment_units_fit(dc)) {  // the almanac shares above are distinct segments: tell the kernel where their vectors live
+                dc.seg_mode = 1;
+                dc.n_useg = distinct_segments(dc, dc.useg_seg);
+                dc.ed_seg_base = (dc.has_grav || dc.has_drag || dc.has_tides) ? 9 : 0;
+                for (int sl = 0; sl < dc.n_slots; ++sl)
+                    for (int k = 0; k < dc.slot[sl].n_chain; ++k)
+                        for (int u = 0; u < dc.n_useg; ++u)
+                            if (dc.useg_seg[u] == dc.slot[sl].seg[k]) dc.slot[sl].useg[k] = u;
+            }
+            return;
+        }
         for (int w = 1; w < DEV_MAX_WAVES; ++w) { dc.role_kind[w] = DEV_ROLE_COLUMNS; dc.role_mask[w] = 0; dc.role_slot[w] = 0; hc[w] = 0.0; }
         dc.n_alm = 1;
     }
@@ -580,7 +617,12 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
         for (int w = 0; w < DEV_MAX_WAVES; ++w) dc.sched[k].n_ranges[w] = 0;
     dc.n_waves = n_waves;
     dc.merge_roles = (ctx->tune.merge_roles && n_waves >= 8) ? 1 : 0;
-    dc.pipe = (n_waves == DEV_MAX_WAVES && !dc.merge_roles && ctx->tune.pipelined != 0) ? 1 : 0;
+    // pipelined stage loop: sixteen-wave workgroups (the column waves go from one stage's harmonics into the next's), and - plain
+    // kernel - any workgroup of dynamics without a gravity field that has the integrator in a wave of its own: the perturbation
+    // waves need the POSITION of the next stage only, which the integrator publishes inside the window, so its phases A and C run
+    // beside the almanac / perturbation duties instead of in front of them
+    const bool stm_cfg = (dc.flags & NYX_HIP_FLAG_STM) != 0;
+    dc.pipe = (!dc.merge_roles && ctx->tune.pipelined != 0 && ((n_waves == DEV_MAX_WAVES && dc.has_grav) || (!dc.has_grav && !stm_cfg && n_waves >= 2))) ? 1 : 0;
     // roles of this workgroup shape and their serial duties (merged roles when there are fewer than three waves)
     double hc[DEV_MAX_WAVES] = {0};
     assign_roles(ctx, n_waves, want_fanout(ctx, quad), hc);
@@ -588,7 +630,7 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
     // then leaves the buffers of stage parity 0 free for the epoch data of t + h)
     dc.spec = (dc.pipe && !(dc.flags & NYX_HIP_FLAG_STM) && dc.stages % 2 == 0 && dc.n_alm == 1 && dc.has_grav &&
                ctx->tune.chained_attempts != 0) ? 1 : 0;
-    dc.ed_reuse = dc.spec ? 0 : ctx->ed_reuse_fit;  // (chained attempts need no copy of the stage-0 epoch data: a rejected lane keeps its k_0)
+    dc.ed_reuse = (dc.spec || dc.seg_mode) ? 0 : ctx->ed_reuse_fit;  // (chained attempts need no copy of the stage-0 epoch data: a rejected lane keeps its k_0)
     if (!dc.has_grav || nc == 0) return;
     // with enough column workers the integrator keeps its window free: its serial phases A / C gate every other wave
     if (n_waves >= 8 && !any_nonzero(ctx->tune.role_duties, 3)) hc[0] = 1e9;

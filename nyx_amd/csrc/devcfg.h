@@ -15,9 +15,10 @@
 #define DEV_MAX_WAVES_STM 4 /* STM variant: dual numbers need 256 VGPRs per wave and 16 partial slots per wave */
 #define DEV_MAX_RANGES 6  /* contiguous column ranges per wave */
 #define DEV_LANES 64
-#define DEV_MAX_ALM 3     /* almanac waves of a workgroup (role fan-out) */
+#define DEV_MAX_ALM 5     /* almanac waves of a workgroup (role fan-out) */
 /* Roles of the waves of a workgroup, dealt by the host (DevCfg.role_kind / role_mask / role_slot).  role_mask: low 16 bits =
- * almanac share (bit s = body slot s, DEV_ROLE_DCM = the body-fixed DCM), high 16 bits = perturbation share. */
+ * almanac share (bit s = body slot s - or distinct segment s, DevCfg.seg_mode -, DEV_ROLE_DCM = the body-fixed DCM), high 16 bits =
+ * perturbation share. */
 enum { DEV_ROLE_COLUMNS = 0, DEV_ROLE_ALL = 1, DEV_ROLE_INTEG = 2, DEV_ROLE_ALMANAC = 3, DEV_ROLE_PERT = 4, DEV_ROLE_ALMANAC_PERT = 5 };
 #define DEV_ROLE_DCM 0x100
 #define DEV_PERT_PM 1  /* point masses + solid tides */
@@ -33,6 +34,7 @@ struct DevSlot { /* one evaluated body: position w.r.t. the integration centre =
     int32_t n_chain;
     int32_t seg[4];
     double sign[4];
+    int32_t useg[4]; /* seg[k] as an index into DevCfg.useg_seg (segment-level almanac units) */
 };
 
 /* One assignment of harmonics columns to the waves of a workgroup. */
@@ -102,6 +104,11 @@ struct DevCfg {
     /* --- roles of the waves (see DEV_ROLE_*) --- */
     int32_t role_kind[DEV_MAX_WAVES], role_mask[DEV_MAX_WAVES], role_slot[DEV_MAX_WAVES]; /* role_slot: index of an almanac wave's status rows */
     int32_t n_alm;
+    /* Segment-level almanac units (role fan-out): the almanac waves evaluate every DISTINCT ephemeris segment once (Earth -> EMB is
+     * on the chain of every body of an Earth-centred run) and leave its vector in rows ed_seg_base + 3 u of the epoch data; whoever
+     * needs body s sums its chain, sign_k * segment_k in chain order - the same additions epoch_data() makes in slot mode. */
+    int32_t seg_mode, n_useg, ed_seg_base;
+    int32_t useg_seg[DEV_MAX_SEG];
     int32_t spec; /* speculative stage 0 of the next attempt (pipelined loop, see role_loop) */
 
     /* --- column schedules: wave w walks n_ranges[w] contiguous column ranges --- */

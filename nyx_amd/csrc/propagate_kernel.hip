@@ -111,14 +111,18 @@ DEVFN int cheby_eval(const CAS DevSeg &sg, P records, double et_s, double *r3) {
         double cv[CHEB_MAXC];
 #pragma unroll
         for (int j = 0; j < CHEB_MAXC; ++j) cv[j] = cf[j];
+        // Coefficients past the segment's own count are taken as +0.0 and every one of the fifteen steps runs: a step with a zero
+        // coefficient and w0 = w1 = +0 leaves +0 (0 + (2t * 0 - 0) = +0 for either sign of t), so the chain reaches j = nc - 1 in the
+        // state it would start from - the same bits as skipping those steps - while the (uniform) `j < nc` selects sit on the loads,
+        // not on the serial w0 / w1 / w2 chain (guarding the steps cost six v_cndmask per step there: two thirds of this function).
+#pragma unroll
+        for (int j = 1; j < CHEB_MAXC; ++j) cv[j] = (j < nc) ? cv[j] : 0.0;
         double w0 = 0.0, w1 = 0.0, w2;
 #pragma unroll
         for (int j = CHEB_MAXC - 1; j >= 1; --j) {
-            if (j < nc) {  // uniform
-                w2 = w1;
-                w1 = w0;
-                w0 = cv[j] + (two_t * w1 - w2);
-            }
+            w2 = w1;
+            w1 = w0;
+            w0 = cv[j] + (two_t * w1 - w2);
         }
         r3[c] = cv[0] + (t * w0 - w1);
     }
@@ -284,6 +288,21 @@ DEVFN int epoch_data(CfgPtr cfg, P records, int64_t epoch_ns, double *slot, int 
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) *dcm_flag = dcm_val;
     }
+    if (cfg->seg_mode) {  // (uniform) one distinct segment per unit: the chains are summed by the readers, ed_bp()
+        const int nu = cfg->n_useg, base = cfg->ed_seg_base;
+#pragma unroll
+        for (int u = 0; u < DEV_MAX_SEG; ++u) {
+            if (u < nu && ((amask >> u) & 1)) {
+                double p[3];
+                const int st = cheby_eval(cfg->seg[cfg->useg_seg[u]], records, et, p);
+                if (st) status = st;
+                slot[(base + 3 * u + 0) * DEV_LANES + lane] = p[0];
+                slot[(base + 3 * u + 1) * DEV_LANES + lane] = p[1];
+                slot[(base + 3 * u + 2) * DEV_LANES + lane] = p[2];
+            }
+        }
+        return status;
+    }
     const int ns = cfg->n_slots;
 #pragma unroll
     for (int s = 0; s < DEV_MAX_SLOTS; ++s) {
@@ -308,7 +327,29 @@ DEVFN int epoch_data(CfgPtr cfg, P records, int64_t epoch_ns, double *slot, int 
     return status;
 }
 
-#define ED_BP(slot, s, c) (slot)[(9 + 3 * (s) + (c)) * DEV_LANES + lane]
+// Position of body slot s.  Slot mode: the rows epoch_data() wrote.  Segment mode: the chain summed here, in chain order (sign = +-1:
+// every product is exact, the additions are those of epoch_data()).
+DEVFN void ed_body(CfgPtr cfg, const double *ed, int lane, int s, double *p) {
+    if (!cfg->seg_mode) {  // (uniform)
+        p[0] = ed[(9 + 3 * s + 0) * DEV_LANES + lane];
+        p[1] = ed[(9 + 3 * s + 1) * DEV_LANES + lane];
+        p[2] = ed[(9 + 3 * s + 2) * DEV_LANES + lane];
+        return;
+    }
+    const int nch = cfg->slot[s].n_chain, base = cfg->ed_seg_base;
+    double b0 = 0.0, b1 = 0.0, b2 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (k < nch) {  // (uniform)
+            const double sg = cfg->slot[s].sign[k];
+            const double *row = ed + (base + 3 * cfg->slot[s].useg[k]) * DEV_LANES + lane;
+            b0 = b0 + sg * row[0];
+            b1 = b1 + sg * row[DEV_LANES];
+            b2 = b2 + sg * row[2 * DEV_LANES];
+        }
+    }
+    p[0] = b0; p[1] = b1; p[2] = b2;
+}
 
 // ---------------------------------------------------------------------------------------------
 // Position-dependent non-harmonic terms (master, inside the harmonics window)
@@ -322,7 +363,8 @@ DEVFN void point_masses_accel(CfgPtr cfg, const double *ed, int lane, const doub
     for (int k = 0; k < DEV_MAX_SLOTS; ++k) {
         if (k < npm) {
             const int s = cfg->pm_slot[k];
-            const double pij[3] = {ED_BP(ed, s, 0), ED_BP(ed, s, 1), ED_BP(ed, s, 2)};
+            double pij[3];
+            ed_body(cfg, ed, lane, s, pij);
             const double r_ij3 = cube(norm3(pij[0], pij[1], pij[2]));
             const double rj0 = r[0] - pij[0], rj1 = r[1] - pij[1], rj2 = r[2] - pij[2];
             const double r_j3 = cube(norm3(rj0, rj1, rj2));
@@ -367,7 +409,8 @@ DEVFN double occultation_pct(double r_back, double r_front, const double *r_eb, 
 // SolarPressure::eom (reference dynamics/solarpressure.rs:135-165) + ShadowModel::compute (cosmic/eclipse.rs:69-83)
 DEVFN double srp_force(CfgPtr cfg, const double *ed, int lane, const double *r, double cr, double area, double *force) {
     const int ss = cfg->sun_slot;
-    const double ps[3] = {ED_BP(ed, ss, 0), ED_BP(ed, ss, 1), ED_BP(ed, ss, 2)};
+    double ps[3];
+    ed_body(cfg, ed, lane, ss, ps);
     const double rs0 = r[0] - ps[0], rs1 = r[1] - ps[1], rs2 = r[2] - ps[2];
     const double n = norm3(rs0, rs1, rs2);
     const double u0 = rs0 / n, u1 = rs1 / n, u2 = rs2 / n;
@@ -381,7 +424,7 @@ DEVFN double srp_force(CfgPtr cfg, const double *ed, int lane, const double *r, 
             double pb[3] = {0.0, 0.0, 0.0};
             double rad = cfg->central_radius;
             if (sb >= 0) {  // uniform
-                pb[0] = ED_BP(ed, sb, 0); pb[1] = ED_BP(ed, sb, 1); pb[2] = ED_BP(ed, sb, 2);
+                ed_body(cfg, ed, lane, sb, pb);
                 rad = cfg->slot[sb].radius;
             }
             const double r_eb[3] = {r[0] - pb[0], r[1] - pb[1], r[2] - pb[2]};
@@ -592,7 +635,9 @@ DEVFN void tides_accel(CfgPtr cfg, const double *ed, int lane, const T (&r)[3], 
     for (int j = 0; j < DEV_MAX_SLOTS; ++j) {
         if (j < np) {
             const int sl = cfg->t_slot[j];
-            const double p0 = ED_BP(ed, sl, 0), p1 = ED_BP(ed, sl, 1), p2 = ED_BP(ed, sl, 2);
+            double psl[3];
+            ed_body(cfg, ed, lane, sl, psl);
+            const double p0 = psl[0], p1 = psl[1], p2 = psl[2];
             const double b0 = m[0] * p0 + m[1] * p1 + m[2] * p2;
             const double b1 = m[3] * p0 + m[4] * p1 + m[5] * p2;
             const double b2 = m[6] * p0 + m[7] * p1 + m[8] * p2;
@@ -1350,7 +1395,9 @@ DEVFN void pert_gradients(CfgPtr cfg, const double *ed, int lane, const double *
         for (int k = 0; k < DEV_MAX_SLOTS; ++k) {
             if (k < npm) {
                 const int s = cfg->pm_slot[k];
-                const D3 rij[3] = {d3c(ED_BP(ed, s, 0)), d3c(ED_BP(ed, s, 1)), d3c(ED_BP(ed, s, 2))};
+                double pb3[3];
+                ed_body(cfg, ed, lane, s, pb3);
+                const D3 rij[3] = {d3c(pb3[0]), d3c(pb3[1]), d3c(pb3[2])};
                 const D3 rij3 = d3cube(d3norm(rij[0], rij[1], rij[2]));
                 const D3 rj[3] = {{r[0] - rij[0].v, 1.0, 0.0, 0.0}, {r[1] - rij[1].v, 0.0, 1.0, 0.0}, {r[2] - rij[2].v, 0.0, 0.0, 1.0}};
                 const D3 rj3 = d3cube(d3norm(rj[0], rj[1], rj[2]));
@@ -1376,7 +1423,8 @@ DEVFN void pert_gradients(CfgPtr cfg, const double *ed, int lane, const double *
     }
     if (has_srp) {
         const int ss = cfg->sun_slot;
-        const double ps[3] = {ED_BP(ed, ss, 0), ED_BP(ed, ss, 1), ED_BP(ed, ss, 2)};
+        double ps[3];
+    ed_body(cfg, ed, lane, ss, ps);
         const D3 rs[3] = {{r[0] - ps[0], 1.0, 0.0, 0.0}, {r[1] - ps[1], 0.0, 1.0, 0.0}, {r[2] - ps[2], 0.0, 0.0, 1.0}};
         const D3 n = d3norm(rs[0], rs[1], rs[2]);
         // illumination factor exactly as the real path computes it (frozen in the partials)
@@ -1441,7 +1489,9 @@ DEVFN void pert_gradients_q(CfgPtr cfg, const double *ed, int lane, int ql, cons
         for (int k = 0; k < DEV_MAX_SLOTS; ++k) {
             if (k < npm) {
                 const int s = cfg->pm_slot[k];
-                const D1 rij[3] = {d1c(ED_BP(ed, s, 0)), d1c(ED_BP(ed, s, 1)), d1c(ED_BP(ed, s, 2))};
+                double pb3[3];
+                ed_body(cfg, ed, lane, s, pb3);
+                const D1 rij[3] = {d1c(pb3[0]), d1c(pb3[1]), d1c(pb3[2])};
                 const D1 rij3 = d1cube(d1norm(rij[0], rij[1], rij[2]));
                 const D1 rj[3] = {d1seed(r[0] - rij[0].v, 0, ql), d1seed(r[1] - rij[1].v, 1, ql), d1seed(r[2] - rij[2].v, 2, ql)};
                 const D1 rj3 = d1cube(d1norm(rj[0], rj[1], rj[2]));
@@ -1464,7 +1514,8 @@ DEVFN void pert_gradients_q(CfgPtr cfg, const double *ed, int lane, int ql, cons
     }
     if (has_srp) {
         const int ss = cfg->sun_slot;
-        const double ps[3] = {ED_BP(ed, ss, 0), ED_BP(ed, ss, 1), ED_BP(ed, ss, 2)};
+        double ps[3];
+    ed_body(cfg, ed, lane, ss, ps);
         const D1 rs[3] = {d1seed(r[0] - ps[0], 0, ql), d1seed(r[1] - ps[1], 1, ql), d1seed(r[2] - ps[2], 2, ql)};
         const D1 n = d1norm(rs[0], rs[1], rs[2]);
         double f3[3];
@@ -2238,6 +2289,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     double *const inbn = ((i + 1) & 1) ? L.inb2 : L.inb;
 #pragma unroll
                     for (int e = 0; e < 3; ++e) ysn[e * DEV_LANES + lane] = nx_pos[e];
+                    if (has_grav) {  // (without a gravity field the position is all the next window needs: the perturbation waves read it after B2)
                     if (need_almanac) {  // the almanac wave writes the DCM of stage i+1 first thing in this window
                         // (bounded: a protocol error must end as a failed run, never as a hung GPU)
                         int spin = 0;
@@ -2262,6 +2314,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     inbn[3 * DEV_LANES + lane] = rho;
                     inbn[4 * DEV_LANES + lane] = r_ * cfg->g_inv_re;
                     if (STM && QUAD) publish_d1_inputs(cfg, rb0, rb1, rb2, ql, inbn, lane);
+                    }
                     shared_nx = coop_on;
                     if (lane == 0) L.ctl[1] = coop_on ? 1 : 0;  // the workers read it after B2(i), for stage i+1
                     if (coop_on) {
@@ -2642,7 +2695,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     }
 }
 
-template <bool STM, bool QUAD = false, bool W16 = true>  // W16: sixteen-wave workgroups (the only shape with a pipelined stage loop)
+template <bool STM, bool QUAD = false, bool W16 = true>  // W16: sixteen-wave workgroups (the shape whose pipelined stage loop serves the column waves)
 DEVFN void propagate_body(const DevBatch &bt, const DevCfg *cfg_g, const HarmEntry *htab_g, const ColHdr *cols_g,
                           const double *__restrict__ records, char *smem) {
     const int lane = threadIdx.x & (DEV_LANES - 1);
@@ -2699,8 +2752,8 @@ DEVFN void propagate_body(const DevBatch &bt, const DevCfg *cfg_g, const HarmEnt
 
 
     // ---- role dispatch (wave-uniform): the host deals the duties (cfg->role_kind / role_mask, see build_schedule)
-    if constexpr ((!STM || QUAD) && W16) {
-        if (cfg->pipe != 0 && cfg->has_grav != 0 && cfg->role_kind[wave] != DEV_ROLE_ALL) {  // pipelined stage loop (uniform)
+    if constexpr (W16 ? (!STM || QUAD) : !STM) {  // (small shapes: the plain kernel only, for dynamics without a gravity field)
+        if (cfg->pipe != 0 && cfg->role_kind[wave] != DEV_ROLE_ALL) {  // pipelined stage loop (uniform; the host sets cfg->pipe per shape)
             switch (cfg->role_kind[wave]) {
             case DEV_ROLE_INTEG: role_loop<true, false, false, STM, QUAD, true>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw); break;
             case DEV_ROLE_ALMANAC: role_loop<false, true, false, STM, QUAD, true>(bt, cfg, cfg_g, htab, cols, records, L, lane, wave, nw); break;

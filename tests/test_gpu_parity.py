@@ -587,3 +587,80 @@ def test_hybrid_stream_feed_is_bit_identical(degree, n, waves):
     assert res[0][3] == res[1][3]  # same launch shape (cooperative from a few hundred trajectories at degree 70+)
     for a, r in zip(res[1][:3], res[0][:3]):
         np.testing.assert_array_equal(a, r)
+
+
+@pytest.mark.parametrize("case", ["jwst", "jwst_fanout_off", "pm_only", "drag_tides", "events_traj"])
+def test_pipelined_loop_without_gravity_field_is_bit_identical(case):
+    """Dynamics without a gravity field run the pipelined stage loop too (round 3: the integrator publishes the next stage's position
+    inside the window; its phases A and C run beside the almanac / perturbation duties).  Same operations in the same order as the
+    plain two-barrier loop (`pipelined = 0`): states, step counts and dense output are bit-identical - with the roles fanned out
+    over eight waves or kept on three, with drag (the one term that waits for the stage VELOCITY) and tides (a DCM without a
+    gravity field), with a stop condition and a trajectory."""
+    import scenarios as sc
+    dur = 3 * 86400 * nx.NS_PER_S
+    kw = {}
+    if case in ("jwst", "jwst_fanout_off", "events_traj"):
+        prop, almanac, central = sc.jwst_setup()
+        b = sc.jwst_batch(150, seed=4)
+        if case == "jwst_fanout_off":
+            kw = dict(role_fanout=0)
+    elif case == "pm_only":
+        prop, almanac, central = leo_full_setup(degree=0, srp=False)
+        b = dispersed_leo_batch(70, seed=8)
+        dur = 6 * 3600 * nx.NS_PER_S
+    else:
+        prop, almanac, central = leo_full_setup(degree=0, drag="exp", tides=True)
+        b = dispersed_leo_batch(70, seed=9)
+        b.drag_area_m2[:] = 2.0
+        b.cd[:] = 2.2
+        dur = 3 * 3600 * nx.NS_PER_S
+    compiled = prop.compile(almanac, central)
+    res = {}
+    for pipe in (0, 1):
+        ctx = nx.GpuContext(compiled, tuning=nx.Tuning(pipelined=pipe, **kw))
+        if case == "events_traj":
+            from nyx_amd import _abi
+            ev = nx.Event(_abi.EV_VMAG_KM_S, float(np.linalg.norm(b.rv()[0, 3:])) * 0.97)
+            out, st, traj = ctx.propagate_with_traj(b, dur, capacity=512)
+            found, fst, ftraj, crossings = ctx.propagate_until_event(b, 40 * 86400 * nx.NS_PER_S, ev, 1, capacity=1024)
+            extra = [traj.epoch_ns.copy(), traj.state.copy(), traj.len.copy(), found.rv().copy(), found.epoch_ns.copy(), fst.status.copy(),
+                     crossings.copy(), ftraj.len.copy()]
+        else:
+            out, st = ctx.propagate(b, dur)
+            extra = []
+        assert (st.status == 0).all()
+        res[pipe] = [out.rv().copy(), out.epoch_ns.copy(), st.n_evals.copy(), st.n_rejected.copy(), st.last_error.copy()] + extra
+        ctx.close()
+    for a, r in zip(res[1], res[0]):
+        np.testing.assert_array_equal(a, r)
+
+
+@pytest.mark.parametrize("case", ["jwst", "stm_quad_21", "stm_quad_pm_tides"])
+def test_segment_level_almanac_units_are_bit_identical(case):
+    """Role fan-out deals the almanac duty by DISTINCT ephemeris segment (Earth -> EMB is on every chain of an Earth-centred run and is
+    evaluated once); the readers sum the chains, in chain order with exact +-1 products - the additions epoch_data() makes when one
+    wave evaluates whole bodies.  Fan-out off (`role_fanout = 0`: whole bodies, one almanac wave) gives the same bits: plain kernel
+    (JWST: three bodies, five distinct segments of eight, over five almanac waves) and the quad STM kernel's dual readers (with a
+    gravity field: 16 waves, DCM + four segments; without: point masses + tides)."""
+    import scenarios as sc
+    if case == "jwst":
+        prop, almanac, central = sc.jwst_setup()
+        b = sc.jwst_batch(150, seed=5)
+        compiled = prop.compile(almanac, central)
+        dur = 3 * 86400 * nx.NS_PER_S
+    else:
+        prop, almanac, central = leo_full_setup(degree=21 if case == "stm_quad_21" else 0, tides=case != "stm_quad_21")
+        compiled = prop.compile(almanac, central, stm=True)
+        b = dispersed_leo_batch(37, seed=12)
+        b.stm = np.zeros((b.n, 81))
+        b.reset_stm()
+        dur = 3600 * nx.NS_PER_S
+    res = {}
+    for fan in (0, 1):
+        ctx = nx.GpuContext(compiled, tuning=nx.Tuning(role_fanout=fan))
+        out, st = ctx.propagate(b, dur)
+        assert (st.status == 0).all()
+        res[fan] = [out.rv().copy(), out.epoch_ns.copy(), st.n_evals.copy(), st.last_error.copy()] + ([out.stm.copy()] if case != "jwst" else [])
+        ctx.close()
+    for a, r in zip(res[1], res[0]):
+        np.testing.assert_array_equal(a, r)

@@ -38,6 +38,12 @@ else:
     ms = ctx.last_kernel_ms()
     evals_last_launch = int(st.n_evals[:64].max())
 ev = int(st.n_evals.sum())
+if os.environ.get("NYX_DIGEST"):  # bit-level digest of the results: compare builds (NYX_HIP_LIB) or switches across processes
+    import hashlib
+    h = hashlib.sha256()
+    for a in ([res.states.rv(), res.covar] if w["stm"] else [out.rv(), out.epoch_ns]) + [st.n_evals, st.n_rejected, st.last_error]:
+        h.update(np.ascontiguousarray(a).tobytes())
+    print(f"digest {h.hexdigest()[:16]}")
 print(f"config {cfg_id}: n={n} hours={hours:g} waves={waves or 'auto'}: device {ms:.2f} ms, evals {ev} -> {ev / ms * 1e3:.3e} evals/s, "
       f"{ms * 1e3 / max(ev / n, 1):.2f} us per evaluation per trajectory-lane, acc {int(st.n_accepted.sum())} rej {int(st.n_rejected.sum())} "
       f"bad {(st.status != 0).sum()}, algorithmic {ev * w['flop'] / ms / 1e9:.2f} TFLOP/s, helpers {ctx.last_coop_helpers()}")
