@@ -233,7 +233,8 @@ typedef struct nyx_hip_tuning {
     int32_t coop_max_columns;  /* 0 auto: columns a helper workgroup may take */
     int32_t coop_mute;         /* test switch: helpers never answer (exercises the owner's fallback) */
     int32_t profile;           /* 1: in-kernel cycle accounting of workgroup 0 (nyx_hip_debug_profile) */
-    int32_t debug_flags;       /* timing-only switches (0x100 skip the serial role work, 0x200 skip the harmonics): WRONG RESULTS */
+    int32_t debug_flags;       /* timing-only switches (0x100 skip the serial role work, 0x200 skip the harmonics): WRONG RESULTS;
+                                * 0x400 host trace, 0x800 no role offload (A/B switches: same results) */
     double coop_fraction;      /* 0 auto: share of the harmonics terms a helper takes */
     double coop_helper_ratio;  /* 0 auto: helper workgroups per trajectory-owning workgroup */
     double column_start_cost;  /* < 0 auto: rows a column's start is charged in the schedule */

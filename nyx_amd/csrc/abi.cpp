@@ -534,6 +534,7 @@ static void assign_roles(nyx_hip_ctx *ctx, int n_waves, bool fanout, double *hc)
     for (int w = 0; w < DEV_MAX_WAVES; ++w) { dc.role_kind[w] = DEV_ROLE_COLUMNS; dc.role_mask[w] = 0; dc.role_slot[w] = 0; hc[w] = 0.0; }
     dc.n_alm = 1;
     dc.seg_mode = 0;
+    dc.offload = 0;
     const double *rh = ctx->role_handicap;
     if (n_waves == 1) { dc.role_kind[0] = DEV_ROLE_ALL; dc.role_mask[0] = all_alm | all_pert; hc[0] = rh[0] + rh[1] + rh[2]; return; }
     dc.role_kind[0] = DEV_ROLE_INTEG; hc[0] = rh[0];
@@ -592,6 +593,24 @@ static void assign_roles(nyx_hip_ctx *ctx, int n_waves, bool fanout, double *hc)
             dc.role_kind[best_w] = d.kind; dc.role_mask[best_w] = d.mask; dc.role_slot[best_w] = d.slot; hc[best_w] = d.cost;
         }
         if (placed_all) {
+            if (dc.pipe && !dc.has_grav && !stm && !(ctx->tune.debug_flags & 0x800)) {  // (0x800: A/B switch, same results)
+                // pipelined, no column waves: the integrator wave is the critical path; the two lightest almanac shares take the two-body
+                // term and the head of the stage sums off it (DevCfg.offload)
+                // (what an almanac wave has to spare depends on whom it shares its SIMD with: the integrator's SIMD last, then by the SIMD's load)
+                int w1 = -1, w2 = -1;
+                auto spare = [&](int w) { return (w % 4 == 0 ? 1e6 : 0.0) + simd_load[w % 4] + hc[w]; };
+                for (int w = 1; w < n_waves; ++w) {
+                    if (dc.role_kind[w] != DEV_ROLE_ALMANAC) continue;
+                    if (w1 < 0 || spare(w) < spare(w1)) { w2 = w1; w1 = w; }
+                    else if (w2 < 0 || spare(w) < spare(w2)) w2 = w;
+                }
+                if (w1 >= 0) {
+                    if (w2 < 0) w2 = w1;
+                    dc.role_mask[w1] |= DEV_ROLE_SUMS; hc[w1] += 4.0;
+                    dc.role_mask[w2] |= DEV_ROLE_TWOBODY; hc[w2] += 2.0;
+                    dc.offload = 1;
+                }
+            }
             if (segment_units_fit(dc)) {  // the almanac shares above are distinct segments: tell the kernel where their vectors live
                 dc.seg_mode = 1;
                 dc.n_useg = distinct_segments(dc, dc.useg_seg);
@@ -628,7 +647,9 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
     assign_roles(ctx, n_waves, want_fanout(ctx, quad), hc);
     // speculative stage 0 (role_loop): the pipelined plain kernel with ONE almanac wave and an even stage count (the last window
     // then leaves the buffers of stage parity 0 free for the epoch data of t + h)
-    dc.spec = (dc.pipe && !(dc.flags & NYX_HIP_FLAG_STM) && dc.stages % 2 == 0 && dc.n_alm == 1 && dc.has_grav &&
+    // (with a gravity field: one almanac wave; without: any fan-out, almanac and perturbation duties in waves of their own)
+    dc.spec = (dc.pipe && !(dc.flags & NYX_HIP_FLAG_STM) && dc.stages % 2 == 0 &&
+               (dc.has_grav ? dc.n_alm == 1 : (n_waves >= 3 && dc.role_kind[1] != DEV_ROLE_ALMANAC_PERT && (dc.n_slots > 0 || dc.has_drag || dc.has_tides))) &&
                ctx->tune.chained_attempts != 0) ? 1 : 0;
     dc.ed_reuse = (dc.spec || dc.seg_mode) ? 0 : ctx->ed_reuse_fit;  // (chained attempts need no copy of the stage-0 epoch data: a rejected lane keeps its k_0)
     if (!dc.has_grav || nc == 0) return;

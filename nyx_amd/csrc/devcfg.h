@@ -21,6 +21,8 @@
  * perturbation share. */
 enum { DEV_ROLE_COLUMNS = 0, DEV_ROLE_ALL = 1, DEV_ROLE_INTEG = 2, DEV_ROLE_ALMANAC = 3, DEV_ROLE_PERT = 4, DEV_ROLE_ALMANAC_PERT = 5 };
 #define DEV_ROLE_DCM 0x100
+#define DEV_ROLE_SUMS 0x200    /* DevCfg.offload: the head of the next-but-one stage's sum_j a_ij k_j (see role_loop) */
+#define DEV_ROLE_TWOBODY 0x400 /* DevCfg.offload: the two-body term of the current stage */
 #define DEV_PERT_PM 1  /* point masses + solid tides */
 #define DEV_PERT_SRP 2 /* solar radiation pressure + drag */
 
@@ -108,6 +110,8 @@ struct DevCfg {
      * on the chain of every body of an Earth-centred run) and leave its vector in rows ed_seg_base + 3 u of the epoch data; whoever
      * needs body s sums its chain, sign_k * segment_k in chain order - the same additions epoch_data() makes in slot mode. */
     int32_t seg_mode, n_useg, ed_seg_base;
+    int32_t offload; /* pipelined loop without a gravity field: almanac waves with time to spare take the two-body term and the head of
+                      * the stage sums off the integrator wave, which is the critical path there (role_mask bits DEV_ROLE_SUMS / _TWOBODY) */
     int32_t useg_seg[DEV_MAX_SEG];
     int32_t spec; /* speculative stage 0 of the next attempt (pipelined loop, see role_loop) */
 

@@ -1963,6 +1963,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     // carried between attempts (no copy of the stage-0 data is needed: nothing is evaluated at a rejected attempt's start) and
     // its LDS.  The exit is seen one (wasted) window late.
     const bool spec = pipe && !STM && cfg->spec != 0;
+    const bool offl = PIPE && !STM && cfg->offload != 0;  // (uniform) see DevCfg.offload
     bool spec_now = false;  // stage 0 of the attempt being started was published in the previous attempt's last window
     bool keep_k0 = false;   // (integrator, per lane) the previous attempt was rejected: k_0 stands
     int att = 0;            // attempts started by this workgroup
@@ -2198,6 +2199,31 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     if (lane == 0) LCTL[2] = i + 1;
                 }
             }
+            if (PIPE && !STM && ALMANAC && offl) {
+                // work taken off the integrator wave (the critical path of a pipelined workgroup without column waves), see DevCfg.offload.
+                // L.part is free without a gravity field: rows 0-11 = two parities of the six partial stage sums, 12-17 = of the two-body term
+                if (amask & DEV_ROLE_TWOBODY) {
+                    const double *const ysp = (i & 1) ? L.ys2 : L.ys;
+                    const double r0 = ysp[0 * DEV_LANES + lane], r1 = ysp[1 * DEV_LANES + lane], r2 = ysp[2 * DEV_LANES + lane];
+                    const double rmag = norm3(r0, r1, r2);
+                    const double f = -cfg->mu_central / cube(rmag);
+                    double *const tb = L.part + (12 + 3 * (i & 1)) * DEV_LANES;
+                    tb[0 * DEV_LANES + lane] = f * r0; tb[1 * DEV_LANES + lane] = f * r1; tb[2 * DEV_LANES + lane] = f * r2;
+                }
+                if ((amask & DEV_ROLE_SUMS) && i >= 2 && i + 2 < stages) {
+                    // stage T = i + 2: sum_{j <= i-2} a_Tj k_j (k_{i-2} was written before the barrier this window started from)
+                    double q6[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+                    for (int j = 0; j <= i - 2; ++j) {
+                        const double a_nj = A_ROW(i + 2, j);
+#pragma unroll
+                        for (int e = 0; e < 6; ++e) q6[e] += a_nj * KB(j, e);
+                    }
+                    double *const qb = L.part + (i & 1) * 6 * DEV_LANES;
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) qb[e * DEV_LANES + lane] = q6[e];
+                }
+            }
             if (PERT && (has_pm || has_srp || has_drag || has_tides)) {
                 // position-dependent third-body and SRP terms of THIS stage
                 double *const ysp = (pipe && (i & 1)) ? L.ys2 : L.ys;
@@ -2244,11 +2270,32 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             double acc[3] = {0.0, 0.0, 0.0};
             if (INTEG) {
                 // two-body term of this stage (orbital.rs:86-92) and sum_{j<i} a_{i+1,j} k_j of the next one
-                const double rmag = norm3(ys[0], ys[1], ys[2]);
-                const double f = -cfg->mu_central / cube(rmag);
-                acc[0] = f * ys[0]; acc[1] = f * ys[1]; acc[2] = f * ys[2];
+                if (!offl) {
+                    const double rmag = norm3(ys[0], ys[1], ys[2]);
+                    const double f = -cfg->mu_central / cube(rmag);
+                    acc[0] = f * ys[0]; acc[1] = f * ys[1]; acc[2] = f * ys[2];
+                }
 #pragma unroll
                 for (int e = 0; e < 6; ++e) wpre[e] = 0.0;
+                if (offl) {
+                    // the terms j <= i - 3 of the sum were added up - from 0.0, j ascending: the same additions - by an almanac wave
+                    // in the previous window (every k_j it read was behind a barrier by then); the two newest terms are added here
+                    if (i + 1 < stages) {
+                        int j0 = 0;
+                        if (i >= 3) {
+                            const double *const qb = L.part + ((i + 1) & 1) * 6 * DEV_LANES;
+#pragma unroll
+                            for (int e = 0; e < 6; ++e) wpre[e] = qb[e * DEV_LANES + lane];
+                            j0 = i - 2;
+                        }
+#pragma unroll 2
+                        for (int j = j0; j < i; ++j) {
+                            const double a_nj = A_ROW(i + 1, j);
+#pragma unroll
+                            for (int e = 0; e < 6; ++e) wpre[e] += a_nj * KB(j, e);
+                        }
+                    }
+                } else
                 if (i + 1 < stages) {
 #pragma unroll
                     for (int j = 0; j < DEV_MAX_STAGES - 2; ++j) {
@@ -2423,6 +2470,10 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             if (INTEG) {
                 // ---- Phase C: assemble the derivative in the reference's order (orbital.rs:80-114, spacecraft.rs:227-243)
                 const double *const pertc = (pipe && (i & 1)) ? L.pert2 : L.pert;
+                if (offl) {  // the two-body term, formed beside the window by an almanac wave from the published position
+                    const double *const tb = L.part + (12 + 3 * (i & 1)) * DEV_LANES;
+                    acc[0] = tb[0 * DEV_LANES + lane]; acc[1] = tb[1 * DEV_LANES + lane]; acc[2] = tb[2 * DEV_LANES + lane];
+                }
                 if (!STM && (has_pm || has_tides)) {
                     acc[0] += pertc[0 * DEV_LANES + lane]; acc[1] += pertc[1 * DEV_LANES + lane]; acc[2] += pertc[2 * DEV_LANES + lane];
                 }
