@@ -158,6 +158,11 @@ typedef struct nyx_hip_rotation {
 typedef struct nyx_hip_gravity_field {
     int32_t degree;
     int32_t order;
+    int32_t offset_body;   /* 0: the field of the integration centre.  k > 0: the field of config.bodies[k - 1], another body than the
+                            * centre - GravityField::eom transforms the orbit into `grav_data.frame` whatever its centre
+                            * (gravity_field.rs:150-154: translation to that body, then its body-fixed rotation) and rotates the
+                            * acceleration back (:258-265); what the spacecraft feels is that body's harmonics at r - r_body(t) */
+    int32_t _pad;
     double mu_km3_s2;
     double eq_radius_km;
     const double *c_nm;

@@ -93,6 +93,8 @@ class GravityField(C.Structure):
     _fields_ = [
         ("degree", C.c_int32),
         ("order", C.c_int32),
+        ("offset_body", C.c_int32),   # 0 = the integration centre's field; k > 0 = the field of bodies[k - 1]
+        ("_pad", C.c_int32),
         ("mu_km3_s2", C.c_double),
         ("eq_radius_km", C.c_double),
         ("c_nm", c_double_p),

@@ -641,7 +641,9 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
     // waves need the POSITION of the next stage only, which the integrator publishes inside the window, so its phases A and C run
     // beside the almanac / perturbation duties instead of in front of them
     const bool stm_cfg = (dc.flags & NYX_HIP_FLAG_STM) != 0;
-    dc.pipe = (!dc.merge_roles && ctx->tune.pipelined != 0 && ((n_waves == DEV_MAX_WAVES && dc.has_grav) || (!dc.has_grav && !stm_cfg && n_waves >= 2))) ? 1 : 0;
+    // (not with a non-central gravity field: its inputs need the body's position of the stage, which the almanac waves write late in the window)
+    dc.pipe = (!dc.merge_roles && ctx->tune.pipelined != 0 && !(dc.has_grav && dc.g_slot >= 0) &&
+               ((n_waves == DEV_MAX_WAVES && dc.has_grav) || (!dc.has_grav && !stm_cfg && n_waves >= 2))) ? 1 : 0;
     // roles of this workgroup shape and their serial duties (merged roles when there are fewer than three waves)
     double hc[DEV_MAX_WAVES] = {0};
     assign_roles(ctx, n_waves, want_fanout(ctx, quad), hc);
@@ -948,6 +950,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
         for (int i = 0; i < tb.stages; ++i) { dc.b[i] = tb.b[i]; dc.bdiff[i] = tb.b[i] - tb.b[i + tb.stages]; }
     }
     dc.mu_central = cfg->central_mu_km3_s2;
+    dc.g_slot = -1;
 
     // ---- bodies -> slots (every non-central body referenced by a model)
     std::vector<int> slot_of(cfg->n_bodies, -1);
@@ -1039,6 +1042,18 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
         const nyx_hip_gravity_field_t *g = cfg->gravity;
         if (g->degree < 1 || !g->c_nm || !g->s_nm) { delete ctx; nyx_set_error("bad gravity field"); return NYX_HIP_RC_BAD_ARG; }
         dc.has_grav = 1; dc.deg = g->degree; dc.ord = std::min(g->order, g->degree);
+        dc.g_slot = -1;
+        if (g->offset_body != 0) {  // the field of another body than the integration centre (gravity_field.rs:150-154)
+            const int sl = slot_for(g->offset_body - 1);
+            if (sl == -2) { delete ctx; nyx_set_error("gravity field: offset_body is not a body of this configuration (or the %d body slots are taken)", DEV_MAX_SLOTS); return NYX_HIP_RC_BAD_ARG; }
+            if (sl >= 0 && (cfg->flags & NYX_HIP_FLAG_STM)) {
+                delete ctx; nyx_set_error("STM propagation with the gravity field of a non-central body is not on the device path"); return NYX_HIP_RC_BAD_ARG;
+            }
+            dc.g_slot = sl;  // (-1: offset_body names the integration centre itself)
+            if (sl >= 0)
+                for (int k = 0; k < dc.slot[sl].n_chain; ++k)
+                    if (dc.slot[sl].seg[k] < 0 || dc.slot[sl].seg[k] >= dc.n_seg) { delete ctx; nyx_set_error("bad chain segment index"); return NYX_HIP_RC_BAD_ARG; }
+        }
         dc.g_mu = g->mu_km3_s2; dc.g_re = g->eq_radius_km; dc.g_inv_re = 1.0 / g->eq_radius_km;
         copy_rotation(dc.g_rot, g->rotation);
         int n_cols = 0;
@@ -1339,7 +1354,7 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
         const int64_t n_own = (in->n + DEV_LANES - 1) / DEV_LANES;
         const int64_t base = (n_own + 7) / 8 * 8;
         const bool stm_ctx = (ctx->host_cfg.flags & NYX_HIP_FLAG_STM) != 0;
-        if (want && !stm_ctx && ctx->host_cfg.has_grav && nw == DEV_MAX_WAVES && ctx->host_cfg.coop_ok &&
+        if (want && !stm_ctx && ctx->host_cfg.has_grav && ctx->host_cfg.g_slot < 0 && nw == DEV_MAX_WAVES && ctx->host_cfg.coop_ok &&
             base + 8 <= ctx->n_cu) {
             // (more helpers than owners: the jobs are claimed, not assigned, so extra helpers shorten the queue of a set)
             double h_ratio = 1.0;

@@ -88,6 +88,7 @@ struct DevCfg {
     double phi, c_m_s;
 
     int32_t has_grav, deg, ord, n_cols; /* columns 1..n_cols (= deg+1) */
+    int32_t g_slot, _pad_g;             /* >= 0: the field belongs to the body of that slot, not to the integration centre (evaluated at r - r_body) */
     double g_mu, g_re, g_inv_re;
     DevRot g_rot;
 

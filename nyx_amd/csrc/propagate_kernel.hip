@@ -2122,9 +2122,17 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     // body-fixed position and the scaled inputs of the column recursion
 #pragma unroll
                     for (int q = 0; q < 9; ++q) m_cur[q] = edc[q * DEV_LANES + lane];
-                    const double rb0 = m_cur[0] * ys[0] + m_cur[1] * ys[1] + m_cur[2] * ys[2];
-                    const double rb1 = m_cur[3] * ys[0] + m_cur[4] * ys[1] + m_cur[5] * ys[2];
-                    const double rb2 = m_cur[6] * ys[0] + m_cur[7] * ys[1] + m_cur[8] * ys[2];
+                    // the field of another body than the integration centre (gravity_field.rs:150-154: transform_to translates to the
+                    // field's body before it rotates): evaluated at r - r_body(t).  Plain stage loop only (the host clears cfg->pipe)
+                    double rg[3] = {ys[0], ys[1], ys[2]};
+                    if (!STM && cfg->g_slot >= 0) {  // (uniform)
+                        double pg[3];
+                        ed_body(cfg, edc, lane, cfg->g_slot, pg);
+                        rg[0] = ys[0] - pg[0]; rg[1] = ys[1] - pg[1]; rg[2] = ys[2] - pg[2];
+                    }
+                    const double rb0 = m_cur[0] * rg[0] + m_cur[1] * rg[1] + m_cur[2] * rg[2];
+                    const double rb1 = m_cur[3] * rg[0] + m_cur[4] * rg[1] + m_cur[5] * rg[2];
+                    const double rb2 = m_cur[6] * rg[0] + m_cur[7] * rg[1] + m_cur[8] * rg[2];
                     // one sqrt and one divide on the critical path; the rest are multiplies
                     const double r_ = norm3(rb0, rb1, rb2);
                     const double inv_r = 1.0 / r_;

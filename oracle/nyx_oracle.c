@@ -993,6 +993,7 @@ static int dual_eom(const prepared_t *p, double et_s, const double *y9, const sc
     }
     if (cfg->gravity) {
         double acc[3], g3[3][3];
+        if (cfg->gravity->offset_body > 0 && cfg->bodies[cfg->gravity->offset_body - 1].n_chain > 0) return NYX_HIP_ERR_NAN; /* (STM with a non-central field: refused by the device path, not restated) */
         { int st = gravity_gradient(cfg->gravity, cfg->segments, &p->gt, et_s, r, acc, g3); if (st) return st; }
         for (int i = 0; i < 3; ++i) {
             fx[i + 3] += acc[i];
@@ -1068,8 +1069,18 @@ static int sc_eom(const prepared_t *p, int64_t ctx_epoch_ns, double dt_s, const 
         for (int c = 0; c < 3; ++c) dy[3 + c] += a[c];
     }
     if (cfg->gravity) {
-        double a[3];
-        { int st = gravity_eom(cfg->gravity, cfg->segments, &p->gt, et_s, r, a, w->a_work, w->rm, w->im); if (st) return st; }
+        double a[3], rg[3] = {r[0], r[1], r[2]};
+        /* almanac.transform_to(osc, grav_data.frame) (gravity_field.rs:150-154) translates to the field's body before it rotates: the
+         * field of another body than the integration centre is evaluated at r - r_body(t); the acceleration is only rotated back
+         * (:258-265, "no center change needed, it's just a vector") */
+        const int gb = cfg->gravity->offset_body - 1;
+        if (gb >= 0 && gb < cfg->n_bodies && cfg->bodies[gb].n_chain > 0) {
+            double pb[3];
+            int st = body_position(cfg, gb, et_s, pb);
+            if (st) return st;
+            for (int c = 0; c < 3; ++c) rg[c] = r[c] - pb[c];
+        }
+        { int st = gravity_eom(cfg->gravity, cfg->segments, &p->gt, et_s, rg, a, w->a_work, w->rm, w->im); if (st) return st; }
         for (int c = 0; c < 3; ++c) dy[3 + c] += a[c];
     }
     if (cfg->tides) { /* third accel model of Dynamics::build (dynamics/sequence/config.rs:105-118) */
