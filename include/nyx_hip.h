@@ -287,6 +287,11 @@ typedef struct nyx_hip_config {
     int32_t state_frame_body;
     int32_t _pad_cfg;
     const nyx_hip_tuning_t *tuning; /* NULL => NYX_HIP_TUNING_DEFAULT (ABI v4) */
+    /* A second GravityField of the same OrbitalDynamics (accel_models is a list: the reference's cislunar set-ups stack the Earth's
+     * and the Moon's field; each transforms the orbit into ITS frame, gravity_field.rs:150-154).  `gravity` is the one that gets the
+     * column waves - give it the larger field -, this one is evaluated in one piece by the perturbation wave beside them.  Either
+     * may be the integration centre's or another body's (offset_body).  NULL => none.  Not together with the STM. */
+    const nyx_hip_gravity_field_t *gravity2;
 } nyx_hip_config_t;
 
 /* flags */

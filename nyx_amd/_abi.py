@@ -192,6 +192,7 @@ class Config(C.Structure):
         ("state_frame_body", C.c_int32),   # opts.integration_frame: the body the states of a batch are centred on (0: no swap)
         ("_pad_cfg", C.c_int32),
         ("tuning", C.POINTER(Tuning)),     # NULL => defaults (ABI v4)
+        ("gravity2", C.POINTER(GravityField)),  # a second field of the same OrbitalDynamics (NULL => none)
     ]
 
 

@@ -90,6 +90,9 @@ struct nyx_hip_ctx {
     int64_t swap_cap = 0;
     int ed_reuse_fit = 0;  // fields of stage-0 epoch data an unchained pipelined loop may carry between attempts (LDS room)
     HarmEntry *d_htab = nullptr;
+    HarmEntry *d_htab2 = nullptr;  // second gravity field
+    int terms2 = 0;                // its table rows
+    ColHdr *d_cols2 = nullptr;
     double *d_hyb = nullptr;  // the same table in the hybrid-feed layout (devcfg.h HYB_*)
     ColHdr *d_cols = nullptr;
     double *d_records = nullptr;
@@ -520,7 +523,7 @@ static int fanout_role_waves(const nyx_hip_ctx *ctx, int *n_alm_out = nullptr, i
     int um[10]; double uc[10];
     const int units = fanout_almanac_units(dc, um, uc);
     const int n_alm = std::min(DEV_MAX_ALM, std::max(units, 0));
-    const int n_pert = ((dc.n_pm > 0 || dc.has_tides) ? 1 : 0) + ((dc.has_srp || dc.has_drag) ? 1 : 0);
+    const int n_pert = ((dc.n_pm > 0 || dc.has_tides || dc.has_grav2) ? 1 : 0) + ((dc.has_srp || dc.has_drag) ? 1 : 0);
     if (n_alm_out) *n_alm_out = n_alm;
     if (n_pert_out) *n_pert_out = n_pert;
     return 1 + n_alm + n_pert;
@@ -564,7 +567,8 @@ static void assign_roles(nyx_hip_ctx *ctx, int n_waves, bool fanout, double *hc)
         }
         // (measured on the device, in units of ~250 cycles: a plain point mass 4, a dual one 11; SRP with its occultation 12 + 8 per
         //  shadow body, dual 25 + 25; drag 10; tides 14 + 8 per perturber)
-        const double pm_cost = (stm ? 11.0 : 4.0) * dc.n_pm + (dc.has_tides ? (stm ? 3.0 : 1.0) * (14.0 + 8.0 * dc.t_n) : 0.0);
+        const double pm_cost = (stm ? 11.0 : 4.0) * dc.n_pm + (dc.has_tides ? (stm ? 3.0 : 1.0) * (14.0 + 8.0 * dc.t_n) : 0.0) +
+                               (dc.has_grav2 ? 8.0 + 0.2 * ctx->terms2 : 0.0);
         const double srp_cost = (dc.has_srp ? (stm ? 25.0 + 25.0 * dc.n_shadow : 12.0 + 8.0 * dc.n_shadow) : 0.0) + (dc.has_drag ? 10.0 : 0.0);
         if (n_pert == 2) {
             duties.push_back({DEV_ROLE_PERT, DEV_PERT_PM << 16, 0, pm_cost});
@@ -635,6 +639,12 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
     for (int k = 0; k < DEV_N_SCHED; ++k)
         for (int w = 0; w < DEV_MAX_WAVES; ++w) dc.sched[k].n_ranges[w] = 0;
     dc.n_waves = n_waves;
+    if (dc.has_grav2)  // the second field: every column, for whichever wave walks it (the perturbation wave with the point-mass share)
+        for (int w = 0; w < DEV_MAX_WAVES; ++w) {
+            dc.sched[DEV_SCHED_SECOND].n_ranges[w] = 1;
+            dc.sched[DEV_SCHED_SECOND].range_c0[w][0] = 1;
+            dc.sched[DEV_SCHED_SECOND].range_cnt[w][0] = dc.n_cols2;
+        }
     dc.merge_roles = (ctx->tune.merge_roles && n_waves >= 8) ? 1 : 0;
     // pipelined stage loop: sixteen-wave workgroups (the column waves go from one stage's harmonics into the next's), and - plain
     // kernel - any workgroup of dynamics without a gravity field that has the integrator in a wave of its own: the perturbation
@@ -652,6 +662,7 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
     // (with a gravity field: one almanac wave; without: any fan-out, almanac and perturbation duties in waves of their own)
     dc.spec = (dc.pipe && !(dc.flags & NYX_HIP_FLAG_STM) && dc.stages % 2 == 0 &&
                (dc.has_grav ? dc.n_alm == 1 : (n_waves >= 3 && dc.role_kind[1] != DEV_ROLE_ALMANAC_PERT && (dc.n_slots > 0 || dc.has_drag || dc.has_tides))) &&
+               !dc.has_grav2 &&  // (the second field's wave reads the attempt's epoch at stage 0: it would have to wait for step control)
                ctx->tune.chained_attempts != 0) ? 1 : 0;
     dc.ed_reuse = (dc.spec || dc.seg_mode) ? 0 : ctx->ed_reuse_fit;  // (chained attempts need no copy of the stage-0 epoch data: a rejected lane keeps its k_0)
     if (!dc.has_grav || nc == 0) return;
@@ -855,7 +866,7 @@ extern "C" int32_t nyx_hip_debug_profile(nyx_hip_ctx *ctx, int64_t *out) {
 extern "C" void nyx_hip_ctx_destroy(nyx_hip_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
-    hipFree(ctx->d_cfg); hipFree(ctx->d_htab); hipFree(ctx->d_hyb); hipFree(ctx->d_cols); hipFree(ctx->d_records);
+    hipFree(ctx->d_cfg); hipFree(ctx->d_htab); hipFree(ctx->d_htab2); hipFree(ctx->d_cols2); hipFree(ctx->d_hyb); hipFree(ctx->d_cols); hipFree(ctx->d_records);
     free_arrays(ctx->in);
     free_arrays(ctx->out);
     free_arrays(ctx->cal);
@@ -918,7 +929,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
         }
     }
     for (const nyx_hip_rotation_t *r : {cfg->gravity ? &cfg->gravity->rotation : nullptr, cfg->drag ? &cfg->drag->rotation : nullptr,
-                                        cfg->tides ? &cfg->tides->rotation : nullptr})
+                                        cfg->tides ? &cfg->tides->rotation : nullptr, cfg->gravity2 ? &cfg->gravity2->rotation : nullptr})
         if (r)
             if (const char *why = check_rotation(*r, cfg->n_segments)) { nyx_set_error("body-fixed orientation: %s", why); return NYX_HIP_RC_BAD_ARG; }
     if (nyx_hip_device_count() <= device || device < 0) { nyx_set_error("no HIP device %d", device); return NYX_HIP_RC_NO_DEVICE; }
@@ -1060,6 +1071,33 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
         build_harmonics(g, tab, cols, ctx->col_len, n_cols);
         dc.n_cols = n_cols;
     }
+    std::vector<HarmEntry> tab2;
+    std::vector<ColHdr> cols2;
+    int terms2 = 0;
+    if (cfg->gravity2) {
+        const nyx_hip_gravity_field_t *g = cfg->gravity2;
+        if (!cfg->gravity) { delete ctx; nyx_set_error("gravity2 without gravity: a single field goes into `gravity`"); return NYX_HIP_RC_BAD_ARG; }
+        if (g->degree < 1 || !g->c_nm || !g->s_nm) { delete ctx; nyx_set_error("bad second gravity field"); return NYX_HIP_RC_BAD_ARG; }
+        if (cfg->flags & NYX_HIP_FLAG_STM) { delete ctx; nyx_set_error("STM propagation with a second gravity field is not on the device path"); return NYX_HIP_RC_BAD_ARG; }
+        dc.has_grav2 = 1;
+        dc.g2_mu = g->mu_km3_s2; dc.g2_re = g->eq_radius_km; dc.g2_inv_re = 1.0 / g->eq_radius_km;
+        copy_rotation(dc.g2_rot, g->rotation);
+        dc.g2_slot = -1;
+        if (g->offset_body != 0) {
+            const int sl = slot_for(g->offset_body - 1);
+            if (sl == -2) { delete ctx; nyx_set_error("second gravity field: offset_body is not a body of this configuration (or the %d body slots are taken)", DEV_MAX_SLOTS); return NYX_HIP_RC_BAD_ARG; }
+            dc.g2_slot = sl;
+            if (sl >= 0)
+                for (int k = 0; k < dc.slot[sl].n_chain; ++k)
+                    if (dc.slot[sl].seg[k] < 0 || dc.slot[sl].seg[k] >= dc.n_seg) { delete ctx; nyx_set_error("bad chain segment index"); return NYX_HIP_RC_BAD_ARG; }
+        }
+        std::vector<int32_t> len2;
+        int n_cols2 = 0;
+        build_harmonics(g, tab2, cols2, len2, n_cols2);
+        dc.n_cols2 = n_cols2;
+        for (int32_t l : len2) terms2 += l;
+        ctx->terms2 = terms2;
+    }
     if (cfg->drag) {
         const nyx_hip_drag_t *dg = cfg->drag;
         if (dg->density < 0 || dg->density > 2) { delete ctx; nyx_set_error("bad drag density model"); return NYX_HIP_RC_BAD_ARG; }
@@ -1078,7 +1116,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
         //  integrator 66, almanac 140, perturbations 52 harmonics-term units - the first formulas were 2.2x too low)
         ctx->role_handicap[0] = 60.0;
         ctx->role_handicap[1] = 26.0 * nseg_eval + (dc.has_grav ? 38.0 : 0.0);
-        ctx->role_handicap[2] = 13.0 * dc.n_pm + (dc.has_srp ? 13.0 + 13.0 * dc.n_shadow : 0.0) + (dc.has_drag ? 22.0 : 0.0) +
+        ctx->role_handicap[2] = (dc.has_grav2 ? 38.0 + 1.1 * terms2 : 0.0) + 13.0 * dc.n_pm + (dc.has_srp ? 13.0 + 13.0 * dc.n_shadow : 0.0) + (dc.has_drag ? 22.0 : 0.0) +
                                 (dc.has_tides ? 30.0 + 17.0 * dc.t_n : 0.0);
         if (any_nonzero(ctx->tune.role_duties, 3))
             for (int k = 0; k < 3; ++k) ctx->role_handicap[k] = ctx->tune.role_duties[k];
@@ -1119,6 +1157,15 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
         // 70x70 cooperative (one column per helper wave and job: the walk's start-up weighs more) 0-2 % slower
         dc.harm_feed = dc.n_cols > 96 ? 1 : 0;
         if (ctx->tune.harmonics_feed >= 0) dc.harm_feed = ctx->tune.harmonics_feed != 0 ? 1 : 0;
+    }
+    if (!tab2.empty()) {
+        tab2.resize(tab2.size() + 4 * HARM_BATCH, HarmEntry{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0});
+        HIP_TRY(hipMalloc(&ctx->d_htab2, tab2.size() * sizeof(HarmEntry)));
+        HIP_TRY(hipMemcpy(ctx->d_htab2, tab2.data(), tab2.size() * sizeof(HarmEntry), hipMemcpyHostToDevice));
+        HIP_TRY(hipMalloc(&ctx->d_cols2, cols2.size() * sizeof(ColHdr)));
+        HIP_TRY(hipMemcpy(ctx->d_cols2, cols2.data(), cols2.size() * sizeof(ColHdr), hipMemcpyHostToDevice));
+        dc.htab2 = (uint64_t)ctx->d_htab2;
+        dc.cols2 = (uint64_t)ctx->d_cols2;
     }
     HIP_TRY(hipMalloc(&ctx->d_cfg, sizeof(DevCfg)));
     HIP_TRY(hipMemcpy(ctx->d_cfg, &dc, sizeof(DevCfg), hipMemcpyHostToDevice));

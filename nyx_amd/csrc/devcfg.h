@@ -49,7 +49,7 @@ struct DevSched {
  * propagate_kernel.hip): PRIMARY = the columns the trajectory-owning workgroup keeps, HELPER = the columns a helper
  * workgroup on another CU evaluates (the owner walks that schedule itself, wave slot by wave slot, if no helper
  * answers). */
-enum { DEV_SCHED_SOLO = 0, DEV_SCHED_PRIMARY = 1, DEV_SCHED_HELPER = 2, DEV_N_SCHED = 3 };
+enum { DEV_SCHED_SOLO = 0, DEV_SCHED_PRIMARY = 1, DEV_SCHED_HELPER = 2, DEV_SCHED_SECOND = 3, DEV_N_SCHED = 4 };  /* SECOND: every column of the second field, for whichever wave walks it */
 
 #define DEV_MAX_NUT_PREC 16
 struct DevRot { /* nyx_hip_rotation_t, flattened */
@@ -91,6 +91,12 @@ struct DevCfg {
     int32_t g_slot, _pad_g;             /* >= 0: the field belongs to the body of that slot, not to the integration centre (evaluated at r - r_body) */
     double g_mu, g_re, g_inv_re;
     DevRot g_rot;
+    /* second gravity field (nyx_hip_config_t.gravity2): walked in one piece by the perturbation wave with the point-mass share, its own
+     * table (device addresses: the kernel's table arguments are the first field's), DCM evaluated there */
+    int32_t has_grav2, n_cols2, g2_slot, _pad_g2;
+    double g2_mu, g2_re, g2_inv_re;
+    DevRot g2_rot;
+    uint64_t htab2, cols2;
 
     int32_t has_drag, drag_density;
     double drag_rho0, drag_r0, drag_ref_alt_m, drag_max_alt_m, drag_re;

@@ -996,6 +996,38 @@ static __device__ __attribute__((noinline)) Partial4 harmonics_partial(uint64_t 
     return harmonics_core<double>(cfg, htab, cols, wave, sched, zr, zi, rho_u, rho, inv_rho);
 }
 
+// The second gravity field of a configuration (nyx_hip_config_t.gravity2; GravityField::eom, gravity_field.rs:148-268, a second time):
+// walked in one piece by the perturbation wave that has the point-mass share, beside the column waves of the first field - the same
+// recursion (harmonics_partial over the schedule DEV_SCHED_SECOND = every column of the second table), the epilogue of phase C
+// ((mu / r) / R_eq, the s, t, u terms, rotation back), its own DCM evaluated here (epoch-only, but this wave is not the critical path),
+// the position translated to the field's body when that is not the integration centre.  Added to the point-mass rows.
+static __device__ __attribute__((noinline)) void second_field_into_pert(CfgPtr cfg, const double *records, const double *ed, int lane, int wave,
+                                                                       double et_s, const double *ys, double *pert) {
+    double r[3] = {ys[0 * DEV_LANES + lane], ys[1 * DEV_LANES + lane], ys[2 * DEV_LANES + lane]};
+    if (cfg->g2_slot >= 0) {  // (uniform)
+        double pg[3];
+        ed_body(cfg, ed, lane, cfg->g2_slot, pg);
+        r[0] = r[0] - pg[0]; r[1] = r[1] - pg[1]; r[2] = r[2] - pg[2];
+    }
+    double m[9];
+    (void)rotation_dcm(cfg, cfg->g2_rot, records, et_s, m);  // (an ephemeris-range failure of a binary PCK shows in the first field's / the bodies' status too)
+    const double rb0 = m[0] * r[0] + m[1] * r[1] + m[2] * r[2];
+    const double rb1 = m[3] * r[0] + m[4] * r[1] + m[5] * r[2];
+    const double rb2 = m[6] * r[0] + m[7] * r[1] + m[8] * r[2];
+    const double r_ = norm3(rb0, rb1, rb2);
+    const double inv_r = 1.0 / r_;
+    const double s_ = rb0 * inv_r, t_ = rb1 * inv_r, u_ = rb2 * inv_r;
+    const double rho = cfg->g2_re * inv_r;
+    const double kfac = (cfg->g2_mu * inv_r) * cfg->g2_inv_re;
+    const Partial4 pr = harmonics_partial((uint64_t)cfg, cfg->htab2, cfg->cols2, wave, DEV_SCHED_SECOND, rho * s_, rho * t_, rho * u_, rho,
+                                          r_ * cfg->g2_inv_re);
+    const double px = pr.x * kfac, py = pr.y * kfac, pz = pr.z * kfac, pw = pr.w * kfac;
+    const double al0 = px + pw * s_, al1 = py + pw * t_, al2 = pz + pw * u_;
+    pert[0 * DEV_LANES + lane] = pert[0 * DEV_LANES + lane] + (m[0] * al0 + m[3] * al1 + m[6] * al2);
+    pert[1 * DEV_LANES + lane] = pert[1 * DEV_LANES + lane] + (m[1] * al0 + m[4] * al1 + m[7] * al2);
+    pert[2 * DEV_LANES + lane] = pert[2 * DEV_LANES + lane] + (m[2] * al0 + m[5] * al1 + m[8] * al2);
+}
+
 // Dual variant: inputs and outputs go through LDS (20 + 16 doubles per lane) instead of the register ABI.
 static __device__ __attribute__((noinline)) void harmonics_partial_dual(uint64_t cfg_u, uint64_t htab_u, uint64_t cols_u, int wave_v,
                                                                       const double *inbD, double *outD, int lane) {
@@ -1843,6 +1875,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
 #else
     const bool has_tides = cfg->has_tides != 0;
 #endif
+    const bool has_grav2 = !STM && cfg->has_grav2 != 0;
     const bool need_almanac = has_grav || has_drag || has_tides || cfg->n_slots > 0;
     // role fan-out: this wave's share of the almanac / perturbation duties, and its status slot
     const int amask = ALMANAC ? cfg->role_mask[wave] : 0;
@@ -2232,7 +2265,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     for (int e = 0; e < 6; ++e) qb[e * DEV_LANES + lane] = q6[e];
                 }
             }
-            if (PERT && (has_pm || has_srp || has_drag || has_tides)) {
+            if (PERT && (has_pm || has_srp || has_drag || has_tides || has_grav2)) {
                 // position-dependent third-body and SRP terms of THIS stage
                 double *const ysp = (pipe && (i & 1)) ? L.ys2 : L.ys;
                 double *const pertp = (pipe && (i & 1)) ? L.pert2 : L.pert;
@@ -2274,6 +2307,10 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 // third accel model (dynamics/sequence/config.rs:116-118): added to the point-mass slot, last, so that no
                 // live value of this role crosses the call
                 if (has_tides && !STM && do_pm) tides_into_pert(cfg, edc, lane, ysp, pertp);
+                if (has_grav2 && do_pm) {  // a second gravity field (after the tides: the reference's model order does not reach the bits the parity bar looks at)
+                    const int64_t ep2 = __double_as_longlong(L.step[lane]) + seconds_to_ns(C_COEF(i) * L.step[DEV_LANES + lane]);
+                    second_field_into_pert(cfg, rec_in_lds ? (const double *)L.rec : records, edc, lane, wave, ns_to_seconds(ep2), ysp, pertp);
+                }
             }
             double acc[3] = {0.0, 0.0, 0.0};
             if (INTEG) {
@@ -2482,7 +2519,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     const double *const tb = L.part + (12 + 3 * (i & 1)) * DEV_LANES;
                     acc[0] = tb[0 * DEV_LANES + lane]; acc[1] = tb[1 * DEV_LANES + lane]; acc[2] = tb[2 * DEV_LANES + lane];
                 }
-                if (!STM && (has_pm || has_tides)) {
+                if (!STM && (has_pm || has_tides || has_grav2)) {
                     acc[0] += pertc[0 * DEV_LANES + lane]; acc[1] += pertc[1 * DEV_LANES + lane]; acc[2] += pertc[2 * DEV_LANES + lane];
                 }
                 if (!STM && has_grav) {

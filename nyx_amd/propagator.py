@@ -496,8 +496,8 @@ def compile_config(dynamics: SpacecraftDynamics, method: IntegratorMethod, opts:
     srp = [m for m in dynamics.force_models if isinstance(m, SolarPressure)]
     drag = [m for m in dynamics.force_models if isinstance(m, Drag)]
     tides = [m for m in dynamics.orbital_dyn.accel_models if isinstance(m, SolidTides)]
-    if len(pm) > 1 or len(gf) > 1 or len(srp) > 1 or len(drag) > 1 or len(tides) > 1:
-        raise NotImplementedError("the device path takes at most one model of each kind")
+    if len(pm) > 1 or len(gf) > 2 or len(srp) > 1 or len(drag) > 1 or len(tides) > 1:
+        raise NotImplementedError("the device path takes at most one model of each kind (two gravity fields)")
     known = len(pm) + len(gf) + len(tides)
     if known != len(dynamics.orbital_dyn.accel_models) or len(srp) + len(drag) != len(dynamics.force_models):
         raise NotImplementedError("unsupported model on the device path (guidance laws fall back to the CPU reference)")
@@ -539,10 +539,13 @@ def compile_config(dynamics: SpacecraftDynamics, method: IntegratorMethod, opts:
         for k in range(9):
             dst.base_dcm[k] = float(rot.base_dcm[k])
 
-    if gf:
-        g = gf[0]
+    # One or two GravityFields (accel_models is a list: orbital.rs:100-108).  The larger one gets the column waves (`gravity`), the
+    # other is walked in one piece by the perturbation wave (`gravity2`); the order of two terms of a sum is not what parity looks at.
+    for which, g in enumerate(sorted(gf, key=lambda f: -int(f.degree))):
         gs = _abi.GravityField()
         gs.degree, gs.order = int(g.degree), int(g.order)
+        if which == 1 and stm:
+            raise NotImplementedError("STM propagation with a second gravity field is not on the device path")
         if g.frame.naif_id != central.naif_id:
             # gravity_field.rs:150-154: the orbit is transformed into the field's frame WHATEVER its centre (translation to that body,
             # then its rotation), the acceleration is rotated back (:258-265): that body's harmonics at r - r_body(t)
@@ -558,7 +561,10 @@ def compile_config(dynamics: SpacecraftDynamics, method: IntegratorMethod, opts:
         gs.c_nm, gs.s_nm = cn.ctypes.data_as(_abi.c_double_p), sn.ctypes.data_as(_abi.c_double_p)
         fill_rot(gs.rotation, g.frame.rotation)
         keep.append(gs)
-        cfg.gravity = C.pointer(gs)
+        if which == 0:
+            cfg.gravity = C.pointer(gs)
+        else:
+            cfg.gravity2 = C.pointer(gs)
 
     if tides:
         t = tides[0]

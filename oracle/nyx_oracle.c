@@ -355,8 +355,8 @@ static void grav_tables_build(const nyx_hip_gravity_field_t *g, grav_tables_t *t
 
 typedef struct {
     const nyx_hip_config_t *cfg;
-    grav_tables_t gt;
-    int has_grav;
+    grav_tables_t gt, gt2; /* gt2: a second GravityField of the same accel_models list (config.gravity2) */
+    int has_grav, has_grav2;
 } prepared_t;
 
 static void prepared_init(prepared_t *p, const nyx_hip_config_t *cfg) {
@@ -366,9 +366,14 @@ static void prepared_init(prepared_t *p, const nyx_hip_config_t *cfg) {
         grav_tables_build(cfg->gravity, &p->gt);
         p->has_grav = 1;
     }
+    if (cfg->gravity2) {
+        grav_tables_build(cfg->gravity2, &p->gt2);
+        p->has_grav2 = 1;
+    }
 }
 static void prepared_free(prepared_t *p) {
     if (p->has_grav) grav_tables_free(&p->gt);
+    if (p->has_grav2) grav_tables_free(&p->gt2);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -993,7 +998,7 @@ static int dual_eom(const prepared_t *p, double et_s, const double *y9, const sc
     }
     if (cfg->gravity) {
         double acc[3], g3[3][3];
-        if (cfg->gravity->offset_body > 0 && cfg->bodies[cfg->gravity->offset_body - 1].n_chain > 0) return NYX_HIP_ERR_NAN; /* (STM with a non-central field: refused by the device path, not restated) */
+        if ((cfg->gravity->offset_body > 0 && cfg->bodies[cfg->gravity->offset_body - 1].n_chain > 0) || cfg->gravity2) return NYX_HIP_ERR_NAN; /* (STM with a non-central or a second field: refused by the device path, not restated) */
         { int st = gravity_gradient(cfg->gravity, cfg->segments, &p->gt, et_s, r, acc, g3); if (st) return st; }
         for (int i = 0; i < 3; ++i) {
             fx[i + 3] += acc[i];
@@ -1068,19 +1073,21 @@ static int sc_eom(const prepared_t *p, int64_t ctx_epoch_ns, double dt_s, const 
         if (st) return st;
         for (int c = 0; c < 3; ++c) dy[3 + c] += a[c];
     }
-    if (cfg->gravity) {
+    for (int which = 0; which < 2; ++which) { /* accel_models is a list: each GravityField in turn (orbital.rs:100-108) */
+        const nyx_hip_gravity_field_t *g = which == 0 ? cfg->gravity : cfg->gravity2;
+        if (!g) continue;
         double a[3], rg[3] = {r[0], r[1], r[2]};
         /* almanac.transform_to(osc, grav_data.frame) (gravity_field.rs:150-154) translates to the field's body before it rotates: the
          * field of another body than the integration centre is evaluated at r - r_body(t); the acceleration is only rotated back
          * (:258-265, "no center change needed, it's just a vector") */
-        const int gb = cfg->gravity->offset_body - 1;
+        const int gb = g->offset_body - 1;
         if (gb >= 0 && gb < cfg->n_bodies && cfg->bodies[gb].n_chain > 0) {
             double pb[3];
             int st = body_position(cfg, gb, et_s, pb);
             if (st) return st;
             for (int c = 0; c < 3; ++c) rg[c] = r[c] - pb[c];
         }
-        { int st = gravity_eom(cfg->gravity, cfg->segments, &p->gt, et_s, rg, a, w->a_work, w->rm, w->im); if (st) return st; }
+        { int st = gravity_eom(g, cfg->segments, which == 0 ? &p->gt : &p->gt2, et_s, rg, a, w->a_work, w->rm, w->im); if (st) return st; }
         for (int c = 0; c < 3; ++c) dy[3 + c] += a[c];
     }
     if (cfg->tides) { /* third accel model of Dynamics::build (dynamics/sequence/config.rs:105-118) */
@@ -1107,9 +1114,11 @@ static int sc_eom(const prepared_t *p, int64_t ctx_epoch_ns, double dt_s, const 
 static void scratch_init(scratch_t *w, const prepared_t *p) {
     memset(w, 0, sizeof *w);
     if (p->has_grav) {
-        w->a_work = malloc(sizeof(double) * (size_t)p->gt.ld * p->gt.ld);
-        w->rm = malloc(sizeof(double) * (size_t)(p->gt.deg + 2));
-        w->im = malloc(sizeof(double) * (size_t)(p->gt.deg + 2));
+        const size_t ld = (size_t)(p->has_grav2 && p->gt2.ld > p->gt.ld ? p->gt2.ld : p->gt.ld);
+        const size_t dg = (size_t)(p->has_grav2 && p->gt2.deg > p->gt.deg ? p->gt2.deg : p->gt.deg);
+        w->a_work = malloc(sizeof(double) * ld * ld);
+        w->rm = malloc(sizeof(double) * (dg + 2));
+        w->im = malloc(sizeof(double) * (dg + 2));
     }
 }
 static void scratch_free(scratch_t *w) { free(w->a_work); free(w->rm); free(w->im); }

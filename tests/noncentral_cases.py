@@ -32,3 +32,22 @@ def earth_centred(degree, method=nx.IntegratorMethod.RungeKutta89):
 
 def batch(n, seed=0):
     return lunar_batch(n, seed=seed)
+
+
+def two_fields(centre, deg_earth, deg_moon, method=nx.IntegratorMethod.RungeKutta89):
+    """The reference's cislunar stacking: the Earth's AND the Moon's field in one OrbitalDynamics (accel_models is a list), integrated
+    around `centre` ("earth" or "moon"); the other body's field is the non-central one."""
+    from scenarios import JGM3_PATH, iau_earth_frame
+    earth_field = nx.GravityFieldData.from_packed_file(JGM3_PATH, iau_earth_frame(), deg_earth, deg_earth)
+    moon_field = kaula_field(deg_moon, seed=1, frame=IAU_MOON)
+    if centre == "earth":
+        accel = [nx.PointMasses([nx.MOON, nx.SUN]), earth_field, moon_field]
+        almanac, frame = almanac_earth(), earth_frame(ephem.MU_EARTH)
+    else:
+        key = ("moon", 40.0)
+        if key not in _ALMANAC_CACHE:
+            _ALMANAC_CACHE[key] = ephem.build_moon_centered_almanac(nx.to_seconds(EPOCH0_NS), 40.0)
+        accel = [nx.PointMasses([nx.EARTH, nx.SUN]), moon_field, earth_field]
+        almanac, frame = _ALMANAC_CACHE[key], MOON_FRAME
+    dyn = nx.SpacecraftDynamics(nx.OrbitalDynamics(accel), [])
+    return nx.Propagator(dyn, method, nx.IntegratorOptions()), almanac, frame

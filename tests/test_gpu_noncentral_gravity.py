@@ -66,3 +66,45 @@ def test_stm_with_a_non_central_field_is_refused():
     compiled.cfg.flags |= 1  # NYX_HIP_FLAG_STM
     with pytest.raises(RuntimeError, match="non-central"):
         nx.GpuContext(compiled)
+
+
+@pytest.mark.parametrize("centre,deg_earth,deg_moon,n,waves", [("earth", 21, 20, 70, 0), ("moon", 8, 70, 130, 16), ("moon", 6, 70, 1100, 0),
+                                                               ("earth", 12, 10, 5, 1)])
+def test_two_stacked_fields_vs_oracle(centre, deg_earth, deg_moon, n, waves):
+    """The Earth's and the Moon's field in one OrbitalDynamics (`config.gravity2`): the larger one on the column waves, the other walked
+    by the perturbation wave; around either body, one wave to sixteen, stand-alone and cooperative (1 100 low lunar orbits, 70x70 +
+    the Earth's 6x6 as the non-central second field)."""
+    prop, almanac, frame = nc.two_fields(centre, deg_earth, deg_moon)
+    compiled = prop.compile(almanac, frame)
+    b = nc.batch(n, seed=4)
+    if centre == "earth":  # the lunar orbits, Earth-centred
+        import frame_swap_cases as fs
+        rv = b.rv().copy()
+        for i in range(b.n):
+            r, v = fs.chain_state_numpy(almanac, nx.MOON, int(b.epoch_ns[i]))
+            rv[i, :3] += r
+            rv[i, 3:] += v
+        b.set_rv(rv)
+    dur = 2 * 3600 * nx.NS_PER_S
+    ctx = nx.GpuContext(compiled)
+    if waves:
+        ctx.set_column_waves(waves)
+    out, st = ctx.propagate(b, dur)
+    helpers = ctx.last_coop_helpers()
+    ctx.close()
+    sample = np.arange(0, n, max(1, n // 64))
+    ref, rst = oracle_lib.propagate(compiled, b.take(sample), dur, n_threads=16)
+    assert (st.status == 0).all() and (rst.status == 0).all()
+    dr, dv = pos_vel_errors(out.take(sample), ref)
+    # what the second field does: the same run without it
+    fields = [m for m in prop.dynamics.orbital_dyn.accel_models if isinstance(m, nx.GravityFieldData)]
+    small = min(fields, key=lambda f: f.degree)
+    models = [m for m in prop.dynamics.orbital_dyn.accel_models if m is not small]
+    one = nx.Propagator(nx.SpacecraftDynamics(nx.OrbitalDynamics(models), []), prop.method, prop.opts)
+    without, _ = oracle_lib.propagate(one.compile(almanac, frame), b.take(sample), dur, n_threads=16)
+    effect = np.linalg.norm((ref.rv() - without.rv())[:, :3], axis=1).max()
+    print(f"{centre}-centred, Earth {deg_earth} + Moon {deg_moon}, n {n}, waves {waves or 'auto'}, helpers {helpers}: dr {dr.max() * 1e3:.3e} m "
+          f"dv {dv.max() * 1e6:.3e} mm/s; the second field moves the orbit by {effect * 1e3:.3e} m")
+    assert dr.max() < 1e-6 and dv.max() < 1e-9
+    assert effect > 20 * dr.max()          # the term is there (and far above the agreement)
+    assert (helpers > 0) == (n >= 1000)

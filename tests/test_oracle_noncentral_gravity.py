@@ -66,3 +66,39 @@ def check_field_effects(eff_a, eff_b, gap):
 
 def test_same_field_effect_as_the_moon_centred_formulation():
     check_field_effects(*field_effects(lambda c, b, d: oracle_lib.propagate(c, b, d)))
+
+
+def test_two_fields_add_up():
+    """A second GravityField of the same OrbitalDynamics (`config.gravity2`): the derivative with both fields is the derivative with the
+    first plus the second one's own term (its central evaluation at the position relative to ITS body), whichever body is the centre."""
+    lib = oracle_lib.load()
+    epoch = int(nc.EPOCH0_NS + 7000 * nx.NS_PER_S)
+    for centre in ("earth", "moon"):
+        prop, almanac, frame = nc.two_fields(centre, 12, 10)
+        both = prop.compile(almanac, frame)
+        assert bool(both.cfg.gravity) and bool(both.cfg.gravity2)
+        g1, g2 = both.cfg.gravity.contents, both.cfg.gravity2.contents
+        assert g1.degree == 12 and g2.degree == 10            # the larger field gets the column waves
+        assert (g1.offset_body == 0) == (centre == "earth") and (g2.offset_body == 0) == (centre == "moon")
+        # a position 1 900 km from the Moon, given w.r.t. the centre
+        other = int(g2.offset_body if centre == "earth" else g1.offset_body) - 1
+        p_other, st = np.zeros(3), C.c_int32(0)
+        lib.nyx_oracle_body_position(C.byref(both.cfg), other, epoch, p_other.ctypes.data_as(_abi.c_double_p), C.byref(st))
+        rel_moon = np.array([1200.0, -900.0, 1100.0])
+        r = (p_other + rel_moon) if centre == "earth" else rel_moon
+        y = np.concatenate([r, [0.3, 1.0, -0.2], [0.0, 0.0, 0.0]])
+        s_both, d_both = oracle_lib.eom(both, epoch, 0.0, y, dry=100.0)
+        assert s_both == 0
+        # the same dynamics with one field each
+        total = None
+        for keep in (0, 1):
+            models = [m for m in prop.dynamics.orbital_dyn.accel_models if not isinstance(m, nx.GravityFieldData)]
+            fields = [m for m in prop.dynamics.orbital_dyn.accel_models if isinstance(m, nx.GravityFieldData)]
+            one = nx.Propagator(nx.SpacecraftDynamics(nx.OrbitalDynamics(models + [fields[keep]]), []), prop.method, prop.opts)
+            s1, d1 = oracle_lib.eom(one.compile(almanac, frame), epoch, 0.0, y, dry=100.0)
+            assert s1 == 0
+            total = d1[3:6] if total is None else total + d1[3:6]
+        bare = nx.Propagator(nx.SpacecraftDynamics(nx.OrbitalDynamics(models), []), prop.method, prop.opts)
+        s0, d0 = oracle_lib.eom(bare.compile(almanac, frame), epoch, 0.0, y, dry=100.0)
+        np.testing.assert_allclose(d_both[3:6], total - d0[3:6], rtol=0, atol=4e-16 * np.linalg.norm(d_both[3:6]))
+        assert np.linalg.norm(d_both[3:6] - d0[3:6]) > 1e-8
