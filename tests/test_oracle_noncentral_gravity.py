@@ -102,3 +102,24 @@ def test_two_fields_add_up():
         s0, d0 = oracle_lib.eom(bare.compile(almanac, frame), epoch, 0.0, y, dry=100.0)
         np.testing.assert_allclose(d_both[3:6], total - d0[3:6], rtol=0, atol=4e-16 * np.linalg.norm(d_both[3:6]))
         assert np.linalg.norm(d_both[3:6] - d0[3:6]) > 1e-8
+
+
+def test_host_mirror_refusals():
+    """What the device path does not take, said by the host mirror before any context exists: the STM with a non-central or a second
+    field, a third field."""
+    import pytest
+    prop, almanac, earth = nc.earth_centred(8)
+    with pytest.raises(NotImplementedError, match="non-central"):
+        prop.compile(almanac, earth, stm=True)
+    prop2, almanac2, moon = nc.two_fields("moon", 4, 8)
+    with pytest.raises(NotImplementedError, match="non-central|second gravity field"):
+        prop2.compile(almanac2, moon, stm=True)
+    fields = [m for m in prop2.dynamics.orbital_dyn.accel_models if isinstance(m, nx.GravityFieldData)]
+    three = nx.Propagator(nx.SpacecraftDynamics(nx.OrbitalDynamics(list(prop2.dynamics.orbital_dyn.accel_models) + [fields[0]]), []), prop2.method, prop2.opts)
+    with pytest.raises(NotImplementedError, match="two gravity fields"):
+        three.compile(almanac2, moon)
+    # and the central case is what it was: offset_body 0, no second field
+    import scenarios as sc
+    p, a, c = sc.leo_full_setup(degree=8)
+    cc = p.compile(a, c)
+    assert cc.cfg.gravity.contents.offset_body == 0 and not bool(cc.cfg.gravity2)
