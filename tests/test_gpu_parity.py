@@ -589,7 +589,7 @@ def test_hybrid_stream_feed_is_bit_identical(degree, n, waves):
         np.testing.assert_array_equal(a, r)
 
 
-@pytest.mark.parametrize("case", ["jwst", "jwst_fanout_off", "pm_only", "drag_tides", "events_traj"])
+@pytest.mark.parametrize("case", ["jwst", "jwst_fanout_off", "pm_only", "drag_tides", "events_traj", "jwst_2_waves", "jwst_16_waves", "drag_tides_4_waves"])
 def test_pipelined_loop_without_gravity_field_is_bit_identical(case):
     """Dynamics without a gravity field run the pipelined stage loop too (round 3: the integrator publishes the next stage's position
     inside the window; its phases A and C run beside the almanac / perturbation duties).  Same operations in the same order as the
@@ -599,7 +599,8 @@ def test_pipelined_loop_without_gravity_field_is_bit_identical(case):
     import scenarios as sc
     dur = 3 * 86400 * nx.NS_PER_S
     kw = {}
-    if case in ("jwst", "jwst_fanout_off", "events_traj"):
+    waves = {"jwst_2_waves": 2, "jwst_16_waves": 16, "drag_tides_4_waves": 4}.get(case, 0)  # (forced shapes: merged almanac + perturbation wave, the sixteen-wave kernel)
+    if case.startswith("jwst") or case == "events_traj":
         prop, almanac, central = sc.jwst_setup()
         b = sc.jwst_batch(150, seed=4)
         if case == "jwst_fanout_off":
@@ -618,6 +619,8 @@ def test_pipelined_loop_without_gravity_field_is_bit_identical(case):
     res = {}
     for pipe in (0, 1):
         ctx = nx.GpuContext(compiled, tuning=nx.Tuning(pipelined=pipe, **kw))
+        if waves:
+            ctx.set_column_waves(waves)
         if case == "events_traj":
             from nyx_amd import _abi
             ev = nx.Event(_abi.EV_VMAG_KM_S, float(np.linalg.norm(b.rv()[0, 3:])) * 0.97)
