@@ -228,7 +228,7 @@ typedef struct nyx_hip_tuning {
     int32_t schedule;          /* enum nyx_hip_schedule */
     int32_t deterministic;     /* 1: bits per trajectory independent of the batch (cooperative mode off) */
     int32_t cooperative;       /* -1 auto (on when the launch has fewer workgroups than CUs), 0 off, 1 on */
-    int32_t pipelined;         /* -1 auto, 0 two-barrier stage loop, 1 pipelined stage loop (sixteen-wave workgroups) */
+    int32_t pipelined;         /* -1 auto, 0 two-barrier stage loop, 1 pipelined stage loop (sixteen-wave workgroups; workgroups without a gravity field) */
     int32_t chained_attempts;  /* -1 auto, 0 off, 1 speculative stage 0 of the next attempt */
     int32_t epoch_data_reuse;  /* -1 auto, 0 off (only read when the attempts are not chained) */
     int32_t role_fanout;       /* -1 auto, 0 off, 1 almanac / perturbation duties dealt over several waves */

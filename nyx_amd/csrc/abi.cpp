@@ -480,7 +480,7 @@ static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, con
 
 // Role fan-out (small ensembles: the STM quad layout, and dynamics without a gravity field): with few workgroups on the
 // chip what counts is the latency of ONE force evaluation, and the almanac and perturbation duties are its longest serial
-// pieces.  They are dealt over several waves - the DCM and the body slots over up to DEV_MAX_ALM almanac waves (longest
+// pieces.  They are dealt over several waves - the DCM and the body slots (or the distinct ephemeris segments, fanout_almanac_units) over up to DEV_MAX_ALM almanac waves (longest
 // first), point masses (+ tides) and SRP (+ drag) over two perturbation waves - each writing its own LDS rows, so the
 // arithmetic and its order do not change.  Costs in harmonics-term units, as `role_handicap`.
 // Units of the almanac duty: the DCM, then either the DISTINCT ephemeris segments of all chains (segment mode: Earth -> EMB sits on

@@ -125,7 +125,7 @@ struct DevCfg {
     /* --- column schedules: wave w walks n_ranges[w] contiguous column ranges --- */
     int32_t n_waves;
     int32_t merge_roles; /* almanac and perturbation duties share wave 1 */
-    int32_t pipe;     /* pipelined stage loop (16-wave workgroups): see role_loop */
+    int32_t pipe;     /* pipelined stage loop (16-wave workgroups; any plain workgroup without a gravity field that has the integrator in a wave of its own): see role_loop */
     int32_t ed_reuse; /* > 0: stage-0 epoch data is carried between attempts; value = fields kept per lane (9 + 3 * n_slots) */
     DevSched sched[DEV_N_SCHED];
     double coop_frac; /* share of the harmonics terms a helper workgroup takes over (cooperative mode) */
