@@ -21,6 +21,13 @@ ensemble is fixed (--n), `value` = all ranks' trajectories / max-over-ranks time
     python bench.py --gpus 1 --steps 3 --warmup 1
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
            --master-port 29500 bench.py --gpus 8 --steps 3 --warmup 1
+    python bench.py --gpus 8                      # started as ONE process: starts its 8 ranks itself (same line, n_gpus 8)
+    python bench.py --gpus 8 --scaling strong     # ONE ensemble of the configuration's size cut 8 ways
+    python bench.py --gpus 8 --single-process     # one process, 8 contexts through nyx_hip_propagate_batch_sharded
+
+`--gpus N` always measures N ranks: under torchrun WORLD_SIZE must equal N, without it the script starts the ranks itself
+(one process per GPU, rendezvous on 127.0.0.1, RCCL) and rank 0 prints the one JSON line with `n_gpus`, `rccl_ranks`,
+`per_rank_kernel_ms` and `all_gather_ms`.
 """
 import argparse
 import ctypes as C
@@ -33,6 +40,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -280,16 +288,123 @@ def cpu_baseline_predict(shard, compiled, p0, end_ns, n_per_gpu, hours):
 
 
 def measured_traffic(cfg_id, n, hours, degree):
-    """HBM bytes per launch from the committed rocprofv3 --pmc pass of this command (profiles/*hbm_traffic*.json), if any."""
-    best = None
+    """HBM bytes per launch from the committed rocprofv3 --pmc pass of this command (profiles/*hbm_traffic*.json) - only when
+    that pass was taken on THIS build: the file carries the stamp of the kernel sources it was measured on
+    (tools/kernel_stamp.py) and a figure whose stamp differs from the tree's is not quoted (traffic = null, the reason in
+    `traffic_source`): counters cannot be read from inside the run, a stale file must not pass for a measurement."""
+    from kernel_stamp import kernel_source_stamp
+    stamp = kernel_source_stamp(ROOT)
+    best, stale = None, None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*hbm_traffic*.json"))):
         try:
             tj = json.load(open(path))
         except Exception:
             continue
         if tj.get("config", 2) == cfg_id and tj.get("n") == n and tj.get("hours") == hours and tj.get("degree") == degree:
-            best = (tj.get("hbm_bytes_per_launch"), os.path.relpath(path, ROOT))
-    return best or (None, None)
+            rel = os.path.relpath(path, ROOT)
+            if tj.get("kernel_source_stamp") == stamp:
+                best = (tj.get("hbm_bytes_per_launch"), rel)
+            else:
+                stale = rel
+    if best:
+        return best
+    if stale:
+        return None, f"stale: {stale} was measured on kernel sources {json.load(open(os.path.join(ROOT, stale))).get('kernel_source_stamp', 'unstamped')}, this tree is {stamp}"
+    return None, None
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n_ranks, argv):
+    """`python bench.py --gpus N` started as ONE process: start the N ranks here (one process per GPU, rendezvous on
+    127.0.0.1) and wait for them; rank 0 prints the line.  Under torchrun (WORLD_SIZE set) this is never reached."""
+    import subprocess
+    port = _free_port()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   NYX_BENCH_SELF_LAUNCHED="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
+    rc = 0
+    try:
+        for p in procs:
+            prc = p.wait()
+            if prc != 0 and rc == 0:
+                rc = prc
+                for q in procs:   # one rank failed: the others would wait in a collective for ever (exact PIDs, our own children)
+                    if q.poll() is None:
+                        q.terminate()
+    except KeyboardInterrupt:
+        for q in procs:
+            if q.poll() is None:
+                q.terminate()
+        raise
+    return rc
+
+
+def selftest_launch(rank, world):
+    """CPU check of the launch layer (tests/test_bench_launch.py): rendezvous, all-gather and max-over-ranks of synthetic
+    numbers over gloo - everything of an N-rank run but the device work."""
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mine = torch.full((4, 7), float(rank + 1), dtype=torch.float64)
+    got = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine)
+    t = torch.tensor([0.5 + rank], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    k = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(k, torch.tensor([10.0 * (rank + 1)], dtype=torch.float64))
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "ranks": world, "backend": "gloo", "self_launched": bool(os.environ.get("NYX_BENCH_SELF_LAUNCHED")),
+                          "gathered_sum": float(sum(g.sum().item() for g in got)), "max_time": float(t.item()),
+                          "per_rank_kernel_ms": [float(x.item()) for x in k]}), flush=True)
+    dist.destroy_process_group()
+
+
+def single_process(args, w):
+    """`--single-process`: ONE process drives every device through the C symbol `nyx_hip_propagate_batch_sharded` (one context
+    and one host thread per device, contiguous index shards, results in place; host buffers: the staging copies are inside
+    the timed call).  The ensemble is `--gpus` x the per-GPU size (weak) or the configuration's own size (strong)."""
+    if w["stm"]:
+        raise SystemExit("--single-process drives nyx_hip_propagate_batch_sharded: plain propagation only (configs 2, 3, 5)")
+    ndev = torch.cuda.device_count()
+    if args.gpus > ndev and not args.oversubscribe:
+        raise SystemExit(f"--single-process --gpus {args.gpus}: {ndev} device(s) visible (--oversubscribe puts several contexts on one device)")
+    n_per = args.n or w["n"]
+    hours = args.hours or w["hours"]
+    total = n_per if args.scaling == "strong" else n_per * args.gpus
+    compiled = w["prop"].compile(w["almanac"], w["central"], stm=False)
+    ctxs = [nx.GpuContext(compiled, device=k % ndev) for k in range(args.gpus)]
+    full = w["batch"](total, seed=0)
+    dur_ns = int(round(hours * 3600)) * nx.NS_PER_S
+    for _ in range(args.warmup):
+        nx.propagate_sharded(ctxs, full, dur_ns)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, st = nx.propagate_sharded(ctxs, full, dur_ns)
+    elapsed = time.perf_counter() - t0
+    if (st.status != 0).any():
+        raise SystemExit(f"{int((st.status != 0).sum())} trajectories failed")
+    k_ms = [c.last_kernel_ms() for c in ctxs]
+    n_evals = int(st.n_evals.sum())
+    achieved_tf = n_evals * w["flop"] / (max(k_ms) * 1e-3) / 1e12 / args.gpus   # per device, on the slowest device's kernel time
+    line = {"metric": w["metric"], "value": total * args.steps / elapsed, "unit": "trajectories/s", "n_gpus": min(args.gpus, ndev), "contexts": args.gpus,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic", "launch": "single-process",
+            "config": {"workload": w["label"](total // args.gpus, hours), "baseline_config": args.config, "trajectories_total": total,
+                       "sharding": "nyx_hip_propagate_batch_sharded: contiguous index shards over the contexts, one host thread per device, host "
+                                   "buffers in and out (PCIe-inclusive), no collective"},
+            "per_rank_kernel_ms": k_ms, "force_evals_per_launch": n_evals,
+            "roofline": {"bound": "valu_fp64", "achieved": achieved_tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved_tf / FP64_VECTOR_PEAK_TFLOPS, "traffic": None, "note": "per device, slowest device's kernel time"}}
+    print(json.dumps(line), flush=True)
 
 
 def main():
@@ -298,47 +413,100 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json configuration (1-based; default 2 = the headline)")
-    ap.add_argument("--n", type=int, default=0, help="trajectories per GPU (0 = the configuration's own size)")
+    ap.add_argument("--n", type=int, default=0, help="trajectories per GPU (weak) or in total (strong); 0 = the configuration's own size")
     ap.add_argument("--hours", type=float, default=0.0, help="propagation length (0 = the configuration's own)")
     ap.add_argument("--degree", type=int, default=None)
     ap.add_argument("--waves", type=int, default=0, help="column-split waves per workgroup (0 = auto)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: every GPU gets the configuration's ensemble (total = N x n); strong: ONE ensemble of that size is cut N ways")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl", help="collective backend of the final-state exchange (nccl = RCCL)")
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="allow more ranks than devices (rank r -> device r mod devices; RCCL refuses two ranks on one device: use --backend gloo)")
+    ap.add_argument("--single-process", action="store_true", help="one process, every device through nyx_hip_propagate_batch_sharded")
+    ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-output", action="store_true", help="skip the extra launch with the trajectories recorded")
     ap.add_argument("--no-host-call", action="store_true", help="skip the PCIe-inclusive host-buffer call")
     args = ap.parse_args()
 
+    # ---- how many ranks, and who starts them.  Under torchrun (the driver's N > 1 launch) WORLD_SIZE is set and must agree
+    # with --gpus; started as one process with --gpus N > 1 the ranks are started HERE (spawn_ranks) - `--gpus N` always
+    # measures N ranks, however the script was started.
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.single_process:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if args.single_process:
+        if world > 1:
+            raise SystemExit("--single-process is one process by definition: do not start it under torchrun")
+    elif world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.selftest_launch:
+        return selftest_launch(rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    w = workload(args.config, args.degree)
+    if args.single_process:
+        return single_process(args, w)
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev:
+        if not args.oversubscribe:
+            raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but {ndev} device(s) visible (--oversubscribe --backend gloo shares devices)")
+        if args.backend == "nccl":
+            raise SystemExit("RCCL refuses two ranks on one device: --oversubscribe needs --backend gloo")
+    device_index = local_rank % ndev
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     dist = None
     if world > 1:
         import torch.distributed as dist  # noqa: F811
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
-    w = workload(args.config, args.degree)
-    n = args.n or w["n"]
     hours = args.hours or w["hours"]
     prop, almanac, central = w["prop"], w["almanac"], w["central"]
     compiled = prop.compile(almanac, central, stm=w["stm"])
-    ctx = nx.GpuContext(compiled, device=local_rank)
+    ctx = nx.GpuContext(compiled, device=device_index)
     if args.waves:
         ctx.set_column_waves(args.waves)
     lib = _abi.load_library()
 
-    # contiguous index shards of ONE ensemble: rank r owns trajectories [r*n, (r+1)*n) (seed = global stream)
-    full = w["batch"](n * world, seed=0)
-    shard = full.slice(rank * n, (rank + 1) * n)
+    # contiguous index shards of ONE ensemble (seed = global stream).  weak: rank r owns [r n, (r + 1) n) of N x n;
+    # strong: the configuration's own ensemble cut N ways (shard_bounds: sizes differ by at most one)
+    n_cfg = args.n or w["n"]
+    total_traj = n_cfg if args.scaling == "strong" else n_cfg * world
+    lo, hi = nx.shard_bounds(total_traj, rank, world)
+    n = hi - lo
+    n_max = nx.shard_bounds(total_traj, 0, world)[1]   # the largest shard (rank 0 holds one of them): all-gather pieces are padded to it
+    full = w["batch"](total_traj, seed=0)
+    shard = full.slice(lo, hi)
     dur_ns = int(round(hours * 3600)) * nx.NS_PER_S
     stream = torch.cuda.current_stream(dev)
-    gathered = [torch.empty((n, 7), dtype=torch.float64, device=dev) for _ in range(world)] if world > 1 else None
+    gdev = dev if args.backend == "nccl" else torch.device("cpu")
+    gathered = [torch.empty((n_max, 7), dtype=torch.float64, device=gdev) for _ in range(world)] if world > 1 else None
+    gather_s = [0.0]
     host_call = None
 
+    def exchange(final):
+        """one all-gather of the final states (n x 7 f64 per rank, padded to the largest shard): RCCL over xGMI, latency-bound"""
+        if final.shape[0] < n_max:
+            final = torch.cat([final, torch.zeros((n_max - final.shape[0], 7), dtype=torch.float64, device=final.device)])
+        if args.backend == "nccl":
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            dist.all_gather(gathered, final)
+            e1.record(stream)
+            return (e0, e1)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        dist.all_gather(gathered, final.cpu())
+        gather_s[0] += time.perf_counter() - t1
+        return None
+
+    gather_events = []
     if not w["stm"]:
         tin, sin = tensor_states(shard, dev)
         tout, sout = tensor_states(shard, dev)
@@ -348,15 +516,15 @@ def main():
             rc = lib.nyx_hip_propagate_batch_device(ctx._h, C.byref(sin), dur_ns, C.byref(sout), C.byref(sst), C.c_void_p(stream.cuda_stream))
             if rc != 0:
                 raise RuntimeError(_abi.last_error())
-            if world > 1:  # final-state collection over RCCL/xGMI (one all-gather, latency-bound: n x 7 f64)
+            if world > 1:  # final-state collection (one all-gather)
                 final = torch.stack([tout[f] for f in _abi.F64_FIELDS[:6]] + [tout["epoch_ns"].to(torch.float64)], dim=1)
-                dist.all_gather(gathered, final)
+                gather_events.append(exchange(final))
     else:
         # covariance mapping: the C-ABI entry takes host buffers (states, covariances) and keeps the whole segment /
         # time-update loop on one stream; the timed region therefore includes the one H2D and the one D2H of the call
         shard.stm = np.zeros((n, 81))
         shard.reset_stm()
-        p0 = init_covar(n)
+        p0 = init_covar(total_traj)[lo:hi]
         end_ns = int(shard.epoch_ns[0]) + dur_ns
         last = {}
 
@@ -365,7 +533,7 @@ def main():
             if world > 1:
                 r = last["res"].states
                 final = torch.from_numpy(np.concatenate([r.rv(), r.epoch_ns[:, None].astype(np.float64)], axis=1)).to(dev)
-                dist.all_gather(gathered, final)
+                gather_events.append(exchange(final))
 
     def barrier():
         if world > 1:
@@ -375,6 +543,8 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    gather_events.clear()
+    gather_s[0] = 0.0
     kernel_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -382,10 +552,22 @@ def main():
         kernel_ms.append(ctx.last_kernel_ms() if not w["stm"] else last["res"].kernel_ms)  # HIP events on the launch stream
     barrier()
     elapsed = time.perf_counter() - t0
+    k_ms = float(np.mean(kernel_ms))
+    per_rank_kernel_ms = [k_ms]
+    gather_ms = None
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        red = dev if args.backend == "nccl" else torch.device("cpu")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=red)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+        if args.backend == "nccl":
+            gather_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in gather_events]))
+        else:
+            gather_ms = gather_s[0] / args.steps * 1e3
+        kall = [torch.zeros(2, dtype=torch.float64, device=red) for _ in range(world)]
+        dist.all_gather(kall, torch.tensor([k_ms, gather_ms], dtype=torch.float64, device=red))
+        per_rank_kernel_ms = [float(t[0].item()) for t in kall]
+        gather_ms = max(float(t[1].item()) for t in kall)
 
     if not w["stm"]:
         n_evals = int(tst["n_evals"].sum().item())
@@ -397,8 +579,12 @@ def main():
         n_acc, n_rej = int(st.n_accepted.sum()), int(st.n_rejected.sum())
     if n_bad:
         raise SystemExit(f"{n_bad} trajectories failed")
-    k_ms = float(np.mean(kernel_ms))
-    total_traj = n * world
+    ev_all = n_evals
+    if world > 1:   # force evaluations of the whole job (strong scaling: the shards differ)
+        red = dev if args.backend == "nccl" else torch.device("cpu")
+        evt = torch.tensor([float(n_evals)], dtype=torch.float64, device=red)
+        dist.all_reduce(evt, op=dist.ReduceOp.SUM)
+        ev_all = int(evt.item())
     value = total_traj * args.steps / elapsed
 
     if rank == 0:
@@ -414,13 +600,17 @@ def main():
         line = {
             "metric": w["metric"],
             "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
+            "launch": "torchrun" if (world > 1 and not os.environ.get("NYX_BENCH_SELF_LAUNCHED")) else ("self-launched ranks" if world > 1 else "single rank"),
+            "rccl_ranks": world if (world > 1 and args.backend == "nccl") else 0, "backend": args.backend if world > 1 else None,
+            "devices_visible": ndev, "per_rank_kernel_ms": per_rank_kernel_ms, "all_gather_ms": gather_ms,
             "config": {"workload": w["label"](n, hours), "baseline_config": args.config,
-                       "trajectories_per_gpu": n, "column_waves": args.waves or "auto",
+                       "trajectories_per_gpu": n, "trajectories_total": total_traj, "column_waves": args.waves or "auto",
                        "tuning": "nyx_hip_tuning_t defaults: NYX_HIP_SCHED_MODEL (process-independent column schedule), cooperative mode auto",
-                       "sharding": "contiguous index shards, no data-path collective; one RCCL all-gather of final states per step"},
-            "force_evals_per_s": n_evals * world / (elapsed / args.steps),
+                       "sharding": "contiguous index shards, no data-path collective; one all-gather of final states per step"
+                                   + (" (strong: ONE ensemble of the configuration's size cut over the ranks)" if args.scaling == "strong" else "")},
+            "force_evals_per_s": ev_all / (elapsed / args.steps),
             "force_evals_per_launch": n_evals, "accepted_steps": n_acc, "rejected_attempts": n_rej,
             "kernel_ms": k_ms,
             "occupancy": {"workgroups": owners + helpers, "owner_workgroups": owners, "helper_workgroups": helpers, "trajectories_per_workgroup": per_wg, "cus": N_CU,

@@ -220,9 +220,13 @@ typedef struct nyx_hip_solid_tides {
  *   NYX_HIP_SCHED_EXPLICIT         wave_weights[] / role_duties[] as given.
  * `deterministic` = 1 additionally makes every trajectory's bits independent of the BATCH it is launched in (batch size,
  * position in the batch, rank-sharding): the cooperative mode - whose column split follows the ratio of idle CUs to
- * workgroups - is switched off.  The reference is reproducible per (seed, index) in exactly this sense
- * (mc/montecarlo.rs:208-224, 290-295).  Cost: none for ensembles that fill the chip (>= 64 trajectories x CUs), the
- * cooperative gain (~1.27x at 10 000 trajectories on 256 CUs) below that. */
+ * workgroups - is switched off, and the workgroup SHAPE (waves per workgroup; the STM layout, which is then the quad layout
+ * unless `stm_quad` says otherwise) is taken from the configuration alone instead of the batch size - both decide the column
+ * split, i.e. the order of the sums.  The reference is reproducible per (seed, index) in exactly this sense
+ * (mc/montecarlo.rs:208-224, 290-295).  Cost: the cooperative gain (~1.27x at 10 000 trajectories on 256 CUs) for ensembles
+ * that leave CUs idle; for very large plain batches (>= 32 705 trajectories) the sixteen-wave shape is kept where eight or
+ * four waves would be a few percent faster; the quad STM layout issues 1.6x the f64 slots of the 64-lane one above ~8 000
+ * trajectories (set stm_quad = 0 there).  nyx_hip_ctx_set_column_waves / stm_quad pin the shape explicitly either way. */
 enum nyx_hip_schedule { NYX_HIP_SCHED_MODEL = 0, NYX_HIP_SCHED_CALIBRATED = 1, NYX_HIP_SCHED_EXPLICIT = 2 };
 typedef struct nyx_hip_tuning {
     int32_t schedule;          /* enum nyx_hip_schedule */
@@ -517,6 +521,21 @@ typedef struct nyx_hip_predict_history {
  * the first failing status per trajectory (0 = Ok) with counters summed over the segments; `hist` may be NULL. */
 int32_t nyx_hip_predict_until(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, const nyx_hip_predict_t *cfg, nyx_hip_estimates_t *est,
                               nyx_hip_states_t *out, nyx_hip_step_stats_t *stats, nyx_hip_predict_history_t *hist);
+
+/* ---- ensemble moments of the final states, on the device (the consumers of mc/results.rs:60-245 reduce a Monte Carlo result to
+ * its mean and covariance; north_star: "RCCL ... only for the final trajectory/covariance reduction") ----
+ *   out55[0]      number of runs whose status is 0 (status == NULL: every run)
+ *   out55[1..9]   sum (x - x0),  x = [x y z vx vy vz Cr Cd prop_mass] (a NULL array of `states` counts as zeros)
+ *   out55[10..54] upper triangle, row-major (i <= j), of sum (x - x0)(x - x0)^T
+ * x0[9] (NULL = zeros): the caller's reference point, any state near the ensemble (the nominal final state, or the first
+ * successful run's, which every rank can hold) - it keeps the sums well conditioned.  A rank-sharded host completes the
+ * ensemble with ONE ncclAllReduce(sum) of these 55 doubles and no device-to-host copy of the states:
+ *   mean = x0 + s / n,   cov = (S - n m m^T) / (n - 1)  with m = s / n.
+ * Two small launches, a fixed grid and fixed summation order (no atomics): bit-reproducible for a given n.
+ * _device: every pointer but x0 is a device pointer (out55 too), asynchronous on `hip_stream`.  Host flavour: host arrays. */
+int32_t nyx_hip_ensemble_moments_device(nyx_hip_ctx *ctx, const nyx_hip_states_t *states, const int32_t *status, const double *x0,
+                                        double *out55, void *hip_stream);
+int32_t nyx_hip_ensemble_moments(nyx_hip_ctx *ctx, const nyx_hip_states_t *states, const int32_t *status, const double *x0, double *out55);
 
 /* Tuning knob: number of waves that split the spherical-harmonics columns of one
  * 64-trajectory workgroup (0 = pick automatically from n). */

@@ -424,7 +424,7 @@ EXPORTS = [
     "nyx_hip_propagate_batch_with_traj", "nyx_hip_propagate_batch_with_traj_device",
     "nyx_hip_traj_at", "nyx_hip_traj_every", "nyx_hip_traj_at_device", "nyx_hip_traj_every_device",
     "nyx_hip_predict_until", "nyx_hip_propagate_until_event", "nyx_hip_last_coop_helpers", "nyx_hip_ctx_set_tuning",
-    "nyx_hip_propagate_batch_sharded",
+    "nyx_hip_propagate_batch_sharded", "nyx_hip_ensemble_moments", "nyx_hip_ensemble_moments_device",
 ]
 
 
@@ -488,6 +488,10 @@ def load_library():
     lib.nyx_hip_propagate_batch_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(States), C.c_int64, C.POINTER(States),
                                                     C.POINTER(StepStats), C.POINTER(Traj)]
     lib.nyx_hip_propagate_batch_sharded.restype = C.c_int32
+    lib.nyx_hip_ensemble_moments.argtypes = [C.c_void_p, C.POINTER(States), c_int32_p, c_double_p, c_double_p]
+    lib.nyx_hip_ensemble_moments.restype = C.c_int32
+    lib.nyx_hip_ensemble_moments_device.argtypes = [C.c_void_p, C.POINTER(States), C.c_void_p, c_double_p, C.c_void_p, C.c_void_p]
+    lib.nyx_hip_ensemble_moments_device.restype = C.c_int32
     lib.nyx_hip_ctx_set_tuning.argtypes = [C.c_void_p, C.POINTER(Tuning)]
     lib.nyx_hip_ctx_set_tuning.restype = C.c_int32
     lib.nyx_hip_abi_sizeof.argtypes = [C.c_int32]

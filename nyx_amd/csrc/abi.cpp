@@ -22,12 +22,14 @@
 #include "devcfg.h"
 #include "predict_args.h"
 #include "traj_args.h"
+#include "moments_args.h"
 
 extern "C" size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles, int stm, int reuse_fields);
 extern "C" hipError_t nyx_launch_predict_init(const PredictArgs *a, const int64_t *epoch0, hipStream_t stream);
 extern "C" hipError_t nyx_launch_time_update(const PredictArgs *a, hipStream_t stream);
 extern "C" hipError_t nyx_launch_event_search(const EventSearchArgs *args, hipStream_t stream);
 extern "C" hipError_t nyx_launch_traj_eval(const TrajEvalArgs *args, hipStream_t stream);
+extern "C" hipError_t nyx_launch_moments(const MomArgs &a, double *out, hipStream_t stream);
 extern "C" hipError_t nyx_launch_frame_shift(const DevCfg *cfg, const double *records, const int32_t *chain_seg, const double *chain_sign,
                                              int n_chain, int64_t n, const int64_t *epoch_ns, double *x, double *y, double *z, double *vx,
                                              double *vy, double *vz, double dir, int32_t *status, const int32_t *prior, hipStream_t stream);
@@ -86,6 +88,7 @@ struct nyx_hip_ctx {
     int swap_n_chain = 0;
     int32_t swap_seg[4] = {0, 0, 0, 0};
     double swap_sign[4] = {0.0, 0.0, 0.0, 0.0};
+    double *d_mom = nullptr;   // scratch of the ensemble-moments reduction: [MOM_BLOCKS][MOM_N] block sums, then MOM_N results (host flavour)
     double *d_swap = nullptr;  // six rows of swap_cap doubles: the translated copy of a batch's Cartesian state
     int64_t swap_cap = 0;
     int ed_reuse_fit = 0;  // fields of stage-0 epoch data an unchained pipelined loop may carry between attempts (LDS room)
@@ -734,6 +737,8 @@ static bool pick_quad(const nyx_hip_ctx *ctx, int64_t n) {
     if (!(ctx->host_cfg.flags & NYX_HIP_FLAG_STM)) return false;
     if (ctx->forced_quad >= 0) return ctx->forced_quad != 0;
     if (ctx->tune.stm_quad >= 0) return ctx->tune.stm_quad != 0;
+    // deterministic: the layout fixes the column split, hence the bits - it must not follow the batch size (a shard is a smaller batch)
+    if (ctx->tune.deterministic) return true;
     const int64_t cus = ctx->n_cu > 0 ? ctx->n_cu : 256;
     return (n + 15) / 16 <= 2 * cus;
 }
@@ -760,8 +765,12 @@ static int pick_waves(const nyx_hip_ctx *ctx, int64_t n) {
     const int64_t wgs = (n + DEV_LANES - 1) / DEV_LANES;
     const int deg = ctx->host_cfg.deg;
     int want = 16;
-    if (wgs >= 2048) want = 4;
-    else if (wgs >= 512) want = 8;
+    // (deterministic: the waves per workgroup fix the column split, i.e. the summation order - from the configuration only, never
+    //  from n: 40 000 trajectories on one context and two shards of 20 000 must walk the same columns in the same order)
+    if (!ctx->tune.deterministic) {
+        if (wgs >= 2048) want = 4;
+        else if (wgs >= 512) want = 8;
+    }
     if (deg < 8) want = std::min(want, 4);
     else if (deg < 24) want = std::min(want, 8);
     return want;
@@ -821,6 +830,9 @@ extern "C" int32_t nyx_hip_ctx_set_tuning(nyx_hip_ctx *ctx, const nyx_hip_tuning
         return NYX_HIP_RC_BAD_ARG;
     }
     ctx->tune = n;
+    // the helper share the schedules are built for follows the new request (auto: 0.30 until a cooperative launch derives it from
+    // its helper / owner ratio); the rebuilt descriptor is uploaded by the next launch (sched_dirty)
+    ctx->host_cfg.coop_frac = n.coop_fraction > 0.0 ? std::min(0.9, std::max(0.05, n.coop_fraction)) : 0.30;
     ctx->weights.clear();
     ctx->weight_spread.clear();
     ctx->sched_dirty = true;
@@ -871,6 +883,7 @@ extern "C" void nyx_hip_ctx_destroy(nyx_hip_ctx *ctx) {
     free_arrays(ctx->out);
     free_arrays(ctx->cal);
     (void)hipFree(ctx->d_swap);
+    (void)hipFree(ctx->d_mom);
     mailbox_release(ctx->device, ctx->d_coop, ctx->coop_cap);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
@@ -1421,6 +1434,9 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
                 }
                 bool have_boxes = ctx->coop_cap >= n_own;
                 if (!have_boxes) {
+                    // the block goes back to the process-wide pool, where another context (another host thread) may take and clear it
+                    // at once: not before every launch of THIS context that uses it has finished (the device entry points are asynchronous)
+                    if (ctx->d_coop && ctx->launched) HIP_TRY(hipEventSynchronize(ctx->ev_done));
                     mailbox_release(ctx->device, ctx->d_coop, ctx->coop_cap);
                     ctx->d_coop = nullptr;
                     ctx->coop_cap = 0;
@@ -1782,6 +1798,76 @@ extern "C" int32_t nyx_hip_traj_at_device(nyx_hip_ctx *ctx, const nyx_hip_traj_t
 extern "C" int32_t nyx_hip_traj_every_device(nyx_hip_ctx *ctx, const nyx_hip_traj_t *traj, int64_t n, int64_t step_ns,
                                              nyx_hip_traj_t *out, void *hip_stream) {
     return traj_eval_device(ctx, traj, n, nullptr, 0, step_ns, out, nullptr, TRAJ_MODE_EVERY, (hipStream_t)hip_stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Ensemble moments of the final states (mc/results.rs:60-245 consumers): moments_kernel.hip
+// ---------------------------------------------------------------------------------------------
+static int moments_device(nyx_hip_ctx *ctx, const nyx_hip_states_t *s, const int32_t *status, const double *x0, double *out55, hipStream_t stream) {
+    if (!ctx || !s || !out55 || s->n < 0 || (s->n > 0 && (!s->x_km || !s->y_km || !s->z_km || !s->vx_km_s || !s->vy_km_s || !s->vz_km_s))) {
+        nyx_set_error("ensemble_moments: ctx, states (six Cartesian arrays) and out are mandatory");
+        return NYX_HIP_RC_BAD_ARG;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!ctx->d_mom) HIP_TRY(hipMalloc((void **)&ctx->d_mom, (size_t)(MOM_BLOCKS + 1) * MOM_N * sizeof(double)));
+    MomArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.n = s->n;
+    const double *f[9] = {s->x_km, s->y_km, s->z_km, s->vx_km_s, s->vy_km_s, s->vz_km_s, s->cr, s->cd, s->prop_mass_kg};
+    for (int k = 0; k < 9; ++k) { a.f[k] = f[k]; a.x0[k] = x0 ? x0[k] : 0.0; }
+    a.status = status;
+    a.partial = ctx->d_mom;
+    if (ctx->launched) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_done, 0));  // (the scratch is the context's: one reduction at a time)
+    HIP_TRY(nyx_launch_moments(a, out55, stream));
+    HIP_TRY(hipEventRecord(ctx->ev_done, stream));
+    ctx->launched = true;
+    return NYX_HIP_RC_OK;
+}
+
+extern "C" int32_t nyx_hip_ensemble_moments_device(nyx_hip_ctx *ctx, const nyx_hip_states_t *states, const int32_t *status, const double *x0,
+                                                   double *out55, void *hip_stream) {
+    if (!ctx) { nyx_set_error("null ctx"); return NYX_HIP_RC_BAD_ARG; }
+    CTX_LOCK(ctx);
+    return moments_device(ctx, states, status, x0, out55, (hipStream_t)hip_stream);
+}
+
+extern "C" int32_t nyx_hip_ensemble_moments(nyx_hip_ctx *ctx, const nyx_hip_states_t *states, const int32_t *status, const double *x0, double *out55) {
+    if (!ctx || !states || !out55 || states->n < 0) { nyx_set_error("ensemble_moments: null argument"); return NYX_HIP_RC_BAD_ARG; }
+    CTX_LOCK(ctx);
+    HIP_TRY(hipSetDevice(ctx->device));
+    const int64_t n = states->n;
+    if (n > 0 && (!states->x_km || !states->y_km || !states->z_km || !states->vx_km_s || !states->vy_km_s || !states->vz_km_s)) {
+        nyx_set_error("ensemble_moments: the six Cartesian arrays are mandatory");
+        return NYX_HIP_RC_BAD_ARG;
+    }
+    // host arrays: one device block of 9 rows (+ the status words), copied row by row; the reduction itself is two small launches
+    char *blk = nullptr;
+    const size_t row = (size_t)std::max<int64_t>(n, 1) * sizeof(double);
+    HIP_TRY(hipMalloc((void **)&blk, 9 * row + (size_t)std::max<int64_t>(n, 1) * sizeof(int32_t)));
+    nyx_hip_states_t d;
+    std::memset(&d, 0, sizeof d);
+    d.n = n;
+    const double *h[9] = {states->x_km, states->y_km, states->z_km, states->vx_km_s, states->vy_km_s, states->vz_km_s, states->cr, states->cd, states->prop_mass_kg};
+    double **dp[9] = {&d.x_km, &d.y_km, &d.z_km, &d.vx_km_s, &d.vy_km_s, &d.vz_km_s, &d.cr, &d.cd, &d.prop_mass_kg};
+    int rc = NYX_HIP_RC_OK;
+    for (int k = 0; k < 9 && rc == NYX_HIP_RC_OK; ++k) {
+        if (!h[k]) continue;
+        *dp[k] = (double *)(blk + (size_t)k * row);
+        if (n > 0 && hipMemcpy(*dp[k], h[k], (size_t)n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) rc = NYX_HIP_RC_HIP_ERROR;
+    }
+    int32_t *dst = nullptr;
+    if (rc == NYX_HIP_RC_OK && status) {
+        dst = (int32_t *)(blk + 9 * row);
+        if (n > 0 && hipMemcpy(dst, status, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) rc = NYX_HIP_RC_HIP_ERROR;
+    }
+    if (rc == NYX_HIP_RC_OK) {
+        if (!ctx->d_mom && hipMalloc((void **)&ctx->d_mom, (size_t)(MOM_BLOCKS + 1) * MOM_N * sizeof(double)) != hipSuccess) rc = NYX_HIP_RC_HIP_ERROR;
+    }
+    if (rc == NYX_HIP_RC_OK) rc = moments_device(ctx, &d, dst, x0, ctx->d_mom + (size_t)MOM_BLOCKS * MOM_N, nullptr);
+    if (rc == NYX_HIP_RC_OK && hipMemcpy(out55, ctx->d_mom + (size_t)MOM_BLOCKS * MOM_N, MOM_N * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = NYX_HIP_RC_HIP_ERROR;
+    if (rc == NYX_HIP_RC_HIP_ERROR) nyx_set_error("ensemble_moments: HIP error: %s", hipGetErrorString(hipGetLastError()));
+    (void)hipFree(blk);
+    return rc;
 }
 
 // A nyx_hip_traj_t whose arrays are one device allocation (RAII).

@@ -34,6 +34,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include "../../include/nyx_hip.h"
 #include "devcfg.h"
 #include "hifitime_dev.h"
@@ -1001,8 +1003,11 @@ static __device__ __attribute__((noinline)) Partial4 harmonics_partial(uint64_t 
 // recursion (harmonics_partial over the schedule DEV_SCHED_SECOND = every column of the second table), the epilogue of phase C
 // ((mu / r) / R_eq, the s, t, u terms, rotation back), its own DCM evaluated here (epoch-only, but this wave is not the critical path),
 // the position translated to the field's body when that is not the integration centre.  Added to the point-mass rows.
-static __device__ __attribute__((noinline)) void second_field_into_pert(CfgPtr cfg, const double *records, const double *ed, int lane, int wave,
-                                                                       double et_s, const double *ys, double *pert) {
+// Returns the status of the field's own orientation (a binary PCK whose coverage the epoch has left: the record is clamped, the
+// DCM is wrong, and neither the first field nor the bodies need share that segment): the caller leaves it in the stage's status
+// row for the integrator wave, as the almanac waves do with theirs.
+static __device__ __attribute__((noinline)) int second_field_into_pert(CfgPtr cfg, const double *records, const double *ed, int lane, int wave,
+                                                                      double et_s, const double *ys, double *pert) {
     double r[3] = {ys[0 * DEV_LANES + lane], ys[1 * DEV_LANES + lane], ys[2 * DEV_LANES + lane]};
     if (cfg->g2_slot >= 0) {  // (uniform)
         double pg[3];
@@ -1010,7 +1015,7 @@ static __device__ __attribute__((noinline)) void second_field_into_pert(CfgPtr c
         r[0] = r[0] - pg[0]; r[1] = r[1] - pg[1]; r[2] = r[2] - pg[2];
     }
     double m[9];
-    (void)rotation_dcm(cfg, cfg->g2_rot, records, et_s, m);  // (an ephemeris-range failure of a binary PCK shows in the first field's / the bodies' status too)
+    const int st = rotation_dcm(cfg, cfg->g2_rot, records, et_s, m);
     const double rb0 = m[0] * r[0] + m[1] * r[1] + m[2] * r[2];
     const double rb1 = m[3] * r[0] + m[4] * r[1] + m[5] * r[2];
     const double rb2 = m[6] * r[0] + m[7] * r[1] + m[8] * r[2];
@@ -1026,6 +1031,7 @@ static __device__ __attribute__((noinline)) void second_field_into_pert(CfgPtr c
     pert[0 * DEV_LANES + lane] = pert[0 * DEV_LANES + lane] + (m[0] * al0 + m[3] * al1 + m[6] * al2);
     pert[1 * DEV_LANES + lane] = pert[1 * DEV_LANES + lane] + (m[1] * al0 + m[4] * al1 + m[7] * al2);
     pert[2 * DEV_LANES + lane] = pert[2 * DEV_LANES + lane] + (m[2] * al0 + m[5] * al1 + m[8] * al2);
+    return st;
 }
 
 // Dual variant: inputs and outputs go through LDS (20 + 16 doubles per lane) instead of the register ABI.
@@ -1774,7 +1780,7 @@ struct LdsMap {
     double *cs;     // [CS_FIELDS][64] integrator cold state
     double *part;   // [P][4][64]     harmonics partials (wave 0's slot unused)
     int *edst;      // [DEV_MAX_ALM][2][64] almanac status per almanac wave and buffer
-    int *pertst;    // [64]
+    int *pertst;    // [2][64]        status of the perturbation wave's own epoch-dependent work (the second field's orientation), by stage parity
     int *ctl;       // [16]
     double *rec;    // [rec_doubles]
     // pipelined stage loop (non-STM): buffers of odd stages
@@ -1803,7 +1809,7 @@ DEVFN LdsMap carve_lds(char *smem, int n_waves, bool stm, int rec_lds_doubles, i
     m.cs = p; p += CS_FIELDS * DEV_LANES;
     m.part = p; p += quad ? DEV_MAX_WAVES * QSLOT : DEV_MAX_WAVES * 4 * DEV_LANES;  // = DEV_MAX_WAVES_STM * 16 * DEV_LANES: reused for the dual partials
     m.edst = (int *)p; p += DEV_MAX_ALM * DEV_LANES;   // DEV_MAX_ALM * 2 * 64 ints
-    m.pertst = (int *)p; p += DEV_LANES / 2; // 64 ints
+    m.pertst = (int *)p; p += DEV_LANES;     // 2 x 64 ints
     m.ctl = (int *)p; p += 8;
     m.inbD = m.pertD = m.sacc = m.partD = m.qpre = nullptr;
     if (stm) {
@@ -1844,7 +1850,7 @@ size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles, int stm, int reuse_fie
     const bool quad = stm == 2;
     size_t d = (size_t)DEV_MAX_STAGES * 6 * (quad ? DEV_LANES / 4 : DEV_LANES) + DEV_MAX_STAGES * DEV_MAX_STAGES + 3 * DEV_MAX_STAGES + 6 * DEV_LANES +
                2 * ED_FIELDS * DEV_LANES + 2 * DEV_LANES + CS_FIELDS * DEV_LANES + (size_t)(quad ? DEV_MAX_WAVES * QSLOT : DEV_MAX_WAVES * 4 * DEV_LANES) + DEV_MAX_ALM * DEV_LANES +
-               DEV_LANES / 2 + 8 + (size_t)rec_doubles;
+               DEV_LANES + 8 + (size_t)rec_doubles;
     d += quad ? (size_t)(10 + 15 + 6 + QPRE_ROWS + 6 + 10 + 15) * DEV_LANES : (stm ? (size_t)(20 + 27 + 12) * DEV_LANES : (size_t)(NIN + 9 + 6 + NIN + 9) * DEV_LANES);
     (void)n_waves;
     if (reuse_fields > 0) d += (size_t)reuse_fields * DEV_LANES + 2 * DEV_LANES + DEV_LANES / 2;
@@ -2309,7 +2315,8 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 if (has_tides && !STM && do_pm) tides_into_pert(cfg, edc, lane, ysp, pertp);
                 if (has_grav2 && do_pm) {  // a second gravity field (after the tides: the reference's model order does not reach the bits the parity bar looks at)
                     const int64_t ep2 = __double_as_longlong(L.step[lane]) + seconds_to_ns(C_COEF(i) * L.step[DEV_LANES + lane]);
-                    second_field_into_pert(cfg, rec_in_lds ? (const double *)L.rec : records, edc, lane, wave, ns_to_seconds(ep2), ysp, pertp);
+                    L.pertst[(i & 1) * DEV_LANES + lane] =
+                        second_field_into_pert(cfg, rec_in_lds ? (const double *)L.rec : records, edc, lane, wave, ns_to_seconds(ep2), ysp, pertp);
                 }
             }
             double acc[3] = {0.0, 0.0, 0.0};
@@ -2521,6 +2528,10 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 }
                 if (!STM && (has_pm || has_tides || has_grav2)) {
                     acc[0] += pertc[0 * DEV_LANES + lane]; acc[1] += pertc[1 * DEV_LANES + lane]; acc[2] += pertc[2 * DEV_LANES + lane];
+                }
+                if (has_grav2 && !(spec_now && i == 0 && keep_k0)) {  // the second field's orientation status of THIS stage (written in the window B2 has just closed; a rejected lane's speculative stage 0 does not count)
+                    const int es = L.pertst[(i & 1) * DEV_LANES + lane];
+                    if (es) st_att = es;
                 }
                 if (!STM && has_grav) {
                     // fixed wave order; all 15 slots are read unconditionally (slots of absent waves hold an exact
@@ -2909,14 +2920,22 @@ extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg
     const int64_t per_wg = quad ? DEV_LANES / 4 : DEV_LANES;
     const int64_t blocks = (bt.n + per_wg - 1) / per_wg;
     if (blocks == 0) return hipSuccess;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_stm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_stmq, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_w8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_stmq_w8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
+    {
+        // the dynamic-LDS limit is a property of the function ON A DEVICE: once per device, and the shard threads of
+        // nyx_hip_propagate_batch_sharded arrive here concurrently
+        static std::mutex attr_mu;
+        static bool attr_set[64] = {false};
+        int devid = 0;
+        (void)hipGetDevice(&devid);
+        std::lock_guard<std::mutex> lk(attr_mu);
+        if (devid < 0 || devid >= 64 || !attr_set[devid]) {
+            (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_stm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_stmq, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_w8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_stmq_w8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (devid >= 0 && devid < 64) attr_set[devid] = true;
+        }
     }
     const bool stm = bt.o_stm != nullptr;
     size_t lds = nyx_kernel_lds_bytes(n_waves, rec_lds_doubles, stm ? (quad ? 2 : 1) : 0, stm ? 0 : reuse_fields);

@@ -244,8 +244,17 @@ class Results:
         try:
             ok = self.ok_runs()
             x0 = _vec9(ok[0].result.state) if ok else np.zeros(d)
-            xs = np.array([_vec9(r.result.state) for r in self._local_runs() if isinstance(r.result, PropResult)]).reshape(-1, d) - x0
-            mom = np.concatenate([[float(len(xs))], xs.sum(axis=0), (xs.T @ xs)[iu]])
+            xs = np.array([_vec9(r.result.state) for r in self._local_runs() if isinstance(r.result, PropResult)]).reshape(-1, d)
+            if hasattr(self._traj_ctx, "ensemble_moments") and len(xs):
+                # the device reduction of the C-ABI (nyx_hip_ensemble_moments: moments_kernel.hip) - the 55 numbers a Rust host
+                # would all-reduce; injected evaluators (the CPU tests' oracle stand-ins) have no such entry and take the numpy sums
+                b = _abi.StateBatch(len(xs))
+                b.set_rv(xs[:, :6])
+                b.cr[:], b.cd[:], b.prop_mass_kg[:] = xs[:, 6], xs[:, 7], xs[:, 8]
+                mom = self._traj_ctx.ensemble_moments(b, None, x0)
+            else:
+                xs = xs - x0
+                mom = np.concatenate([[float(len(xs))], xs.sum(axis=0), (xs.T @ xs)[iu]])
         except Exception as e:  # noqa: BLE001 - re-raised on every rank below
             err = e
         self._sync_errors(err)

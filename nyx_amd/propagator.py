@@ -649,6 +649,22 @@ def unpack_spacecraft(batch: _abi.StateBatch, template: Sequence[Spacecraft]) ->
     return out
 
 
+def moments_to_mean_cov(mom: np.ndarray, x0: Optional[np.ndarray] = None):
+    """(mean[9], unbiased cov[9, 9]) from the 55 moments of `nyx_hip_ensemble_moments` (summed over the ranks of a sharded run):
+    mean = x0 + s / n, cov = (S - n m m^T) / (n - 1).  No successful run: NaNs; one: the covariance is NaN."""
+    d = 9
+    n, sx = float(mom[0]), np.asarray(mom[1:1 + d], dtype=np.float64)
+    if n < 1:
+        return np.full(d, np.nan), np.full((d, d), np.nan)
+    iu = np.triu_indices(d)
+    sxx = np.zeros((d, d))
+    sxx[iu] = mom[1 + d:]
+    sxx = sxx + np.triu(sxx, 1).T
+    m = sx / n
+    cov = (sxx - n * np.outer(m, m)) / (n - 1.0) if n > 1 else np.full((d, d), np.nan)
+    return m + (np.zeros(d) if x0 is None else np.asarray(x0, dtype=np.float64)), cov
+
+
 def propagate_sharded(contexts, batch: "_abi.StateBatch", duration_ns: int):
     """``nyx_hip_propagate_batch_sharded``: one batch over several contexts (one per device of the node, driven by this process):
     contiguous index shards, concurrent devices, results in place.  Returns (out, stats)."""
@@ -713,6 +729,20 @@ class GpuContext:
 
     def last_kernel_ms(self) -> float:
         return float(self._lib.nyx_hip_last_kernel_ms(self._h))
+
+    def ensemble_moments(self, batch: _abi.StateBatch, status: Optional[np.ndarray] = None, x0: Optional[np.ndarray] = None) -> np.ndarray:
+        """``nyx_hip_ensemble_moments``: [count, sum(x - x0) (9), upper triangle of sum((x - x0)(x - x0)^T) (45)] of the runs whose
+        status is 0, reduced on the device (what the consumers of mc/results.rs:60-245 need of an ensemble; a sharded run adds the
+        55 numbers of its ranks with one all-reduce).  `moments_to_mean_cov` turns them into mean and covariance."""
+        out = np.zeros(55)
+        cin = batch.as_c()
+        st = None if status is None else np.ascontiguousarray(status, dtype=np.int32)
+        x = None if x0 is None else np.ascontiguousarray(x0, dtype=np.float64)
+        rc = self._lib.nyx_hip_ensemble_moments(self._h, C.byref(cin), None if st is None else st.ctypes.data_as(_abi.c_int32_p),
+                                                None if x is None else x.ctypes.data_as(_abi.c_double_p), out.ctypes.data_as(_abi.c_double_p))
+        if rc != 0:
+            raise RuntimeError(f"nyx_hip_ensemble_moments failed (rc={rc}): {_abi.last_error()}")
+        return out
 
     def propagate(self, batch: _abi.StateBatch, duration_ns: int, out: Optional[_abi.StateBatch] = None):
         out = out if out is not None else batch.copy()
@@ -1020,22 +1050,27 @@ _ARRAY_DIGESTS: dict = {}
 
 
 def _array_digest(a: np.ndarray) -> bytes:
-    """Digest of an array's content.  The ephemeris records and Stokes coefficients are megabytes and are hashed for every
-    `Propagator.with_()`: the digest of a large array is memoised under its buffer (address, shape, strides, type) and revalidated
-    with a strided sample of 256 elements - an in-place edit that leaves all of them untouched would be missed, a rebuilt table
-    (the way these are produced) is not."""
-    if a.nbytes <= 4096:
-        return hashlib.blake2b(np.ascontiguousarray(a).tobytes(), digest_size=16).digest()
-    flat = a.reshape(-1)
-    sample = np.ascontiguousarray(flat[:: max(1, flat.size // 256)]).tobytes()
+    """Digest of an array's content (blake2b over the whole buffer: ~1 ms per megabyte).  The digest is memoised ONLY for
+    arrays that cannot change under it - `a.flags.writeable == False` all the way down to the buffer's owner (freeze a table
+    with `arr.setflags(write=False)` to get the cached path) - keyed on (address, shape, strides, type).  A writable array is
+    hashed in full every time: an in-place edit of one Stokes coefficient must give a new context, never a stale one."""
+    def frozen(x):
+        while isinstance(x, np.ndarray):
+            if x.flags.writeable:
+                return False
+            x = x.base
+        return True   # (the owner is read-only: nobody holds a writable view through numpy)
     key = (a.__array_interface__["data"][0], a.shape, a.strides, a.dtype.str)
+    if a.nbytes <= 4096 or not frozen(a):
+        _ARRAY_DIGESTS.pop(key, None)   # (a buffer seen writable may be edited before it is frozen again: forget what was known of it)
+        return hashlib.blake2b(np.ascontiguousarray(a).tobytes(), digest_size=16).digest()
     hit = _ARRAY_DIGESTS.get(key)
-    if hit is not None and hit[0] == sample:
-        return hit[1]
+    if hit is not None:
+        return hit
     d = hashlib.blake2b(np.ascontiguousarray(a).tobytes(), digest_size=16).digest()
     if len(_ARRAY_DIGESTS) > 256:
         _ARRAY_DIGESTS.clear()
-    _ARRAY_DIGESTS[key] = (sample, d)
+    _ARRAY_DIGESTS[key] = d
     return d
 
 

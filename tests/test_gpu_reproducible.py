@@ -92,3 +92,40 @@ def test_sharded_entry_point_equals_the_single_context_run():
     np.testing.assert_array_equal(st.n_evals, rst.n_evals)
     for c in ctxs + [one]:
         c.close()
+
+
+def test_deterministic_mode_across_the_workgroup_shape_thresholds():
+    """the workgroup shape (waves per workgroup) used to follow the batch size even with deterministic = 1 - 8 waves from
+    32 705 trajectories on, 16 below - and with it the column split and the last bits.  A batch above the threshold against its two
+    halves below it, and against a few trajectories propagated alone: bit for bit."""
+    prop, almanac, central = leo_full_setup(degree=24)   # (degree >= 24: the sixteen-wave shape is the configuration's)
+    compiled = prop.compile(almanac, central)
+    n = 33_000
+    b = dispersed_leo_batch(n, seed=11)
+    dur = 10 * 60 * nx.NS_PER_S
+    ctx = nx.GpuContext(compiled, tuning=nx.Tuning(deterministic=1))
+    full, st = ctx.propagate(b, dur)
+    assert (st.status == 0).all()
+    for lo, hi in ((0, n // 2), (n // 2, n), (777, 841)):
+        part, pst = ctx.propagate(b.slice(lo, hi), dur)
+        np.testing.assert_array_equal(part.rv(), full.rv()[lo:hi])
+        np.testing.assert_array_equal(pst.n_evals, st.n_evals[lo:hi])
+    ctx.close()
+
+
+def test_deterministic_stm_layout_does_not_follow_the_batch():
+    """The STM layout (quad below ~8 000 trajectories, 64-lane duals above) is part of the shape: deterministic = 1 pins it."""
+    prop, almanac, central = leo_full_setup(degree=8)
+    compiled = prop.compile(almanac, central, stm=True)
+    n = 8704   # > 2 x 256 x 16: the automatic choice for the full batch would be the 64-lane layout, for a slice the quad layout
+    b = dispersed_leo_batch(n, seed=3)
+    b.stm = np.zeros((n, 81))
+    b.reset_stm()
+    dur = 120 * nx.NS_PER_S
+    ctx = nx.GpuContext(compiled, tuning=nx.Tuning(deterministic=1))
+    full, st = ctx.propagate(b, dur)
+    assert (st.status == 0).all()
+    part, _ = ctx.propagate(b.slice(100, 164), dur)
+    np.testing.assert_array_equal(part.rv(), full.rv()[100:164])
+    np.testing.assert_array_equal(part.stm, full.stm[100:164])
+    ctx.close()
