@@ -334,13 +334,19 @@ def spawn_ranks(n_ranks, argv):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
     rc = 0
     try:
-        for p in procs:
-            prc = p.wait()
-            if prc != 0 and rc == 0:
-                rc = prc
-                for q in procs:   # one rank failed: the others would wait in a collective for ever (exact PIDs, our own children)
-                    if q.poll() is None:
+        live = list(procs)
+        while live:   # poll ALL ranks: the one that fails is rarely the first in the list, and the others would sit in a collective for ever
+            for p in list(live):
+                prc = p.poll()
+                if prc is None:
+                    continue
+                live.remove(p)
+                if prc != 0 and rc == 0:
+                    rc = prc
+                    for q in live:   # (exact PIDs, our own children)
                         q.terminate()
+            if live:
+                time.sleep(0.05)
     except KeyboardInterrupt:
         for q in procs:
             if q.poll() is None:
@@ -353,6 +359,8 @@ def selftest_launch(rank, world):
     """CPU check of the launch layer (tests/test_bench_launch.py): rendezvous, all-gather and max-over-ranks of synthetic
     numbers over gloo - everything of an N-rank run but the device work."""
     import torch.distributed as dist
+    if os.environ.get("NYX_BENCH_SELFTEST_FAIL_RANK") == str(rank):   # (the test of the launcher's supervision: this rank dies before the rendezvous)
+        raise SystemExit(3)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     mine = torch.full((4, 7), float(rank + 1), dtype=torch.float64)
     got = [torch.empty_like(mine) for _ in range(world)]
@@ -433,6 +441,14 @@ def main():
     # with --gpus; started as one process with --gpus N > 1 the ranks are started HERE (spawn_ranks) - `--gpus N` always
     # measures N ranks, however the script was started.
     if "WORLD_SIZE" not in os.environ and args.gpus > 1 and not args.single_process:
+        if not args.selftest_launch:   # what every rank would find out on its own, said once and before anything is started
+            ndev0 = torch.cuda.device_count() if torch.cuda.is_available() else 0
+            if ndev0 == 0:
+                raise SystemExit("bench.py needs an MI355X: no HIP device visible")
+            if args.gpus > ndev0 and not args.oversubscribe:
+                raise SystemExit(f"--gpus {args.gpus}: {ndev0} device(s) visible (--oversubscribe --backend gloo shares devices)")
+            if args.gpus > ndev0 and args.backend == "nccl":
+                raise SystemExit("RCCL refuses two ranks on one device: --oversubscribe needs --backend gloo")
         raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -224,9 +224,9 @@ typedef struct nyx_hip_solid_tides {
  * unless `stm_quad` says otherwise) is taken from the configuration alone instead of the batch size - both decide the column
  * split, i.e. the order of the sums.  The reference is reproducible per (seed, index) in exactly this sense
  * (mc/montecarlo.rs:208-224, 290-295).  Cost: the cooperative gain (~1.27x at 10 000 trajectories on 256 CUs) for ensembles
- * that leave CUs idle; for very large plain batches (>= 32 705 trajectories) the sixteen-wave shape is kept where eight or
- * four waves would be a few percent faster; the quad STM layout issues 1.6x the f64 slots of the 64-lane one above ~8 000
- * trajectories (set stm_quad = 0 there).  nyx_hip_ctx_set_column_waves / stm_quad pin the shape explicitly either way. */
+ * that leave CUs idle; the quad STM layout issues 1.6x the f64 slots of the 64-lane one above ~8 000 trajectories (set
+ * stm_quad = 0 there).  (Since round 4 the plain kernel's shape - sixteen waves per workgroup from degree 24 on - does not depend
+ * on the batch size in any mode.)  nyx_hip_ctx_set_column_waves / stm_quad pin the shape explicitly either way. */
 enum nyx_hip_schedule { NYX_HIP_SCHED_MODEL = 0, NYX_HIP_SCHED_CALIBRATED = 1, NYX_HIP_SCHED_EXPLICIT = 2 };
 typedef struct nyx_hip_tuning {
     int32_t schedule;          /* enum nyx_hip_schedule */
@@ -238,12 +238,15 @@ typedef struct nyx_hip_tuning {
     int32_t role_fanout;       /* -1 auto, 0 off, 1 almanac / perturbation duties dealt over several waves */
     int32_t merge_roles;       /* 0 / 1: almanac and perturbation duties share one wave */
     int32_t stm_quad;          /* -1 by ensemble size, 0 64 trajectories x 3-partial duals, 1 quad layout */
-    int32_t harmonics_feed;    /* -1 auto, 0 scalar stream, 1 hybrid scalar + DPP stream */
+    int32_t harmonics_feed;    /* -1 auto, 0 scalar stream, 1 hybrid scalar + DPP stream, 2 hybrid in the trajectory-owning workgroups only, 3 in the helpers only */
     int32_t coop_max_columns;  /* 0 auto: columns a helper workgroup may take */
     int32_t coop_mute;         /* test switch: helpers never answer (exercises the owner's fallback) */
     int32_t profile;           /* 1: in-kernel cycle accounting of workgroup 0 (nyx_hip_debug_profile) */
     int32_t debug_flags;       /* timing-only switches (0x100 skip the serial role work, 0x200 skip the harmonics): WRONG RESULTS;
-                                * 0x400 host trace, 0x800 no role offload (A/B switches: same results) */
+                                * 0x400 host trace; A/B switches with the SAME results: 0x800 no role offload, 0x1000 no segment-level almanac
+                                * units on a single almanac wave, 0x2000 packed Chebyshev records; schedule switches (another summation order):
+                                * 0x8000 the two-ended column fill everywhere, 0x10000 one contiguous run of columns per wave whatever the feed; 0x4000 full-range sincos for a polynomial
+                                * IAU orientation every stage (results differ by the rounding of the large argument) */
     double coop_fraction;      /* 0 auto: share of the harmonics terms a helper takes */
     double coop_helper_ratio;  /* 0 auto: helper workgroups per trajectory-owning workgroup */
     double column_start_cost;  /* < 0 auto: rows a column's start is charged in the schedule */

@@ -111,6 +111,8 @@ struct nyx_hip_ctx {
     std::map<WKey, double> weight_spread;  // (max - min) / mean of the per-wave windows after calibration
     WKey last_key = WKey(0, 0, 0, 0);      // shape of the last launch
     DevArrays cal;                         // scratch outputs of the calibration launches
+    bool block_schedule = true;  // one contiguous run of columns per wave where the owner streams the table (fill_schedule)
+    bool block_force = false;
     int forced_quad = -1;  // STM layout: -1 = by ensemble size, 0 = 64 trajectories x D3 per workgroup, 1 = quad layout (16 x 4 lanes, D1)
     double role_handicap[3] = {0.0, 0.0, 0.0};  // integrator, almanac, perturbations (harmonics-term units)
     DevArrays in, out;
@@ -423,7 +425,17 @@ static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, con
         static const double model_coop[16] = {1.70, 1.66, 1.48, 2.14, 2.08, 1.70, 1.65, 1.67, 1.45, 0.97, 1.05, 1.02, 0.70, 0.53, 0.56, 0.55};
         static const double model_solo[16] = {1.41, 1.41, 1.26, 1.61, 1.59, 1.29, 1.375, 1.23, 1.06, 0.98, 0.98, 0.98, 0.77, 0.69, 0.70, 0.70};
         static const double model_quad[16] = {0.70, 0.70, 0.70, 0.70, 1.26, 2.03, 1.78, 1.59, 1.58, 1.68, 0.96, 1.02, 0.875, 0.93, 0.86, 0.91};
-        const double *model = ctx->sched_quad ? model_quad : (all_columns ? model_solo : model_coop);
+        // Round 4, the shapes that deal ONE contiguous run of columns per wave (below) and stream the table in the trajectory-owning
+        // workgroups: fitted with tools/tune_schedule.py (windows of every wave -> rows that would equalise them -> weights, best
+        // kernel time of 8-14 iterations, two boxes) on configs[1] at 10 000 (cooperative) and 16 384 trajectories (alone) and on
+        // configs[4] (150x150, cooperative, helper jobs of several columns).  The role duties of the water-filling are unchanged.
+        static const double model_coop_blk[16] = {1.00, 1.48, 0.98, 1.90, 1.79, 1.44, 1.386, 1.264, 0.984, 0.83, 0.754, 0.69, 0.52, 0.362, 0.31, 0.302};
+        static const double model_coop_big_blk[16] = {1.00, 1.755, 1.706, 1.802, 1.733, 1.22, 1.246, 1.181, 1.087, 0.672, 0.621, 0.604, 0.549, 0.279, 0.284, 0.255};
+        static const double model_solo_blk[16] = {1.00, 1.612, 1.263, 1.906, 1.764, 1.346, 1.331, 1.198, 1.113, 0.757, 0.659, 0.568, 0.513, 0.398, 0.291, 0.27};
+        const bool blk = ctx->block_schedule && n_waves == DEV_MAX_WAVES && !ctx->sched_quad && ((ctx->host_cfg.harm_feed & 1) || ctx->block_force);
+        const double *model = ctx->sched_quad ? model_quad
+                              : (blk ? (all_columns ? model_solo_blk : (ctx->host_cfg.n_cols > 96 ? model_coop_big_blk : model_coop_blk))
+                                     : (all_columns ? model_solo : model_coop));
         for (int w = 0; w < DEV_MAX_WAVES; ++w)
             per_wave[w] = it != ctx->weights.end() ? it->second[w] : (n_waves == 16 ? model[w] : 1.0);
         if (it != ctx->weights.end())  // measured duties replace the model's (the integrator keeps its window free: hc_model[0])
@@ -450,6 +462,39 @@ static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, con
             for (int w = 0; w < n_waves; ++w) sum += std::max(0.0, level * wgt(w) - hc[w]);
             if (sum < terms) lo = level; else hi = level;
         }
+    }
+    if (ctx->block_schedule && n_waves == DEV_MAX_WAVES && !ctx->sched_quad && ((ctx->host_cfg.harm_feed & 1) || ctx->block_force)) {
+        // ONE contiguous run of columns per wave (the hybrid stream walks a run as one piece of the table: every range START costs it a
+        // pipeline fill, the complex power of the range and up to seven rows in front of the run - with two or three ranges per wave
+        // and evaluation that is a third of a 70x70 owner's work).  Linear partition of the list (longest columns first) at the
+        // cumulative targets; the waves with the largest targets take the long columns, role waves the short ones at the end, where
+        // the granularity is finest.  The integrator wave (target 0 in the pipelined loop) gets nothing.
+        std::vector<int> order;
+        for (int w = 0; w < n_waves; ++w) order.push_back(w);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return std::max(0.0, level * wgt(a) - hc[a]) > std::max(0.0, level * wgt(b) - hc[b]); });
+        double cum_t = 0.0, cum_r = 0.0;
+        size_t k = 0;
+        for (size_t q = 0; q < order.size(); ++q) {
+            const int w = order[q];
+            cum_t += std::max(0.0, level * wgt(w) - hc[w]);
+            const size_t k0 = k;
+            const bool last = q + 1 == order.size() || std::max(0.0, level * wgt(order[q + 1]) - hc[order[q + 1]]) <= 0.0;
+            while (k < list.size() && (last || cum_r + 0.5 * cost(list[k]) <= cum_t)) { cum_r += cost(list[k]); ++k; }
+            if (k > k0) {
+                // (the list is ascending in column number but may have gaps - the helper's columns: split the run at every gap)
+                int nr = 0;
+                for (size_t a = k0; a < k;) {
+                    size_t e = a + 1;
+                    while (e < k && list[e] == list[e - 1] + 1) ++e;
+                    if (nr >= DEV_MAX_RANGES) return false;
+                    sd.range_c0[w][nr] = list[a]; sd.range_cnt[w][nr] = (int)(e - a); ++nr;
+                    a = e;
+                }
+                sd.n_ranges[w] = nr;
+            }
+            if (last) break;
+        }
+        return true;
     }
     int lo = 0, hi = (int)list.size() - 1;  // indices into `list`
     // plain column workers first (highest wave index), role waves last so they take what is left
@@ -634,6 +679,22 @@ static void assign_roles(nyx_hip_ctx *ctx, int n_waves, bool fanout, double *hc)
     }
     dc.role_kind[1] = DEV_ROLE_ALMANAC; dc.role_mask[1] = all_alm; hc[1] = rh[1];
     dc.role_kind[2] = DEV_ROLE_PERT; dc.role_mask[2] = all_pert; hc[2] = rh[2];
+    // ONE almanac wave (the sixteen-wave column shapes): distinct-segment units pay here too - Earth -> EMB sits on the chain of
+    // every body of an Earth-centred run and was evaluated once per BODY per stage (five Chebyshev evaluations for Sun + Moon where
+    // four segments are distinct).  The wave evaluates every distinct segment once, the readers sum the chains (ed_body(): the same
+    // additions in the same order, bit-identical).  (0x1000: A/B switch, same results)
+    int chain_evals = 0;
+    for (int sl = 0; sl < dc.n_slots; ++sl) chain_evals += dc.slot[sl].n_chain;
+    if (segment_units_fit(dc) && distinct_segments(dc) < chain_evals && !(ctx->tune.debug_flags & 0x1000)) {
+        dc.seg_mode = 1;
+        dc.n_useg = distinct_segments(dc, dc.useg_seg);
+        dc.ed_seg_base = (dc.has_grav || dc.has_drag || dc.has_tides) ? 9 : 0;
+        for (int sl = 0; sl < dc.n_slots; ++sl)
+            for (int k = 0; k < dc.slot[sl].n_chain; ++k)
+                for (int u = 0; u < dc.n_useg; ++u)
+                    if (dc.useg_seg[u] == dc.slot[sl].seg[k]) dc.slot[sl].useg[k] = u;
+        dc.role_mask[1] = DEV_ROLE_DCM | ((1 << dc.n_useg) - 1);
+    }
 }
 
 static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
@@ -760,17 +821,14 @@ static int pick_waves(const nyx_hip_ctx *ctx, int64_t n) {
         if (!(ctx->host_cfg.n_slots > 0 || ctx->host_cfg.has_drag || ctx->host_cfg.has_tides)) return 1;
         return want_fanout(ctx, false) ? (fanout_role_waves(ctx) > 4 ? 8 : std::max(3, fanout_role_waves(ctx))) : 3;  // (8: two role waves per SIMD can be placed)
     }
-    // Fill the 256 CUs: workgroups = ceil(n/64); with fewer than ~2 workgroups per CU the column
-    // split is what creates the waves that keep the SIMDs busy.
-    const int64_t wgs = (n + DEV_LANES - 1) / DEV_LANES;
+    // Sixteen waves whatever the ensemble size: a workgroup's LDS (~150 KB) gives it a CU to itself, so the column split is what puts
+    // four waves on every SIMD.  (Rounds 1-3 went down to eight and four waves for >= 32 705 / >= 131 009 trajectories, sized when a
+    // workgroup was small enough to share a CU; measured in round 4 on configs[1]'s force model, 1 h: 32 768 trajectories 104.2 ms
+    // with eight waves against 69.1 with sixteen, 131 072: 521 (four) / 410 (eight) / 277 ms (sixteen) - 0.44 / 0.56 / 0.83 of the
+    // FP64 peak.)  The shape therefore depends on the configuration alone, which is also what tuning.deterministic promises.
+    (void)n;
     const int deg = ctx->host_cfg.deg;
     int want = 16;
-    // (deterministic: the waves per workgroup fix the column split, i.e. the summation order - from the configuration only, never
-    //  from n: 40 000 trajectories on one context and two shards of 20 000 must walk the same columns in the same order)
-    if (!ctx->tune.deterministic) {
-        if (wgs >= 2048) want = 4;
-        else if (wgs >= 512) want = 8;
-    }
     if (deg < 8) want = std::min(want, 4);
     else if (deg < 24) want = std::min(want, 8);
     return want;
@@ -847,6 +905,23 @@ extern "C" int32_t nyx_hip_debug_schedule_weights(nyx_hip_ctx *ctx, double *out)
     for (int w = 0; w < 2 * DEV_MAX_WAVES; ++w) out[w] = it != ctx->weights.end() ? it->second[w] : 0.0;
     const auto sp = ctx->weight_spread.find(ctx->last_key);
     out[2 * DEV_MAX_WAVES] = sp != ctx->weight_spread.end() ? sp->second : -1.0;
+    return NYX_HIP_RC_OK;
+}
+
+// Table rows each wave walks under schedule `sched` (DEV_SCHED_*) of the current descriptor, and the role duties the water-filling
+// charged (integrator, almanac, perturbations; harmonics-term units): what tools/tune_schedule.py turns measured windows into weights with.
+extern "C" int32_t nyx_hip_debug_schedule_rows(nyx_hip_ctx *ctx, int32_t sched, int32_t *rows16, double *duties3) {
+    if (!ctx || !rows16 || sched < 0 || sched >= DEV_N_SCHED) return NYX_HIP_RC_BAD_ARG;
+    CTX_LOCK(ctx);
+    const DevSched &sd = ctx->host_cfg.sched[sched];
+    for (int w = 0; w < DEV_MAX_WAVES; ++w) {
+        int rows = 0;
+        for (int q = 0; q < sd.n_ranges[w]; ++q)
+            for (int c = sd.range_c0[w][q]; c < sd.range_c0[w][q] + sd.range_cnt[w][q]; ++c)
+                rows += (c >= 0 && c < (int)ctx->col_len.size()) ? ctx->col_len[c] : 0;
+        rows16[w] = rows;
+    }
+    if (duties3) for (int k = 0; k < 3; ++k) duties3[k] = ctx->role_handicap[k];
     return NYX_HIP_RC_OK;
 }
 
@@ -951,6 +1026,8 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
     nyx_hip_ctx *ctx = new nyx_hip_ctx();
     ctx->device = device;
     ctx->tune = resolve_tuning(cfg->tuning);
+    ctx->block_schedule = (ctx->tune.debug_flags & 0x8000) == 0;  // (0x8000: the two-ended column fill of rounds 1-3 everywhere)
+    ctx->block_force = (ctx->tune.debug_flags & 0x10000) != 0;    // (0x10000: contiguous runs whatever the feed - the A/B partner of the streamed walk)
     DevCfg &dc = ctx->host_cfg;
     std::memset(&dc, 0, sizeof dc);
     const NyxTableau &tb = NYX_TABLEAUX[o.method];
@@ -1046,14 +1123,47 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
     if (cfg->n_segments > DEV_MAX_SEG) { delete ctx; nyx_set_error("too many ephemeris segments"); return NYX_HIP_RC_BAD_ARG; }
     std::vector<double> records;
     dc.n_seg = cfg->n_segments;
+    // Device layout of the records.  cheby_eval() works on a sixteen-coefficient register window and has to blank the entries past a
+    // segment's own count (two v_cndmask per coefficient on the almanac wave, every stage).  When the whole table stays small the
+    // records of segments with <= 16 coefficients are therefore laid out SIXTEEN wide, zero-padded: the zeros are in the table, the
+    // selects go (DevSeg.stride = 50 tells the kernel; same values, same bits).  (0x2000: A/B switch, same results)
+    const int kChebWin = 16;
+    bool pad16 = !(ctx->tune.debug_flags & 0x2000);
+    {
+        size_t packed = 0, padded = 0;
+        for (int i = 0; i < cfg->n_segments; ++i) {
+            const nyx_hip_cheby_segment_t &sg = cfg->segments[i];
+            packed += (size_t)sg.n_records * (size_t)(2 + 3 * sg.n_coeffs);
+            padded += (size_t)sg.n_records * (size_t)(2 + 3 * (sg.n_coeffs <= kChebWin ? kChebWin : sg.n_coeffs));
+        }
+        auto fits_lds = [&](size_t doubles) {  // the staging rule further down (rec_in_lds), for this context's kernel family
+            const int rd = (int)doubles + 16;
+            if ((size_t)rd * sizeof(double) > 24 * 1024) return false;
+            return (cfg->flags & NYX_HIP_FLAG_STM) ? nyx_kernel_lds_bytes(DEV_MAX_WAVES_STM, rd, 1, 0) <= 160 * 1024
+                                                   : nyx_kernel_lds_bytes(DEV_MAX_WAVES, rd, 0, 0) <= 160 * 1024;
+        };
+        if (fits_lds(packed) && !fits_lds(padded)) pad16 = false;  // (never push the table out of LDS)
+        if (padded * sizeof(double) > (size_t)8 << 20) pad16 = false;
+    }
     for (int i = 0; i < cfg->n_segments; ++i) {
         const nyx_hip_cheby_segment_t &sg = cfg->segments[i];
         DevSeg &d = dc.seg[i];
         d.init_et = sg.init_et_s; d.interval = sg.interval_s; d.n_rec = sg.n_records; d.n_coef = sg.n_coeffs;
         d.end_et = sg.init_et_s + sg.interval_s * (double)sg.n_records;
-        d.stride = 2 + 3 * sg.n_coeffs;
+        const int src_stride = 2 + 3 * sg.n_coeffs;
         d.offset = (int32_t)records.size();
-        records.insert(records.end(), sg.records, sg.records + (size_t)sg.n_records * d.stride);
+        if (pad16 && sg.n_coeffs < kChebWin) {
+            d.stride = 2 + 3 * kChebWin;
+            for (int r = 0; r < sg.n_records; ++r) {
+                const double *src = sg.records + (size_t)r * src_stride;
+                records.push_back(src[0]); records.push_back(src[1]);
+                for (int c = 0; c < 3; ++c)
+                    for (int j = 0; j < kChebWin; ++j) records.push_back(j < sg.n_coeffs ? src[2 + c * sg.n_coeffs + j] : 0.0);
+            }
+        } else {
+            d.stride = src_stride;
+            records.insert(records.end(), sg.records, sg.records + (size_t)sg.n_records * d.stride);
+        }
     }
     for (int s = 0; s < dc.n_slots; ++s)
         for (int k = 0; k < dc.slot[s].n_chain; ++k)
@@ -1134,6 +1244,14 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
         if (any_nonzero(ctx->tune.role_duties, 3))
             for (int k = 0; k < 3; ++k) ctx->role_handicap[k] = ctx->tune.role_duties[k];
     }
+    {
+        // the body-fixed frame of the epoch data (the kernel's choice: gravity field, else drag, else tides): a polynomial IAU
+        // orientation is advanced from a base epoch instead of being evaluated with three full-range sincos per stage
+        const DevRot &er = dc.has_grav ? dc.g_rot : (dc.has_drag ? dc.d_rot : dc.t_rot);
+        // (plain kernels only: the STM tests hold the device to the oracle's step sequence, bit for bit)
+        dc.dcm_incr = ((dc.has_grav || dc.has_drag || dc.has_tides) && er.kind == NYX_HIP_ROT_IAU && er.n_np == 0 && !(cfg->flags & NYX_HIP_FLAG_STM) &&
+                       !(ctx->tune.debug_flags & 0x4000)) ? 1 : 0;
+    }
     records.resize(records.size() + 16, 0.0);  // padding for the 16-wide coefficient window
     dc.rec_doubles = (int32_t)records.size();
     dc.rec_in_lds = (records.size() * sizeof(double) <= 24 * 1024) ? 1 : 0;
@@ -1168,8 +1286,11 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
         dc.hyb_v = (uint64_t)(ctx->d_hyb + vec_off);
         // measured (same box, calibrated): 150x150 cooperative 373 -> 334 ms per 6 250 x 3 h (1.12x); 70x70 alone 1.02-1.11x;
         // 70x70 cooperative (one column per helper wave and job: the walk's start-up weighs more) 0-2 % slower
-        dc.harm_feed = dc.n_cols > 96 ? 1 : 0;
-        if (ctx->tune.harmonics_feed >= 0) dc.harm_feed = ctx->tune.harmonics_feed != 0 ? 1 : 0;
+        // (DevCfg.harm_feed: bit 0 = the trajectory-owning workgroups, bit 1 = the helpers and the owner's fallback for them)
+        // Round 4: the trajectory-owning workgroups stream the table from degree 40 on (with ONE contiguous run of columns per wave,
+        // fill_schedule: the start-up of a run is what the walk costs at 70x70), the helpers - one column per wave and job - above 95
+        dc.harm_feed = dc.n_cols > 96 ? 3 : (dc.n_cols > 40 ? 1 : 0);
+        if (ctx->tune.harmonics_feed >= 0) dc.harm_feed = ctx->tune.harmonics_feed == 0 ? 0 : (ctx->tune.harmonics_feed == 2 ? 1 : (ctx->tune.harmonics_feed == 3 ? 2 : 3));
     }
     if (!tab2.empty()) {
         tab2.resize(tab2.size() + 4 * HARM_BATCH, HarmEntry{0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0});

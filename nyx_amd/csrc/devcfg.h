@@ -121,6 +121,8 @@ struct DevCfg {
                       * the stage sums off the integrator wave, which is the critical path there (role_mask bits DEV_ROLE_SUMS / _TWOBODY) */
     int32_t useg_seg[DEV_MAX_SEG];
     int32_t spec; /* speculative stage 0 of the next attempt (pipelined loop, see role_loop) */
+    int32_t dcm_incr, _pad_di; /* the body-fixed frame of the epoch data is a polynomial IAU orientation: its DCM is advanced from a base
+                                * epoch by angle addition (rotation_dcm_iau_poly) instead of three full-range sincos per stage */
 
     /* --- column schedules: wave w walks n_ranges[w] contiguous column ranges --- */
     int32_t n_waves;
@@ -130,7 +132,8 @@ struct DevCfg {
     DevSched sched[DEV_N_SCHED];
     double coop_frac; /* share of the harmonics terms a helper workgroup takes over (cooperative mode) */
     int32_t coop_ok;  /* PRIMARY / HELPER schedules are valid */
-    int32_t harm_feed; /* 0: every table operand through the scalar data path (HarmEntry stream); 1: hybrid feed (HYB_* below) */
+    int32_t harm_feed; /* hybrid feed (HYB_* below) instead of the scalar HarmEntry stream: bit 0 = in the trajectory-owning workgroups,
+                        * bit 1 = in the helpers (and the owner's fallback for a helper that does not answer) */
     uint64_t hyb;     /* device address of the hybrid-feed stream: scalar side (24 bytes per stream row) */
     uint64_t hyb_v;   /* its vector side (groups of sixteen stream rows, [t3..t6][16]) */
 };
@@ -178,10 +181,14 @@ struct HarmEntry {
  * words the helpers scan (posted, claimed, finished) are packed per set of 16 owners (one 64-byte line per set and
  * kind: word index = set * 16 + slot, owner = set + slot * n_sets), so one load scans a set. */
 struct CoopBox { /* double-buffered by the parity of `seq`: the next evaluation is posted before the previous answer is read */
-    double in[2][5][DEV_LANES];
-    double out[2][4][DEV_LANES];
-    uint32_t done[2]; /* written by the helper that claimed the job */
-    uint32_t pad[14];
+    /* Every double travels as two TAGGED 8-byte granules, {low half | seq << 32} and {high half | seq << 32}, each written by one
+     * naturally aligned 8-byte store - the unit the memory system never tears.  A reader accepts a value when both tags carry the
+     * sequence number it expects; nothing has to be ordered against anything (no drain of the stores before a flag, no flag for the
+     * answer, no second round trip for the data behind a flag): the memory was zeroed before the launch, sequence numbers start
+     * at 1, and a slot is rewritten two evaluations later, with another tag. */
+    uint64_t in[2][5][2][DEV_LANES];
+    uint64_t out[2][4][2][DEV_LANES];
+    uint32_t pad[16];
 };
 
 struct DevBatch { /* device pointers of one launch */

@@ -89,6 +89,7 @@ DEVFN int cheby_eval(const CAS DevSeg &sg, P records, double et_s, double *r3) {
     if (idx < 0 || idx > sg.n_rec || (idx == sg.n_rec && et_s > sg.end_et)) st = NYX_HIP_ERR_EPHEM_RANGE;
     idx = idx < 0 ? 0 : (idx >= sg.n_rec ? sg.n_rec - 1 : idx);
     const int nc = sg.n_coef;
+    const int cs = (sg.stride - 2) / 3;  // doubles per component: n_coef, or CHEB_MAXC when the host padded the record with zeros (below)
     P rec = records + sg.offset + idx * sg.stride;
     const double t = (et_s - rec[0]) / rec[1];
     const double two_t = 2.0 * t;
@@ -96,7 +97,7 @@ DEVFN int cheby_eval(const CAS DevSeg &sg, P records, double et_s, double *r3) {
         // coefficient by coefficient from the table - the same recurrence in the same order (DE440's Mercury / Sun segments, binary PCKs)
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            P cf = rec + 2 + c * nc;
+            P cf = rec + 2 + c * cs;
             double w0 = 0.0, w1 = 0.0, w2;
             for (int j = nc - 1; j >= 1; --j) {
                 w2 = w1;
@@ -104,6 +105,26 @@ DEVFN int cheby_eval(const CAS DevSeg &sg, P records, double et_s, double *r3) {
                 w0 = cf[j] + (two_t * w1 - w2);
             }
             r3[c] = cf[0] + (t * w0 - w1);
+        }
+        return st;
+    }
+    if (cs == CHEB_MAXC) {
+        // (uniform) the host laid the record out sixteen-wide, the coefficients past the segment's count being +0.0 IN THE TABLE: the
+        // selects below (two v_cndmask per coefficient, a quarter of this function's instructions) are not needed - same values, same bits
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            P cf = rec + 2 + c * CHEB_MAXC;
+            double cv[CHEB_MAXC];
+#pragma unroll
+            for (int j = 0; j < CHEB_MAXC; ++j) cv[j] = cf[j];
+            double w0 = 0.0, w1 = 0.0, w2;
+#pragma unroll
+            for (int j = CHEB_MAXC - 1; j >= 1; --j) {
+                w2 = w1;
+                w1 = w0;
+                w0 = cv[j] + (two_t * w1 - w2);
+            }
+            r3[c] = cv[0] + (t * w0 - w1);
         }
         return st;
     }
@@ -144,8 +165,9 @@ DEVFN int cheby_eval_pv(const CAS DevSeg &sg, P records, double et_s, double *r3
     P rec = records + sg.offset + idx * sg.stride;
     const double t = (et_s - rec[0]) / rec[1];
     const double two_t = 2.0 * t;
+    const int cs = (sg.stride - 2) / 3;  // (component stride: see cheby_eval)
     for (int c = 0; c < 3; ++c) {
-        P cf = rec + 2 + c * nc;
+        P cf = rec + 2 + c * cs;
         double w0 = 0.0, w1 = 0.0, w2, d0 = 0.0, d1 = 0.0, d2;
         for (int j = nc - 1; j >= 1; --j) {
             w2 = w1; w1 = w0;
@@ -201,11 +223,15 @@ extern "C" hipError_t nyx_launch_frame_shift(const DevCfg *cfg, const double *re
 
 // Body-fixed orientation (nyx_hip_rotation_t, see include/nyx_hip.h): the IAU phase angles with their trigonometric series, or
 // the Chebyshev Euler angles of a binary PCK.  `w_rate` (optional): dW/dt in rad/s (the drag model's velocity transform).
+DEVFN void dcm_from_sincos(double s1, double c1, double s2, double c2, double s3, double c3, double *m);
 DEVFN void r3r1r3(double a1, double a2, double a3, double *m) {
     double s1, c1, s2, c2, s3, c3;
     sincos(a1, &s1, &c1);
     sincos(a2, &s2, &c2);
     sincos(a3, &s3, &c3);
+    dcm_from_sincos(s1, c1, s2, c2, s3, c3, m);
+}
+DEVFN void dcm_from_sincos(double s1, double c1, double s2, double c2, double s3, double c3, double *m) {
     m[0] = c3 * c1 - s3 * c2 * s1;
     m[1] = c3 * s1 + s3 * c2 * c1;
     m[2] = s3 * s2;
@@ -235,7 +261,7 @@ DEVFN int rotation_dcm(CfgPtr cfg, const CAS DevRot &rot, P records, double et_s
             idx = idx < 0 ? 0 : (idx >= sg.n_rec ? sg.n_rec - 1 : idx);
             P rec = records + sg.offset + idx * sg.stride;
             const double t = (et_s - rec[0]) / rec[1];
-            P cf = rec + 2 + 2 * sg.n_coef;
+            P cf = rec + 2 + 2 * ((sg.stride - 2) / 3);
             double tjm1 = 1.0, tj = t, djm1 = 0.0, dj = 1.0, acc = 0.0;
             for (int j = 1; j < sg.n_coef; ++j) {
                 acc = acc + cf[j] * dj;
@@ -268,17 +294,103 @@ DEVFN int rotation_dcm(CfgPtr cfg, const CAS DevRot &rot, P records, double et_s
     return NYX_HIP_OK;
 }
 
+// ---- IAU orientation advanced from a base epoch (almanac wave, per lane) -------------------------------------------------------
+// A body whose pole and prime meridian are POLYNOMIALS of time (no trigonometric terms: the Earth of the IAU reports) is rotated
+// by three angles that move by less than 0.1 rad within a quarter of an hour.  rotation_dcm() pays three full-range sincos per
+// stage for that (arguments of ~5e4 rad: ~600 instructions on the almanac wave, a quarter of its duty).  Here the sines and cosines
+// are computed at the nearest point of a fixed 2 048 s grid of epochs (the same expressions, the same bits as rotation_dcm there)
+// and advanced to the stage epoch by the angle-addition formulas with the increment's own short series:
+//     delta = p(t0 + tau) - p(t0) = (p1 + p2 (2 t0 + tau)) tau          (tau = the integer-ns epoch difference: exact)
+//     sin(a0 + delta) = s0 cos(delta) + c0 sin(delta),  |delta| < 0.25:  sin to delta^13, cos to delta^14  (< 3e-18)
+// The base is a function of the lane's own epoch alone (its grid point), renewed per lane when the epoch moves to another grid
+// point: a trajectory's bits do not depend on which lanes share its wave (tuning.deterministic, the quad / 64-lane STM layouts).
+// Against rotation_dcm() the angles differ by the rounding of the LARGE argument there (ulp(3e6 deg) = 8e-12 rad), not by anything
+// this formulation adds: a change of summation-order size (0.06 mm on the Earth's surface), inside every parity bar.  Plain
+// kernels only (the STM tests compare step sequences with the oracle bit for bit); tuning.debug_flags 0x4000 switches it off.
+#define ROT_GRID_NS (2048LL * 1000000000LL)
+struct RotBase {
+    int64_t ep;  // the grid epoch the sines and cosines belong to (INT64_MIN: none yet)
+    double sn[3], cs[3];
+};
+DEVFN void small_sincos(double d, double &sn, double &cs) {  // |d| < 0.25
+    const double z = d * d;
+    double p = __builtin_fma(z, 1.0 / 6227020800.0, -1.0 / 39916800.0);
+    p = __builtin_fma(z, p, 1.0 / 362880.0);
+    p = __builtin_fma(z, p, -1.0 / 5040.0);
+    p = __builtin_fma(z, p, 1.0 / 120.0);
+    p = __builtin_fma(z, p, -1.0 / 6.0);
+    sn = __builtin_fma(d * z, p, d);
+    double q = __builtin_fma(z, -1.0 / 87178291200.0, 1.0 / 479001600.0);
+    q = __builtin_fma(z, q, -1.0 / 3628800.0);
+    q = __builtin_fma(z, q, 1.0 / 40320.0);
+    q = __builtin_fma(z, q, -1.0 / 720.0);
+    q = __builtin_fma(z, q, 1.0 / 24.0);
+    q = __builtin_fma(z, q, -0.5);
+    cs = __builtin_fma(z, q, 1.0);
+}
+DEVFN void iau_poly_angles(const CAS DevRot &rot, double et_s, double *a) {  // rotation_dcm's expressions (n_np == 0), radians
+    const double DEG = 3.14159265358979323846 / 180.0;
+    const double HALF_PI = 1.57079632679489661923;
+    const double d = et_s / 86400.0;
+    const double T = et_s / (86400.0 * 36525.0);
+    const double ra = rot.ra[0] + rot.ra[1] * T + rot.ra[2] * T * T;
+    const double dec = rot.dec[0] + rot.dec[1] * T + rot.dec[2] * T * T;
+    const double w = rot.w[0] + rot.w[1] * d + rot.w[2] * d * d;
+    a[0] = HALF_PI + ra * DEG; a[1] = HALF_PI - dec * DEG; a[2] = w * DEG;
+}
+DEVFN void rotation_dcm_iau_poly(const CAS DevRot &rot, int64_t epoch_ns, RotBase &rb, double *m) {
+    const double DEG = 3.14159265358979323846 / 180.0;
+    // nearest grid point (floor division: epochs before J2000 are negative)
+    const int64_t sh = epoch_ns + ROT_GRID_NS / 2;
+    const int64_t grid = (sh >= 0 ? sh / ROT_GRID_NS : -((-sh + ROT_GRID_NS - 1) / ROT_GRID_NS)) * ROT_GRID_NS;
+    if (grid != rb.ep) {  // (per lane: usually the whole wave crosses a grid boundary within a few stages of each other)
+        double a[3];
+        iau_poly_angles(rot, ns_to_seconds(grid), a);
+        sincos(a[0], &rb.sn[0], &rb.cs[0]);
+        sincos(a[1], &rb.sn[1], &rb.cs[1]);
+        sincos(a[2], &rb.sn[2], &rb.cs[2]);
+        rb.ep = grid;
+    }
+    const double et0 = ns_to_seconds(grid);
+    const double tau = ns_to_seconds(epoch_ns - grid);
+    const double dd = tau / 86400.0, dT = tau / (86400.0 * 36525.0);
+    const double day0 = et0 / 86400.0, T0 = et0 / (86400.0 * 36525.0);
+    const double dl[3] = {((rot.ra[1] + rot.ra[2] * (2.0 * T0 + dT)) * dT) * DEG, -(((rot.dec[1] + rot.dec[2] * (2.0 * T0 + dT)) * dT) * DEG),
+                          ((rot.w[1] + rot.w[2] * (2.0 * day0 + dd)) * dd) * DEG};
+    double s[3], c[3];
+    if (fabs(dl[0]) < 0.25 && fabs(dl[1]) < 0.25 && fabs(dl[2]) < 0.25) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            double sd, cd;
+            small_sincos(dl[k], sd, cd);
+            s[k] = __builtin_fma(rb.sn[k], cd, rb.cs[k] * sd);
+            c[k] = __builtin_fma(rb.cs[k], cd, -(rb.sn[k] * sd));
+        }
+    } else {  // (a rotator too fast for the grid: the full-range evaluation, per lane)
+        double a[3];
+        iau_poly_angles(rot, ns_to_seconds(epoch_ns), a);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) sincos(a[k], &s[k], &c[k]);
+    }
+    dcm_from_sincos(s[0], c[0], s[1], c[1], s[2], c[2], m);
+}
+
 template <typename P>
 // `dcm_flag` (pipelined stage loop): LDS word that is set to `dcm_val` as soon as the DCM is written - the integrator wave
 // needs only that to form the next stage's recursion inputs, the body positions are for the next window.
 // `amask`: the share of this almanac wave when the duty is dealt over several (role fan-out, DEV_ROLE_DCM = the DCM, bit s =
 // body slot s); every wave writes only its own rows of `slot`.
-DEVFN int epoch_data(CfgPtr cfg, P records, int64_t epoch_ns, double *slot, int lane, int amask, LdsFlagPtr dcm_flag = nullptr, int dcm_val = 0) {
+DEVFN int epoch_data(CfgPtr cfg, P records, int64_t epoch_ns, double *slot, int lane, int amask, LdsFlagPtr dcm_flag = nullptr, int dcm_val = 0,
+                     RotBase *rbase = nullptr) {
     const double et = ns_to_seconds(epoch_ns);
     int status = NYX_HIP_OK;
     if ((amask & DEV_ROLE_DCM) && (cfg->has_grav || cfg->has_drag || cfg->has_tides)) {  // (ctx_create requires these body-fixed frames to coincide)
         double m[9];
         int st;
+        if (rbase && cfg->dcm_incr) {  // (uniform; the host sets dcm_incr for a polynomial IAU orientation of the frame this wave rotates into)
+            rotation_dcm_iau_poly(cfg->has_grav ? cfg->g_rot : (cfg->has_drag ? cfg->d_rot : cfg->t_rot), epoch_ns, *rbase, m);
+            st = NYX_HIP_OK;
+        } else
         if (cfg->has_grav) st = rotation_dcm(cfg, cfg->g_rot, records, et, m);
         else if (cfg->has_drag) st = rotation_dcm(cfg, cfg->d_rot, records, et, m);
         else st = rotation_dcm(cfg, cfg->t_rot, records, et, m);
@@ -383,6 +495,23 @@ DEVFN double circ_seg_area(double r, double d) { return r * r * acos(d / r) - d 
 // anise Occultation.percentage restated (apparent-disk overlap); see oracle for the definition.
 DEVFN double occultation_pct(double r_back, double r_front, const double *r_eb, const double *r_ls) {
     const double n_ls = norm3(r_ls[0], r_ls[1], r_ls[2]), n_eb = norm3(r_eb[0], r_eb[1], r_eb[2]);
+    {
+        // Full sunlight and full umbra decided on COSINES, for the whole wave at once.  The exact path below compares angles -
+        // d_p - ls_p > fo_p  (no occultation: 0.0 exactly)  and  fo_p > d_p + ls_p  (total: 100.0 exactly) - which costs two asin and one
+        // acos per shadow body per stage, almost always to return one of those two constants.  With all three angles in [0, pi] and
+        // the apparent radii below pi / 2 the same inequalities read  cos d_p < cos(ls_p + fo_p)  and  cos d_p > cos(fo_p - ls_p);
+        // they are taken here only with a margin of 1e-9 in the cosine (>= 1e-9 rad in the angles, seven orders above the rounding of
+        // either formulation), and only when EVERY lane of the wave is decided - then the exact path would return the same constant,
+        // bit for bit; in the penumbra band, or when any lane is near a boundary, the exact path runs as before.
+        const double dotq = r_ls[0] * r_eb[0] + r_ls[1] * r_eb[1] + r_ls[2] * r_eb[2];
+        const double sl = r_back / n_ls, sf = r_front / n_eb;  // sines of the apparent radii
+        const double cd = -dotq / (n_eb * n_ls);               // the argument of the exact path's acos, same expression
+        const double cl = sqrt(1.0 - sl * sl), cf = sqrt(1.0 - sf * sf);
+        const bool angles = r_back < n_ls && r_front < n_eb && cd >= -1.0 && cd <= 1.0;
+        const bool lit = angles && cd < (cl * cf - sl * sf) - 1e-9;
+        const bool dark = angles && sf > sl && cd > (cf * cl + sf * sl) + 1e-9;
+        if (__all(lit || dark)) return lit ? 0.0 : 100.0;
+    }
     const double ls_p = (r_back >= n_ls) ? r_back : asin(r_back / n_ls);
     const double fo_p = (r_front >= n_eb) ? r_front : asin(r_front / n_eb);
     const double dot = r_ls[0] * r_eb[0] + r_ls[1] * r_eb[1] + r_ls[2] * r_eb[2];
@@ -1135,12 +1264,27 @@ DEVFN void coop_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"
 #define COOP_TIMEOUT_TICKS 200000LL  /* 2 ms of the 100 MHz realtime counter */
 #define COOP_SET 16                  /* owners per set */
 
+DEVFN uint64_t coop_loadu(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEVFN void coop_storeu(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// a double as two tagged granules (CoopBox): g[0] = {low half | seq << 32}, g[DEV_LANES] = {high half | seq << 32}
+DEVFN void coop_put(uint64_t *g, double v, uint32_t seq) {
+    const uint64_t b = (uint64_t)__double_as_longlong(v), t = (uint64_t)seq << 32;
+    coop_storeu(g, (b & 0xffffffffull) | t);
+    coop_storeu(g + DEV_LANES, (b >> 32) | t);
+}
+DEVFN bool coop_get(const uint64_t *g, uint32_t seq, double &v) {
+    const uint64_t lo = coop_loadu(g), hi = coop_loadu(g + DEV_LANES);
+    v = __longlong_as_double((long long)((lo & 0xffffffffull) | (hi << 32)));
+    return (uint32_t)(lo >> 32) == seq && (uint32_t)(hi >> 32) == seq;
+}
+
 // Posting happens from the LDS copy of the inputs, when the integrator wave has nothing else to do (start of the
-// window in the plain loop, right after the next stage's inputs are formed in the pipelined one).
+// window in the plain loop, right after the next stage's inputs are formed in the pipelined one).  The inputs are tagged
+// granules: the sequence number is written right behind them, with no wait in between - a helper that sees it before the
+// data simply polls the granules until their tags agree.
 static __device__ __attribute__((noinline)) void coop_post(CoopBox *box, uint32_t *posted, int lane, uint32_t seq, const double *inb) {
 #pragma unroll
-    for (int q = 0; q < 5; ++q) coop_stored(&box->in[seq & 1u][q][lane], inb[q * DEV_LANES + lane]);
-    coop_release();  // the inputs have reached memory before the sequence number is written
+    for (int q = 0; q < 5; ++q) coop_put(&box->in[seq & 1u][q][0][lane], inb[q * DEV_LANES + lane], seq);
     if (lane == 0) coop_store(posted, seq);
 }
 
@@ -1148,17 +1292,22 @@ struct CoopAnswer {
     double x, y, z, w;
     int ok;
 };
+// The answer needs no flag: every lane polls the LAST granule the helper writes for it, and when all of them carry this
+// evaluation's tag the other seven are read and checked the same way (they were stored earlier, but nothing orders them).
 static __device__ __attribute__((noinline)) CoopAnswer coop_wait(CoopBox *box, int lane, uint32_t seq) {
     CoopAnswer a = {0.0, 0.0, 0.0, 0.0, 0};
     const int64_t t0 = (int64_t)__builtin_amdgcn_s_memrealtime();
+    const unsigned par = seq & 1u;
     for (;;) {
-        if (coop_load(&box->done[seq & 1u]) == seq) break;
-        if ((int64_t)__builtin_amdgcn_s_memrealtime() - t0 > COOP_TIMEOUT_TICKS) return a;
+        const uint64_t last = coop_loadu(&box->out[par][3][1][lane]);
+        if (__all((uint32_t)(last >> 32) == seq)) {
+            const bool ok = coop_get(&box->out[par][0][0][lane], seq, a.x) & coop_get(&box->out[par][1][0][lane], seq, a.y) &
+                            coop_get(&box->out[par][2][0][lane], seq, a.z) & coop_get(&box->out[par][3][0][lane], seq, a.w);
+            if (__all(ok)) break;
+        }
+        if ((int64_t)__builtin_amdgcn_s_memrealtime() - t0 > COOP_TIMEOUT_TICKS) { a.x = a.y = a.z = a.w = 0.0; return a; }
         __builtin_amdgcn_s_sleep(1);
     }
-    coop_acquire();
-    a.x = coop_loadd(&box->out[seq & 1u][0][lane]); a.y = coop_loadd(&box->out[seq & 1u][1][lane]);
-    a.z = coop_loadd(&box->out[seq & 1u][2][lane]); a.w = coop_loadd(&box->out[seq & 1u][3][lane]);
     a.ok = 1;
     return a;
 }
@@ -1171,7 +1320,7 @@ static __device__ __attribute__((noinline)) Partial4 coop_fallback(uint64_t cfg_
                  v3 = inb[3 * DEV_LANES + lane], v4 = inb[4 * DEV_LANES + lane];
     Partial4 o = {0.0, 0.0, 0.0, 0.0};
     for (int hw = 0; hw < DEV_MAX_WAVES; ++hw) {
-        const Partial4 p = ((CfgPtr)uniform_u64(cfg_u))->harm_feed ? harmonics_stream(cfg_u, cols_u, hw, DEV_SCHED_HELPER, v0, v1, v2, v3, v4)
+        const Partial4 p = (((CfgPtr)uniform_u64(cfg_u))->harm_feed & 2) ? harmonics_stream(cfg_u, cols_u, hw, DEV_SCHED_HELPER, v0, v1, v2, v3, v4)
                                                                      : harmonics_partial(cfg_u, htab_u, cols_u, hw, DEV_SCHED_HELPER, v0, v1, v2, v3, v4);
         o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
     }
@@ -1251,14 +1400,24 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
                                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1 : 0;
                     }
                     const CoopBox *b = bt.coop_box + owner_c;
-                    coop_acquire();
                     const unsigned par = seq_c & 1u;
                     // (measured: fetching only after the claim has succeeded costs 7 % of the north-star run - the helper's job
                     //  latency is what bounds its share)
-                    const double v0 = coop_loadd(&b->in[par][0][lane]), v1 = coop_loadd(&b->in[par][1][lane]),
-                                 v2 = coop_loadd(&b->in[par][2][lane]), v3 = coop_loadd(&b->in[par][3][lane]),
-                                 v4 = coop_loadd(&b->in[par][4][lane]);
+                    double v0, v1, v2, v3, v4;
+                    bool got = coop_get(&b->in[par][0][0][lane], seq_c, v0) & coop_get(&b->in[par][1][0][lane], seq_c, v1) &
+                               coop_get(&b->in[par][2][0][lane], seq_c, v2) & coop_get(&b->in[par][3][0][lane], seq_c, v3) &
+                               coop_get(&b->in[par][4][0][lane], seq_c, v4);
                     if (__shfl(won, pick)) {
+                        // the job is ours; its inputs were stored before the sequence number, but nothing orders the two: poll until
+                        // every granule carries the tag (normally the first look already does)
+                        const int64_t tw = (int64_t)__builtin_amdgcn_s_memrealtime();
+                        while (!__all(got)) {
+                            if ((int64_t)__builtin_amdgcn_s_memrealtime() - tw > 100 * COOP_TIMEOUT_TICKS) break;  // (0.2 s: the owner has long given up on us)
+                            __builtin_amdgcn_s_sleep(1);
+                            got = coop_get(&b->in[par][0][0][lane], seq_c, v0) & coop_get(&b->in[par][1][0][lane], seq_c, v1) &
+                                  coop_get(&b->in[par][2][0][lane], seq_c, v2) & coop_get(&b->in[par][3][0][lane], seq_c, v3) &
+                                  coop_get(&b->in[par][4][0][lane], seq_c, v4);
+                        }
                         owner = owner_c;
                         seq = seq_c;
                         double *il = inl + s * 5 * DEV_LANES;
@@ -1297,7 +1456,7 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
             const double *il = inl + s * 5 * DEV_LANES;
             const double v0 = il[0 * DEV_LANES + lane], v1 = il[1 * DEV_LANES + lane], v2 = il[2 * DEV_LANES + lane],
                          v3 = il[3 * DEV_LANES + lane], v4 = il[4 * DEV_LANES + lane];
-            const Partial4 pr = cfg->harm_feed ? harmonics_stream((uint64_t)cfg, (uint64_t)cols, wave, DEV_SCHED_HELPER, v0, v1, v2, v3, v4)
+            const Partial4 pr = (cfg->harm_feed & 2) ? harmonics_stream((uint64_t)cfg, (uint64_t)cols, wave, DEV_SCHED_HELPER, v0, v1, v2, v3, v4)
                                                : harmonics_partial((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, DEV_SCHED_HELPER, v0, v1, v2, v3, v4);
             double *pp = ps + wave * 4 * DEV_LANES;
             pp[0 * DEV_LANES + lane] = pr.x; pp[1 * DEV_LANES + lane] = pr.y; pp[2 * DEV_LANES + lane] = pr.z; pp[3 * DEV_LANES + lane] = pr.w;
@@ -1323,12 +1482,10 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
             for (int q = 0; q < 4; ++q) o[q] += ps[(w * 4 + q) * DEV_LANES + lane];
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) coop_stored(&b->out[par][q][lane], o[q]);
+        for (int q = 0; q < 4; ++q) coop_put(&b->out[par][q][0][lane], o[q], seq);  // tagged granules: no drain, no flag (the owner polls the last one)
         if (lane == 0) __hip_atomic_store(cnt + s, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) answered[s] = j + 1;  // the slot may be refilled: its partial sums are in registers
-        coop_release();
-        if (lane == 0) coop_store(&b->done[par], seq);
         if (lane == 0 && bt.prof != nullptr) atomicAdd((unsigned long long *)bt.prof + 16 * 8 + 4, 1ull);
     }
 }
@@ -1986,6 +2143,10 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     // is computed by the almanac wave in the LAST window (where it has no next stage to prepare; buffer 0 is free by
     // then), the second is this attempt's own stage-0 data, kept aside.  Both are keyed by their integer epoch, so the
     // prologue only has to compare epochs - whatever the step logic did - and falls back to computing.
+    RotBase rot_base;  // (almanac wave with the DCM share: the orientation's base epoch, see rotation_dcm_iau_poly)
+    rot_base.ep = INT64_MIN;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { rot_base.sn[q] = 0.0; rot_base.cs[q] = 1.0; }
     const int reuse_nf = (!STM && ALMANAC && !INTEG && need_almanac && cfg->n_alm == 1) ? cfg->ed_reuse : 0;  // (one almanac wave only: the epoch tags have one writer)
     if (reuse_nf > 0) { L.ed0_ep[lane] = INT64_MIN; L.spec_ep[lane] = INT64_MIN; }
     // Speculative stage 0.  The attempt boundary is the one place where the pipelined loop still drains: phase C of the last stage,
@@ -2073,7 +2234,8 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 }
             }
             if (compute) {
-                int st = rec_in_lds ? epoch_data(cfg, (const double *)L.rec, ep, L.ed, lane, amask) : epoch_data(cfg, records, ep, L.ed, lane, amask);
+                int st = rec_in_lds ? epoch_data(cfg, (const double *)L.rec, ep, L.ed, lane, amask, nullptr, 0, &rot_base)
+                                    : epoch_data(cfg, records, ep, L.ed, lane, amask, nullptr, 0, &rot_base);
                 my_edst[lane] = st;
             }
             if (reuse_nf > 0) {
@@ -2238,7 +2400,8 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 if (!dbg_skip_serial || i == 0)  // (timing switch: reuse the data of stages 0/1)
                 {
                     const LdsFlagPtr fl = (pipe && (!last_stage || spec) && (amask & DEV_ROLE_DCM)) ? LCTL + 2 : nullptr;
-                    st = rec_in_lds ? epoch_data(cfg, (const double *)L.rec, ep, edn, lane, amask, fl, i + 1) : epoch_data(cfg, records, ep, edn, lane, amask, fl, i + 1);
+                    st = rec_in_lds ? epoch_data(cfg, (const double *)L.rec, ep, edn, lane, amask, fl, i + 1, &rot_base)
+                                    : epoch_data(cfg, records, ep, edn, lane, amask, fl, i + 1, &rot_base);
                 }
                 my_edst[((i + 1) & 1) * DEV_LANES + lane] = st;
                 if (pipe && (!last_stage || spec) && (amask & DEV_ROLE_DCM)) {  // tell the integrator wave (which publishes the inputs of stage i+1 inside this window)
@@ -2478,7 +2641,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 if (!(pipe && INTEG)) {
                     const double v0 = inbw[0 * DEV_LANES + lane], v1 = inbw[1 * DEV_LANES + lane], v2 = inbw[2 * DEV_LANES + lane],
                                  v3 = inbw[3 * DEV_LANES + lane], v4 = inbw[4 * DEV_LANES + lane];
-                    pr = cfg->harm_feed ? harmonics_stream((uint64_t)cfg, (uint64_t)cols, wave, sched, v0, v1, v2, v3, v4)
+                    pr = (cfg->harm_feed & 1) ? harmonics_stream((uint64_t)cfg, (uint64_t)cols, wave, sched, v0, v1, v2, v3, v4)
                                         : harmonics_partial((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, sched, v0, v1, v2, v3, v4);
                 }
                 px = pr.x; py = pr.y; pz = pr.z; pw = pr.w;

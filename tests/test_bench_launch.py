@@ -34,6 +34,14 @@ def test_self_launch_starts_n_ranks(n):
     assert len([ln for ln in p.stdout.splitlines() if ln.startswith("{")]) == 1   # ONE line, from rank 0
 
 
+def test_a_failing_rank_ends_the_run_instead_of_hanging_it():
+    """The launcher polls ALL its ranks: rank 1 dies before the rendezvous, rank 0 waits in it - the run must end with rank 1's code."""
+    import time
+    t0 = time.time()
+    p, line = _run(["--gpus", "2", "--selftest-launch"], env={"NYX_BENCH_SELFTEST_FAIL_RANK": "1"}, timeout=120)
+    assert p.returncode == 3 and line is None and time.time() - t0 < 60
+
+
 def test_world_size_must_agree_with_gpus():
     p, line = _run(["--gpus", "2", "--selftest-launch"], env={"WORLD_SIZE": "3", "RANK": "0", "LOCAL_RANK": "0"})
     assert p.returncode != 0 and line is None and "WORLD_SIZE=3" in p.stderr

@@ -561,11 +561,14 @@ def test_pipelined_stage_loop_is_bit_identical(n, drag):
 
 @pytest.mark.parametrize("degree,n,waves", [(2, 70, 0), (8, 70, 3), (21, 130, 16), (33, 64, 16), (70, 700, 16), (70, 2048, 16), (97, 192, 16),
                                             (150, 128, 5), (150, 1100, 16)])
-def test_hybrid_stream_feed_is_bit_identical(degree, n, waves):
+@pytest.mark.parametrize("fill", [0x8000, 0x10000])
+def test_hybrid_stream_feed_is_bit_identical(degree, n, waves, fill):
     """The hybrid scalar + DPP stream loop (nyx_hip_tuning_t.harmonics_feed = 1: hand-scheduled asm, csrc/harm_stream_asm.h)
     does the same operations on the same operands in the same order as the scalar loop: bit-identical states and step counts for
     small and large fields, every column split (a wave's range may start anywhere in a scalar batch / vector group and end at the
-    table's last row), ragged batches, stand-alone and cooperative (700 / 2 048 / 1 100 trajectories: helpers walk single columns)."""
+    table's last row), ragged batches, stand-alone and cooperative (700 / 2 048 / 1 100 trajectories: helpers walk single columns).
+    The column split follows the feed by default (round 4: one contiguous run of columns per wave where the table is streamed), so
+    both contexts are pinned to the same split: `fill` = the two-ended fill of rounds 1-3 (0x8000) or contiguous runs (0x10000)."""
     if degree <= 70:
         prop, almanac, central = leo_full_setup(degree=degree)
         b = dispersed_leo_batch(n, seed=31)
@@ -577,7 +580,7 @@ def test_hybrid_stream_feed_is_bit_identical(degree, n, waves):
     dur = 40 * 60 * nx.NS_PER_S
     res = {}
     for feed in (0, 1):
-        ctx = nx.GpuContext(compiled, tuning=nx.Tuning(harmonics_feed=feed))
+        ctx = nx.GpuContext(compiled, tuning=nx.Tuning(harmonics_feed=feed, debug_flags=fill))
         if waves:
             ctx.set_column_waves(waves)
         out, st = ctx.propagate(b, dur)

@@ -25,9 +25,14 @@ n = int(sys.argv[2]) or w["n"]
 hours = float(sys.argv[3]) or w["hours"]
 variants = json.loads(sys.argv[4])
 reps = int(sys.argv[5]) if len(sys.argv) > 5 else 1
+check = int(sys.argv[6]) if len(sys.argv) > 6 else 0   # parity of every variant against the oracle on the first `check` trajectories
 compiled = w["prop"].compile(w["almanac"], w["central"], stm=w["stm"])
 b = w["batch"](n, seed=0)
 dur = int(round(hours * 3600)) * nx.NS_PER_S
+ref = None
+if check and not w["stm"]:
+    import oracle_lib
+    ref, _ = oracle_lib.propagate(compiled, b.slice(0, check), dur, n_threads=os.cpu_count())
 if w["stm"]:
     b.stm = np.zeros((n, 81))
     b.reset_stm()
@@ -50,6 +55,9 @@ for rep in range(reps):
         ev = int(st.n_evals.sum())
         print(f"{name:28s} {ms:9.3f} ms  evals {ev}  bad {(st.status != 0).sum()}  helpers {ctx.last_coop_helpers() if not w['stm'] else 0}  "
               f"frac {ev * w['flop'] / ms / 1e9 / bench.FP64_VECTOR_PEAK_TFLOPS:.4f}  digest {h.hexdigest()[:12]}  ({time.time() - t0:.1f} s)", flush=True)
+        if ref is not None:
+            d = out.rv()[:check] - ref.rv()
+            print(f"   parity vs oracle on {check}: max dr {np.linalg.norm(d[:, :3], axis=1).max() * 1e6:.4f} mm, max dv {np.linalg.norm(d[:, 3:], axis=1).max() * 1e6:.3e} mm/s", flush=True)
         if fields.get("profile"):
             buf = (C.c_int64 * 136)()
             ctx._lib.nyx_hip_debug_profile.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
