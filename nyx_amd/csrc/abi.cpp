@@ -113,6 +113,7 @@ struct nyx_hip_ctx {
     DevArrays cal;                         // scratch outputs of the calibration launches
     bool block_schedule = true;  // one contiguous run of columns per wave where the owner streams the table (fill_schedule)
     bool block_force = false;
+    int coop_parts = 1;  // sub-jobs per evaluation of the schedules in host_cfg (1, or 2: two helper workgroups per owner and evaluation)
     int forced_quad = -1;  // STM layout: -1 = by ensemble size, 0 = 64 trajectories x D3 per workgroup, 1 = quad layout (16 x 4 lanes, D1)
     double role_handicap[3] = {0.0, 0.0, 0.0};  // integrator, almanac, perturbations (harmonics-term units)
     DevArrays in, out;
@@ -152,7 +153,7 @@ static void *mailbox_acquire(int device, int64_t want_cap, int64_t *cap_out) {
             }
     }
     const int64_t cap = (want_cap + 255) / 256 * 256;
-    const size_t bytes = (size_t)cap * sizeof(CoopBox) + 3 * (size_t)(cap + 64) * sizeof(uint32_t);  // sets of 16: <= cap + 16 words
+    const size_t bytes = (size_t)cap * (sizeof(CoopBox) + sizeof(CoopOut)) + 3 * (size_t)(cap + 64) * sizeof(uint32_t);  // sets of 16: <= cap + 16 words; the part-1 answers last
     void *p = nullptr;
     if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
     *cap_out = cap;
@@ -750,6 +751,7 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
         // half - so when the one-column rule leaves the helpers below HALF of their share, their waves take up to
         // DEV_MAX_RANGES columns each (config 5: 12.05 s with 14 columns, 11.36 s with 21, 10.31 s with 28).
         int max_cols = col_waves;
+        const int parts_cfg = ctx->coop_parts == 2 ? 2 : 1;
         double share = dc.coop_frac;
         {
             double first = 0.0;
@@ -759,7 +761,8 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
                 share = 0.92 * dc.coop_frac;  // (several columns per wave: a job is longer for the same share; 35 / 38 / 42 columns at 150x150: 9.24 / 9.04 / 9.72 s)
             }
         }
-        if (ctx->tune.coop_max_columns > 0) max_cols = std::min(DEV_MAX_RANGES * col_waves, (int)ctx->tune.coop_max_columns);
+        if (parts_cfg == 2 && max_cols > col_waves) max_cols = 2 * DEV_MAX_RANGES * col_waves;  // (each part has its own DEV_MAX_RANGES per wave)
+        if (ctx->tune.coop_max_columns > 0) max_cols = std::min(parts_cfg * DEV_MAX_RANGES * col_waves, (int)ctx->tune.coop_max_columns);
         for (int c = 1; c <= nc; ++c) {
             if ((int)help.size() < max_cols && c < nc - 1 && given + 0.5 * ctx->col_len[c] <= share * terms) {
                 help.push_back(c);
@@ -771,20 +774,29 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
         // helper: one column per wave, longest first; the two SIMDs that also host the producer and the answering wave have
         // three column waves (4 8 12 / 3 7 11) and take the six longest, the other two SIMDs four each
         static const int wave_order[DEV_MAX_WAVES - 2] = {4, 3, 8, 7, 12, 11, 1, 2, 5, 6, 9, 10, 13, 14};
-        DevSched &hs = dc.sched[DEV_SCHED_HELPER];
-        for (int w = 0; w < DEV_MAX_WAVES; ++w) hs.n_ranges[w] = 0;
-        for (size_t k = 0; k < help.size(); ++k) {
-            // further rounds are dealt in alternating directions: every wave's set has about the same length
-            const int round = (int)k / col_waves, pos = (int)k % col_waves;
-            const int w = (round & 1) ? wave_order[col_waves - 1 - pos] : wave_order[pos];
-            const int r = hs.n_ranges[w]++;
-            hs.range_c0[w][r] = help[k]; hs.range_cnt[w][r] = 1;
+        // Two-part hand-off (ctx->coop_parts == 2, chosen by launch() when the idle CUs outnumber the owners and the helpers' jobs hold
+        // several columns per wave): the helpers' columns are dealt alternately into two sub-jobs that two DIFFERENT helper workgroups
+        // claim - half the job per helper, so the turnaround the owner waits for halves and twice the helpers find work.
+        const int parts = ctx->coop_parts == 2 ? 2 : 1;
+        for (int part = 0; part < 2; ++part) {
+            DevSched &hs = dc.sched[part ? DEV_SCHED_HELPER2 : DEV_SCHED_HELPER];
+            for (int w = 0; w < DEV_MAX_WAVES; ++w) hs.n_ranges[w] = 0;
+            if (part >= parts) continue;
+            std::vector<int> mine;
+            for (size_t k = 0; k < help.size(); ++k) if ((int)(k % (size_t)parts) == part) mine.push_back(help[k]);
+            for (size_t k = 0; k < mine.size(); ++k) {
+                // further rounds are dealt in alternating directions: every wave's set has about the same length
+                const int round = (int)k / col_waves, pos = (int)k % col_waves;
+                const int w = (round & 1) ? wave_order[col_waves - 1 - pos] : wave_order[pos];
+                const int r = hs.n_ranges[w]++;
+                hs.range_c0[w][r] = mine[k]; hs.range_cnt[w][r] = 1;
+            }
         }
         if (!help.empty() && !own.empty() && fill_schedule(ctx, dc.sched[DEV_SCHED_PRIMARY], n_waves, own, hc, false)) {
             dc.coop_ok = 1;
         } else {
             dc.coop_ok = 0;
-            for (int w = 0; w < DEV_MAX_WAVES; ++w) dc.sched[DEV_SCHED_PRIMARY].n_ranges[w] = dc.sched[DEV_SCHED_HELPER].n_ranges[w] = 0;
+            for (int w = 0; w < DEV_MAX_WAVES; ++w) dc.sched[DEV_SCHED_PRIMARY].n_ranges[w] = dc.sched[DEV_SCHED_HELPER].n_ranges[w] = dc.sched[DEV_SCHED_HELPER2].n_ranges[w] = 0;
         }
     } else {
         dc.coop_ok = 0;
@@ -1533,20 +1545,39 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
         // on by default; tuning.cooperative = 0 (or .deterministic: the split follows the batch size) makes every workgroup work alone
         const bool want = ctx->tune.cooperative != 0 && !ctx->tune.deterministic;
         const int64_t n_own = (in->n + DEV_LANES - 1) / DEV_LANES;
-        const int64_t base = (n_own + 7) / 8 * 8;
+        // Helpers start right behind the owners and fill every CU that is left (round 4: 99 helpers instead of 96 for 157 owners is
+        // 3.9 % of the north-star run - the helpers' queues are what the owners wait in; rounds 1-3 rounded both to multiples of
+        // eight for XCD affinity, which buys nothing measurable: debug_flags 0x20000 restores it).
+        const bool pack = (ctx->tune.debug_flags & 0x20000) == 0;
+        const int64_t base = pack ? n_own : (n_own + 7) / 8 * 8;
         const bool stm_ctx = (ctx->host_cfg.flags & NYX_HIP_FLAG_STM) != 0;
         if (want && !stm_ctx && ctx->host_cfg.has_grav && ctx->host_cfg.g_slot < 0 && nw == DEV_MAX_WAVES && ctx->host_cfg.coop_ok &&
             base + 8 <= ctx->n_cu) {
             // (more helpers than owners: the jobs are claimed, not assigned, so extra helpers shorten the queue of a set)
-            double h_ratio = 1.0;
+            // Two-part hand-off: when the idle CUs outnumber the owners by a quarter and a helper job holds several columns per wave
+            // (large fields), every evaluation's hand-off is split in two sub-jobs for two helper workgroups (see build_schedule); the
+            // helper count then goes up to two per owner.  (debug_flags 0x40000 / 0x80000 force two parts / one part.)
+            const int64_t free_cus = pack ? ctx->n_cu - base : (ctx->n_cu - base) / 8 * 8;
+            int parts = (ctx->host_cfg.n_cols > 96 && 4 * free_cus >= 5 * n_own) ? 2 : 1;
+            if (ctx->tune.debug_flags & 0x40000) parts = 2;
+            if (ctx->tune.debug_flags & 0x80000) parts = 1;
+            double h_ratio = parts == 2 ? 2.0 : 1.0;
             if (ctx->tune.coop_helper_ratio > 0.0) h_ratio = std::min(3.0, std::max(0.25, ctx->tune.coop_helper_ratio));
-            const int64_t helpers = std::min<int64_t>((int64_t)((double)n_own * h_ratio), (ctx->n_cu - base) / 8 * 8);
+            const int64_t helpers = std::min<int64_t>((int64_t)((double)n_own * h_ratio), free_cus);
+            if (parts != ctx->coop_parts) {
+                ctx->coop_parts = parts;
+                build_schedule(ctx, nw, false);
+                HIP_TRY(hipMemcpyAsync(ctx->d_cfg, &ctx->host_cfg, sizeof(DevCfg), hipMemcpyHostToDevice, stream));
+            }
             if (helpers >= 8 && 4 * helpers >= n_own) {
                 // share of the terms the helpers take: owners keep (1 - x), each helper does x * owners / helpers jobs' worth
                 // per evaluation period, plus its hand-off overhead: x ~ 0.95 r / (1 + r) with r = helpers / owners
                 if (!(ctx->tune.coop_fraction > 0.0)) {
                     const double r = (double)helpers / (double)n_own;
-                    const double x = std::min(0.55, std::max(0.10, 0.95 * r / (1.0 + r)));
+                    // (two parts, measured on configs[4] with 158 helpers for 98 owners: 0.55 / 0.60 / 0.65 / 0.70 / 0.75 of the terms ->
+                    //  98.1 / 97.9 / 93.4 / 92.9 / 102.6 ms per hour of the ensemble - half a job per helper takes the knee further out)
+                    const double x = ctx->coop_parts == 2 ? std::min(0.68, std::max(0.10, 1.10 * r / (1.0 + r)))
+                                                          : std::min(0.55, std::max(0.10, 0.95 * r / (1.0 + r)));
                     if (std::fabs(x - ctx->host_cfg.coop_frac) > 0.01) {
                         ctx->host_cfg.coop_frac = x;
                         build_schedule(ctx, nw, false);
@@ -1571,11 +1602,17 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
                     }  // (else: no such memory here, every workgroup works alone)
                 }
                 if (have_boxes && ctx->host_cfg.coop_ok) {
-                    HIP_TRY(hipMemsetAsync(ctx->d_coop, 0, (size_t)ctx->coop_cap * sizeof(CoopBox) + 3 * (size_t)(ctx->coop_cap + 64) * sizeof(uint32_t), stream));
+                    // (only what this launch touches: n_own mailboxes, the scan words, and the part-1 answers when there are two parts)
+                    HIP_TRY(hipMemsetAsync(ctx->d_coop, 0, (size_t)n_own * sizeof(CoopBox), stream));
+                    HIP_TRY(hipMemsetAsync(ctx->d_coop + ctx->coop_cap, 0, 3 * (size_t)(ctx->coop_cap + 64) * sizeof(uint32_t), stream));
+                    CoopOut *out2 = (CoopOut *)((char *)(ctx->d_coop + ctx->coop_cap) + 3 * (size_t)(ctx->coop_cap + 64) * sizeof(uint32_t));
+                    if (ctx->coop_parts == 2) HIP_TRY(hipMemsetAsync(out2, 0, (size_t)n_own * sizeof(CoopOut), stream));
+                    bt.coop_out2 = ctx->coop_parts == 2 ? out2 : nullptr;
                     bt.coop_helpers = (int32_t)helpers; bt.coop_base = (int32_t)base; bt.coop_box = ctx->d_coop;
                     uint32_t *words = (uint32_t *)(ctx->d_coop + ctx->coop_cap);
                     bt.coop_posted = words; bt.coop_claimed = words + (ctx->coop_cap + 64); bt.coop_finished = words + 2 * (ctx->coop_cap + 64);
                     bt.coop_sets = (int32_t)((n_own + 15) / 16);
+                    bt.coop_parts = ctx->coop_parts;
                     bt.coop_mute = ctx->tune.coop_mute ? 1 : 0;
                     ctx->last_coop_helpers = (int)helpers;
                 }

@@ -49,7 +49,10 @@ struct DevSched {
  * propagate_kernel.hip): PRIMARY = the columns the trajectory-owning workgroup keeps, HELPER = the columns a helper
  * workgroup on another CU evaluates (the owner walks that schedule itself, wave slot by wave slot, if no helper
  * answers). */
-enum { DEV_SCHED_SOLO = 0, DEV_SCHED_PRIMARY = 1, DEV_SCHED_HELPER = 2, DEV_SCHED_SECOND = 3, DEV_N_SCHED = 4 };  /* SECOND: every column of the second field, for whichever wave walks it */
+enum { DEV_SCHED_SOLO = 0, DEV_SCHED_PRIMARY = 1, DEV_SCHED_HELPER = 2, DEV_SCHED_SECOND = 3, DEV_SCHED_HELPER2 = 4, DEV_N_SCHED = 5 };
+/* SECOND: every column of the second field, for whichever wave walks it.  HELPER2: the second PART of an evaluation's hand-off when the
+ * helpers' columns travel as two sub-jobs claimed by two different helper workgroups (DevBatch.coop_parts = 2, see propagate_kernel.hip). */
+#define DEV_COOP_PARTS 2
 
 #define DEV_MAX_NUT_PREC 16
 struct DevRot { /* nyx_hip_rotation_t, flattened */
@@ -187,8 +190,14 @@ struct CoopBox { /* double-buffered by the parity of `seq`: the next evaluation 
      * answer, no second round trip for the data behind a flag): the memory was zeroed before the launch, sequence numbers start
      * at 1, and a slot is rewritten two evaluations later, with another tag. */
     uint64_t in[2][5][2][DEV_LANES];
-    uint64_t out[2][4][2][DEV_LANES];
+    uint64_t out[2][4][2][DEV_LANES]; /* the answer (of part 0 when the hand-off has two parts) */
     uint32_t pad[16];
+};
+/* The answer of part 1, in an array of its own (DevBatch.coop_out2) that exists only when the hand-off has two parts.  Measured in
+ * round 4: the mailboxes of configs[1] (157 owners) in ONE array of 26.6 KB boxes - 4.2 MB of uncached memory, whatever the padding -
+ * cost 7 % of the run against the same code on 18.4 KB boxes (2.9 MB); the footprint of this memory is not free. */
+struct CoopOut {
+    uint64_t out[2][4][2][DEV_LANES];
 };
 
 struct DevBatch { /* device pointers of one launch */
@@ -210,9 +219,10 @@ struct DevBatch { /* device pointers of one launch */
     int32_t *ev_found; /* [n] 1 when the propagation stopped on the event */
     /* cooperative mode: workgroups [0, ceil(n/64)) own trajectories, [coop_base, coop_base + coop_helpers) help */
     int32_t coop_helpers, coop_base;
-    int32_t lds_bytes, _pad_lds; /* dynamic LDS of the launch: zeroed by every workgroup before use (see propagate_body) */
+    int32_t lds_bytes, coop_parts; /* dynamic LDS of the launch: zeroed by every workgroup before use (see propagate_body); coop_parts: sub-jobs per evaluation (1 or 2) */
     int32_t coop_mute, coop_sets; /* coop_sets: owners are dealt into this many sets of <= 16, each watched by its own helpers */ /* test switch (NYX_HIP_COOP_MUTE): helpers exit at once, as if they had never become resident */
     struct CoopBox *coop_box; /* one mailbox per trajectory-owning workgroup, zeroed before the launch */
+    struct CoopOut *coop_out2; /* [owners] answers of part 1 (coop_parts == 2), else NULL */
     uint32_t *coop_posted, *coop_claimed, *coop_finished; /* [owners] packed scan words, zeroed before the launch */
     const int64_t *dur_ns; /* optional per-trajectory duration (covariance-mapping segments); overrides duration_ns */
     const double *stm; /* [n][81] column-major per trajectory, or NULL */

@@ -1282,10 +1282,15 @@ DEVFN bool coop_get(const uint64_t *g, uint32_t seq, double &v) {
 // window in the plain loop, right after the next stage's inputs are formed in the pipelined one).  The inputs are tagged
 // granules: the sequence number is written right behind them, with no wait in between - a helper that sees it before the
 // data simply polls the granules until their tags agree.
-static __device__ __attribute__((noinline)) void coop_post(CoopBox *box, uint32_t *posted, int lane, uint32_t seq, const double *inb) {
+// `parts` sub-jobs per evaluation (1, or 2: the helpers' columns in two halves, claimed by two helper workgroups): the words the
+// helpers scan count SUB-JOBS - posted = parts * seq; sub-job c (1, 2, ...) is part (c - 1) % parts of evaluation (c + parts - 1) / parts.
+// (`seq_p`: the sequence number, bit 31 set when the hand-off has two parts - the call keeps the argument list it always had)
+#define COOP_TWO_PARTS 0x80000000u
+static __device__ __attribute__((noinline)) void coop_post(CoopBox *box, uint32_t *posted, int lane, uint32_t seq_p, const double *inb) {
+    const uint32_t seq = seq_p & ~COOP_TWO_PARTS;
 #pragma unroll
     for (int q = 0; q < 5; ++q) coop_put(&box->in[seq & 1u][q][0][lane], inb[q * DEV_LANES + lane], seq);
-    if (lane == 0) coop_store(posted, seq);
+    if (lane == 0) coop_store(posted, (seq_p & COOP_TWO_PARTS) ? 2u * seq : seq);
 }
 
 struct CoopAnswer {
@@ -1294,19 +1299,27 @@ struct CoopAnswer {
 };
 // The answer needs no flag: every lane polls the LAST granule the helper writes for it, and when all of them carry this
 // evaluation's tag the other seven are read and checked the same way (they were stored earlier, but nothing orders them).
-static __device__ __attribute__((noinline)) CoopAnswer coop_wait(CoopBox *box, int lane, uint32_t seq) {
+static __device__ __attribute__((noinline)) CoopAnswer coop_wait(CoopBox *box, CoopOut *out2, int lane, uint32_t seq_p) {
     CoopAnswer a = {0.0, 0.0, 0.0, 0.0, 0};
     const int64_t t0 = (int64_t)__builtin_amdgcn_s_memrealtime();
+    const uint32_t seq = seq_p & ~COOP_TWO_PARTS;
     const unsigned par = seq & 1u;
-    for (;;) {
-        const uint64_t last = coop_loadu(&box->out[par][3][1][lane]);
-        if (__all((uint32_t)(last >> 32) == seq)) {
-            const bool ok = coop_get(&box->out[par][0][0][lane], seq, a.x) & coop_get(&box->out[par][1][0][lane], seq, a.y) &
-                            coop_get(&box->out[par][2][0][lane], seq, a.z) & coop_get(&box->out[par][3][0][lane], seq, a.w);
-            if (__all(ok)) break;
+    const int parts = ((seq_p & COOP_TWO_PARTS) && out2 != nullptr) ? 2 : 1;
+    for (int part = 0; part < parts; ++part) {  // (the second part is added after the first: a fixed order, whichever helper answered first)
+        uint64_t *o = part ? &out2->out[par][0][0][0] : &box->out[par][0][0][0];  // [4][2][64] granules of this part
+        double x, y, z, w;
+        for (;;) {
+            const bool there = (uint32_t)(coop_loadu(o + (3 * 2 + 1) * DEV_LANES + lane) >> 32) == seq;
+            if (__all(there)) {
+                const bool ok = coop_get(o + 0 * 2 * DEV_LANES + lane, seq, x) & coop_get(o + 1 * 2 * DEV_LANES + lane, seq, y) &
+                                coop_get(o + 2 * 2 * DEV_LANES + lane, seq, z) & coop_get(o + 3 * 2 * DEV_LANES + lane, seq, w);
+                if (__all(ok)) break;
+            }
+            if ((int64_t)__builtin_amdgcn_s_memrealtime() - t0 > COOP_TIMEOUT_TICKS) { a.x = a.y = a.z = a.w = 0.0; return a; }
+            __builtin_amdgcn_s_sleep(1);
         }
-        if ((int64_t)__builtin_amdgcn_s_memrealtime() - t0 > COOP_TIMEOUT_TICKS) { a.x = a.y = a.z = a.w = 0.0; return a; }
-        __builtin_amdgcn_s_sleep(1);
+        if (part == 0) { a.x = x; a.y = y; a.z = z; a.w = w; }
+        else { a.x += x; a.y += y; a.z += z; a.w += w; }
     }
     a.ok = 1;
     return a;
@@ -1315,16 +1328,23 @@ static __device__ __attribute__((noinline)) CoopAnswer coop_wait(CoopBox *box, i
 // What the owner does when no helper answers: the helper's sixteen wave slots one after the other, summed in the
 // helper's fold order, i.e. bit for bit the answer it did not get.  Out of line: a rare path must not cost the
 // integrator role registers.
-static __device__ __attribute__((noinline)) Partial4 coop_fallback(uint64_t cfg_u, uint64_t htab_u, uint64_t cols_u, const double *inb, int lane) {
+static __device__ __attribute__((noinline)) Partial4 coop_fallback(uint64_t cfg_u, uint64_t htab_u, uint64_t cols_u, const double *inb, int lane_p) {
+    const int lane = lane_p & 0xff, parts = (lane_p & 0x100) ? 2 : 1;  // (bit 8 of the lane argument: two parts)
     const double v0 = inb[0 * DEV_LANES + lane], v1 = inb[1 * DEV_LANES + lane], v2 = inb[2 * DEV_LANES + lane],
                  v3 = inb[3 * DEV_LANES + lane], v4 = inb[4 * DEV_LANES + lane];
-    Partial4 o = {0.0, 0.0, 0.0, 0.0};
-    for (int hw = 0; hw < DEV_MAX_WAVES; ++hw) {
-        const Partial4 p = (((CfgPtr)uniform_u64(cfg_u))->harm_feed & 2) ? harmonics_stream(cfg_u, cols_u, hw, DEV_SCHED_HELPER, v0, v1, v2, v3, v4)
-                                                                     : harmonics_partial(cfg_u, htab_u, cols_u, hw, DEV_SCHED_HELPER, v0, v1, v2, v3, v4);
-        o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+    Partial4 tot = {0.0, 0.0, 0.0, 0.0};
+    for (int part = 0; part < parts; ++part) {  // (every part summed on its own, then added in part order: what coop_wait does with the answers)
+        const int sched = part ? DEV_SCHED_HELPER2 : DEV_SCHED_HELPER;
+        Partial4 o = {0.0, 0.0, 0.0, 0.0};
+        for (int hw = 0; hw < DEV_MAX_WAVES; ++hw) {
+            const Partial4 p = (((CfgPtr)uniform_u64(cfg_u))->harm_feed & 2) ? harmonics_stream(cfg_u, cols_u, hw, sched, v0, v1, v2, v3, v4)
+                                                                             : harmonics_partial(cfg_u, htab_u, cols_u, hw, sched, v0, v1, v2, v3, v4);
+            o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w;
+        }
+        if (part == 0) tot = o;
+        else { tot.x += o.x; tot.y += o.y; tot.z += o.z; tot.w += o.w; }
     }
-    return o;
+    return tot;
 }
 
 // Helper workgroup.  Jobs are CLAIMED, not assigned: the owners are dealt into sets of at most 16, a helper watches
@@ -1344,8 +1364,9 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
     double *part = (double *)smem;                                 // [2][16][4][64]
     double *inl = part + 2 * DEV_MAX_WAVES * 4 * DEV_LANES;        // [2][5][64]
     int *ctl = (int *)(inl + 2 * 5 * DEV_LANES);
-    const LdsFlagPtr ready = (LdsFlagPtr)ctl, answered = (LdsFlagPtr)ctl + 2, jown = (LdsFlagPtr)ctl + 4, jseq = (LdsFlagPtr)ctl + 6;
+    const LdsFlagPtr ready = (LdsFlagPtr)ctl, answered = (LdsFlagPtr)ctl + 2, jown = (LdsFlagPtr)ctl + 4, jseq = (LdsFlagPtr)ctl + 6, jpart = (LdsFlagPtr)ctl + 10;
     int *cnt = ctl + 8;
+    const int parts = bt.coop_parts > 1 ? DEV_COOP_PARTS : 1;
     const int answer_wave = (int)(blockDim.x / DEV_LANES) - 1;
     const int n_col_waves = answer_wave - 1;
     if (wave == 0 || wave == answer_wave) {
@@ -1368,7 +1389,7 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
         unsigned turn = (unsigned)h;
         for (int j = 0;; ++j) {
             const int s = j & 1;
-            int owner = -1;
+            int owner = -1, sub = 0;
             uint32_t seq = 0;
             const int64_t t0 = (int64_t)__builtin_amdgcn_s_memrealtime();
             bool slot_free = j < 2;
@@ -1392,7 +1413,9 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
                     // stage i+1 before it has read the answer of stage i).  The five input rows of the job are fetched in the
                     // shadow of the compare-and-swap (they were complete before `posted` moved): one memory round trip, not two.
                     const int owner_c = (int)__shfl((int)mine, pick);
-                    const uint32_t seq_c = (uint32_t)__shfl((int)claimed, pick) + 1u;
+                    const uint32_t sub_c = (uint32_t)__shfl((int)claimed, pick) + 1u;           // the sub-job being claimed (1, 2, ...)
+                    const uint32_t seq_c = (sub_c + (uint32_t)parts - 1u) / (uint32_t)parts;   // its evaluation ...
+                    const int part_c = (int)((sub_c - 1u) % (uint32_t)parts);                  // ... and which part of the hand-off
                     int won = 0;
                     if (lane == pick) {
                         uint32_t expect = claimed;
@@ -1420,6 +1443,7 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
                         }
                         owner = owner_c;
                         seq = seq_c;
+                        sub = part_c;
                         double *il = inl + s * 5 * DEV_LANES;
                         il[0 * DEV_LANES + lane] = v0; il[1 * DEV_LANES + lane] = v1; il[2 * DEV_LANES + lane] = v2;
                         il[3 * DEV_LANES + lane] = v3; il[4 * DEV_LANES + lane] = v4;
@@ -1431,7 +1455,7 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
                 if (__all(fin != 0u)) { owner = -1; break; }
                 __builtin_amdgcn_s_sleep(8);  // ~0.2 us between scans: the set's words are one memory line shared by ~10 helpers
             }
-            if (lane == 0) { jown[s] = owner; jseq[s] = (int)seq; }
+            if (lane == 0) { jown[s] = owner; jseq[s] = (int)seq; jpart[s] = sub; }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) ready[s] = j + 1;
             if (owner < 0) break;
@@ -1450,14 +1474,16 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const int owner = jown[s];
         const uint32_t seq = (uint32_t)jseq[s];
+        const int sub = jpart[s];
         if (owner < 0) break;
         double *ps = part + s * DEV_MAX_WAVES * 4 * DEV_LANES;
         if (wave != answer_wave) {
             const double *il = inl + s * 5 * DEV_LANES;
             const double v0 = il[0 * DEV_LANES + lane], v1 = il[1 * DEV_LANES + lane], v2 = il[2 * DEV_LANES + lane],
                          v3 = il[3 * DEV_LANES + lane], v4 = il[4 * DEV_LANES + lane];
-            const Partial4 pr = (cfg->harm_feed & 2) ? harmonics_stream((uint64_t)cfg, (uint64_t)cols, wave, DEV_SCHED_HELPER, v0, v1, v2, v3, v4)
-                                               : harmonics_partial((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, DEV_SCHED_HELPER, v0, v1, v2, v3, v4);
+            const int hsched = sub ? DEV_SCHED_HELPER2 : DEV_SCHED_HELPER;
+            const Partial4 pr = (cfg->harm_feed & 2) ? harmonics_stream((uint64_t)cfg, (uint64_t)cols, wave, hsched, v0, v1, v2, v3, v4)
+                                               : harmonics_partial((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, hsched, v0, v1, v2, v3, v4);
             double *pp = ps + wave * 4 * DEV_LANES;
             pp[0 * DEV_LANES + lane] = pr.x; pp[1 * DEV_LANES + lane] = pr.y; pp[2 * DEV_LANES + lane] = pr.z; pp[3 * DEV_LANES + lane] = pr.w;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1481,8 +1507,11 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
 #pragma unroll
             for (int q = 0; q < 4; ++q) o[q] += ps[(w * 4 + q) * DEV_LANES + lane];
         }
+        {
+            uint64_t *og = (sub && bt.coop_out2) ? &bt.coop_out2[owner].out[par][0][0][0] : &b->out[par][0][0][0];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) coop_put(&b->out[par][q][0][lane], o[q], seq);  // tagged granules: no drain, no flag (the owner polls the last one)
+            for (int q = 0; q < 4; ++q) coop_put(og + q * 2 * DEV_LANES + lane, o[q], seq);  // tagged granules: no drain, no flag (the owner polls the last one)
+        }
         if (lane == 0) __hip_atomic_store(cnt + s, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) answered[s] = j + 1;  // the slot may be refilled: its partial sums are in registers
@@ -2121,6 +2150,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     // cooperative mode (see above): the integrator owns the conversation with the helper
     CoopBox *const cbox = bt.coop_box + blockIdx.x;
     const int coop_widx = bt.coop_sets > 0 ? ((int)blockIdx.x % bt.coop_sets) * COOP_SET + (int)blockIdx.x / bt.coop_sets : 0;
+#define coop_two (bt.coop_parts > 1 ? COOP_TWO_PARTS : 0u) /* (read from the launch descriptor where it is used: nothing more to keep live in the role code) */
     bool coop_on = !STM && LCTL[1] != 0;
     const bool coop_started = coop_on;
     uint32_t coop_seq = 0;
@@ -2381,7 +2411,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             // ---- window --------------------------------------------------------------------------
             if (INTEG && !STM && coop_on && has_grav && (!pipe || (i == 0 && !spec_now))) {
                 seq_cur = ++coop_seq;
-                coop_post(cbox, bt.coop_posted + coop_widx, lane, seq_cur, L.inb);
+                coop_post(cbox, bt.coop_posted + coop_widx, lane, seq_cur | coop_two, L.inb);
             }
             const bool last_stage = i + 1 == stages;
             if (ALMANAC && need_almanac && (!last_stage || reuse_nf > 0 || spec)) {
@@ -2581,7 +2611,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     if (lane == 0) L.ctl[1] = coop_on ? 1 : 0;  // the workers read it after B2(i), for stage i+1
                     if (coop_on) {
                         seq_nx = ++coop_seq;
-                        coop_post(cbox, bt.coop_posted + coop_widx, lane, seq_nx, inbn);
+                        coop_post(cbox, bt.coop_posted + coop_widx, lane, seq_nx | coop_two, inbn);
                     }
                 }
             }
@@ -2657,13 +2687,13 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             }
             if (INTEG && !STM && has_grav && (pipe ? shared_cur : coop_on)) {
                 // the helper's answer is collected INSIDE the window (this wave has nothing else to do): phase C never waits
-                const CoopAnswer ans = coop_on ? coop_wait(cbox, lane, seq_cur) : CoopAnswer{0.0, 0.0, 0.0, 0.0, 0};
+                const CoopAnswer ans = coop_on ? coop_wait(cbox, bt.coop_out2 ? bt.coop_out2 + blockIdx.x : nullptr, lane, seq_cur | coop_two) : CoopAnswer{0.0, 0.0, 0.0, 0.0, 0};
                 if (ans.ok) {
                     coop_x = ans.x; coop_y = ans.y; coop_z = ans.z; coop_w = ans.w;
                     ++dbg_answers;
                 } else {
                     if (coop_on) { ++dbg_fallbacks; dbg_fb_seq = seq_cur; }  // no answer in time: do the helper's columns here, then carry on alone
-                    const Partial4 fb = coop_fallback((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, (pipe && (i & 1)) ? L.inb2 : L.inb, lane);
+                    const Partial4 fb = coop_fallback((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, (pipe && (i & 1)) ? L.inb2 : L.inb, lane | (coop_two ? 0x100 : 0));
                     coop_x = fb.x; coop_y = fb.y; coop_z = fb.z; coop_w = fb.w;
                     coop_on = false;
                     coop_drop = !pipe;  // (pipelined: ctl[1] is rewritten for every stage, nothing to undo)
@@ -2964,6 +2994,8 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
         if (bt.n_evals) bt.n_evals[gid] = c.n_evals;
     }
 }
+
+#undef coop_two
 
 template <bool STM, bool QUAD = false, bool W16 = true>  // W16: sixteen-wave workgroups (the shape whose pipelined stage loop serves the column waves)
 DEVFN void propagate_body(const DevBatch &bt, const DevCfg *cfg_g, const HarmEntry *htab_g, const ColHdr *cols_g,

@@ -475,7 +475,7 @@ def test_cooperative_mode_matches_solo_and_oracle():
     solo_ms = ctx.last_kernel_ms()
     ctx.set_tuning(None)
     coop, cst = ctx.propagate(b, dur)
-    assert ctx.last_coop_helpers() == 96          # ceil(10000/64) = 157 owners, base 160, 96 helpers on the idle CUs
+    assert ctx.last_coop_helpers() == 99          # ceil(10000/64) = 157 owners, 99 helpers on the idle CUs
     coop_ms = ctx.last_kernel_ms()
     again, ast = ctx.propagate(b, dur)
     assert (sst.status == 0).all() and (cst.status == 0).all()
@@ -495,7 +495,7 @@ def test_cooperative_mode_matches_solo_and_oracle():
     ctx.set_tuning(nx.Tuning(coop_mute=1))
     mute, mst = ctx.propagate(b, dur)
     ctx.set_tuning(None)
-    assert ctx.last_coop_helpers() == 96 and (mst.status == 0).all()
+    assert ctx.last_coop_helpers() == 99 and (mst.status == 0).all()
     dr, dv = pos_vel_errors(mute, solo)
     print(f"muted helpers: kernel {ctx.last_kernel_ms():.1f} ms, max dr vs solo {dr.max()*1e3:.2e} m")
     assert dr.max() < 1e-6 and dv.max() < 1e-9 and ctx.last_kernel_ms() < solo_ms + 50.0
