@@ -808,6 +808,7 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
 // the chip without a workgroup, i.e. up to ~2 quad workgroups per CU.
 static bool pick_quad(const nyx_hip_ctx *ctx, int64_t n) {
     if (!(ctx->host_cfg.flags & NYX_HIP_FLAG_STM)) return false;
+    if (ctx->host_cfg.has_grav2) return false;  // (the second field's dual form is walked by the perturbation wave of the 64-lane layout only)
     if (ctx->forced_quad >= 0) return ctx->forced_quad != 0;
     if (ctx->tune.stm_quad >= 0) return ctx->tune.stm_quad != 0;
     // deterministic: the layout fixes the column split, hence the bits - it must not follow the batch size (a shard is a smaller batch)
@@ -1192,9 +1193,6 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
         if (g->offset_body != 0) {  // the field of another body than the integration centre (gravity_field.rs:150-154)
             const int sl = slot_for(g->offset_body - 1);
             if (sl == -2) { delete ctx; nyx_set_error("gravity field: offset_body is not a body of this configuration (or the %d body slots are taken)", DEV_MAX_SLOTS); return NYX_HIP_RC_BAD_ARG; }
-            if (sl >= 0 && (cfg->flags & NYX_HIP_FLAG_STM)) {
-                delete ctx; nyx_set_error("STM propagation with the gravity field of a non-central body is not on the device path"); return NYX_HIP_RC_BAD_ARG;
-            }
             dc.g_slot = sl;  // (-1: offset_body names the integration centre itself)
             if (sl >= 0)
                 for (int k = 0; k < dc.slot[sl].n_chain; ++k)
@@ -1213,7 +1211,6 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
         const nyx_hip_gravity_field_t *g = cfg->gravity2;
         if (!cfg->gravity) { delete ctx; nyx_set_error("gravity2 without gravity: a single field goes into `gravity`"); return NYX_HIP_RC_BAD_ARG; }
         if (g->degree < 1 || !g->c_nm || !g->s_nm) { delete ctx; nyx_set_error("bad second gravity field"); return NYX_HIP_RC_BAD_ARG; }
-        if (cfg->flags & NYX_HIP_FLAG_STM) { delete ctx; nyx_set_error("STM propagation with a second gravity field is not on the device path"); return NYX_HIP_RC_BAD_ARG; }
         dc.has_grav2 = 1;
         dc.g2_mu = g->mu_km3_s2; dc.g2_re = g->eq_radius_km; dc.g2_inv_re = 1.0 / g->eq_radius_km;
         copy_rotation(dc.g2_rot, g->rotation);

@@ -1163,6 +1163,53 @@ static __device__ __attribute__((noinline)) int second_field_into_pert(CfgPtr cf
     return st;
 }
 
+// GravityField::gradient (gravity_field.rs:273-431) of the SECOND field, for the 64-lane dual (D3) layout of the STM kernel: the same
+// frame handling as eom (:279-283: translate to the field's body, rotate; the translation carries no partials), duals seeded on the
+// body-fixed position (hyperspace_from_vector, :285), the column recursion on value + three partials over every column of the second
+// table, the epilogue of phase C in duals, a = R^T a_bf and G = R^T G_bf R (:403-430).  Added to the point-mass rows of the dual
+// perturbation block (a_pm, G_pm: the integrator adds them after the two-body term, like the first field's - the order of two terms
+// of a sum).  Returns the status of the field's own orientation.
+static __device__ __attribute__((noinline)) int second_field_into_pertD(CfgPtr cfg, const double *records, const double *ed, int lane, int wave,
+                                                                       double et_s, const double *ys, double *pertD) {
+    double r[3] = {ys[0 * DEV_LANES + lane], ys[1 * DEV_LANES + lane], ys[2 * DEV_LANES + lane]};
+    if (cfg->g2_slot >= 0) {  // (uniform)
+        double pg[3];
+        ed_body(cfg, ed, lane, cfg->g2_slot, pg);
+        r[0] = r[0] - pg[0]; r[1] = r[1] - pg[1]; r[2] = r[2] - pg[2];
+    }
+    double m[9];
+    const int st = rotation_dcm(cfg, cfg->g2_rot, records, et_s, m);
+    const D3 x0 = {m[0] * r[0] + m[1] * r[1] + m[2] * r[2], 1.0, 0.0, 0.0};
+    const D3 x1 = {m[3] * r[0] + m[4] * r[1] + m[5] * r[2], 0.0, 1.0, 0.0};
+    const D3 x2 = {m[6] * r[0] + m[7] * r[1] + m[8] * r[2], 0.0, 0.0, 1.0};
+    const D3 rD = d3norm(x0, x1, x2);
+    const D3 sD = d3div(x0, rD), tD = d3div(x1, rD), uD = d3div(x2, rD);
+    const D3 rhoD = d3div(d3c(cfg->g2_re), rD);
+    const D3 kD = d3div(d3div(d3c(cfg->g2_mu), rD), d3c(cfg->g2_re));
+    const D3 invD = rD * cfg->g2_inv_re;
+    // (arguments arrive in VGPRs under the device-function ABI: the wave-uniform ones are re-scalarised, as in harmonics_partial)
+    CfgPtr cfg_s = (CfgPtr)uniform_u64((uint64_t)cfg);
+    Partial4T<D3> pd = harmonics_core<D3>(cfg_s, (HarmPtr)uniform_u64(cfg_s->htab2), (ColPtr)uniform_u64(cfg_s->cols2), __builtin_amdgcn_readfirstlane(wave),
+                                          DEV_SCHED_SECOND, rhoD * sD, rhoD * tD, rhoD * uD, rhoD, invD);
+    const D3 p0 = pd.x * kD, p1 = pd.y * kD, p2 = pd.z * kD, p3 = pd.w * kD;
+    const D3 al[3] = {p0 + p3 * sD, p1 + p3 * tD, p2 + p3 * uD};
+    double tmp[9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        pertD[a * DEV_LANES + lane] = pertD[a * DEV_LANES + lane] + (m[0 + a] * al[0].v + m[3 + a] * al[1].v + m[6 + a] * al[2].v);
+        tmp[3 * a + 0] = m[0 + a] * al[0].x + m[3 + a] * al[1].x + m[6 + a] * al[2].x;
+        tmp[3 * a + 1] = m[0 + a] * al[0].y + m[3 + a] * al[1].y + m[6 + a] * al[2].y;
+        tmp[3 * a + 2] = m[0 + a] * al[0].z + m[3 + a] * al[1].z + m[6 + a] * al[2].z;
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            pertD[(3 + 3 * a + b) * DEV_LANES + lane] =
+                pertD[(3 + 3 * a + b) * DEV_LANES + lane] + (tmp[3 * a + 0] * m[0 + b] + tmp[3 * a + 1] * m[3 + b] + tmp[3 * a + 2] * m[6 + b]);
+    return st;
+}
+
 // Dual variant: inputs and outputs go through LDS (20 + 16 doubles per lane) instead of the register ABI.
 static __device__ __attribute__((noinline)) void harmonics_partial_dual(uint64_t cfg_u, uint64_t htab_u, uint64_t cols_u, int wave_v,
                                                                       const double *inbD, double *outD, int lane) {
@@ -2067,7 +2114,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
 #else
     const bool has_tides = cfg->has_tides != 0;
 #endif
-    const bool has_grav2 = !STM && cfg->has_grav2 != 0;
+    const bool has_grav2 = !QUAD && cfg->has_grav2 != 0;  // (plain kernel: value; 64-lane dual layout of the STM kernel: value and gradient; the quad layout is not launched with a second field)
     const bool need_almanac = has_grav || has_drag || has_tides || cfg->n_slots > 0;
     // role fan-out: this wave's share of the almanac / perturbation duties, and its status slot
     const int amask = ALMANAC ? cfg->role_mask[wave] : 0;
@@ -2356,7 +2403,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     // the field of another body than the integration centre (gravity_field.rs:150-154: transform_to translates to the
                     // field's body before it rotates): evaluated at r - r_body(t).  Plain stage loop only (the host clears cfg->pipe)
                     double rg[3] = {ys[0], ys[1], ys[2]};
-                    if (!STM && cfg->g_slot >= 0) {  // (uniform)
+                    if (cfg->g_slot >= 0) {  // (uniform; the translation carries no partials: d(r - r_body(t)) / dr = 1)
                         double pg[3];
                         ed_body(cfg, edc, lane, cfg->g_slot, pg);
                         rg[0] = ys[0] - pg[0]; rg[1] = ys[1] - pg[1]; rg[2] = ys[2] - pg[2];
@@ -2506,10 +2553,14 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 // third accel model (dynamics/sequence/config.rs:116-118): added to the point-mass slot, last, so that no
                 // live value of this role crosses the call
                 if (has_tides && !STM && do_pm) tides_into_pert(cfg, edc, lane, ysp, pertp);
-                if (has_grav2 && do_pm) {  // a second gravity field (after the tides: the reference's model order does not reach the bits the parity bar looks at)
+                if (has_grav2 && (do_pm || STM)) {  // a second gravity field (after the tides: the reference's model order does not reach the bits the parity bar looks at)
                     const int64_t ep2 = __double_as_longlong(L.step[lane]) + seconds_to_ns(C_COEF(i) * L.step[DEV_LANES + lane]);
-                    L.pertst[(i & 1) * DEV_LANES + lane] =
-                        second_field_into_pert(cfg, rec_in_lds ? (const double *)L.rec : records, edc, lane, wave, ns_to_seconds(ep2), ysp, pertp);
+                    if (STM)
+                        L.pertst[(i & 1) * DEV_LANES + lane] =
+                            second_field_into_pertD(cfg, rec_in_lds ? (const double *)L.rec : records, edc, lane, wave, ns_to_seconds(ep2), ysp, L.pertD);
+                    else
+                        L.pertst[(i & 1) * DEV_LANES + lane] =
+                            second_field_into_pert(cfg, rec_in_lds ? (const double *)L.rec : records, edc, lane, wave, ns_to_seconds(ep2), ysp, pertp);
                 }
             }
             double acc[3] = {0.0, 0.0, 0.0};
@@ -2631,9 +2682,15 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     double m[9];
 #pragma unroll
                     for (int q = 0; q < 9; ++q) m[q] = edc[q * DEV_LANES + lane];
-                    const D1 x0 = d1seed(m[0] * ys[0] + m[1] * ys[1] + m[2] * ys[2], 0, ql);
-                    const D1 x1 = d1seed(m[3] * ys[0] + m[4] * ys[1] + m[5] * ys[2], 1, ql);
-                    const D1 x2 = d1seed(m[6] * ys[0] + m[7] * ys[1] + m[8] * ys[2], 2, ql);
+                    double rq[3] = {ys[0], ys[1], ys[2]};
+                    if (cfg->g_slot >= 0) {  // (uniform; plain stage loop then: edc is this stage's data)
+                        double pg[3];
+                        ed_body(cfg, edc, lane, cfg->g_slot, pg);
+                        rq[0] = ys[0] - pg[0]; rq[1] = ys[1] - pg[1]; rq[2] = ys[2] - pg[2];
+                    }
+                    const D1 x0 = d1seed(m[0] * rq[0] + m[1] * rq[1] + m[2] * rq[2], 0, ql);
+                    const D1 x1 = d1seed(m[3] * rq[0] + m[4] * rq[1] + m[5] * rq[2], 1, ql);
+                    const D1 x2 = d1seed(m[6] * rq[0] + m[7] * rq[1] + m[8] * rq[2], 2, ql);
                     const D1 rD = d1norm(x0, x1, x2);
                     q_aux[0] = d1div(x0, rD); q_aux[1] = d1div(x1, rD); q_aux[2] = d1div(x2, rD);
                     q_aux[3] = d1div(d1div(d1c(cfg->g_mu), rD), d1c(cfg->g_re));
@@ -2773,7 +2830,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                         const D3 a = rad[q] * fac;
                         acc[q] = a.v; G[3 * q + 0] = a.x; G[3 * q + 1] = a.y; G[3 * q + 2] = a.z;
                     }
-                    if (has_pm || has_tides) {
+                    if (has_pm || has_tides || has_grav2) {
 #pragma unroll
                         for (int q = 0; q < 3; ++q) acc[q] += L.pertD[q * DEV_LANES + lane];
 #pragma unroll
@@ -2793,9 +2850,15 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
 #pragma unroll
                         for (int q = 0; q < 9; ++q) m[q] = edc[q * DEV_LANES + lane];
                         // s, t, u, (mu / r) / R_eq as duals of the body-fixed position (recomputed: cheaper than 16 LDS slots)
-                        const D3 x0 = {m[0] * ys[0] + m[1] * ys[1] + m[2] * ys[2], 1.0, 0.0, 0.0};
-                        const D3 x1 = {m[3] * ys[0] + m[4] * ys[1] + m[5] * ys[2], 0.0, 1.0, 0.0};
-                        const D3 x2 = {m[6] * ys[0] + m[7] * ys[1] + m[8] * ys[2], 0.0, 0.0, 1.0};
+                        double rg[3] = {ys[0], ys[1], ys[2]};
+                        if (cfg->g_slot >= 0) {  // (uniform) the field of another body: at r - r_body(t), as phase A formed the inputs
+                            double pg[3];
+                            ed_body(cfg, edc, lane, cfg->g_slot, pg);
+                            rg[0] = ys[0] - pg[0]; rg[1] = ys[1] - pg[1]; rg[2] = ys[2] - pg[2];
+                        }
+                        const D3 x0 = {m[0] * rg[0] + m[1] * rg[1] + m[2] * rg[2], 1.0, 0.0, 0.0};
+                        const D3 x1 = {m[3] * rg[0] + m[4] * rg[1] + m[5] * rg[2], 0.0, 1.0, 0.0};
+                        const D3 x2 = {m[6] * rg[0] + m[7] * rg[1] + m[8] * rg[2], 0.0, 0.0, 1.0};
                         const D3 rD = d3norm(x0, x1, x2);
                         const D3 aux[4] = {d3div(x0, rD), d3div(x1, rD), d3div(x2, rD), d3div(d3div(d3c(cfg->g_mu), rD), d3c(cfg->g_re))};
 #pragma unroll

@@ -544,13 +544,9 @@ def compile_config(dynamics: SpacecraftDynamics, method: IntegratorMethod, opts:
     for which, g in enumerate(sorted(gf, key=lambda f: -int(f.degree))):
         gs = _abi.GravityField()
         gs.degree, gs.order = int(g.degree), int(g.order)
-        if which == 1 and stm:
-            raise NotImplementedError("STM propagation with a second gravity field is not on the device path")
         if g.frame.naif_id != central.naif_id:
             # gravity_field.rs:150-154: the orbit is transformed into the field's frame WHATEVER its centre (translation to that body,
             # then its rotation), the acceleration is rotated back (:258-265): that body's harmonics at r - r_body(t)
-            if stm:
-                raise NotImplementedError("STM propagation with the gravity field of a non-central body is not on the device path")
             gs.offset_body = body_of(g.frame.naif_id) + 1
         gs.mu_km3_s2, gs.eq_radius_km = float(g.frame.mu_km3_s2), float(g.frame.mean_equatorial_radius_km)
         cn = np.ascontiguousarray(g.c_nm, dtype=np.float64)

@@ -996,10 +996,21 @@ static int dual_eom(const prepared_t *p, double et_s, const double *y9, const sc
             for (int j = 0; j < 3; ++j) G(i + 3, j) += g3[i][j];
         }
     }
-    if (cfg->gravity) {
-        double acc[3], g3[3][3];
-        if ((cfg->gravity->offset_body > 0 && cfg->bodies[cfg->gravity->offset_body - 1].n_chain > 0) || cfg->gravity2) return NYX_HIP_ERR_NAN; /* (STM with a non-central or a second field: refused by the device path, not restated) */
-        { int st = gravity_gradient(cfg->gravity, cfg->segments, &p->gt, et_s, r, acc, g3); if (st) return st; }
+    for (int which = 0; which < 2; ++which) { /* every GravityField of accel_models in turn (orbital.rs:116-172 dual_eom -> gradient of each model) */
+        const nyx_hip_gravity_field_t *g = which == 0 ? cfg->gravity : cfg->gravity2;
+        if (!g) continue;
+        double acc[3], g3[3][3], rg[3] = {r[0], r[1], r[2]};
+        /* GravityField::gradient, gravity_field.rs:279-283: almanac.transform_to(osc, grav_data.frame) translates to the field's body and
+         * rotates; the duals are seeded on THAT radius (:285), so the partials are with respect to r - r_body(t), i.e. to r: the
+         * translation carries none.  The gradient is rotated back, dcm * grad_local * dcm^T (:429), like the acceleration. */
+        const int gb = g->offset_body - 1;
+        if (gb >= 0 && gb < cfg->n_bodies && cfg->bodies[gb].n_chain > 0) {
+            double pb[3];
+            int st = body_position(cfg, gb, et_s, pb);
+            if (st) return st;
+            for (int c = 0; c < 3; ++c) rg[c] = r[c] - pb[c];
+        }
+        { int st = gravity_gradient(g, cfg->segments, which == 0 ? &p->gt : &p->gt2, et_s, rg, acc, g3); if (st) return st; }
         for (int i = 0; i < 3; ++i) {
             fx[i + 3] += acc[i];
             for (int j = 0; j < 3; ++j) G(i + 3, j) += g3[i][j];

@@ -1,5 +1,5 @@
 """-m gpu: the gravity field of a non-central body on the device (`nyx_hip_gravity_field_t.offset_body`, gravity_field.rs:150-154,
-258-265) against the oracle, the field's effect against the central formulation of the same system, and the refusal that is left."""
+258-265) against the oracle, the field's effect against the central formulation of the same system, and the STM forms (round 4)."""
 import numpy as np
 import pytest
 
@@ -57,15 +57,112 @@ def test_same_field_effect_as_the_moon_centred_formulation_on_the_device():
     check_field_effects(*field_effects(run, n=70))
 
 
-def test_stm_with_a_non_central_field_is_refused():
-    prop, almanac, earth = nc.earth_centred(8)
-    with pytest.raises(NotImplementedError, match="non-central"):
-        prop.compile(almanac, earth, stm=True)
-    # and at the boundary itself (a caller that fills the structs by hand)
-    compiled = prop.compile(almanac, earth)
-    compiled.cfg.flags |= 1  # NYX_HIP_FLAG_STM
-    with pytest.raises(RuntimeError, match="non-central"):
-        nx.GpuContext(compiled)
+def _stm_batch(b):
+    b = b.copy()
+    b.stm = np.zeros((b.n, 81))
+    b.reset_stm()
+    return b
+
+
+def _earth_centred(b, almanac):
+    import frame_swap_cases as fs
+    rv = b.rv().copy()
+    for i in range(b.n):
+        r, v = fs.chain_state_numpy(almanac, nx.MOON, int(b.epoch_ns[i]))
+        rv[i, :3] += r
+        rv[i, 3:] += v
+    b = b.copy()
+    b.set_rv(rv)
+    return b
+
+
+def _phi_err(out, ref):
+    scale = np.maximum(np.abs(ref.stm), 1e-6 * np.abs(ref.stm).max(axis=1, keepdims=True))
+    return (np.abs(out.stm - ref.stm) / scale).max()
+
+
+@pytest.mark.parametrize("layout", [0, 1])
+def test_stm_with_a_non_central_field(layout):
+    """Round 4 (VERDICT round 3, item 5): GravityField::gradient is as frame-agnostic as eom (gravity_field.rs:279-283: transform_to
+    translates to the field's body, the duals are seeded on that radius, the gradient is rotated back) - the Moon's 20x20 field in an
+    EARTH-centred STM propagation, both STM layouts (64-lane duals, quad), in the OD pattern (1-minute segments from an identity
+    Phi: one attempt at the same step on both sides, so Phi is comparable to 1e-9) and over ten minutes with fixed steps."""
+    prop, almanac, earth = nc.earth_centred(20)
+    b = _stm_batch(_earth_centred(nc.batch(37, seed=6), almanac))
+    compiled = prop.compile(almanac, earth, stm=True)
+    ctx = nx.GpuContext(compiled)
+    ctx.set_stm_layout(layout)
+    out, st = ctx.propagate(b, 60 * nx.NS_PER_S)
+    ref, rst = oracle_lib.propagate(compiled, b, 60 * nx.NS_PER_S, n_threads=8)
+    assert (st.status == 0).all() and (rst.status == 0).all()
+    dr, dv = pos_vel_errors(out, ref)
+    e = _phi_err(out, ref)
+    print(f"non-central field, STM layout {layout}: 1-min segment dr {dr.max() * 1e3:.3e} m, Phi rel err {e:.3e}")
+    assert dr.max() < 1e-6 and dv.max() < 1e-9 and e < 1e-9
+    np.testing.assert_array_equal(st.n_accepted, rst.n_accepted)
+    ctx.close()
+    # the field's gradient is in Phi: the same segment without the field differs in the velocity rows by far more than the agreement
+    bare, _, _ = nc.earth_centred(0)
+    cb = bare.compile(almanac, earth, stm=True)
+    ref0, _ = oracle_lib.propagate(cb, b, 60 * nx.NS_PER_S, n_threads=8)
+    assert np.abs(ref.stm - ref0.stm).max() > 1e3 * np.abs(out.stm - ref.stm).max()
+    # fixed 30 s steps, ten minutes
+    fixed = nx.Propagator(prop.dynamics, prop.method, nx.IntegratorOptions.with_fixed_step_s(30.0))
+    cf = fixed.compile(almanac, earth, stm=True)
+    ctx = nx.GpuContext(cf)
+    ctx.set_stm_layout(layout)
+    out, st = ctx.propagate(b, 600 * nx.NS_PER_S)
+    ref, rst = oracle_lib.propagate(cf, b, 600 * nx.NS_PER_S, n_threads=8)
+    assert (st.status == 0).all() and (rst.status == 0).all() and _phi_err(out, ref) < 1e-9
+    # frame-independent check: the STM run follows the orbit of the plain run
+    plain = nx.GpuContext(fixed.compile(almanac, earth))
+    pout, _ = plain.propagate(b, 600 * nx.NS_PER_S)
+    dr, dv = pos_vel_errors(out, pout)
+    assert dr.max() < 1e-6 and dv.max() < 1e-9
+    plain.close()
+    ctx.close()
+
+
+@pytest.mark.parametrize("centre", ["earth", "moon"])
+def test_stm_with_two_stacked_fields(centre):
+    """Earth 21x21 + Moon 20x20 in one OrbitalDynamics with the STM, around either body (the cislunar OD set-up): sixty 1-minute
+    segments with Phi reset (od/process/mod.rs:466-483) against the oracle's twin - states to 1 mm, Phi element-wise to 1e-9 - and the
+    second field's gradient visibly in Phi.  The 64-lane dual layout (the quad layout is not launched with a second field)."""
+    prop, almanac, frame = nc.two_fields(centre, 21, 20)
+    b = nc.batch(70, seed=8)
+    if centre == "earth":
+        b = _earth_centred(b, almanac)
+    b = _stm_batch(b)
+    compiled = prop.compile(almanac, frame, stm=True)
+    ctx = nx.GpuContext(compiled)
+    cur_d, cur_o = b, b
+    worst = 0.0
+    for seg in range(60):
+        out, st = ctx.propagate(cur_d, 60 * nx.NS_PER_S)
+        ref, rst = oracle_lib.propagate(compiled, cur_o, 60 * nx.NS_PER_S, n_threads=8)
+        assert (st.status == 0).all() and (rst.status == 0).all()
+        worst = max(worst, _phi_err(out, ref))
+        cur_d, cur_o = out.copy(), ref.copy()
+        cur_d.reset_stm()
+        cur_o.reset_stm()
+    dr, dv = pos_vel_errors(cur_d, cur_o)
+    print(f"{centre}-centred, two fields, STM, 60 one-minute segments: dr {dr.max() * 1e3:.3e} m dv {dv.max() * 1e6:.3e} mm/s, worst Phi rel err {worst:.3e}")
+    assert dr.max() < 1e-6 and dv.max() < 1e-9 and worst < 1e-9
+    # what the second field contributes to Phi: the same segment with the larger field alone
+    fields = [m for m in prop.dynamics.orbital_dyn.accel_models if isinstance(m, nx.GravityFieldData)]
+    small = min(fields, key=lambda f: f.degree)
+    one = nx.Propagator(nx.SpacecraftDynamics(nx.OrbitalDynamics([m for m in prop.dynamics.orbital_dyn.accel_models if m is not small]), []), prop.method, prop.opts)
+    seg1, _ = ctx.propagate(b, 60 * nx.NS_PER_S)
+    ref1, _ = oracle_lib.propagate(compiled, b, 60 * nx.NS_PER_S, n_threads=8)
+    alone, _ = oracle_lib.propagate(one.compile(almanac, frame, stm=True), b, 60 * nx.NS_PER_S, n_threads=8)
+    assert np.abs(ref1.stm - alone.stm).max() > 30 * np.abs(seg1.stm - ref1.stm).max()
+    # and the orbit of the STM run is the plain run's
+    plain = nx.GpuContext(prop.compile(almanac, frame))
+    pout, _ = plain.propagate(b, 60 * nx.NS_PER_S)
+    dr, dv = pos_vel_errors(seg1, pout)
+    assert dr.max() < 1e-6 and dv.max() < 1e-9
+    plain.close()
+    ctx.close()
 
 
 @pytest.mark.parametrize("centre,deg_earth,deg_moon,n,waves", [("earth", 21, 20, 70, 0), ("moon", 8, 70, 130, 16), ("moon", 6, 70, 1100, 0),
