@@ -245,7 +245,9 @@ typedef struct nyx_hip_tuning {
     int32_t debug_flags;       /* timing-only switches (0x100 skip the serial role work, 0x200 skip the harmonics): WRONG RESULTS;
                                 * 0x400 host trace; A/B switches with the SAME results: 0x800 no role offload, 0x1000 no segment-level almanac
                                 * units on a single almanac wave, 0x2000 packed Chebyshev records; schedule switches (another summation order):
-                                * 0x8000 the two-ended column fill everywhere, 0x10000 one contiguous run of columns per wave whatever the feed; 0x4000 full-range sincos for a polynomial
+                                * 0x8000 the two-ended column fill everywhere, 0x10000 one contiguous run of columns per wave whatever the feed,
+                                * 0x20000 owners / helpers rounded to multiples of eight, 0x40000 / 0x80000 two-part / one-part hand-off,
+                                * 0x100000 no mailbox pool (allocate and free per context); 0x4000 full-range sincos for a polynomial
                                 * IAU orientation every stage (results differ by the rounding of the large argument) */
     double coop_fraction;      /* 0 auto: share of the harmonics terms a helper takes */
     double coop_helper_ratio;  /* 0 auto: helper workgroups per trajectory-owning workgroup */
@@ -562,7 +564,21 @@ int32_t nyx_hip_ctx_set_tuning(nyx_hip_ctx *ctx, const nyx_hip_tuning_t *tuning)
 
 /* Number of helper workgroups of the last propagate launch on this ctx (0 = every workgroup worked alone).  Cooperative
  * mode is chosen automatically when the 64-trajectory workgroups leave CUs idle (propagate_kernel.hip);
- * tuning.cooperative = 0 or tuning.deterministic = 1 disables it. */
+ * tuning.cooperative = 0 or tuning.deterministic = 1 disables it.
+ *
+ * Cooperative mode - what the library relies on, and what it does not:
+ *   memory      the owner <-> helper mailboxes are one block of hipExtMallocWithFlags(hipDeviceMallocUncached) memory per context
+ *               (pooled per process and device, zeroed by hipMemsetAsync on the launch stream before every cooperative launch); it
+ *               is touched by device-scope RELAXED 8-byte atomic loads and stores and one compare-and-swap per job, nothing else;
+ *   visibility  every value travels as naturally aligned 8-byte granules {half of a double | sequence number << 32}; a reader
+ *               accepts a value when both tags carry the number it expects.  No ordering between two stores is assumed (no
+ *               fence, no drain, no flag behind the data); single-copy atomicity of an aligned 8-byte access is;
+ *   progress    NOT assumed.  Helpers may never become resident, or die: an owner waits at most 2 ms for an answer, then walks
+ *               the helper's columns itself (bit-identical to the answer it did not get) and finishes alone; every spin in the
+ *               kernel is bounded, a protocol error ends as a failed run (NYX_HIP_ERR_NAN) or a slow one, never as a hung device;
+ *   placement   NOT assumed: no workgroup -> CU / XCD mapping, no dispatch order.
+ * (tools/uncached_churn.hip exercises exactly this exchange stand-alone; tests/test_gpu_coop_contexts.py runs 40 cooperative contexts
+ *  in one process with and without the pool.) */
 int32_t nyx_hip_last_coop_helpers(nyx_hip_ctx *ctx);
 
 /* Elapsed device time (ms) of the kernels launched by the last propagate call on

@@ -133,16 +133,20 @@ struct nyx_hip_ctx {
 };
 #define CTX_LOCK(ctx) std::lock_guard<std::recursive_mutex> lock_((ctx)->mu)
 
-// Cooperative-mode mailboxes live in UNCACHED device memory (hipExtMallocWithFlags), and that kind of allocation must not be
-// churned: in round 3 the ~17th allocate / free cycle of one in a process handed back memory on which the owner <-> helper
-// exchange no longer worked (a cooperative launch that never finished, reproducibly, only after ~90 other tests).  The blocks
-// are therefore pooled per process and device: a context borrows one at its first cooperative launch and returns it when it
-// is destroyed; a block is never freed before the process ends.
+// Cooperative-mode mailboxes live in UNCACHED device memory (hipExtMallocWithFlags).  The blocks are pooled per process and device:
+// a context borrows one at its first cooperative launch and returns it when it is destroyed; a pooled block is never freed before
+// the process ends.  History: in round 3 the ~17th cooperative context of one process never finished (only behind ~90 other tests),
+// the pool and the zeroing of a workgroup's LDS went in together, and the hang was gone - attributed, without a reproducer, to
+// allocate / free churn of this kind of memory.  Round 4 looked for it and did NOT find it there: tools/uncached_churn.hip (the
+// exchange alone: 400 allocate / free cycles x 96 pairs x 300 round trips, with and without unrelated allocator traffic, no stall)
+// and tests/test_gpu_coop_contexts.py (40 cooperative contexts in one process with the pool switched OFF, debug_flags 0x100000:
+// every launch completes, bit-identical results).  What the library relies on is stated in include/nyx_hip.h ("Cooperative mode");
+// the pool stays because it saves an allocation and a 7 MB memset per context, not because freeing is known to be unsafe.
 struct MailboxBlock { int device; void *ptr; int64_t cap; };
 static std::mutex g_mailbox_mu;
 static std::vector<MailboxBlock> g_mailbox_free;
-static void *mailbox_acquire(int device, int64_t want_cap, int64_t *cap_out) {
-    {
+static void *mailbox_acquire(int device, int64_t want_cap, int64_t *cap_out, bool pooled = true) {
+    if (pooled) {
         std::lock_guard<std::mutex> lk(g_mailbox_mu);
         for (size_t k = 0; k < g_mailbox_free.size(); ++k)
             if (g_mailbox_free[k].device == device && g_mailbox_free[k].cap >= want_cap) {
@@ -159,8 +163,9 @@ static void *mailbox_acquire(int device, int64_t want_cap, int64_t *cap_out) {
     *cap_out = cap;
     return p;
 }
-static void mailbox_release(int device, void *ptr, int64_t cap) {
+static void mailbox_release(int device, void *ptr, int64_t cap, bool pooled = true) {
     if (!ptr) return;
+    if (!pooled) { (void)hipFree(ptr); return; }
     std::lock_guard<std::mutex> lk(g_mailbox_mu);
     g_mailbox_free.push_back(MailboxBlock{device, ptr, cap});
 }
@@ -972,7 +977,7 @@ extern "C" void nyx_hip_ctx_destroy(nyx_hip_ctx *ctx) {
     free_arrays(ctx->cal);
     (void)hipFree(ctx->d_swap);
     (void)hipFree(ctx->d_mom);
-    mailbox_release(ctx->device, ctx->d_coop, ctx->coop_cap);
+    mailbox_release(ctx->device, ctx->d_coop, ctx->coop_cap, !(ctx->tune.debug_flags & 0x100000));
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     if (ctx->ev_done) hipEventDestroy(ctx->ev_done);
@@ -1586,13 +1591,13 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
                     // the block goes back to the process-wide pool, where another context (another host thread) may take and clear it
                     // at once: not before every launch of THIS context that uses it has finished (the device entry points are asynchronous)
                     if (ctx->d_coop && ctx->launched) HIP_TRY(hipEventSynchronize(ctx->ev_done));
-                    mailbox_release(ctx->device, ctx->d_coop, ctx->coop_cap);
+                    mailbox_release(ctx->device, ctx->d_coop, ctx->coop_cap, !(ctx->tune.debug_flags & 0x100000));
                     ctx->d_coop = nullptr;
                     ctx->coop_cap = 0;
                     // uncached device memory: the mailboxes are coherent across the XCDs' L2s without any cache
                     // write-back / invalidate in the kernel (those would also flush the harmonics table out of L2)
                     int64_t got = 0;
-                    ctx->d_coop = (CoopBox *)mailbox_acquire(ctx->device, std::max<int64_t>(n_own, 256), &got);
+                    ctx->d_coop = (CoopBox *)mailbox_acquire(ctx->device, std::max<int64_t>(n_own, 256), &got, !(ctx->tune.debug_flags & 0x100000));
                     if (ctx->d_coop) {
                         ctx->coop_cap = got;
                         have_boxes = true;

@@ -1,0 +1,39 @@
+"""Cooperative mode across MANY contexts of one process.  Round 3 saw the ~17th cooperative context of a
+process never finish and answered with a per-process pool of mailbox blocks; round 4 could not reproduce a failure of the memory
+itself (tools/uncached_churn.hip).  Here: 40 contexts, each with a cooperative launch, created and destroyed one after the other -
+with the pool (one block reused) and WITHOUT it (debug_flags 0x100000: hipExtMallocWithFlags / hipFree per context): every launch
+completes in bounded time and gives the same bits."""
+import time
+
+import numpy as np
+import pytest
+
+import nyx_amd as nx
+from scenarios import dispersed_leo_batch, leo_full_setup
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("pooled", [True, False])
+def test_forty_cooperative_contexts_in_one_process(pooled):
+    prop, almanac, central = leo_full_setup(degree=70)
+    compiled = prop.compile(almanac, central)
+    b = dispersed_leo_batch(1500, seed=17)           # 24 owners, 24 helpers
+    dur = 5 * 60 * nx.NS_PER_S
+    first = None
+    slow = 0
+    for k in range(40):
+        t0 = time.time()
+        ctx = nx.GpuContext(compiled, tuning=nx.Tuning(debug_flags=0 if pooled else 0x100000))
+        out, st = ctx.propagate(b, dur)
+        helpers = ctx.last_coop_helpers()
+        ctx.close()
+        assert (st.status == 0).all() and helpers == 24, (k, helpers)
+        if time.time() - t0 > 5.0:      # (a launch is ~10 ms; an exchange that stopped working shows as 2 ms time-outs per evaluation)
+            slow += 1
+        if first is None:
+            first = (out.rv().copy(), st.n_evals.copy())
+        else:
+            np.testing.assert_array_equal(out.rv(), first[0])
+            np.testing.assert_array_equal(st.n_evals, first[1])
+    assert slow == 0
