@@ -528,13 +528,30 @@ def main():
         tout, sout = tensor_states(shard, dev)
         tst, sst = tensor_stats(n, dev)
 
+        # ensemble moments on the device (nyx_hip_ensemble_moments_device: count, sum(x - x0), sum((x - x0)(x - x0)^T) of the final
+        # 9-vectors = 55 doubles; x0 = the nominal start state, the same on every rank): what mean and covariance of the whole
+        # ensemble need from a rank is ONE all-reduce of these, no D2H of the states (north_star's "covariance reduction")
+        mom = torch.zeros(55, dtype=torch.float64, device=dev)
+        x0 = np.concatenate([full.rv()[0], [full.cr[0], full.cd[0], full.prop_mass_kg[0]]]).astype(np.float64)
+        x0_p = x0.ctypes.data_as(_abi.c_double_p)
+
         def step():
             rc = lib.nyx_hip_propagate_batch_device(ctx._h, C.byref(sin), dur_ns, C.byref(sout), C.byref(sst), C.c_void_p(stream.cuda_stream))
             if rc != 0:
                 raise RuntimeError(_abi.last_error())
-            if world > 1:  # final-state collection (one all-gather)
+            rc = lib.nyx_hip_ensemble_moments_device(ctx._h, C.byref(sout), C.c_void_p(tst["status"].data_ptr()), x0_p, C.c_void_p(mom.data_ptr()),
+                                                     C.c_void_p(stream.cuda_stream))
+            if rc != 0:
+                raise RuntimeError(_abi.last_error())
+            if world > 1:  # final-state collection (one all-gather) and the moments (one all-reduce of 55 doubles)
                 final = torch.stack([tout[f] for f in _abi.F64_FIELDS[:6]] + [tout["epoch_ns"].to(torch.float64)], dim=1)
                 gather_events.append(exchange(final))
+                if args.backend == "nccl":
+                    dist.all_reduce(mom)
+                else:
+                    mh = mom.cpu()
+                    dist.all_reduce(mh)
+                    mom.copy_(mh)
     else:
         # covariance mapping: the C-ABI entry takes host buffers (states, covariances) and keeps the whole segment /
         # time-update loop on one stream; the timed region therefore includes the one H2D and the one D2H of the call
@@ -626,6 +643,9 @@ def main():
                        "tuning": "nyx_hip_tuning_t defaults: NYX_HIP_SCHED_MODEL (process-independent column schedule), cooperative mode auto",
                        "sharding": "contiguous index shards, no data-path collective; one all-gather of final states per step"
                                    + (" (strong: ONE ensemble of the configuration's size cut over the ranks)" if args.scaling == "strong" else "")},
+            "ensemble_moments": (None if w["stm"] else {"count": float(mom[0].item()), "reduced_over_ranks": world,
+                                                        "trace_cov_pos_km2": float(((mom[10] + mom[19] + mom[27]) - (mom[1] ** 2 + mom[2] ** 2 + mom[3] ** 2) / mom[0]).item() / max(float(mom[0].item()) - 1.0, 1.0)),
+                                                        "note": "nyx_hip_ensemble_moments_device inside every timed step; N > 1: one all-reduce of 55 f64"}),
             "force_evals_per_s": ev_all / (elapsed / args.steps),
             "force_evals_per_launch": n_evals, "accepted_steps": n_acc, "rejected_attempts": n_rej,
             "kernel_ms": k_ms,

@@ -11,6 +11,8 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from kernel_stamp import kernel_source_stamp  # noqa: E402
 tag = sys.argv[1]
 cfgs = [int(x) for x in sys.argv[2:]] or [2, 3, 4, 5]
 CLOCK_HZ, SIMDS = 2.4e9, 1024
@@ -51,6 +53,12 @@ for cfg in cfgs:
     for k in sorted(c):
         out.append(f"| {k} | {c[k]:.6g} |")
     out += ["", "Derived:", ""]
+    if "SQ_INSTS_FLAT" in c and "SQ_INSTS_VALU" in c:
+        out.append(f"* memory instructions per launch: FLAT (scratch spills and generic pointers) {c['SQ_INSTS_FLAT']:.4g}, VMEM reads {c.get('SQ_INSTS_VMEM_RD', 0):.4g}, "
+                   f"VMEM writes {c.get('SQ_INSTS_VMEM_WR', 0):.4g}, LDS {c.get('SQ_INSTS_LDS', 0):.4g} against {c['SQ_INSTS_VALU']:.4g} VALU instructions "
+                   f"(FLAT / VALU = {c['SQ_INSTS_FLAT'] / c['SQ_INSTS_VALU']:.4f})")
+    if "SQ_WAIT_INST_ANY" in c and "SQ_WAVE_CYCLES" in c:
+        out.append(f"* SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES = {c['SQ_WAIT_INST_ANY'] / c['SQ_WAVE_CYCLES']:.3f} of the wave-cycles are spent waiting on an instruction's operands or pipe")
     if "SQ_ACTIVE_INST_VALU" in c:
         out.append(f"* VALU issue: SQ_ACTIVE_INST_VALU x 4 cycles = {c['SQ_ACTIVE_INST_VALU'] * 4:.4g} of {simd_cycles:.4g} SIMD-cycles "
                    f"(1024 SIMDs x kernel time x 2.4 GHz) = **{c['SQ_ACTIVE_INST_VALU'] * 4 / simd_cycles:.3f}** of all issue slots on the chip "
@@ -71,6 +79,7 @@ for cfg in cfgs:
     hours = {2: 24.0, 3: 720.0, 4: 1.0, 5: 72.0}[cfg]
     degree = {2: 70, 3: 0, 4: 21, 5: 150}[cfg]
     json.dump({"config": cfg, "n": n, "hours": hours, "degree": degree, "hbm_bytes_per_launch": traffic * launches,
+               "kernel_source_stamp": kernel_source_stamp(ROOT),
                "fetch_size_bytes_raw": fetch_b * launches, "write_size_bytes": write_b * launches,
                "note": "2 x FETCH_SIZE + WRITE_SIZE of the timed step (gfx950 correction of MI355X_MICROARCH.md), rocprofv3 --pmc, separate passes",
                "workload": w}, open(os.path.join(ROOT, "profiles", f"{tag}_cfg{cfg}_hbm_traffic.json"), "w"), indent=1)

@@ -15,7 +15,7 @@ DB=$(find $OUT/kt -name "*.db" | head -1)
 python tools/rocpd_summary.py "$DB" $OUT/kernel_trace_stats.md > /dev/null 2>&1 || echo "summary failed"
 head -6 $OUT/kernel_trace_stats.md
 [ -n "${SKIP_PMC:-}" ] && exit 0
-for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INSTS_SALU" "SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES"; do
+for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INSTS_SALU" "SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" "SQ_INSTS_FLAT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS"; do
   TAG=$(echo $C | tr ' ' '_')
   timeout 400 rocprofv3 --pmc $C -d $OUT/pmc_$TAG --output-format csv -- python bench.py --config $CFG --steps 1 --warmup 0 --no-cpu-baseline --no-dense-output --no-host-call > $OUT/pmc_$TAG.log 2>&1
 done
