@@ -435,7 +435,10 @@ static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, con
         // workgroups: fitted with tools/tune_schedule.py (windows of every wave -> rows that would equalise them -> weights, best
         // kernel time of 8-14 iterations, two boxes) on configs[1] at 10 000 (cooperative) and 16 384 trajectories (alone) and on
         // configs[4] (150x150, cooperative, helper jobs of several columns).  The role duties of the water-filling are unchanged.
-        static const double model_coop_blk[16] = {1.00, 1.48, 0.98, 1.90, 1.79, 1.44, 1.386, 1.264, 0.984, 0.83, 0.754, 0.69, 0.52, 0.362, 0.31, 0.302};
+        // (cooperative 70x70 table: fitted on the FULL day of configs[1] - the perturbation wave's duty grows over the day, 14 k -> 20 k cycles
+        //  per evaluation once the lanes' eclipse transitions no longer coincide, and a table fitted on the first three hours overloaded it:
+        //  719 -> 680 ms per 10 000 x 24 h, same box)
+        static const double model_coop_blk[16] = {1.00, 1.413, 0.549, 1.946, 1.892, 1.523, 1.588, 1.292, 1.066, 0.828, 0.937, 0.692, 0.430, 0.347, 0.357, 0.142};
         static const double model_coop_big_blk[16] = {1.00, 1.755, 1.706, 1.802, 1.733, 1.22, 1.246, 1.181, 1.087, 0.672, 0.621, 0.604, 0.549, 0.279, 0.284, 0.255};
         static const double model_solo_blk[16] = {1.00, 1.612, 1.263, 1.906, 1.764, 1.346, 1.331, 1.198, 1.113, 0.757, 0.659, 0.568, 0.513, 0.398, 0.291, 0.27};
         const bool blk = ctx->block_schedule && n_waves == DEV_MAX_WAVES && !ctx->sched_quad && ((ctx->host_cfg.harm_feed & 1) || ctx->block_force);

@@ -50,6 +50,15 @@
 #define NYX_EMIT_STM 4      /* D3 duals: at most DEV_MAX_WAVES_STM waves (dual-number harmonics need ~4x the registers) */
 #define NYX_EMIT_STMQ16 8   /* quad layout (16 trajectories per workgroup, four lanes per trajectory, D1 duals), sixteen waves */
 #define NYX_EMIT_STMQ8 16   /* quad layout, eight waves or fewer */
+#define NYX_EMIT_PLAIN16_P2 32 /* sixteen waves, cooperative launches whose hand-off has TWO parts (two helper workgroups per owner and evaluation) */
+// The two-part hand-off is a property of the TRANSLATION UNIT (NYX_COOP_TWO_PARTS, set by propagate_p2.hip), not a run-time branch:
+// the role code of the integrator is register-allocated around the mailbox calls, and the mere presence of the two-part calls in
+// the default kernel cost 3-5 % of the north-star run (8 h of propagation: 246.7 against 235.7 ms), whichever way they were folded.
+#ifdef NYX_COOP_TWO_PARTS
+#define COOP_PARTS_HERE 2
+#else
+#define COOP_PARTS_HERE 1
+#endif
 
 #define CAS __attribute__((address_space(4)))
 typedef const CAS DevCfg *CfgPtr;
@@ -1331,13 +1340,18 @@ DEVFN bool coop_get(const uint64_t *g, uint32_t seq, double &v) {
 // data simply polls the granules until their tags agree.
 // `parts` sub-jobs per evaluation (1, or 2: the helpers' columns in two halves, claimed by two helper workgroups): the words the
 // helpers scan count SUB-JOBS - posted = parts * seq; sub-job c (1, 2, ...) is part (c - 1) % parts of evaluation (c + parts - 1) / parts.
-// (`seq_p`: the sequence number, bit 31 set when the hand-off has two parts - the call keeps the argument list it always had)
-#define COOP_TWO_PARTS 0x80000000u
-static __device__ __attribute__((noinline)) void coop_post(CoopBox *box, uint32_t *posted, int lane, uint32_t seq_p, const double *inb) {
-    const uint32_t seq = seq_p & ~COOP_TWO_PARTS;
+// The single-part functions are kept exactly as small as they were before the two-part hand-off existed, and the two-part ones are
+// their own functions behind a uniform branch at the call site: measured on the north-star run (8 h of propagation), folding both into
+// one function with a run-time part count cost 2.8 % - the integrator's role code is register-allocated around these calls.
+static __device__ __attribute__((noinline)) void coop_post(CoopBox *box, uint32_t *posted, int lane, uint32_t seq, const double *inb) {
 #pragma unroll
     for (int q = 0; q < 5; ++q) coop_put(&box->in[seq & 1u][q][0][lane], inb[q * DEV_LANES + lane], seq);
-    if (lane == 0) coop_store(posted, (seq_p & COOP_TWO_PARTS) ? 2u * seq : seq);
+    if (lane == 0) coop_store(posted, seq);
+}
+static __device__ __attribute__((noinline)) void coop_post2(CoopBox *box, uint32_t *posted, int lane, uint32_t seq, const double *inb) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q) coop_put(&box->in[seq & 1u][q][0][lane], inb[q * DEV_LANES + lane], seq);
+    if (lane == 0) coop_store(posted, 2u * seq);  // (the scan words count SUB-JOBS)
 }
 
 struct CoopAnswer {
@@ -1346,13 +1360,29 @@ struct CoopAnswer {
 };
 // The answer needs no flag: every lane polls the LAST granule the helper writes for it, and when all of them carry this
 // evaluation's tag the other seven are read and checked the same way (they were stored earlier, but nothing orders them).
-static __device__ __attribute__((noinline)) CoopAnswer coop_wait(CoopBox *box, CoopOut *out2, int lane, uint32_t seq_p) {
+static __device__ __attribute__((noinline)) CoopAnswer coop_wait(CoopBox *box, int lane, uint32_t seq) {
     CoopAnswer a = {0.0, 0.0, 0.0, 0.0, 0};
     const int64_t t0 = (int64_t)__builtin_amdgcn_s_memrealtime();
-    const uint32_t seq = seq_p & ~COOP_TWO_PARTS;
     const unsigned par = seq & 1u;
-    const int parts = ((seq_p & COOP_TWO_PARTS) && out2 != nullptr) ? 2 : 1;
-    for (int part = 0; part < parts; ++part) {  // (the second part is added after the first: a fixed order, whichever helper answered first)
+    for (;;) {
+        const uint64_t last = coop_loadu(&box->out[par][3][1][lane]);
+        if (__all((uint32_t)(last >> 32) == seq)) {
+            const bool ok = coop_get(&box->out[par][0][0][lane], seq, a.x) & coop_get(&box->out[par][1][0][lane], seq, a.y) &
+                            coop_get(&box->out[par][2][0][lane], seq, a.z) & coop_get(&box->out[par][3][0][lane], seq, a.w);
+            if (__all(ok)) break;
+        }
+        if ((int64_t)__builtin_amdgcn_s_memrealtime() - t0 > COOP_TIMEOUT_TICKS) { a.x = a.y = a.z = a.w = 0.0; return a; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    a.ok = 1;
+    return a;
+}
+// two parts: part 0 from the mailbox, part 1 from the array of second answers, added in that order whichever helper answered first
+static __device__ __attribute__((noinline)) CoopAnswer coop_wait2(CoopBox *box, CoopOut *out2, int lane, uint32_t seq) {
+    CoopAnswer a = {0.0, 0.0, 0.0, 0.0, 0};
+    const int64_t t0 = (int64_t)__builtin_amdgcn_s_memrealtime();
+    const unsigned par = seq & 1u;
+    for (int part = 0; part < 2; ++part) {
         uint64_t *o = part ? &out2->out[par][0][0][0] : &box->out[par][0][0][0];  // [4][2][64] granules of this part
         double x, y, z, w;
         for (;;) {
@@ -1413,7 +1443,7 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
     int *ctl = (int *)(inl + 2 * 5 * DEV_LANES);
     const LdsFlagPtr ready = (LdsFlagPtr)ctl, answered = (LdsFlagPtr)ctl + 2, jown = (LdsFlagPtr)ctl + 4, jseq = (LdsFlagPtr)ctl + 6, jpart = (LdsFlagPtr)ctl + 10;
     int *cnt = ctl + 8;
-    const int parts = bt.coop_parts > 1 ? DEV_COOP_PARTS : 1;
+    constexpr int parts = COOP_PARTS_HERE;
     const int answer_wave = (int)(blockDim.x / DEV_LANES) - 1;
     const int n_col_waves = answer_wave - 1;
     if (wave == 0 || wave == answer_wave) {
@@ -1461,8 +1491,8 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
                     // shadow of the compare-and-swap (they were complete before `posted` moved): one memory round trip, not two.
                     const int owner_c = (int)__shfl((int)mine, pick);
                     const uint32_t sub_c = (uint32_t)__shfl((int)claimed, pick) + 1u;           // the sub-job being claimed (1, 2, ...)
-                    const uint32_t seq_c = (sub_c + (uint32_t)parts - 1u) / (uint32_t)parts;   // its evaluation ...
-                    const int part_c = (int)((sub_c - 1u) % (uint32_t)parts);                  // ... and which part of the hand-off
+                    const uint32_t seq_c = parts == 2 ? (sub_c + 1u) >> 1 : sub_c;             // its evaluation ...
+                    const int part_c = parts == 2 ? (int)((sub_c - 1u) & 1u) : 0;              // ... and which part of the hand-off
                     int won = 0;
                     if (lane == pick) {
                         uint32_t expect = claimed;
@@ -2197,7 +2227,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     // cooperative mode (see above): the integrator owns the conversation with the helper
     CoopBox *const cbox = bt.coop_box + blockIdx.x;
     const int coop_widx = bt.coop_sets > 0 ? ((int)blockIdx.x % bt.coop_sets) * COOP_SET + (int)blockIdx.x / bt.coop_sets : 0;
-#define coop_two (bt.coop_parts > 1 ? COOP_TWO_PARTS : 0u) /* (read from the launch descriptor where it is used: nothing more to keep live in the role code) */
+#define coop_two (COOP_PARTS_HERE == 2) /* (compile-time: see NYX_COOP_TWO_PARTS) */
     bool coop_on = !STM && LCTL[1] != 0;
     const bool coop_started = coop_on;
     uint32_t coop_seq = 0;
@@ -2458,7 +2488,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             // ---- window --------------------------------------------------------------------------
             if (INTEG && !STM && coop_on && has_grav && (!pipe || (i == 0 && !spec_now))) {
                 seq_cur = ++coop_seq;
-                coop_post(cbox, bt.coop_posted + coop_widx, lane, seq_cur | coop_two, L.inb);
+                if (coop_two) coop_post2(cbox, bt.coop_posted + coop_widx, lane, seq_cur, L.inb); else coop_post(cbox, bt.coop_posted + coop_widx, lane, seq_cur, L.inb);
             }
             const bool last_stage = i + 1 == stages;
             if (ALMANAC && need_almanac && (!last_stage || reuse_nf > 0 || spec)) {
@@ -2662,7 +2692,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     if (lane == 0) L.ctl[1] = coop_on ? 1 : 0;  // the workers read it after B2(i), for stage i+1
                     if (coop_on) {
                         seq_nx = ++coop_seq;
-                        coop_post(cbox, bt.coop_posted + coop_widx, lane, seq_nx | coop_two, inbn);
+                        if (coop_two) coop_post2(cbox, bt.coop_posted + coop_widx, lane, seq_nx, inbn); else coop_post(cbox, bt.coop_posted + coop_widx, lane, seq_nx, inbn);
                     }
                 }
             }
@@ -2744,7 +2774,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             }
             if (INTEG && !STM && has_grav && (pipe ? shared_cur : coop_on)) {
                 // the helper's answer is collected INSIDE the window (this wave has nothing else to do): phase C never waits
-                const CoopAnswer ans = coop_on ? coop_wait(cbox, bt.coop_out2 ? bt.coop_out2 + blockIdx.x : nullptr, lane, seq_cur | coop_two) : CoopAnswer{0.0, 0.0, 0.0, 0.0, 0};
+                const CoopAnswer ans = !coop_on ? CoopAnswer{0.0, 0.0, 0.0, 0.0, 0} : (coop_two ? coop_wait2(cbox, bt.coop_out2 + blockIdx.x, lane, seq_cur) : coop_wait(cbox, lane, seq_cur));
                 if (ans.ok) {
                     coop_x = ans.x; coop_y = ans.y; coop_z = ans.z; coop_w = ans.w;
                     ++dbg_answers;
@@ -3166,12 +3196,16 @@ NYX_KERNEL(nyx_propagate_kernel_stmq, DEV_MAX_WAVES *DEV_LANES, true, true)
 #if NYX_EMIT & NYX_EMIT_STMQ8
 NYX_KERNEL(nyx_propagate_kernel_stmq_w8, 8 * DEV_LANES, true, true, false)
 #endif
+#if NYX_EMIT & NYX_EMIT_PLAIN16_P2
+NYX_KERNEL(nyx_propagate_kernel_p2, DEV_MAX_WAVES *DEV_LANES, false)
+#endif
 
 #if NYX_EMIT & NYX_EMIT_PLAIN16
 NYX_KERNEL_DECL(nyx_propagate_kernel_w8)
 NYX_KERNEL_DECL(nyx_propagate_kernel_stm)
 NYX_KERNEL_DECL(nyx_propagate_kernel_stmq)
 NYX_KERNEL_DECL(nyx_propagate_kernel_stmq_w8)
+NYX_KERNEL_DECL(nyx_propagate_kernel_p2)
 extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg, const HarmEntry *htab,
                                            const ColHdr *cols, const double *records, int n_waves, int rec_lds_doubles,
                                            int reuse_fields, hipStream_t stream, int quad) {
@@ -3192,6 +3226,7 @@ extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg
             (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_stmq, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_w8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_stmq_w8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_p2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (devid >= 0 && devid < 64) attr_set[devid] = true;
         }
     }
@@ -3209,7 +3244,8 @@ extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg
                            htab, cols, records);
     else {
         const int64_t grid = bt.coop_helpers > 0 ? (int64_t)bt.coop_base + bt.coop_helpers : blocks;
-        hipLaunchKernelGGL((small && bt.coop_helpers == 0) ? nyx_propagate_kernel_w8 : nyx_propagate_kernel, dim3((unsigned)grid),
+        const bool two_parts = bt.coop_helpers > 0 && bt.coop_parts == 2 && bt.coop_out2 != nullptr;  // (its own kernel: NYX_COOP_TWO_PARTS)
+        hipLaunchKernelGGL((small && bt.coop_helpers == 0) ? nyx_propagate_kernel_w8 : (two_parts ? nyx_propagate_kernel_p2 : nyx_propagate_kernel), dim3((unsigned)grid),
                            dim3((unsigned)(n_waves * DEV_LANES)), lds, stream, btl, cfg, htab, cols, records);
     }
     return hipGetLastError();

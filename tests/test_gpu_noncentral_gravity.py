@@ -214,3 +214,36 @@ def test_two_stacked_fields_vs_oracle(centre, deg_earth, deg_moon, n, waves):
         print(f"   step decisions equal for {same.sum()} of {len(sample)} sampled trajectories; accepted {int(rst.n_accepted.min())}-{int(rst.n_accepted.max())}, "
               f"rejected up to {int(rst.n_rejected.max())}; last step sizes agree to {rel.max():.1e}")
         assert same.all() and rel.max() < 5e-3   # (the NEXT step is 0.9 h (tol / err)^(1/9): the error estimate, ~1e-13, carries the summation order in its third digit)
+
+
+@pytest.mark.parametrize("stm", [False, True])
+def test_second_field_orientation_leaving_its_coverage_is_reported(stm):
+    """the second field's orientation is evaluated by the perturbation wave, and a binary-PCK orientation whose
+    coverage the epoch leaves used to be clamped silently there (the first field and the bodies need not share that segment).  The
+    Moon's field as the SECOND field of an Earth-centred run, its orientation a Chebyshev Euler-angle segment covering ONE day: inside
+    the coverage device == oracle, beyond it every trajectory ends with NYX_HIP_ERR_EPHEM_RANGE on both sides."""
+    from nyx_amd import _abi
+    from rotation_cases import euler_rotation_like
+    from scenarios import EPOCH0_NS, JGM3_PATH, iau_earth_frame, almanac_earth, earth_frame, kaula_field
+    from nyx_amd import ephem
+    moon_bpc = nx.Frame(nx.MOON, ephem.MU_MOON, ephem.R_MOON, euler_rotation_like(nx.IAU_MOON_ROTATION_POLY, nx.to_seconds(EPOCH0_NS) - 600.0, 1.0))
+    earth_field = nx.GravityFieldData.from_packed_file(JGM3_PATH, iau_earth_frame(), 12, 12)
+    moon_field = kaula_field(8, seed=1, frame=moon_bpc)
+    dyn = nx.SpacecraftDynamics(nx.OrbitalDynamics([nx.PointMasses([nx.MOON, nx.SUN]), earth_field, moon_field]), [])
+    prop = nx.Propagator(dyn, nx.IntegratorMethod.RungeKutta89, nx.IntegratorOptions())
+    almanac, frame = almanac_earth(), earth_frame(ephem.MU_EARTH)
+    compiled = prop.compile(almanac, frame, stm=stm)
+    b = _earth_centred(nc.batch(5, seed=3), almanac)
+    if stm:
+        b = _stm_batch(b)
+    ctx = nx.GpuContext(compiled)
+    out, st = ctx.propagate(b, 3600 * nx.NS_PER_S)
+    ref, rst = oracle_lib.propagate(compiled, b, 3600 * nx.NS_PER_S, n_threads=4)
+    assert (st.status == 0).all() and (rst.status == 0).all()
+    dr, dv = pos_vel_errors(out, ref)
+    assert dr.max() < 1e-6 and dv.max() < 1e-9
+    out2, st2 = ctx.propagate(b, 25 * 3600 * nx.NS_PER_S)
+    _, rst2 = oracle_lib.propagate(compiled, b, 25 * 3600 * nx.NS_PER_S, n_threads=8)
+    assert (rst2.status == _abi.ERR_EPHEM_RANGE).all()
+    assert (st2.status == _abi.ERR_EPHEM_RANGE).all()
+    ctx.close()
