@@ -1618,7 +1618,7 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
                     bt.coop_posted = words; bt.coop_claimed = words + (ctx->coop_cap + 64); bt.coop_finished = words + 2 * (ctx->coop_cap + 64);
                     bt.coop_sets = (int32_t)((n_own + 15) / 16);
                     bt.coop_parts = ctx->coop_parts;
-                    bt.coop_mute = ctx->tune.coop_mute ? 1 : 0;
+                    bt.coop_mute = (ctx->tune.coop_mute ? 1 : 0) | ((ctx->tune.debug_flags & 0x200000) ? 2 : 0);  // (bit 1: helpers fetch a job's inputs speculatively, before they know they won its claim)
                     ctx->last_coop_helpers = (int)helpers;
                 }
             }

@@ -1364,6 +1364,12 @@ static __device__ __attribute__((noinline)) CoopAnswer coop_wait(CoopBox *box, i
     CoopAnswer a = {0.0, 0.0, 0.0, 0.0, 0};
     const int64_t t0 = (int64_t)__builtin_amdgcn_s_memrealtime();
     const unsigned par = seq & 1u;
+    // (poll ONE granule - lane 0's last one, a single request - until it carries the tag: the traffic of 157 polling owners is
+    //  not free, the exchange is faster with less of it; then every lane checks its own)
+    while ((uint32_t)(coop_loadu(&box->out[par][3][1][0]) >> 32) != seq) {
+        if ((int64_t)__builtin_amdgcn_s_memrealtime() - t0 > COOP_TIMEOUT_TICKS) return a;
+        __builtin_amdgcn_s_sleep(1);
+    }
     for (;;) {
         const uint64_t last = coop_loadu(&box->out[par][3][1][lane]);
         if (__all((uint32_t)(last >> 32) == seq)) {
@@ -1385,6 +1391,10 @@ static __device__ __attribute__((noinline)) CoopAnswer coop_wait2(CoopBox *box, 
     for (int part = 0; part < 2; ++part) {
         uint64_t *o = part ? &out2->out[par][0][0][0] : &box->out[par][0][0][0];  // [4][2][64] granules of this part
         double x, y, z, w;
+        while ((uint32_t)(coop_loadu(o + (3 * 2 + 1) * DEV_LANES) >> 32) != seq) {  // (one granule, one request: see coop_wait)
+            if ((int64_t)__builtin_amdgcn_s_memrealtime() - t0 > COOP_TIMEOUT_TICKS) return a;
+            __builtin_amdgcn_s_sleep(1);
+        }
         for (;;) {
             const bool there = (uint32_t)(coop_loadu(o + (3 * 2 + 1) * DEV_LANES + lane) >> 32) == seq;
             if (__all(there)) {
@@ -1503,17 +1513,26 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
                     const unsigned par = seq_c & 1u;
                     // (measured: fetching only after the claim has succeeded costs 7 % of the north-star run - the helper's job
                     //  latency is what bounds its share)
-                    double v0, v1, v2, v3, v4;
-                    bool got = coop_get(&b->in[par][0][0][lane], seq_c, v0) & coop_get(&b->in[par][1][0][lane], seq_c, v1) &
-                               coop_get(&b->in[par][2][0][lane], seq_c, v2) & coop_get(&b->in[par][3][0][lane], seq_c, v3) &
-                               coop_get(&b->in[par][4][0][lane], seq_c, v4);
+                    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0;
+                    bool got = false;
+                    // Fetch the inputs only AFTER the claim has succeeded.  (Rounds 1-3 fetched them in the shadow of the compare-and-swap -
+                    // measured then as 7 % faster; with the tagged-granule transport the opposite holds: every lost race was 5 KB of
+                    // uncached reads, and the north-star run is 5.5 % FASTER without them - 719.5 -> 679.8 ms, same box.  coop_mute bit 1
+                    // = debug_flags 0x200000 restores the speculative fetch.)
+                    const bool lazy = (bt.coop_mute & 2) == 0;
+                    if (!lazy)
+                        got = coop_get(&b->in[par][0][0][lane], seq_c, v0) & coop_get(&b->in[par][1][0][lane], seq_c, v1) &
+                              coop_get(&b->in[par][2][0][lane], seq_c, v2) & coop_get(&b->in[par][3][0][lane], seq_c, v3) &
+                              coop_get(&b->in[par][4][0][lane], seq_c, v4);
                     if (__shfl(won, pick)) {
                         // the job is ours; its inputs were stored before the sequence number, but nothing orders the two: poll until
                         // every granule carries the tag (normally the first look already does)
                         const int64_t tw = (int64_t)__builtin_amdgcn_s_memrealtime();
+                        bool first = lazy;
                         while (!__all(got)) {
                             if ((int64_t)__builtin_amdgcn_s_memrealtime() - tw > 100 * COOP_TIMEOUT_TICKS) break;  // (0.2 s: the owner has long given up on us)
-                            __builtin_amdgcn_s_sleep(1);
+                            if (!first) __builtin_amdgcn_s_sleep(1);
+                            first = false;
                             got = coop_get(&b->in[par][0][0][lane], seq_c, v0) & coop_get(&b->in[par][1][0][lane], seq_c, v1) &
                                   coop_get(&b->in[par][2][0][lane], seq_c, v2) & coop_get(&b->in[par][3][0][lane], seq_c, v3) &
                                   coop_get(&b->in[par][4][0][lane], seq_c, v4);
@@ -1530,7 +1549,7 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
                 }
                 const uint32_t fin = has ? coop_load(bt.coop_finished + widx) : 1u;
                 if (__all(fin != 0u)) { owner = -1; break; }
-                __builtin_amdgcn_s_sleep(8);  // ~0.2 us between scans: the set's words are one memory line shared by ~10 helpers
+                __builtin_amdgcn_s_sleep(8);  // ~0.2 us between scans: the set's words are one memory line shared by ~10 helpers (scanning 2-5x less often: no change)
             }
             if (lane == 0) { jown[s] = owner; jseq[s] = (int)seq; jpart[s] = sub; }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
