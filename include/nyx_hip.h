@@ -292,8 +292,12 @@ typedef struct nyx_hip_config {
      * body w.r.t. the integration centre.  nyx_hip_propagate_batch[_device] and nyx_hip_propagate_until_epoch then translate every
      * state into the integration frame at its start epoch (position AND velocity of the chain, no aberration: what
      * almanac.transform_to(orbit, frame, None) does between two frames of one orientation), propagate, and translate the final
-     * state back at its final epoch.  0 (the integration centre itself) or a body without a chain: no swap.  The entry points
-     * that record trajectories, search events or map covariances refuse a swap (NYX_HIP_RC_UNSUPPORTED). */
+     * state back at its final epoch.  0 (the integration centre itself) or a body without a chain: no swap.
+     * With dense output (nyx_hip_traj_t) the reference's `Traj` is reproduced as it is built (instance.rs:297-326): entry 0 is the
+     * start state in the CALLER's frame, every published state is in the INTEGRATION frame, only the returned final state is
+     * translated back.  nyx_hip_predict_until translates in and out per segment, as the reference's loop of `until_epoch` calls does
+     * (od/process/mod.rs:440-486).  The event search refuses a swap (NYX_HIP_RC_UNSUPPORTED): the reference returns from inside its
+     * loop there without translating back (instance.rs:243-250). */
     int32_t state_frame_body;
     int32_t _pad_cfg;
     const nyx_hip_tuning_t *tuning; /* NULL => NYX_HIP_TUNING_DEFAULT (ABI v4) */

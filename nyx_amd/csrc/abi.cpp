@@ -32,7 +32,8 @@ extern "C" hipError_t nyx_launch_traj_eval(const TrajEvalArgs *args, hipStream_t
 extern "C" hipError_t nyx_launch_moments(const MomArgs &a, double *out, hipStream_t stream);
 extern "C" hipError_t nyx_launch_frame_shift(const DevCfg *cfg, const double *records, const int32_t *chain_seg, const double *chain_sign,
                                              int n_chain, int64_t n, const int64_t *epoch_ns, double *x, double *y, double *z, double *vx,
-                                             double *vy, double *vz, double dir, int32_t *status, const int32_t *prior, hipStream_t stream);
+                                             double *vy, double *vz, double dir, int32_t *status, const int32_t *prior, const int64_t *dur_ns,
+                                             hipStream_t stream);
 extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg, const HarmEntry *htab,
                                            const ColHdr *cols, const double *records, int n_waves, int rec_lds_doubles,
                                            int reuse_fields, hipStream_t stream, int quad);
@@ -1455,8 +1456,13 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
     if (ctx->swap_n_chain > 0 && !swapped && !calibrating) {
         // opts.integration_frame (instance.rs:117-142, 211-220): translate a COPY of the Cartesian state into the integration frame
         // at the start epochs, propagate that, translate the final states back at their own epochs
-        if (traj || dur_ns || ev) {
-            nyx_set_error("integration-frame swap: only the plain propagation entry points take states of another frame");
+        // Dense output and per-trajectory durations go through (round 4).  What the reference's `Traj` holds then (instance.rs:297-326
+        // around :117-142): the START state as it was handed in - its own frame -, every published state in the INTEGRATION frame (the
+        // channel is fed inside the loop, the translation back is applied to the returned state only, :211-220).  Reproduced as is:
+        // entry 0 of the dense output is rewritten with the caller's state below.  The event search is still refused: there the
+        // reference returns from inside the loop without translating back (:243-250) - a state whose frame depends on how the run ended.
+        if (ev) {
+            nyx_set_error("integration-frame swap: the event search does not take states of another frame");
             return NYX_HIP_RC_UNSUPPORTED;
         }
         if (ctx->launched) HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_done, 0));  // (the copy below is shared by the launches of this context)
@@ -1479,11 +1485,16 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
         int32_t *fwd_status = (int32_t *)(ctx->d_swap + (size_t)6 * (size_t)ctx->swap_cap);
         HIP_TRY(hipMemsetAsync(fwd_status, 0, (size_t)in->n * sizeof(int32_t), stream));
         HIP_TRY(nyx_launch_frame_shift(ctx->d_cfg, ctx->d_records, ctx->swap_seg, ctx->swap_sign, ctx->swap_n_chain, in->n, in->epoch_ns,
-                                       rows[0], rows[1], rows[2], rows[3], rows[4], rows[5], +1.0, fwd_status, nullptr, stream));
-        if (int rc = launch(ctx, &in2, out, st, duration_ns, end_epoch_ns, use_end, stream, time_it, nullptr, nullptr, nullptr, false, true)) return rc;
+                                       rows[0], rows[1], rows[2], rows[3], rows[4], rows[5], +1.0, fwd_status, nullptr, dur_ns, stream));
+        if (int rc = launch(ctx, &in2, out, st, duration_ns, end_epoch_ns, use_end, stream, time_it, traj, dur_ns, nullptr, false, true)) return rc;
+        if (traj && traj->capacity > 0) {  // entry 0 (step-major: the first n elements of every array) = the state in the caller's frame
+            double *dst[6] = {traj->x_km, traj->y_km, traj->z_km, traj->vx_km_s, traj->vy_km_s, traj->vz_km_s};
+            for (int q = 0; q < 6; ++q)
+                if (dst[q]) HIP_TRY(hipMemcpyAsync(dst[q], src[q], (size_t)in->n * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        }
         HIP_TRY(nyx_launch_frame_shift(ctx->d_cfg, ctx->d_records, ctx->swap_seg, ctx->swap_sign, ctx->swap_n_chain, in->n, out->epoch_ns,
                                        out->x_km, out->y_km, out->z_km, out->vx_km_s, out->vy_km_s, out->vz_km_s, -1.0, st ? st->status : nullptr,
-                                       fwd_status, stream));
+                                       fwd_status, dur_ns, stream));
         HIP_TRY(hipEventRecord(ctx->ev_done, stream));
         return NYX_HIP_RC_OK;
     }

@@ -199,9 +199,13 @@ struct FrameChain {
 // trajectory's epoch); dir = +1 into the integration frame, -1 back.  One thread per trajectory.
 __global__ __launch_bounds__(256) void nyx_frame_shift_kernel(const DevCfg *cfg_g, const double *records, FrameChain ch, int64_t n,
                                                               const int64_t *epoch_ns, double *x, double *y, double *z, double *vx,
-                                                              double *vy, double *vz, double dir, int32_t *status, const int32_t *prior) {
+                                                              double *vy, double *vz, double dir, int32_t *status, const int32_t *prior,
+                                                              const int64_t *dur_ns) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    // per-trajectory durations (the covariance-mapping loop): a run that has reached its end is not propagated by the reference any
+    // more - it is not translated either ((x + b) - b is not x)
+    if (dur_ns && dur_ns[i] == 0) return;
     CfgPtr cfg = (CfgPtr)cfg_g;
     const double et = ns_to_seconds(epoch_ns[i]);
     double b[3] = {0.0, 0.0, 0.0}, bv[3] = {0.0, 0.0, 0.0};
@@ -219,13 +223,14 @@ __global__ __launch_bounds__(256) void nyx_frame_shift_kernel(const DevCfg *cfg_
 }
 extern "C" hipError_t nyx_launch_frame_shift(const DevCfg *cfg, const double *records, const int32_t *chain_seg, const double *chain_sign,
                                              int n_chain, int64_t n, const int64_t *epoch_ns, double *x, double *y, double *z, double *vx,
-                                             double *vy, double *vz, double dir, int32_t *status, const int32_t *prior, hipStream_t stream) {
+                                             double *vy, double *vz, double dir, int32_t *status, const int32_t *prior, const int64_t *dur_ns,
+                                             hipStream_t stream) {
     FrameChain ch;
     ch.n_chain = n_chain;
     for (int k = 0; k < 4; ++k) { ch.seg[k] = k < n_chain ? chain_seg[k] : 0; ch.sign[k] = k < n_chain ? chain_sign[k] : 0.0; }
     if (n <= 0) return hipSuccess;
     hipLaunchKernelGGL(nyx_frame_shift_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, cfg, records, ch, n, epoch_ns, x, y, z,
-                       vx, vy, vz, dir, status, prior);
+                       vx, vy, vz, dir, status, prior, dur_ns);
     return hipGetLastError();
 }
 #endif

@@ -42,10 +42,10 @@ class ProcessNoise3D:
         return me
 
     @classmethod
-    def from_diagonal(cls, values: Sequence[float], disable_time_ns: int):
+    def from_diagonal(cls, values: Sequence[float], disable_time_ns: int, local_frame: Optional[str] = None):
         """snc.rs:108-135."""
         assert len(values) == 3, "Not enough values for the size of the SNC matrix"
-        return cls([float(v) for v in values], int(disable_time_ns))
+        return cls([float(v) for v in values], int(disable_time_ns), local_frame=local_frame)
 
     @classmethod
     def with_start_time(cls, disable_time_ns: int, values: Sequence[float], start_time_ns: int):

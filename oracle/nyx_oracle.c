@@ -1582,9 +1582,12 @@ static void run_one(const job_t *jb, inst_t *s, int64_t i) {
     s->traj = jb->traj;
     if (jb->traj) jb->traj->len[i] = 0;
     const nyx_hip_config_t *cfg = jb->p->cfg;
-    const int swap = !jb->traj && cfg->state_frame_body > 0 && cfg->state_frame_body < cfg->n_bodies && cfg->bodies[cfg->state_frame_body].n_chain > 0;
-    if (swap) (void)frame_shift(cfg, cfg->state_frame_body, s->epoch_ns, s->y, +1.0);  /* instance.rs:117-142 */
+    const int swap = cfg->state_frame_body > 0 && cfg->state_frame_body < cfg->n_bodies && cfg->bodies[cfg->state_frame_body].n_chain > 0;
+    /* with a trajectory (instance.rs:297-326): `start_state = self.state` is taken BEFORE propagate() translates the state, the channel is
+     * fed inside the loop (integration frame, :188-193, :254-259) and only the RETURNED state is translated back (:211-220): the Traj
+     * holds its first state in the caller's frame and every other one in the integration frame.  Restated as is. */
     traj_push(s);
+    if (swap) (void)frame_shift(cfg, cfg->state_frame_body, s->epoch_ns, s->y, +1.0);  /* instance.rs:117-142 */
     int st = propagate(s, jb->duration_ns);
     if (swap) {  /* instance.rs:211-220; an epoch outside the ephemeris is reported by this translation */
         const int s2 = frame_shift(cfg, cfg->state_frame_body, s->epoch_ns, s->y, -1.0);
@@ -1913,8 +1916,16 @@ int32_t nyx_oracle_predict_until(const nyx_hip_config_t *cfg, const nyx_hip_stat
         const int64_t init_epoch = s->epoch_ns; /* ProcessNoise::init_epoch = the initial estimate's epoch (kalman/initializers.rs:75) */
         int32_t n_up = 0;
         int st = NYX_HIP_OK;
+        /* opts.integration_frame: every segment is one `prop.until_epoch` (mod.rs:453-468), i.e. one translation in and one back
+         * (instance.rs:117-142, 211-220); the STM does not see a translation */
+        const int swap = cfg->state_frame_body > 0 && cfg->state_frame_body < cfg->n_bodies && cfg->bodies[cfg->state_frame_body].n_chain > 0;
         for (;;) {
+            if (swap) (void)frame_shift(cfg, cfg->state_frame_body, s->epoch_ns, s->y, +1.0);
             st = propagate(s, pc->max_step_ns);
+            if (swap) {
+                const int s2 = frame_shift(cfg, cfg->state_frame_body, s->epoch_ns, s->y, -1.0);
+                if (s2 && st == NYX_HIP_OK) st = s2;
+            }
             if (st) break;
             const double *stm = s->y + 9;
             double m[81], cb[81];

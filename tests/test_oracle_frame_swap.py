@@ -53,3 +53,58 @@ def test_mirror_resolves_the_frames():
     # an integration frame equal to the state's frame is no swap (instance.rs:118-119)
     prop.opts = dataclasses.replace(prop.opts, integration_frame=MOON_FRAME)
     assert prop.compile(almanac, MOON_FRAME, state_frame=MOON_FRAME).cfg.state_frame_body == 0
+
+
+def test_trajectory_of_a_swapped_run_is_the_references_mixture():
+    """instance.rs:297-326 around :117-142 / :211-220: `start_state` is taken before propagate() translates the state, the channel is
+    fed inside the loop and only the returned state is translated back - the Traj's first state is in the caller's frame, every
+    other one in the integration frame.  The oracle restates that as it is."""
+    prop, almanac, earth = setup()
+    b = moon_batch(4, seed=2)
+    dur = 30 * 60 * nx.NS_PER_S
+    swapped = prop.compile(almanac, earth, state_frame=MOON_FRAME)
+    out, st, traj = oracle_lib.propagate_with_traj(swapped, b, dur, 256)
+    plain_out, plain_st = oracle_lib.propagate(swapped, b, dur)
+    assert (st.status == 0).all()
+    np.testing.assert_array_equal(out.rv(), plain_out.rv())            # recording changes nothing
+    np.testing.assert_array_equal(st.n_accepted, plain_st.n_accepted)
+    assert (traj.len == st.n_accepted + 1).all()
+    for i in range(b.n):
+        ep, rv = traj.trajectory(i)
+        np.testing.assert_array_equal(rv[0], b.rv()[i])                # the start state: Moon-centred, untouched
+        assert ep[0] == b.epoch_ns[i] and ep[-1] == out.epoch_ns[i]
+        assert np.all(np.linalg.norm(rv[1:, :3], axis=1) > 3.0e5)      # every published state: Earth-centred
+        r, v = chain_state_numpy(almanac, nx.MOON, int(ep[-1]))        # the last one, translated back by hand, is the returned state
+        assert np.abs(rv[-1, :3] - r - out.rv()[i, :3]).max() < 1e-6 and np.abs(rv[-1, 3:] - v - out.rv()[i, 3:]).max() < 1e-9
+
+
+def test_covariance_map_of_a_swapped_run():
+    """od/process/mod.rs:453-468: every segment is one `until_epoch`, i.e. one translation in and one back.  A translation does not
+    touch the STM: the mapped covariance of the Moon-centred formulation equals the one of the same states handed in Earth-centred."""
+    from scenarios import EPOCH0_NS
+    prop, almanac, earth = setup()
+    b = moon_batch(3, seed=5)
+    b.epoch_ns[:] = EPOCH0_NS
+    b.stm = np.zeros((b.n, 81))
+    b.reset_stm()
+    rng = np.random.default_rng(0)
+    p0 = np.zeros((b.n, 9, 9))
+    for i in range(b.n):
+        a = rng.standard_normal((9, 9)) * np.array([1.0, 1.0, 1.0, 1e-3, 1e-3, 1e-3, 1e-2, 0.0, 0.0])[:, None]
+        p0[i] = a @ a.T
+    end = EPOCH0_NS + 5 * 60 * nx.NS_PER_S
+    swapped = prop.compile(almanac, earth, stm=True, state_frame=MOON_FRAME)
+    plain = prop.compile(almanac, earth, stm=True)
+    got = oracle_lib.predict_until(swapped, b, p0, end, 60 * nx.NS_PER_S, history=5)
+    e = b.copy()
+    rv = b.rv().copy()
+    for i in range(b.n):
+        r, v = chain_state_numpy(almanac, nx.MOON, int(b.epoch_ns[i]))
+        rv[i, :3] += r
+        rv[i, 3:] += v
+    e.set_rv(rv)
+    ref = oracle_lib.predict_until(plain, e, p0, end, 60 * nx.NS_PER_S, history=5)
+    assert (got.stats.status == 0).all() and (got.n_updates == 5).all() and (ref.n_updates == 5).all()
+    assert np.all(np.linalg.norm(got.states.rv()[:, :3], axis=1) < 2200.0)       # handed back Moon-centred
+    scale = np.abs(ref.covar).max(axis=(-2, -1), keepdims=True)
+    assert (np.abs(got.covar - ref.covar) / scale).max() < 1e-7                  # (positions differ by the 0.1 mm of the hand translation)
