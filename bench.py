@@ -431,6 +431,9 @@ def main():
     ap.add_argument("--oversubscribe", action="store_true",
                     help="allow more ranks than devices (rank r -> device r mod devices; RCCL refuses two ranks on one device: use --backend gloo)")
     ap.add_argument("--single-process", action="store_true", help="one process, every device through nyx_hip_propagate_batch_sharded")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="initialise the process group and run the all-gather / all-reduce of every step even with ONE rank "
+                         "(exercises the RCCL path on a 1-GPU box; the line says so in `launch`)")
     ap.add_argument("--selftest-launch", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-output", action="store_true", help="skip the extra launch with the trajectories recorded")
@@ -475,8 +478,15 @@ def main():
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
     dist = None
-    if world > 1:
+    coll = world > 1 or args.force_collectives   # the collectives of a step are issued (N > 1, or asked for with one rank)
+    if coll:
         import torch.distributed as dist  # noqa: F811
+        if world == 1 and "MASTER_ADDR" not in os.environ:   # one rank started by hand: a rendezvous of its own
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                port = sk.getsockname()[1]
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK=str(local_rank))
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -502,7 +512,7 @@ def main():
     dur_ns = int(round(hours * 3600)) * nx.NS_PER_S
     stream = torch.cuda.current_stream(dev)
     gdev = dev if args.backend == "nccl" else torch.device("cpu")
-    gathered = [torch.empty((n_max, 7), dtype=torch.float64, device=gdev) for _ in range(world)] if world > 1 else None
+    gathered = [torch.empty((n_max, 7), dtype=torch.float64, device=gdev) for _ in range(world)] if coll else None
     gather_s = [0.0]
     host_call = None
 
@@ -543,7 +553,7 @@ def main():
                                                      C.c_void_p(stream.cuda_stream))
             if rc != 0:
                 raise RuntimeError(_abi.last_error())
-            if world > 1:  # final-state collection (one all-gather) and the moments (one all-reduce of 55 doubles)
+            if coll:  # final-state collection (one all-gather) and the moments (one all-reduce of 55 doubles)
                 final = torch.stack([tout[f] for f in _abi.F64_FIELDS[:6]] + [tout["epoch_ns"].to(torch.float64)], dim=1)
                 gather_events.append(exchange(final))
                 if args.backend == "nccl":
@@ -563,13 +573,13 @@ def main():
 
         def step():
             last["res"] = nx.predict_until(ctx, shard, p0, end_ns, 60 * nx.NS_PER_S)
-            if world > 1:
+            if coll:
                 r = last["res"].states
                 final = torch.from_numpy(np.concatenate([r.rv(), r.epoch_ns[:, None].astype(np.float64)], axis=1)).to(dev)
                 gather_events.append(exchange(final))
 
     def barrier():
-        if world > 1:
+        if coll:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -588,7 +598,7 @@ def main():
     k_ms = float(np.mean(kernel_ms))
     per_rank_kernel_ms = [k_ms]
     gather_ms = None
-    if world > 1:
+    if coll:
         red = dev if args.backend == "nccl" else torch.device("cpu")
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=red)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -613,7 +623,7 @@ def main():
     if n_bad:
         raise SystemExit(f"{n_bad} trajectories failed")
     ev_all = n_evals
-    if world > 1:   # force evaluations of the whole job (strong scaling: the shards differ)
+    if coll:   # force evaluations of the whole job (strong scaling: the shards differ)
         red = dev if args.backend == "nccl" else torch.device("cpu")
         evt = torch.tensor([float(n_evals)], dtype=torch.float64, device=red)
         dist.all_reduce(evt, op=dist.ReduceOp.SUM)
@@ -635,8 +645,8 @@ def main():
             "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "launch": "torchrun" if (world > 1 and not os.environ.get("NYX_BENCH_SELF_LAUNCHED")) else ("self-launched ranks" if world > 1 else "single rank"),
-            "rccl_ranks": world if (world > 1 and args.backend == "nccl") else 0, "backend": args.backend if world > 1 else None,
+            "launch": "torchrun" if (world > 1 and not os.environ.get("NYX_BENCH_SELF_LAUNCHED")) else ("self-launched ranks" if world > 1 else ("single rank, collectives forced" if coll else "single rank")),
+            "rccl_ranks": world if (coll and args.backend == "nccl") else 0, "backend": args.backend if coll else None,
             "devices_visible": ndev, "per_rank_kernel_ms": per_rank_kernel_ms, "all_gather_ms": gather_ms,
             "config": {"workload": w["label"](n, hours), "baseline_config": args.config,
                        "trajectories_per_gpu": n, "trajectories_total": total_traj, "column_waves": args.waves or "auto",
@@ -726,7 +736,7 @@ def main():
                                           "max_rel_covar": float((np.abs(got.covar[:ns] - ref.covar) / scale).max())}
             line["cpu_baseline"] = cb
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if coll:
         dist.destroy_process_group()
 
 

@@ -84,6 +84,20 @@ def test_two_ranks_on_one_device():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [[], ["--config", "4", "--n", "64"]])
+def test_the_rccl_path_runs_with_one_rank(cfg):
+    """The N > 1 launches of the driver are the first time RCCL sees this script; `--force-collectives` issues every collective of
+    a step (all-gather of the final states, all-reduce of the 55 moments, the reductions of the report) on a one-rank nccl group,
+    on the tensors and streams the N-rank run uses.  Plain kernel and the covariance-mapping loop."""
+    p, line = _run(["--gpus", "1", "--force-collectives", *SMALL, *cfg])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert line["n_gpus"] == 1 and line["launch"] == "single rank, collectives forced"
+    assert line["backend"] == "nccl" and line["rccl_ranks"] == 1 and line["all_gather_ms"] is not None and line["all_gather_ms"] >= 0.0
+    if not cfg:
+        assert line["ensemble_moments"]["count"] == 256.0 and line["ensemble_moments"]["trace_cov_pos_km2"] > 0.0
+
+
+@pytest.mark.gpu
 def test_strong_scaling_cuts_one_ensemble():
     p, line = _run(["--gpus", "2", "--oversubscribe", "--backend", "gloo", "--scaling", "strong", *SMALL[:1], "257", *SMALL[2:]])
     assert p.returncode == 0, p.stderr[-2000:]
