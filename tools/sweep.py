@@ -63,7 +63,7 @@ for rep in range(reps):
             ctx._lib.nyx_hip_debug_profile.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
             if ctx._lib.nyx_hip_debug_profile(ctx._h, buf) == 0:
                 p = np.array(buf[:]).reshape(17, 8)
-                print("   mailbox: answers %d fallbacks %d fb_seq_sum %d posted %d helper_jobs %d paired_passes %d" % tuple(p[16, :6]))
+                print("   mailbox: answers %d fallbacks %d fb_seq_sum %d posted %d helper_jobs %d" % tuple(p[16, :5]))
                 print("   wg0 cycles per eval (phaseA duty harmonics phaseC stepctl | total barrier-wait), clock %.0f MHz, %d evals" % (p[0, 5] / max(p[0, 7], 1) * 100.0, ne))
                 for wv in range(16):
                     if p[wv, 5]:
