@@ -408,8 +408,11 @@ static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, con
     // cost of a column in rows: its length plus what it costs to START one (header, complex power of the range, a cold first batch).
     // With the short columns of a small field in the quad layout that start is most of a column: 21x21, 1 000 trajectories, sixty
     // segments: 11.45 ms with 0 rows, 11.1 with 4, 10.83 with 6, 10.95 with 8 (four runs each, +-0.03).  70x70 plain kernel: no effect
-    // up to 6, slower beyond (the measured per-wave weights already carry it there).
-    double col_fix = (ctx->sched_quad && n_waves == DEV_MAX_WAVES) ? 6.0 : 0.0;  // (the quad layout's production shape: sixteen waves)
+    // up to 6, slower beyond (the measured per-wave weights already carry it there).  Round 4, with the roles fanned out over eight of
+    // the sixteen waves: 6 rows left the oldest pure column wave without a column (the two-ended fill ran out of columns before it
+    // reached wave 4) and the youngest ones with the longest; config 4, three runs each: 10.10 ms with 6, 9.83 with 8, 9.55-9.60 with
+    // 9 ... 18 (a plateau: every wave holds one or two columns then) - same bits, the quad layout's sums do not depend on the split.
+    double col_fix = (ctx->sched_quad && n_waves == DEV_MAX_WAVES) ? 12.0 : 0.0;  // (the quad layout's production shape: sixteen waves)
     if (ctx->tune.column_start_cost >= 0.0) col_fix = ctx->tune.column_start_cost;
     auto cost = [&](int c) { return (double)ctx->col_len[c] + col_fix; };
     double terms = 0.0;
