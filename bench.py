@@ -415,6 +415,45 @@ def single_process(args, w):
     print(json.dumps(line), flush=True)
 
 
+class ClockSampler:
+    """Shader clock of the device WHILE the timed steps run (amdsmi through torch.cuda.clock_rate, 5 Hz from a side thread; best
+    effort: None where the query is not available).  Diagnostic only - a box whose clock is capped shows up here, not as a regression."""
+
+    def __init__(self, device_index):
+        import threading
+        self.dev, self.samples, self._stop = device_index, [], threading.Event()
+        self._t = threading.Thread(target=self._run, daemon=True)
+        try:   # (the first query initialises the library: not inside the timed region)
+            torch.cuda.clock_rate(self.dev)
+            self.ok = True
+        except Exception:
+            self.ok = False
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                self.samples.append(int(torch.cuda.clock_rate(self.dev)))
+            except Exception:
+                return
+            self._stop.wait(0.2)
+
+    def __enter__(self):
+        if self.ok:
+            self._t.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self.ok:
+            self._t.join(timeout=2.0)
+
+    def report(self):
+        if not self.samples:
+            return None
+        v = sorted(self.samples)
+        return {"median": v[len(v) // 2], "min": v[0], "max": v[-1], "samples": len(v), "source": "torch.cuda.clock_rate (amdsmi), sampled during the timed steps"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -589,12 +628,14 @@ def main():
     gather_events.clear()
     gather_s[0] = 0.0
     kernel_ms = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        kernel_ms.append(ctx.last_kernel_ms() if not w["stm"] else last["res"].kernel_ms)  # HIP events on the launch stream
-    barrier()
-    elapsed = time.perf_counter() - t0
+    clocks = ClockSampler(device_index)
+    with clocks:
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+            kernel_ms.append(ctx.last_kernel_ms() if not w["stm"] else last["res"].kernel_ms)  # HIP events on the launch stream
+        barrier()
+        elapsed = time.perf_counter() - t0
     k_ms = float(np.mean(kernel_ms))
     per_rank_kernel_ms = [k_ms]
     gather_ms = None
@@ -647,7 +688,7 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "launch": "torchrun" if (world > 1 and not os.environ.get("NYX_BENCH_SELF_LAUNCHED")) else ("self-launched ranks" if world > 1 else ("single rank, collectives forced" if coll else "single rank")),
             "rccl_ranks": world if (coll and args.backend == "nccl") else 0, "backend": args.backend if coll else None,
-            "devices_visible": ndev, "per_rank_kernel_ms": per_rank_kernel_ms, "all_gather_ms": gather_ms,
+            "devices_visible": ndev, "per_rank_kernel_ms": per_rank_kernel_ms, "all_gather_ms": gather_ms, "sclk_mhz": clocks.report(),
             "config": {"workload": w["label"](n, hours), "baseline_config": args.config,
                        "trajectories_per_gpu": n, "trajectories_total": total_traj, "column_waves": args.waves or "auto",
                        "tuning": "nyx_hip_tuning_t defaults: NYX_HIP_SCHED_MODEL (process-independent column schedule), cooperative mode auto",
