@@ -36,7 +36,7 @@ extern "C" hipError_t nyx_launch_frame_shift(const DevCfg *cfg, const double *re
                                              hipStream_t stream);
 extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg, const HarmEntry *htab,
                                            const ColHdr *cols, const double *records, int n_waves, int rec_lds_doubles,
-                                           int reuse_fields, hipStream_t stream, int quad);
+                                           int reuse_fields, hipStream_t stream, int quad, int no_body_fixed);
 
 // ---------------------------------------------------------------------------------------------
 // error reporting
@@ -1660,7 +1660,8 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
     const bool quad = pick_quad(ctx, in->n);
     // (the LDS staging of the ephemeris records was decided at ctx_create for the D3 layout; the quad layout is smaller)
     HIP_TRY(nyx_launch_propagate(bt, ctx->d_cfg, ctx->d_htab, ctx->d_cols, ctx->d_records, nw,
-                                 ctx->host_cfg.rec_in_lds ? ctx->host_cfg.rec_doubles : 0, ctx->host_cfg.ed_reuse, stream, quad ? 1 : 0));
+                                 ctx->host_cfg.rec_in_lds ? ctx->host_cfg.rec_doubles : 0, ctx->host_cfg.ed_reuse, stream, quad ? 1 : 0,
+                                 (!ctx->host_cfg.has_grav && !ctx->host_cfg.has_drag && !ctx->host_cfg.has_tides && !ctx->host_cfg.has_grav2) ? 1 : 0));
     if (time_it) HIP_TRY(hipEventRecord(ctx->ev1, stream));
     HIP_TRY(hipEventRecord(ctx->ev_done, stream));
     ctx->launched = true;

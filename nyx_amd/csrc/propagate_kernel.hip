@@ -51,6 +51,7 @@
 #define NYX_EMIT_STMQ16 8   /* quad layout (16 trajectories per workgroup, four lanes per trajectory, D1 duals), sixteen waves */
 #define NYX_EMIT_STMQ8 16   /* quad layout, eight waves or fewer */
 #define NYX_EMIT_PLAIN16_P2 32 /* sixteen waves, cooperative launches whose hand-off has TWO parts (two helper workgroups per owner and evaluation) */
+#define NYX_EMIT_PLAIN8N 64   /* eight waves or fewer, dynamics WITHOUT a body-fixed model (no gravity field, drag, tides): NYX_ASSUME_SMALL */
 // The two-part hand-off is a property of the TRANSLATION UNIT (NYX_COOP_TWO_PARTS, set by propagate_p2.hip), not a run-time branch:
 // the role code of the integrator is register-allocated around the mailbox calls, and the mere presence of the two-part calls in
 // the default kernel cost 3-5 % of the north-star run (8 h of propagation: 246.7 against 235.7 ms), whichever way they were folded.
@@ -2159,6 +2160,15 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     double *const kbuf = L.kbuf;
     double *const tabl = L.tabl;
     const int stages = cfg->stages;
+#ifdef NYX_ASSUME_SMALL
+    // propagate_w8n.hip: the kernel of workgroups whose dynamics have no body-fixed model at all (point masses and SRP around a
+    // two-body term: BASELINE config 3) - the four switches are compile-time constants there.  The general eight-wave kernel is 2.8 MB
+    // of code with every force model behind uniform branches and misses its instruction cache three to five times per wave and
+    // stage; the same source without those models runs config 3 in 51.5 ms instead of 56.2, bit for bit the same results.
+    const bool has_grav = false, has_drag = false, has_tides = false, has_grav2 = false;
+    const bool has_srp = cfg->has_srp != 0;
+    const bool has_pm = cfg->n_pm > 0;
+#else
     const bool has_grav = cfg->has_grav != 0;
     const bool has_srp = cfg->has_srp != 0;
     const bool has_pm = cfg->n_pm > 0;
@@ -2169,6 +2179,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     const bool has_tides = cfg->has_tides != 0;
 #endif
     const bool has_grav2 = !QUAD && cfg->has_grav2 != 0;  // (plain kernel: value; 64-lane dual layout of the STM kernel: value and gradient; the quad layout is not launched with a second field)
+#endif
     const bool need_almanac = has_grav || has_drag || has_tides || cfg->n_slots > 0;
     // role fan-out: this wave's share of the almanac / perturbation duties, and its status slot
     const int amask = ALMANAC ? cfg->role_mask[wave] : 0;
@@ -3223,6 +3234,9 @@ NYX_KERNEL(nyx_propagate_kernel_stmq_w8, 8 * DEV_LANES, true, true, false)
 #if NYX_EMIT & NYX_EMIT_PLAIN16_P2
 NYX_KERNEL(nyx_propagate_kernel_p2, DEV_MAX_WAVES *DEV_LANES, false)
 #endif
+#if NYX_EMIT & NYX_EMIT_PLAIN8N
+NYX_KERNEL(nyx_propagate_kernel_w8n, 8 * DEV_LANES, false, false, false)
+#endif
 
 #if NYX_EMIT & NYX_EMIT_PLAIN16
 NYX_KERNEL_DECL(nyx_propagate_kernel_w8)
@@ -3230,9 +3244,10 @@ NYX_KERNEL_DECL(nyx_propagate_kernel_stm)
 NYX_KERNEL_DECL(nyx_propagate_kernel_stmq)
 NYX_KERNEL_DECL(nyx_propagate_kernel_stmq_w8)
 NYX_KERNEL_DECL(nyx_propagate_kernel_p2)
+NYX_KERNEL_DECL(nyx_propagate_kernel_w8n)
 extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg, const HarmEntry *htab,
                                            const ColHdr *cols, const double *records, int n_waves, int rec_lds_doubles,
-                                           int reuse_fields, hipStream_t stream, int quad) {
+                                           int reuse_fields, hipStream_t stream, int quad, int no_body_fixed) {
     const int64_t per_wg = quad ? DEV_LANES / 4 : DEV_LANES;
     const int64_t blocks = (bt.n + per_wg - 1) / per_wg;
     if (blocks == 0) return hipSuccess;
@@ -3251,6 +3266,7 @@ extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg
             (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_w8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_stmq_w8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_p2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_w8n, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (devid >= 0 && devid < 64) attr_set[devid] = true;
         }
     }
@@ -3269,7 +3285,9 @@ extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg
     else {
         const int64_t grid = bt.coop_helpers > 0 ? (int64_t)bt.coop_base + bt.coop_helpers : blocks;
         const bool two_parts = bt.coop_helpers > 0 && bt.coop_parts == 2 && bt.coop_out2 != nullptr;  // (its own kernel: NYX_COOP_TWO_PARTS)
-        hipLaunchKernelGGL((small && bt.coop_helpers == 0) ? nyx_propagate_kernel_w8 : (two_parts ? nyx_propagate_kernel_p2 : nyx_propagate_kernel), dim3((unsigned)grid),
+        // (no_body_fixed: the host's statement that the configuration has no gravity field, drag or tides - propagate_w8n.hip)
+        hipLaunchKernelGGL((small && bt.coop_helpers == 0) ? (no_body_fixed ? nyx_propagate_kernel_w8n : nyx_propagate_kernel_w8)
+                                                             : (two_parts ? nyx_propagate_kernel_p2 : nyx_propagate_kernel), dim3((unsigned)grid),
                            dim3((unsigned)(n_waves * DEV_LANES)), lds, stream, btl, cfg, htab, cols, records);
     }
     return hipGetLastError();
