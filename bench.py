@@ -43,7 +43,19 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
+
+
+class _LazyTorch:
+    """`import torch` costs one to two minutes on a fresh GPU box (the image pages in); tools/sweep.py and friends import this module
+    for workload() only and must not pay for it: the module is imported at its first use."""
+
+    def __getattr__(self, name):
+        import torch as _t
+        globals()["torch"] = _t
+        return getattr(_t, name)
+
+
+torch = _LazyTorch()
 
 import nyx_amd as nx  # noqa: E402
 from nyx_amd import _abi, ephem  # noqa: E402

@@ -98,6 +98,20 @@ struct nyx_hip_ctx {
     int terms2 = 0;                // its table rows
     ColHdr *d_cols2 = nullptr;
     double *d_hyb = nullptr;  // the same table in the hybrid-feed layout (devcfg.h HYB_*)
+    // the helpers' columns as a stream of their own, every column at the head of a sixteen-row group (DevCfg.hyb_h): rebuilt when the
+    // helper schedule changes (build_schedule sets hyb_h_dirty), uploaded by launch() before a cooperative launch that streams in the helpers
+    std::vector<HarmEntry> h_tab;  // host copy of the entry table (without its tail padding)
+    std::vector<ColHdr> h_cols;
+    std::vector<double> h_hyb_h;   // (kept: the asynchronous upload reads it)
+    std::vector<ColHdr> h_cols_h;
+    double *d_hyb_h = nullptr;
+    size_t hyb_h_cap = 0;
+    ColHdr *d_cols_h = nullptr;
+    bool hyb_h_dirty = true;
+    // experiment knobs of the helper dealing (environment, only with NYX_HIP_TUNING_ENV: tools/sweep.py)
+    double coop_fast_weight = 4.0 / 3.0;  // speed of a helper column wave on a SIMD that hosts three of them (beside the producer / the answering wave)
+    double coop_start_rows = 4.0;         // what the start of one more column on a helper wave is charged, in rows
+    int coop_deal = 1;                    // 1: balanced dealing (build_schedule), 0: the longest columns, one per wave
     ColHdr *d_cols = nullptr;
     double *d_records = nullptr;
     std::vector<int32_t> col_len;  // rows per column (index = c)
@@ -259,10 +273,19 @@ static double ns_to_seconds_host(int64_t ns) {  // Duration::to_seconds for |ns|
 
 // config.tuning -> the context's copy.  The process environment is consulted ONLY when NYX_HIP_TUNING_ENV is set (the A/B
 // tools of this repository: tools/*.py, tools/*.sh): a library behind a C-ABI takes its switches through its config struct.
-static nyx_hip_tuning_t resolve_tuning(const nyx_hip_tuning_t *t) {
+struct ExpKnobs {  // experiment knobs of tools/sweep.py that have no field in nyx_hip_tuning_t (the helper dealing, round 5); < 0 / 0: unset
+    double fast_weight = 0.0, start_rows = -1.0;
+    int deal = -1;
+};
+static nyx_hip_tuning_t resolve_tuning(const nyx_hip_tuning_t *t, ExpKnobs *xk = nullptr) {
     nyx_hip_tuning_t r = NYX_HIP_TUNING_DEFAULT;
     if (t) r = *t;
     if (!std::getenv("NYX_HIP_TUNING_ENV")) return r;
+    if (xk) {
+        if (const char *e = std::getenv("NYX_HIP_COOP_FASTW")) xk->fast_weight = std::atof(e);
+        if (const char *e = std::getenv("NYX_HIP_COOP_START")) xk->start_rows = std::atof(e);
+        if (const char *e = std::getenv("NYX_HIP_COOP_DEAL")) xk->deal = std::atoi(e);
+    }
     auto geti = [](const char *name, int32_t &dst) { if (const char *e = std::getenv(name)) dst = (int32_t)std::strtol(e, nullptr, 0); };
     auto getd = [](const char *name, double &dst) { if (const char *e = std::getenv(name)) dst = std::atof(e); };
     int32_t cal = -1;
@@ -389,6 +412,30 @@ static void build_hybrid(const std::vector<HarmEntry> &tab, std::vector<double> 
                 const HarmEntry &e = r < n ? tab[r] : z;
                 hyb.push_back(j == 0 ? e.t3 : j == 1 ? e.t4 : j == 2 ? e.t5 : e.t6);
             }
+}
+
+// The helpers' columns as a stream of their own (DevCfg.hyb_h): every column of the helper schedules at the head of a sixteen-row
+// group, so that a helper wave - ONE column per range - starts its walk on the column's first row (in the common stream it starts at
+// the batch that holds it, with up to seven rows of the previous column in front).  `cols_h` = the headers with `start` moved.
+static void build_helper_stream(const nyx_hip_ctx *ctx, std::vector<double> &hyb, int64_t &vec_off, std::vector<ColHdr> &cols_h) {
+    cols_h = ctx->h_cols;
+    std::vector<HarmEntry> t;
+    const HarmEntry z = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    std::vector<char> seen(cols_h.size(), 0);
+    for (int k : {DEV_SCHED_HELPER, DEV_SCHED_HELPER2}) {
+        const DevSched &sd = ctx->host_cfg.sched[k];
+        for (int w = 0; w < DEV_MAX_WAVES; ++w)
+            for (int r = 0; r < sd.n_ranges[w]; ++r)
+                for (int c = sd.range_c0[w][r]; c < sd.range_c0[w][r] + sd.range_cnt[w][r]; ++c) {
+                    if (c < 1 || c >= (int)cols_h.size() || seen[c]) continue;
+                    seen[c] = 1;
+                    t.resize((t.size() + 15) / 16 * 16, z);
+                    const int32_t src = ctx->h_cols[c].start;
+                    cols_h[c].start = (int32_t)t.size();
+                    for (int q = 0; q < ctx->h_cols[c].rows; ++q) t.push_back(ctx->h_tab[(size_t)src + q]);
+                }
+    }
+    build_hybrid(t, hyb, vec_off);
 }
 
 // Column schedule: wave w walks at most two contiguous ranges — long columns from the low-c end,
@@ -775,10 +822,39 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
         }
         if (parts_cfg == 2 && max_cols > col_waves) max_cols = 2 * DEV_MAX_RANGES * col_waves;  // (each part has its own DEV_MAX_RANGES per wave)
         if (ctx->tune.coop_max_columns > 0) max_cols = std::min(parts_cfg * DEV_MAX_RANGES * col_waves, (int)ctx->tune.coop_max_columns);
+        // Balanced dealing (round 5; one-part hand-off of a field whose helper jobs hold ONE long column per wave, i.e. 70x70):
+        // the column waves of a helper are not alike - the two SIMDs that host the producer and the answering wave run three of them,
+        // the other two four - and with the streamed table a helper is bound by its SIMDs' issue, so a wave of a three-wave SIMD walks
+        // 4/3 the rows of the others in the same time.  The longest columns still go one per wave; when the share asks for more than
+        // those, the FAST waves get a second, medium column each out of one contiguous block of the table (the owners keep contiguous
+        // runs on either side), chosen so that every SIMD of the helper finishes together.  (debug_flags 0x400000: the old dealing.)
+        const bool balanced = ctx->coop_deal != 0 && parts_cfg == 1 && max_cols == col_waves && nc > 3 * col_waves;
+        std::vector<int> topup;
+        if (balanced) {
+            double first = 0.0;
+            for (int c = 1; c <= col_waves; ++c) first += ctx->col_len[c];
+            const double extra = share * terms - first;
+            const int n_fast = 6;
+            const double per = extra / n_fast - ctx->coop_start_rows;  // rows of the second column of a fast wave
+            if (per >= 6.0) {
+                // columns of `per` rows: col_len[c] = deg + 2 - c
+                int c_mid = dc.deg + 2 - (int)(per + 0.5);
+                int c_lo = c_mid - n_fast / 2, c_hi = c_lo + n_fast - 1;
+                if (c_lo <= col_waves) { c_lo = col_waves + 1; c_hi = c_lo + n_fast - 1; }
+                if (c_hi > nc - 2) { c_hi = nc - 2; c_lo = c_hi - n_fast + 1; }
+                if (c_lo > col_waves)
+                    for (int c = c_lo; c <= c_hi; ++c) topup.push_back(c);
+            }
+        }
+        int n_long = 0;  // columns taken from the head of the table (the longest)
         for (int c = 1; c <= nc; ++c) {
-            if ((int)help.size() < max_cols && c < nc - 1 && given + 0.5 * ctx->col_len[c] <= share * terms) {
+            const bool is_top = std::find(topup.begin(), topup.end(), c) != topup.end();
+            // (with a second column on the fast waves the long block is the full first round: one column per wave)
+            const bool long_ok = n_long < max_cols && c < nc - 1 && (!topup.empty() || given + 0.5 * ctx->col_len[c] <= share * terms) && (topup.empty() || c <= col_waves);
+            if (is_top || long_ok) {
                 help.push_back(c);
                 given += ctx->col_len[c];
+                if (!is_top) ++n_long;
             } else {
                 own.push_back(c);
             }
@@ -796,6 +872,27 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
             if (part >= parts) continue;
             std::vector<int> mine;
             for (size_t k = 0; k < help.size(); ++k) if ((int)(k % (size_t)parts) == part) mine.push_back(help[k]);
+            if (balanced) {
+                // longest column first onto the wave that would finish it soonest: load / speed, speed = coop_fast_weight on the SIMDs with
+                // three column waves (waves 4 8 12 beside the producer, 3 7 11 beside the answering wave)
+                double load[DEV_MAX_WAVES] = {0.0};
+                for (int c : mine) {  // (ascending column number = descending length)
+                    int best = -1;
+                    double best_t = 1e300;
+                    for (int q = 0; q < col_waves; ++q) {
+                        const int w = wave_order[q];
+                        if (hs.n_ranges[w] >= DEV_MAX_RANGES) continue;
+                        const double speed = (w % 4 == 0 || w % 4 == 3) ? ctx->coop_fast_weight : 1.0;
+                        const double t = (load[w] + ctx->col_len[c] + (hs.n_ranges[w] > 0 ? ctx->coop_start_rows : 0.0)) / speed;
+                        if (t < best_t - 1e-9) { best_t = t; best = w; }
+                    }
+                    if (best < 0) break;
+                    load[best] += ctx->col_len[c] + (hs.n_ranges[best] > 0 ? ctx->coop_start_rows : 0.0);
+                    const int r = hs.n_ranges[best]++;
+                    hs.range_c0[best][r] = c; hs.range_cnt[best][r] = 1;
+                }
+                continue;
+            }
             for (size_t k = 0; k < mine.size(); ++k) {
                 // further rounds are dealt in alternating directions: every wave's set has about the same length
                 const int round = (int)k / col_waves, pos = (int)k % col_waves;
@@ -804,6 +901,7 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
                 hs.range_c0[w][r] = mine[k]; hs.range_cnt[w][r] = 1;
             }
         }
+        ctx->hyb_h_dirty = true;  // (the helpers' own stream follows their schedule: rebuilt before the next cooperative launch)
         if (!help.empty() && !own.empty() && fill_schedule(ctx, dc.sched[DEV_SCHED_PRIMARY], n_waves, own, hc, false)) {
             dc.coop_ok = 1;
         } else {
@@ -969,6 +1067,11 @@ extern "C" double nyx_hip_last_kernel_ms(nyx_hip_ctx *ctx) {
 }
 
 // Cycle accounting of workgroup 0 of the last launch (NYX_HIP_PROFILE=1): out[17][8], see the kernel (row 16: mailbox counters).
+extern "C" int32_t nyx_hip_debug_profile_helper(nyx_hip_ctx *ctx, int64_t *out /* [16][8] */) {
+    if (!ctx || !ctx->d_prof) return NYX_HIP_RC_BAD_ARG;
+    if (hipMemcpy(out, ctx->d_prof + 17 * 8, 16 * 8 * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return NYX_HIP_RC_HIP_ERROR;
+    return NYX_HIP_RC_OK;
+}
 extern "C" int32_t nyx_hip_debug_profile(nyx_hip_ctx *ctx, int64_t *out) {
     if (!ctx || !ctx->d_prof) return NYX_HIP_RC_BAD_ARG;
     if (hipMemcpy(out, ctx->d_prof, 17 * 8 * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return NYX_HIP_RC_HIP_ERROR;
@@ -978,7 +1081,7 @@ extern "C" int32_t nyx_hip_debug_profile(nyx_hip_ctx *ctx, int64_t *out) {
 extern "C" void nyx_hip_ctx_destroy(nyx_hip_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
-    hipFree(ctx->d_cfg); hipFree(ctx->d_htab); hipFree(ctx->d_htab2); hipFree(ctx->d_cols2); hipFree(ctx->d_hyb); hipFree(ctx->d_cols); hipFree(ctx->d_records);
+    hipFree(ctx->d_cfg); hipFree(ctx->d_htab); hipFree(ctx->d_htab2); hipFree(ctx->d_cols2); hipFree(ctx->d_hyb); hipFree(ctx->d_hyb_h); hipFree(ctx->d_cols_h); hipFree(ctx->d_cols); hipFree(ctx->d_records);
     free_arrays(ctx->in);
     free_arrays(ctx->out);
     free_arrays(ctx->cal);
@@ -1050,9 +1153,14 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
 
     nyx_hip_ctx *ctx = new nyx_hip_ctx();
     ctx->device = device;
-    ctx->tune = resolve_tuning(cfg->tuning);
+    ExpKnobs xk;
+    ctx->tune = resolve_tuning(cfg->tuning, &xk);
     ctx->block_schedule = (ctx->tune.debug_flags & 0x8000) == 0;  // (0x8000: the two-ended column fill of rounds 1-3 everywhere)
     ctx->block_force = (ctx->tune.debug_flags & 0x10000) != 0;    // (0x10000: contiguous runs whatever the feed - the A/B partner of the streamed walk)
+    ctx->coop_deal = (ctx->tune.debug_flags & 0x400000) ? 0 : 1;  // (0x400000: the helper dealing of rounds 1-4 - the longest columns, one per wave)
+    if (xk.fast_weight > 0.0) ctx->coop_fast_weight = xk.fast_weight;  // (experiment knobs of the tools, never of a caller: resolve_tuning)
+    if (xk.start_rows >= 0.0) ctx->coop_start_rows = xk.start_rows;
+    if (xk.deal >= 0) ctx->coop_deal = xk.deal;
     DevCfg &dc = ctx->host_cfg;
     std::memset(&dc, 0, sizeof dc);
     const NyxTableau &tb = NYX_TABLEAUX[o.method];
@@ -1215,6 +1323,8 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
         int n_cols = 0;
         build_harmonics(g, tab, cols, ctx->col_len, n_cols);
         dc.n_cols = n_cols;
+        ctx->h_tab = tab;
+        ctx->h_cols = cols;
     }
     std::vector<HarmEntry> tab2;
     std::vector<ColHdr> cols2;
@@ -1286,6 +1396,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
         if (nyx_kernel_lds_bytes(DEV_MAX_WAVES, dc.rec_in_lds ? dc.rec_doubles : 0, 0, nf) <= 160 * 1024) dc.ed_reuse = nf;
     }
     ctx->ed_reuse_fit = dc.ed_reuse;
+    dc.coop_late = (ctx->tune.debug_flags & 0x1000000) ? 0 : 1;  // (0x1000000: the answer collected inside the window, rounds 1-4)
     dc.coop_frac = 0.30;  // measured optimum with two owners per helper (10 000 trajectories, 70x70): 0.28-0.33 is flat
     if (ctx->tune.coop_fraction > 0.0) dc.coop_frac = std::min(0.9, std::max(0.05, ctx->tune.coop_fraction));
     {
@@ -1638,6 +1749,33 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
             }
         }
     }
+    if (bt.coop_helpers > 0 && (ctx->host_cfg.harm_feed & 2) && !ctx->h_tab.empty()) {
+        // helpers that stream the table walk a stream of their own, one column per sixteen-row group (DevCfg.hyb_h; debug_flags
+        // 0x800000: the common stream, as in round 4 - same bits)
+        const bool want = (ctx->tune.debug_flags & 0x800000) == 0;
+        if (want && ctx->hyb_h_dirty) {
+            int64_t vec_off = 0;
+            build_helper_stream(ctx, ctx->h_hyb_h, vec_off, ctx->h_cols_h);
+            if (ctx->h_hyb_h.size() > ctx->hyb_h_cap) {
+                if (ctx->launched) HIP_TRY(hipEventSynchronize(ctx->ev_done));
+                (void)hipFree(ctx->d_hyb_h);
+                ctx->d_hyb_h = nullptr; ctx->hyb_h_cap = 0;
+                HIP_TRY(hipMalloc(&ctx->d_hyb_h, ctx->h_hyb_h.size() * sizeof(double)));
+                ctx->hyb_h_cap = ctx->h_hyb_h.size();
+            }
+            if (!ctx->d_cols_h) HIP_TRY(hipMalloc(&ctx->d_cols_h, ctx->h_cols_h.size() * sizeof(ColHdr)));
+            HIP_TRY(hipMemcpyAsync(ctx->d_hyb_h, ctx->h_hyb_h.data(), ctx->h_hyb_h.size() * sizeof(double), hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(ctx->d_cols_h, ctx->h_cols_h.data(), ctx->h_cols_h.size() * sizeof(ColHdr), hipMemcpyHostToDevice, stream));
+            ctx->host_cfg.hyb_h = (uint64_t)ctx->d_hyb_h;
+            ctx->host_cfg.hyb_h_v = (uint64_t)(ctx->d_hyb_h + vec_off);
+            ctx->host_cfg.cols_h = (uint64_t)ctx->d_cols_h;
+            ctx->hyb_h_dirty = false;
+            HIP_TRY(hipMemcpyAsync(ctx->d_cfg, &ctx->host_cfg, sizeof(DevCfg), hipMemcpyHostToDevice, stream));
+        } else if (!want && ctx->host_cfg.hyb_h != 0) {
+            ctx->host_cfg.hyb_h = 0;
+            HIP_TRY(hipMemcpyAsync(ctx->d_cfg, &ctx->host_cfg, sizeof(DevCfg), hipMemcpyHostToDevice, stream));
+        }
+    }
     {
         // the column weights of this launch's workgroup shape: measured once per context (see calibrate())
         const bool stm_k = (ctx->host_cfg.flags & NYX_HIP_FLAG_STM) != 0;
@@ -1652,8 +1790,8 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
         }
     }
     if (ctx->tune.profile || calibrating) {
-        if (!ctx->d_prof) HIP_TRY(hipMalloc(&ctx->d_prof, 17 * 8 * sizeof(int64_t)));
-        HIP_TRY(hipMemsetAsync(ctx->d_prof, 0, 17 * 8 * sizeof(int64_t), stream));
+        if (!ctx->d_prof) HIP_TRY(hipMalloc(&ctx->d_prof, 34 * 8 * sizeof(int64_t)));  // rows 0-15 owner workgroup 0, 16 mailbox counts, 17-32 the first helper workgroup
+        HIP_TRY(hipMemsetAsync(ctx->d_prof, 0, 34 * 8 * sizeof(int64_t), stream));
         bt.prof = ctx->d_prof;
     }
     if (time_it) HIP_TRY(hipEventRecord(ctx->ev0, stream));

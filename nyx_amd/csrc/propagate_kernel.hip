@@ -1109,7 +1109,11 @@ static __device__ __attribute__((noinline)) Partial4 harmonics_stream(uint64_t c
     const double rho2 = rho * rho;
     const CAS DevSched &sd = cfg->sched[sched];
     const int nr = sd.n_ranges[wave];
-    const uint64_t hs0 = cfg->hyb, hv0 = cfg->hyb_v;
+    uint64_t hs0 = cfg->hyb, hv0 = cfg->hyb_v;
+    if ((sched == DEV_SCHED_HELPER || sched == DEV_SCHED_HELPER2) && cfg->hyb_h != 0) {  // (uniform) the helpers' columns, each at the head of a group of its own (DevCfg.hyb_h)
+        hs0 = cfg->hyb_h; hv0 = cfg->hyb_h_v;
+        cols = (ColPtr)cfg->cols_h;
+    }
     const int voff = (lane & 15) * 8;
     for (int q = 0; q < nr; ++q) {
         const int c0 = sd.range_c0[wave][q];
@@ -1452,22 +1456,31 @@ static __device__ __attribute__((noinline)) Partial4 coop_fallback(uint64_t cfg_
 // ~2 us each on uncached memory) overlap the arithmetic of its neighbours: a helper's job period is its longest
 // column, not column + latencies.  LDS words: ready[s] / answered[s] = 1 + number of the job last published /
 // answered in slot s, cnt[s] = column waves that have delivered.
-#define HELPER_LDS_BYTES ((2 * DEV_MAX_WAVES * 4 * DEV_LANES + 2 * 5 * DEV_LANES) * 8 + 64 * 4)
+#ifndef HELPER_SLOTS
+#define HELPER_SLOTS 2  /* jobs in flight inside a helper (see helper_body: three and four were measured, slower) */
+#endif
+#define HELPER_LDS_BYTES ((HELPER_SLOTS * DEV_MAX_WAVES * 4 * DEV_LANES + HELPER_SLOTS * 5 * DEV_LANES) * 8 + 64 * 4)
 DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols, char *smem, int lane, int wave) {
-    double *part = (double *)smem;                                 // [2][16][4][64]
-    double *inl = part + 2 * DEV_MAX_WAVES * 4 * DEV_LANES;        // [2][5][64]
-    int *ctl = (int *)(inl + 2 * 5 * DEV_LANES);
-    const LdsFlagPtr ready = (LdsFlagPtr)ctl, answered = (LdsFlagPtr)ctl + 2, jown = (LdsFlagPtr)ctl + 4, jseq = (LdsFlagPtr)ctl + 6, jpart = (LdsFlagPtr)ctl + 10;
-    int *cnt = ctl + 8;
+    // HELPER_SLOTS jobs in flight.  Round 5 measured three and four (in-kernel accounting of a helper, tools/sweep.py "profile"): with
+    // two slots the producer waits ~9 k cycles per job for a slot and only then scans, claims and fetches (~10 k cycles of uncached
+    // round trips); more slots do move the claim under the arithmetic - and lose, 84.9 -> 92.3 -> 103.3 ms per 3 h of configs[1]:
+    // a job claimed early queues INSIDE this helper behind two or three others while another helper would have been free sooner
+    // (lost claims per job 2.4 -> 2.6 -> 4.0): the rate of jobs is the owners', what counts is each job's turnaround.
+    constexpr int NS = HELPER_SLOTS;
+    double *part = (double *)smem;                                  // [NS][16][4][64]
+    double *inl = part + NS * DEV_MAX_WAVES * 4 * DEV_LANES;        // [NS][5][64]
+    int *ctl = (int *)(inl + NS * 5 * DEV_LANES);
+    const LdsFlagPtr ready = (LdsFlagPtr)ctl, answered = (LdsFlagPtr)ctl + 4, jown = (LdsFlagPtr)ctl + 8, jseq = (LdsFlagPtr)ctl + 12, jpart = (LdsFlagPtr)ctl + 20;
+    int *cnt = ctl + 16;
     constexpr int parts = COOP_PARTS_HERE;
     const int answer_wave = (int)(blockDim.x / DEV_LANES) - 1;
     const int n_col_waves = answer_wave - 1;
     if (wave == 0 || wave == answer_wave) {
-        if (wave == 0 && lane < 16) ctl[lane] = 0;
+        if (wave == 0 && lane < 32) ctl[lane] = 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            part[(wave * 4 + q) * DEV_LANES + lane] = 0.0;
-            part[((DEV_MAX_WAVES + wave) * 4 + q) * DEV_LANES + lane] = 0.0;
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) part[((sl * DEV_MAX_WAVES + wave) * 4 + q) * DEV_LANES + lane] = 0.0;
         }
     }
     __syncthreads();
@@ -1480,17 +1493,23 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
         const bool has = lane < COOP_SET && mine < n_own;
         const int widx = set * COOP_SET + lane;                       // its scan words
         unsigned turn = (unsigned)h;
+        const bool pprof = bt.prof != nullptr && (int)blockIdx.x == bt.coop_base;
+        int64_t pp_slot = 0, pp_scan = 0, pp_jobs = 0, pp_lost = 0;
+        const int64_t pp_start = pprof ? (int64_t)__builtin_readcyclecounter() : 0;
         for (int j = 0;; ++j) {
-            const int s = j & 1;
+            const int s = j % NS;
             int owner = -1, sub = 0;
             uint32_t seq = 0;
             const int64_t t0 = (int64_t)__builtin_amdgcn_s_memrealtime();
-            bool slot_free = j < 2;
+            const int64_t pc0 = pprof ? (int64_t)__builtin_readcyclecounter() : 0;
+            int64_t pc1 = pc0;
+            bool slot_free = j < NS;
             for (;;) {
                 if ((int64_t)__builtin_amdgcn_s_memrealtime() - t0 > 5000 * COOP_TIMEOUT_TICKS) { owner = -1; break; }  // 10 s: never spin forever
-                if (!slot_free) {  // the job that used this slot two rounds ago has been answered
-                    slot_free = answered[s] == j - 1;
+                if (!slot_free) {  // the job that used this slot NS rounds ago has been answered
+                    slot_free = answered[s] == j - (NS - 1);
                     if (!slot_free) { __builtin_amdgcn_s_sleep(4); continue; }
+                    if (pprof) pc1 = (int64_t)__builtin_readcyclecounter();
                 }
                 // the two words are read by independent loads: a pair (old posted, new claimed) is possible and must not look
                 // like a job, hence "posted is AHEAD of claimed", not "differs from"
@@ -1551,6 +1570,7 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
                         il[3 * DEV_LANES + lane] = v3; il[4 * DEV_LANES + lane] = v4;
                         break;
                     }
+                    if (pprof) ++pp_lost;
                     continue;  // another helper was faster: look again
                 }
                 const uint32_t fin = has ? coop_load(bt.coop_finished + widx) : 1u;
@@ -1560,18 +1580,30 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
             if (lane == 0) { jown[s] = owner; jseq[s] = (int)seq; jpart[s] = sub; }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) ready[s] = j + 1;
+            if (pprof) { const int64_t now = (int64_t)__builtin_readcyclecounter(); pp_slot += pc1 - pc0; pp_scan += now - pc1; ++pp_jobs; }
             if (owner < 0) break;
+        }
+        if (pprof && lane == 0) {  // [0] cycles waiting for a free slot (the column waves are behind), [1] cycles from a free slot to a won and fetched job, [2] jobs, [3] lost claims
+            int64_t *row = bt.prof + 17 * 8;
+            row[0] = pp_slot; row[1] = pp_scan; row[2] = pp_jobs; row[3] = pp_lost; row[5] = (int64_t)__builtin_readcyclecounter() - pp_start;
         }
         return;
     }
+    // optional accounting of the FIRST helper workgroup (NYX_HIP_PROFILE; rows 17.. of the profile, one per wave): [0] cycles in the
+    // column walk, [1] cycles waiting for a job, [2] jobs, [3] cycles from a job's publication in LDS to this wave's delivery, [5] total
+    const bool hprof = bt.prof != nullptr && (int)blockIdx.x == bt.coop_base;
+    int64_t hp_busy = 0, hp_wait = 0, hp_jobs = 0;
+    const int64_t hp_start = hprof ? (int64_t)__builtin_readcyclecounter() : 0;
     for (int j = 0;; ++j) {
-        const int s = j & 1;
+        const int s = j % NS;
         {
             const int64_t t0 = (int64_t)__builtin_amdgcn_s_memrealtime();
+            const int64_t c0 = hprof ? (int64_t)__builtin_readcyclecounter() : 0;
             while (ready[s] != j + 1) {
                 if ((int64_t)__builtin_amdgcn_s_memrealtime() - t0 > 6000 * COOP_TIMEOUT_TICKS) return;  // (the producer gives up after 10 s)
                 __builtin_amdgcn_s_sleep(4);
             }
+            if (hprof) hp_wait += (int64_t)__builtin_readcyclecounter() - c0;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         const int owner = jown[s];
@@ -1579,6 +1611,7 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
         const int sub = jpart[s];
         if (owner < 0) break;
         double *ps = part + s * DEV_MAX_WAVES * 4 * DEV_LANES;
+        const int64_t hp_c0 = hprof ? (int64_t)__builtin_readcyclecounter() : 0;
         if (wave != answer_wave) {
             const double *il = inl + s * 5 * DEV_LANES;
             const double v0 = il[0 * DEV_LANES + lane], v1 = il[1 * DEV_LANES + lane], v2 = il[2 * DEV_LANES + lane],
@@ -1590,6 +1623,7 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
             pp[0 * DEV_LANES + lane] = pr.x; pp[1 * DEV_LANES + lane] = pr.y; pp[2 * DEV_LANES + lane] = pr.z; pp[3 * DEV_LANES + lane] = pr.w;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) (void)__hip_atomic_fetch_add(cnt + s, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (hprof) { hp_busy += (int64_t)__builtin_readcyclecounter() - hp_c0; ++hp_jobs; }
             continue;
         }
         // ---- the answering wave: wait for the column waves, fold in the fixed wave order (the slots of the producer and of
@@ -1618,6 +1652,11 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) answered[s] = j + 1;  // the slot may be refilled: its partial sums are in registers
         if (lane == 0 && bt.prof != nullptr) atomicAdd((unsigned long long *)bt.prof + 16 * 8 + 4, 1ull);
+        if (hprof) { hp_busy += (int64_t)__builtin_readcyclecounter() - hp_c0; ++hp_jobs; }
+    }
+    if (hprof && lane == 0) {
+        int64_t *row = bt.prof + (17 + wave) * 8;
+        row[0] = hp_busy; row[1] = hp_wait; row[2] = hp_jobs; row[5] = (int64_t)__builtin_readcyclecounter() - hp_start;
     }
 }
 
@@ -2807,21 +2846,28 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     pp[2 * DEV_LANES + lane] = pz; pp[3 * DEV_LANES + lane] = pw;
                 }
             }
-            if (INTEG && !STM && has_grav && (pipe ? shared_cur : coop_on)) {
-                // the helper's answer is collected INSIDE the window (this wave has nothing else to do): phase C never waits
-                const CoopAnswer ans = !coop_on ? CoopAnswer{0.0, 0.0, 0.0, 0.0, 0} : (coop_two ? coop_wait2(cbox, bt.coop_out2 + blockIdx.x, lane, seq_cur) : coop_wait(cbox, lane, seq_cur));
-                if (ans.ok) {
-                    coop_x = ans.x; coop_y = ans.y; coop_z = ans.z; coop_w = ans.w;
-                    ++dbg_answers;
-                } else {
-                    if (coop_on) { ++dbg_fallbacks; dbg_fb_seq = seq_cur; }  // no answer in time: do the helper's columns here, then carry on alone
-                    const Partial4 fb = coop_fallback((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, (pipe && (i & 1)) ? L.inb2 : L.inb, lane | (coop_two ? 0x100 : 0));
-                    coop_x = fb.x; coop_y = fb.y; coop_z = fb.z; coop_w = fb.w;
-                    coop_on = false;
-                    coop_drop = !pipe;  // (pipelined: ctl[1] is rewritten for every stage, nothing to undo)
-                    if (lane == 0) coop_store(bt.coop_finished + coop_widx, 1u);
-                }
+#define COOP_COLLECT()                                                                                                                          \
+            if (INTEG && !STM && has_grav && (pipe ? shared_cur : coop_on)) {                                                                     \
+                const CoopAnswer ans = !coop_on ? CoopAnswer{0.0, 0.0, 0.0, 0.0, 0} : (coop_two ? coop_wait2(cbox, bt.coop_out2 + blockIdx.x, lane, seq_cur) : coop_wait(cbox, lane, seq_cur)); \
+                if (ans.ok) {                                                                                                                     \
+                    coop_x = ans.x; coop_y = ans.y; coop_z = ans.z; coop_w = ans.w;                                                               \
+                    ++dbg_answers;                                                                                                                \
+                } else {                                                                                                                          \
+                    if (coop_on) { ++dbg_fallbacks; dbg_fb_seq = seq_cur; }  /* no answer in time: do the helper's columns here, then carry on alone */ \
+                    const Partial4 fb = coop_fallback((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, (pipe && (i & 1)) ? L.inb2 : L.inb, lane | (coop_two ? 0x100 : 0)); \
+                    coop_x = fb.x; coop_y = fb.y; coop_z = fb.z; coop_w = fb.w;                                                                   \
+                    coop_on = false;                                                                                                              \
+                    coop_drop = !pipe;  /* (pipelined: ctl[1] is rewritten for every stage, nothing to undo) */                                   \
+                    if (lane == 0) coop_store(bt.coop_finished + coop_widx, 1u);                                                                  \
+                }                                                                                                                                 \
             }
+            // The helper's answer.  Rounds 1-4 collected it INSIDE the window, in front of B2 - a late answer then held the whole
+            // workgroup at the barrier.  Pipelined loop (round 5): it is collected in phase C, BEHIND B2: the column waves are already
+            // walking stage i + 1 (its inputs were published in this window), and what a late answer delays is this wave's serial chain
+            // C(i) -> A(i + 1) -> the inputs of stage i + 2, which has ~12 k cycles to spare before the column waves ask for them.  The
+            // deadline of a job moves out by that much: the helpers can be loaded further.  (The inputs of this stage in LDS - the
+            // fallback's operands - are not overwritten before window i + 1 publishes stage i + 2 into the same parity: behind this point.)
+            if (!pipe || cfg->coop_late == 0) { COOP_COLLECT() }
             if (prof_on) prof_acc[2] += (int64_t)__builtin_readcyclecounter() - pth_;
             {
                 PROF_T0();
@@ -2859,6 +2905,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         if (lane == 0) LCTL[3] = fold_base + i + 1;
                     }
+                    if (pipe && cfg->coop_late != 0) { COOP_COLLECT() }
                     px += coop_x; py += coop_y; pz += coop_z; pw += coop_w;  // + the helper's columns (0 when working alone)
                     if (coop_drop) {  // (between B2 and the next B1: no worker is reading ctl[1])
                         if (lane == 0) L.ctl[1] = 0;

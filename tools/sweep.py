@@ -40,7 +40,21 @@ print(f"config {cfg_id} n={n} hours={hours:g}", flush=True)
 for rep in range(reps):
     for name, fields in variants.items():
         t0 = time.time()
+        fields = dict(fields)
+        env = fields.pop("env", None)   # experiment knobs that travel through the environment (read at ctx_create, only with NYX_HIP_TUNING_ENV)
+        show = fields.pop("show_sched", 0)
+        saved = {}
+        if env:
+            env = dict(env, NYX_HIP_TUNING_ENV="1")
+            for k, v in env.items():
+                saved[k] = os.environ.get(k)
+                os.environ[k] = str(v)
         ctx = nx.GpuContext(compiled, tuning=nx.Tuning(**fields))
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
         if w["stm"]:
             for _ in range(2):
                 res = nx.predict_until(ctx, b, bench.init_covar(n), int(b.epoch_ns[0]) + dur, 60 * nx.NS_PER_S)
@@ -58,6 +72,12 @@ for rep in range(reps):
         if ref is not None:
             d = out.rv()[:check] - ref.rv()
             print(f"   parity vs oracle on {check}: max dr {np.linalg.norm(d[:, :3], axis=1).max() * 1e6:.4f} mm, max dv {np.linalg.norm(d[:, 3:], axis=1).max() * 1e6:.3e} mm/s", flush=True)
+        if show:
+            rows = (C.c_int32 * 16)()
+            ctx._lib.nyx_hip_debug_schedule_rows.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+            for sc_id, nm in ((1, "owner"), (2, "helper")):
+                ctx._lib.nyx_hip_debug_schedule_rows(ctx._h, sc_id, rows, None)
+                print(f"   {nm} rows/wave " + " ".join(f"{x:4d}" for x in rows[:]) + f"  sum {sum(rows[:])}")
         if fields.get("profile"):
             buf = (C.c_int64 * 136)()
             ctx._lib.nyx_hip_debug_profile.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
@@ -68,4 +88,14 @@ for rep in range(reps):
                 for wv in range(16):
                     if p[wv, 5]:
                         print(f"    wave {wv:2d}: " + " ".join(f"{p[wv, q] / ne:8.0f}" for q in (0, 1, 2, 3, 4)) + f" | {p[wv, 5] / ne:8.0f} {p[wv, 6] / ne:8.0f}")
+            hb = (C.c_int64 * 128)()
+            if hasattr(ctx._lib, "nyx_hip_debug_profile_helper"):
+                ctx._lib.nyx_hip_debug_profile_helper.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+                if ctx._lib.nyx_hip_debug_profile_helper(ctx._h, hb) == 0:
+                    hp = np.array(hb[:]).reshape(16, 8)
+                    if hp[0, 2]:
+                        print(f"   first helper: producer {hp[0, 2]} jobs, per job: wait-for-slot {hp[0, 0] / hp[0, 2]:.0f}, scan+claim+fetch {hp[0, 1] / hp[0, 2]:.0f}, lost claims {hp[0, 3] / hp[0, 2]:.2f}; total {hp[0, 5] / hp[0, 2]:.0f} cycles/job")
+                        for wv in range(1, 16):
+                            if hp[wv, 2]:
+                                print(f"    hwave {wv:2d}: busy {hp[wv, 0] / hp[wv, 2]:8.0f}  wait {hp[wv, 1] / hp[wv, 2]:8.0f}  per job ({hp[wv, 2]} jobs)")
         ctx.close()
