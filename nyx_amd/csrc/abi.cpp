@@ -1067,9 +1067,9 @@ extern "C" double nyx_hip_last_kernel_ms(nyx_hip_ctx *ctx) {
 }
 
 // Cycle accounting of workgroup 0 of the last launch (NYX_HIP_PROFILE=1): out[17][8], see the kernel (row 16: mailbox counters).
-extern "C" int32_t nyx_hip_debug_profile_helper(nyx_hip_ctx *ctx, int64_t *out /* [16][8] */) {
+extern "C" int32_t nyx_hip_debug_profile_helper(nyx_hip_ctx *ctx, int64_t *out /* [17][8] */) {
     if (!ctx || !ctx->d_prof) return NYX_HIP_RC_BAD_ARG;
-    if (hipMemcpy(out, ctx->d_prof + 17 * 8, 16 * 8 * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return NYX_HIP_RC_HIP_ERROR;
+    if (hipMemcpy(out, ctx->d_prof + 17 * 8, 17 * 8 * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return NYX_HIP_RC_HIP_ERROR;  // (row 16 of `out` = row 33: the owner's latency loop)
     return NYX_HIP_RC_OK;
 }
 extern "C" int32_t nyx_hip_debug_profile(nyx_hip_ctx *ctx, int64_t *out) {

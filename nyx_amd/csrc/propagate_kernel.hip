@@ -1321,17 +1321,18 @@ DEVFN int quad_or(int x) {
 // that go past the L1 / the XCD's L2), ordered by workgroup-scope fences, i.e. s_waitcnt on the wave's own accesses: no
 // cache write-back or invalidate anywhere (a device-scope fence per evaluation also throws the harmonics table out of
 // L2 and doubled the run time).
-DEVFN uint32_t coop_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-DEVFN void coop_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-DEVFN double coop_loadd(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-DEVFN void coop_stored(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// (through GLOBAL-qualified pointers: a generic pointer makes these flat_load / flat_store, which count on lgkmcnt as well as on vmcnt -
+//  every LDS wait behind a post then also waited for the stores' round trip to uncached memory)
+#define GAS __attribute__((address_space(1)))
+DEVFN uint32_t coop_load(const uint32_t *p) { return __hip_atomic_load((const GAS uint32_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEVFN void coop_store(uint32_t *p, uint32_t v) { __hip_atomic_store((GAS uint32_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 DEVFN void coop_release() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }  // (inline asm: never elided by the compiler)
 DEVFN void coop_acquire() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 #define COOP_TIMEOUT_TICKS 200000LL  /* 2 ms of the 100 MHz realtime counter */
 #define COOP_SET 16                  /* owners per set */
 
-DEVFN uint64_t coop_loadu(const uint64_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-DEVFN void coop_storeu(uint64_t *p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEVFN uint64_t coop_loadu(const uint64_t *p) { return __hip_atomic_load((const GAS uint64_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEVFN void coop_storeu(uint64_t *p, uint64_t v) { __hip_atomic_store((GAS uint64_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 // a double as two tagged granules (CoopBox): g[0] = {low half | seq << 32}, g[DEV_LANES] = {high half | seq << 32}
 DEVFN void coop_put(uint64_t *g, double v, uint32_t seq) {
     const uint64_t b = (uint64_t)__double_as_longlong(v), t = (uint64_t)seq << 32;
@@ -1353,14 +1354,31 @@ DEVFN bool coop_get(const uint64_t *g, uint32_t seq, double &v) {
 // The single-part functions are kept exactly as small as they were before the two-part hand-off existed, and the two-part ones are
 // their own functions behind a uniform branch at the call site: measured on the north-star run (8 h of propagation), folding both into
 // one function with a run-time part count cost 2.8 % - the integrator's role code is register-allocated around these calls.
-static __device__ __attribute__((noinline)) void coop_post(CoopBox *box, uint32_t *posted, int lane, uint32_t seq, const double *inb) {
+// (round 5: the five rows are read from LDS through an LDS-qualified pointer and all at once, THEN stored.  Through the generic pointer
+//  of rounds 1-4 every row was a flat_load behind `s_waitcnt vmcnt(0) lgkmcnt(0)`, i.e. behind the previous row's stores to uncached
+//  memory: five serial round trips, 4.7 k cycles of the integrator's window per evaluation.)
+#ifndef COOP_INLINE
+#define COOP_INLINE 0
+#endif
+#if COOP_INLINE
+#define COOP_FN static __device__ __forceinline__
+#else
+#define COOP_FN static __device__ __attribute__((noinline))
+#endif
+COOP_FN void coop_post(CoopBox *box, uint32_t *posted, int lane, uint32_t seq, LdsCPtr inb) {
+    double v[5];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) coop_put(&box->in[seq & 1u][q][0][lane], inb[q * DEV_LANES + lane], seq);
+    for (int q = 0; q < 5; ++q) v[q] = inb[q * DEV_LANES + lane];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) coop_put(&box->in[seq & 1u][q][0][lane], v[q], seq);
     if (lane == 0) coop_store(posted, seq);
 }
-static __device__ __attribute__((noinline)) void coop_post2(CoopBox *box, uint32_t *posted, int lane, uint32_t seq, const double *inb) {
+static __device__ __attribute__((noinline)) void coop_post2(CoopBox *box, uint32_t *posted, int lane, uint32_t seq, LdsCPtr inb) {
+    double v[5];
 #pragma unroll
-    for (int q = 0; q < 5; ++q) coop_put(&box->in[seq & 1u][q][0][lane], inb[q * DEV_LANES + lane], seq);
+    for (int q = 0; q < 5; ++q) v[q] = inb[q * DEV_LANES + lane];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) coop_put(&box->in[seq & 1u][q][0][lane], v[q], seq);
     if (lane == 0) coop_store(posted, 2u * seq);  // (the scan words count SUB-JOBS)
 }
 
@@ -1370,7 +1388,7 @@ struct CoopAnswer {
 };
 // The answer needs no flag: every lane polls the LAST granule the helper writes for it, and when all of them carry this
 // evaluation's tag the other seven are read and checked the same way (they were stored earlier, but nothing orders them).
-static __device__ __attribute__((noinline)) CoopAnswer coop_wait(CoopBox *box, int lane, uint32_t seq) {
+COOP_FN CoopAnswer coop_wait(CoopBox *box, int lane, uint32_t seq) {
     CoopAnswer a = {0.0, 0.0, 0.0, 0.0, 0};
     const int64_t t0 = (int64_t)__builtin_amdgcn_s_memrealtime();
     const unsigned par = seq & 1u;
@@ -1591,6 +1609,15 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
     }
     // optional accounting of the FIRST helper workgroup (NYX_HIP_PROFILE; rows 17.. of the profile, one per wave): [0] cycles in the
     // column walk, [1] cycles waiting for a job, [2] jobs, [3] cycles from a job's publication in LDS to this wave's delivery, [5] total
+#ifdef HELPER_PRIO
+    // issue priority against the arbiter's oldest-first rule: the four waves of a SIMD start a job together, and served oldest first the
+    // oldest is done after half the job's time and runs ahead into the next job while the youngest - whose column the answer waits
+    // for - gets what is left
+    if (wave != answer_wave) {
+        const int pr = HELPER_PRIO == 1 ? (wave >> 2) : (3 - (wave >> 2));
+        if (pr == 3) __builtin_amdgcn_s_setprio(3); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    }
+#endif
     const bool hprof = bt.prof != nullptr && (int)blockIdx.x == bt.coop_base;
     int64_t hp_busy = 0, hp_wait = 0, hp_jobs = 0;
     const int64_t hp_start = hprof ? (int64_t)__builtin_readcyclecounter() : 0;
@@ -1728,6 +1755,25 @@ DEVFN double error_estimate(int ec, const double *e, const double *cand, const d
 // Fold of the 15 workers' partial accelerations (fixed wave order => deterministic).  Kept out of line on purpose:
 // inside the integrator role (at its 128-VGPR cap) the scheduler serialised the 60 LDS reads at one LDS latency each
 // (5 k cycles on the critical path of every force evaluation); on its own the function batches them.
+#ifndef FOLD_INLINE
+#define FOLD_INLINE 0
+#endif
+#if FOLD_INLINE
+// (inlined variant: the sixty reads in four batches of fifteen - one component at a time - so that they need 30 registers, not 120)
+static __device__ __forceinline__ Partial4 fold_partials(LdsCPtr part, int lane, double px, double py, double pz, double pw) {
+    double o[4] = {px, py, pz, pw};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        double v[DEV_MAX_WAVES - 1];
+#pragma unroll
+        for (int w = 1; w < DEV_MAX_WAVES; ++w) v[w - 1] = part[(w * 4 + q) * DEV_LANES + lane];
+#pragma unroll
+        for (int w = 1; w < DEV_MAX_WAVES; ++w) o[q] += v[w - 1];
+    }
+    Partial4 r = {o[0], o[1], o[2], o[3]};
+    return r;
+}
+#else
 static __device__ __attribute__((noinline)) Partial4 fold_partials(LdsCPtr part, int lane, double px, double py, double pz, double pw) {
     double v[4][DEV_MAX_WAVES - 1];
 #pragma unroll
@@ -1742,6 +1788,7 @@ static __device__ __attribute__((noinline)) Partial4 fold_partials(LdsCPtr part,
     Partial4 r = {px, py, pz, pw};
     return r;
 }
+#endif
 
 // ---------------------------------------------------------------------------------------------
 // STM variant: position partials of the perturbations (perturbation wave) and the per-step update
@@ -2038,6 +2085,13 @@ static __device__ __attribute__((noinline)) void phase_c_quad(LdsCPtr pertD, Lds
 // ---------------------------------------------------------------------------------------------
 
 #define NIN 5
+// Pipelined plain loop: what the integrator forms in window i for stage i + 1 - its position, s, t, u, (mu / r) / R_eq, its DCM - is
+// left in LDS and read back in phase A of stage i + 1 instead of being carried in registers across the window's and phase C's calls
+// (coop_post, fold_partials, coop_wait: the ABI keeps 48 VGPRs across a call, the role had ~90 live and spilled the rest to scratch
+// around each of them, every evaluation).  Same values, same bits.
+#ifndef NX_IN_LDS
+#define NX_IN_LDS 1
+#endif
 // timing-only debug switches (NYX_HIP_DEBUG env, never set in production): results are physically wrong
 #define DBG_SKIP_SERIAL 0x100
 #define DBG_SKIP_HARMONICS 0x200
@@ -2354,6 +2408,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     for (int q = 0; q < 9; ++q) { m_cur[q] = 0.0; m_nx[q] = 0.0; }
     uint32_t seq_cur = 0, seq_nx = 0;   // mailbox sequence numbers of this stage / the next one
     unsigned long long dbg_answers = 0, dbg_fallbacks = 0, dbg_fb_seq = 0;  // (NYX_HIP_PROFILE: row 16 of the profile)
+    int64_t pl_tc = 0, pl_chain = 0, pl_wait = 0, pl_n = 0, pl_post = 0;  // (NYX_HIP_PROFILE, row 33: the latency loop of a cooperative owner - answer in hand -> next post)
     bool shared_cur = false, shared_nx = false;  // did the workers of this / the next stage leave columns to a helper?
 
     // start of a step: final-step test on integer epochs (instance.rs:149-186), then epoch and step published to the other waves
@@ -2434,6 +2489,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
 
         int st_att = NYX_HIP_OK;
         double wpre[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        double pre_wr[3] = {0.0, 0.0, 0.0};  // position part of the stage sum the current window publishes from (pipelined plain loop; stage 0: empty)
         for (int i = 0; i < stages; ++i) {
             double *const edc = L.ed + (i & 1) * ED_FIELDS * DEV_LANES;
             double s_ = 0.0, t_ = 0.0, u_ = 0.0, kfac = 0.0;
@@ -2454,8 +2510,13 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                         for (int e = 3; e < 6; ++e) ysb[e * DEV_LANES + lane] = ys[e];
                     } else {
                     const double a_last = A_ROW(i, i - 1);
+                    if (!STM && NX_IN_LDS) {  // (the position the previous window published: read back, not carried - see NX_IN_LDS)
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) ys[e] = ysb[e * DEV_LANES + lane];
+                    } else {
 #pragma unroll
                     for (int e = 0; e < 3; ++e) ys[e] = nx_pos[e];
+                    }
 #pragma unroll
                     for (int e = 3; e < 6; ++e) {
                         const double wi = wpre[e] + a_last * KB(i - 1, e);
@@ -2474,9 +2535,21 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                             if (es) st_att = es;
                         }
                     }
+                    if (!STM && NX_IN_LDS) {
+                        if (has_grav) {
+                            // s, t, u, (mu / r) / R_eq of this stage from the rows the publishing window left them in (wave 0's slot of the partial
+                            // sums: the integrator of a pipelined workgroup carries no columns), its DCM from the epoch data (this parity's
+                            // buffer is rewritten in the NEXT window, behind the barrier this stage ends with; phase C needs it after that
+                            // barrier: registers from here on)
+                            s_ = L.part[0 * DEV_LANES + lane]; t_ = L.part[1 * DEV_LANES + lane]; u_ = L.part[2 * DEV_LANES + lane]; kfac = L.part[3 * DEV_LANES + lane];
+#pragma unroll
+                            for (int q = 0; q < 9; ++q) m_cur[q] = edc[q * DEV_LANES + lane];
+                        }
+                    } else {
                     s_ = nx_s; t_ = nx_t; u_ = nx_u; kfac = nx_kfac;
 #pragma unroll
                     for (int q = 0; q < 9; ++q) m_cur[q] = m_nx[q];
+                    }
                     seq_cur = seq_nx; shared_cur = shared_nx;
                 } else {
                 if (i == 0) {
@@ -2562,7 +2635,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             // ---- window --------------------------------------------------------------------------
             if (INTEG && !STM && coop_on && has_grav && (!pipe || (i == 0 && !spec_now))) {
                 seq_cur = ++coop_seq;
-                if (coop_two) coop_post2(cbox, bt.coop_posted + coop_widx, lane, seq_cur, L.inb); else coop_post(cbox, bt.coop_posted + coop_widx, lane, seq_cur, L.inb);
+                if (coop_two) coop_post2(cbox, bt.coop_posted + coop_widx, lane, seq_cur, (LdsCPtr)L.inb); else coop_post(cbox, bt.coop_posted + coop_widx, lane, seq_cur, (LdsCPtr)L.inb);
             }
             const bool last_stage = i + 1 == stages;
             if (ALMANAC && need_almanac && (!last_stage || reuse_nf > 0 || spec)) {
@@ -2668,6 +2741,139 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 }
             }
             double acc[3] = {0.0, 0.0, 0.0};
+            // The integrator's window.  Round 5: in the pipelined plain loop the position and the recursion inputs of the next stage are
+            // formed and POSTED first, everything else (two-body term, the velocity part of the next stage sum, the position part of the
+            // one after) behind them.  The helper's answer of stage i - 1 and the post of stage i + 1 are the two ends of the loop
+            // that bounds a cooperative workgroup's period, (chain + helper latency) / 2: the chain was phase C, phase A, two-body,
+            // the whole 6 x i stage sum out of LDS, THEN the position.  The position part of the stage sum needs the stage VELOCITIES
+            // only - known one window earlier - and is carried in registers (pre_wr); same terms, same order, same bits.
+            const bool fastp = PIPE && !STM && !offl;
+            auto publish_next = [&](const bool from_pre) __attribute__((always_inline)) {
+                if (pipe && (i + 1 < stages || spec)) {
+                    // ---- position and recursion inputs of stage i+1, published inside the window of stage i.
+                    // k_i[0..2] is this stage's velocity, so  y + h (wpre + a_{i+1,i} k_i)  is complete for the position
+                    if (i + 1 < stages) {
+                    const double a_nl = A_ROW(i + 1, i);
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) {
+                        const double wi = (from_pre ? pre_wr[e] : wpre[e]) + a_nl * ys[3 + e];
+                        nx_pos[e] = CS_Y(e) + h * wi;
+                    }
+                    } else {
+                        // last window: stage 0 of the next attempt, should this one be accepted - the position step control will form
+                        // (same operations in the same order: next[e] = y[e]; next[e] += (h b_j) k_j[e], j ascending)
+                        if (from_pre) {  // (y + the terms j < i: added up in the previous window)
+#pragma unroll
+                            for (int e = 0; e < 3; ++e) nx_pos[e] = pre_wr[e];
+                        } else {
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) nx_pos[e] = CS_Y(e);
+                        for (int j = 0; j < i; ++j) {
+                            const double cb = h * B_COEF(j);
+#pragma unroll
+                            for (int e = 0; e < 3; ++e) nx_pos[e] += cb * KB(j, e);
+                        }
+                        }
+                        {
+                            const double cb = h * B_COEF(i);
+#pragma unroll
+                            for (int e = 0; e < 3; ++e) nx_pos[e] += cb * ys[3 + e];
+                        }
+                    }
+                    double *const ysn = ((i + 1) & 1) ? L.ys2 : L.ys;
+                    double *const inbn = ((i + 1) & 1) ? L.inb2 : L.inb;
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) ysn[e * DEV_LANES + lane] = nx_pos[e];
+                    if (has_grav) {  // (without a gravity field the position is all the next window needs: the perturbation waves read it after B2)
+                    if (need_almanac) {  // the almanac wave writes the DCM of stage i+1 first thing in this window
+                        // (bounded: a protocol error must end as a failed run, never as a hung GPU)
+                        int spin = 0;
+                        while (LCTL[2] != i + 1 && ++spin < 4000000) __builtin_amdgcn_s_sleep(4);
+                        if (spin >= 4000000) st_att = NYX_HIP_ERR_NAN;
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                    }
+                    const double *const edn = L.ed + ((i + 1) & 1) * ED_FIELDS * DEV_LANES;  // (its DCM: the flag is raised before the body positions are evaluated)
+#pragma unroll
+                    for (int q = 0; q < 9; ++q) m_nx[q] = edn[q * DEV_LANES + lane];
+                    const double rb0 = m_nx[0] * nx_pos[0] + m_nx[1] * nx_pos[1] + m_nx[2] * nx_pos[2];
+                    const double rb1 = m_nx[3] * nx_pos[0] + m_nx[4] * nx_pos[1] + m_nx[5] * nx_pos[2];
+                    const double rb2 = m_nx[6] * nx_pos[0] + m_nx[7] * nx_pos[1] + m_nx[8] * nx_pos[2];
+                    const double r_ = norm3(rb0, rb1, rb2);
+                    const double inv_r = 1.0 / r_;
+                    nx_s = rb0 * inv_r; nx_t = rb1 * inv_r; nx_u = rb2 * inv_r;
+                    const double rho = cfg->g_re * inv_r;
+                    nx_kfac = (cfg->g_mu * inv_r) * cfg->g_inv_re;
+                    inbn[0 * DEV_LANES + lane] = rho * nx_s;
+                    inbn[1 * DEV_LANES + lane] = rho * nx_t;
+                    inbn[2 * DEV_LANES + lane] = rho * nx_u;
+                    inbn[3 * DEV_LANES + lane] = rho;
+                    inbn[4 * DEV_LANES + lane] = r_ * cfg->g_inv_re;
+                    if (STM && QUAD) publish_d1_inputs(cfg, rb0, rb1, rb2, ql, inbn, lane);
+                    if (!STM && NX_IN_LDS) {
+                        L.part[0 * DEV_LANES + lane] = nx_s; L.part[1 * DEV_LANES + lane] = nx_t; L.part[2 * DEV_LANES + lane] = nx_u; L.part[3 * DEV_LANES + lane] = nx_kfac;
+                    }
+                    }
+                    shared_nx = coop_on;
+                    if (lane == 0) L.ctl[1] = coop_on ? 1 : 0;  // the workers read it after B2(i), for stage i+1
+                    if (coop_on) {
+                        seq_nx = ++coop_seq;
+                        const int64_t p0_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;
+                        if (coop_two) coop_post2(cbox, bt.coop_posted + coop_widx, lane, seq_nx, (LdsCPtr)inbn); else coop_post(cbox, bt.coop_posted + coop_widx, lane, seq_nx, (LdsCPtr)inbn);
+                        if (prof_on && pl_tc != 0) { const int64_t now_ = (int64_t)__builtin_readcyclecounter(); pl_chain += p0_ - pl_tc; pl_post += now_ - p0_; ++pl_n; pl_tc = 0; }
+                    }
+                }
+            };
+            if (INTEG && fastp) {
+                publish_next(true);
+                // two-body term of this stage (orbital.rs:86-92)
+                {
+                    const double rmag = norm3(ys[0], ys[1], ys[2]);
+                    const double f = -cfg->mu_central / cube(rmag);
+                    acc[0] = f * ys[0]; acc[1] = f * ys[1]; acc[2] = f * ys[2];
+                }
+                // velocity part of sum_{j<i} a_{i+1,j} k_j (phase A of the next stage adds the newest term)
+#pragma unroll
+                for (int e = 0; e < 6; ++e) wpre[e] = 0.0;
+                if (i + 1 < stages) {
+#pragma unroll
+                    for (int j = 0; j < DEV_MAX_STAGES - 2; ++j) {
+                        if (j < i) {  // uniform
+                            const double a_nj = A_ROW(i + 1, j);
+#pragma unroll
+                            for (int e = 3; e < 6; ++e) wpre[e] += a_nj * KB(j, e);
+                        }
+                    }
+                }
+                // position part of the stage sum the NEXT window publishes from: k_j[0..2] are the stage velocities, this stage's (ys[3..5],
+                // written to k_i in phase C) included - j ascending from 0.0, the newest term last, as the plain loop adds them
+                if (i + 2 < stages) {
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) pre_wr[e] = 0.0;
+#pragma unroll
+                    for (int j = 0; j < DEV_MAX_STAGES - 2; ++j) {
+                        if (j < i) {  // uniform
+                            const double a_nj = A_ROW(i + 2, j);
+#pragma unroll
+                            for (int e = 0; e < 3; ++e) pre_wr[e] += a_nj * KB(j, e);
+                        }
+                    }
+                    const double a_ni = A_ROW(i + 2, i);
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) pre_wr[e] += a_ni * ys[3 + e];
+                } else if (i + 2 == stages && spec) {
+                    // the next window is the last: it publishes stage 0 of the next attempt, y + sum_j (h b_j) k_j
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) pre_wr[e] = CS_Y(e);
+                    for (int j = 0; j < i; ++j) {
+                        const double cb = h * B_COEF(j);
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) pre_wr[e] += cb * KB(j, e);
+                    }
+                    const double cbi = h * B_COEF(i);
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) pre_wr[e] += cbi * ys[3 + e];
+                }
+            } else
             if (INTEG) {
                 // two-body term of this stage (orbital.rs:86-92) and sum_{j<i} a_{i+1,j} k_j of the next one
                 if (!offl) {
@@ -2706,69 +2912,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                         }
                     }
                 }
-                if (pipe && (i + 1 < stages || spec)) {
-                    // ---- position and recursion inputs of stage i+1, published inside the window of stage i.
-                    // k_i[0..2] is this stage's velocity, so  y + h (wpre + a_{i+1,i} k_i)  is complete for the position
-                    if (i + 1 < stages) {
-                    const double a_nl = A_ROW(i + 1, i);
-#pragma unroll
-                    for (int e = 0; e < 3; ++e) {
-                        const double wi = wpre[e] + a_nl * ys[3 + e];
-                        nx_pos[e] = CS_Y(e) + h * wi;
-                    }
-                    } else {
-                        // last window: stage 0 of the next attempt, should this one be accepted - the position step control will form
-                        // (same operations in the same order: next[e] = y[e]; next[e] += (h b_j) k_j[e], j ascending)
-#pragma unroll
-                        for (int e = 0; e < 3; ++e) nx_pos[e] = CS_Y(e);
-                        for (int j = 0; j < i; ++j) {
-                            const double cb = h * B_COEF(j);
-#pragma unroll
-                            for (int e = 0; e < 3; ++e) nx_pos[e] += cb * KB(j, e);
-                        }
-                        {
-                            const double cb = h * B_COEF(i);
-#pragma unroll
-                            for (int e = 0; e < 3; ++e) nx_pos[e] += cb * ys[3 + e];
-                        }
-                    }
-                    double *const ysn = ((i + 1) & 1) ? L.ys2 : L.ys;
-                    double *const inbn = ((i + 1) & 1) ? L.inb2 : L.inb;
-#pragma unroll
-                    for (int e = 0; e < 3; ++e) ysn[e * DEV_LANES + lane] = nx_pos[e];
-                    if (has_grav) {  // (without a gravity field the position is all the next window needs: the perturbation waves read it after B2)
-                    if (need_almanac) {  // the almanac wave writes the DCM of stage i+1 first thing in this window
-                        // (bounded: a protocol error must end as a failed run, never as a hung GPU)
-                        int spin = 0;
-                        while (LCTL[2] != i + 1 && ++spin < 4000000) __builtin_amdgcn_s_sleep(4);
-                        if (spin >= 4000000) st_att = NYX_HIP_ERR_NAN;
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                    }
-                    const double *const edn = L.ed + ((i + 1) & 1) * ED_FIELDS * DEV_LANES;  // (its DCM: the flag is raised before the body positions are evaluated)
-#pragma unroll
-                    for (int q = 0; q < 9; ++q) m_nx[q] = edn[q * DEV_LANES + lane];
-                    const double rb0 = m_nx[0] * nx_pos[0] + m_nx[1] * nx_pos[1] + m_nx[2] * nx_pos[2];
-                    const double rb1 = m_nx[3] * nx_pos[0] + m_nx[4] * nx_pos[1] + m_nx[5] * nx_pos[2];
-                    const double rb2 = m_nx[6] * nx_pos[0] + m_nx[7] * nx_pos[1] + m_nx[8] * nx_pos[2];
-                    const double r_ = norm3(rb0, rb1, rb2);
-                    const double inv_r = 1.0 / r_;
-                    nx_s = rb0 * inv_r; nx_t = rb1 * inv_r; nx_u = rb2 * inv_r;
-                    const double rho = cfg->g_re * inv_r;
-                    nx_kfac = (cfg->g_mu * inv_r) * cfg->g_inv_re;
-                    inbn[0 * DEV_LANES + lane] = rho * nx_s;
-                    inbn[1 * DEV_LANES + lane] = rho * nx_t;
-                    inbn[2 * DEV_LANES + lane] = rho * nx_u;
-                    inbn[3 * DEV_LANES + lane] = rho;
-                    inbn[4 * DEV_LANES + lane] = r_ * cfg->g_inv_re;
-                    if (STM && QUAD) publish_d1_inputs(cfg, rb0, rb1, rb2, ql, inbn, lane);
-                    }
-                    shared_nx = coop_on;
-                    if (lane == 0) L.ctl[1] = coop_on ? 1 : 0;  // the workers read it after B2(i), for stage i+1
-                    if (coop_on) {
-                        seq_nx = ++coop_seq;
-                        if (coop_two) coop_post2(cbox, bt.coop_posted + coop_widx, lane, seq_nx, inbn); else coop_post(cbox, bt.coop_posted + coop_widx, lane, seq_nx, inbn);
-                    }
-                }
+                publish_next(false);
             }
             // quad layout: the position-only parts of phase C (two-body dual, the duals of s, t, u and (mu / r) / R_eq) are formed
             // HERE, inside the window, where the integrator wave has nothing else to do (after the next stage's inputs: those gate the column waves)
@@ -2867,7 +3011,11 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             // C(i) -> A(i + 1) -> the inputs of stage i + 2, which has ~12 k cycles to spare before the column waves ask for them.  The
             // deadline of a job moves out by that much: the helpers can be loaded further.  (The inputs of this stage in LDS - the
             // fallback's operands - are not overwritten before window i + 1 publishes stage i + 2 into the same parity: behind this point.)
-            if (!pipe || cfg->coop_late == 0) { COOP_COLLECT() }
+            if (!pipe || cfg->coop_late == 0) {
+                const int64_t w0_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;
+                COOP_COLLECT()
+                if (prof_on && INTEG) { pl_tc = (int64_t)__builtin_readcyclecounter(); pl_wait += pl_tc - w0_; }
+            }
             if (prof_on) prof_acc[2] += (int64_t)__builtin_readcyclecounter() - pth_;
             {
                 PROF_T0();
@@ -2905,7 +3053,11 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         if (lane == 0) LCTL[3] = fold_base + i + 1;
                     }
-                    if (pipe && cfg->coop_late != 0) { COOP_COLLECT() }
+                    if (pipe && cfg->coop_late != 0) {
+                        const int64_t w0_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;
+                        COOP_COLLECT()
+                        if (prof_on) { pl_tc = (int64_t)__builtin_readcyclecounter(); pl_wait += pl_tc - w0_; }
+                    }
                     px += coop_x; py += coop_y; pz += coop_z; pw += coop_w;  // + the helper's columns (0 when working alone)
                     if (coop_drop) {  // (between B2 and the next B1: no worker is reading ctl[1])
                         if (lane == 0) L.ctl[1] = 0;
@@ -3132,6 +3284,10 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
         if (prof_on) prof_acc[4] += (int64_t)__builtin_readcyclecounter() - pts_;
         spec_now = spec;
         ++att;
+    }
+    if (prof_on && lane == 0 && INTEG) {
+        int64_t *row = bt.prof + 33 * 8;
+        row[0] = pl_wait; row[1] = pl_chain; row[2] = pl_post; row[3] = pl_n;
     }
     if (prof_on && lane == 0) {
         prof_acc[5] = (int64_t)__builtin_readcyclecounter() - prof_start;

@@ -83,16 +83,18 @@ for rep in range(reps):
             ctx._lib.nyx_hip_debug_profile.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
             if ctx._lib.nyx_hip_debug_profile(ctx._h, buf) == 0:
                 p = np.array(buf[:]).reshape(17, 8)
-                print("   mailbox: answers %d fallbacks %d fb_seq_sum %d posted %d helper_jobs %d" % tuple(p[16, :5]))
+                print("   mailbox: answers %d fallbacks %d fb_seq_sum %d posted %d helper_jobs %d paired_passes %d" % tuple(p[16, :6]))
                 print("   wg0 cycles per eval (phaseA duty harmonics phaseC stepctl | total barrier-wait), clock %.0f MHz, %d evals" % (p[0, 5] / max(p[0, 7], 1) * 100.0, ne))
                 for wv in range(16):
                     if p[wv, 5]:
                         print(f"    wave {wv:2d}: " + " ".join(f"{p[wv, q] / ne:8.0f}" for q in (0, 1, 2, 3, 4)) + f" | {p[wv, 5] / ne:8.0f} {p[wv, 6] / ne:8.0f}")
-            hb = (C.c_int64 * 128)()
+            hb = (C.c_int64 * 136)()
             if hasattr(ctx._lib, "nyx_hip_debug_profile_helper"):
                 ctx._lib.nyx_hip_debug_profile_helper.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
                 if ctx._lib.nyx_hip_debug_profile_helper(ctx._h, hb) == 0:
-                    hp = np.array(hb[:]).reshape(16, 8)
+                    hp = np.array(hb[:]).reshape(17, 8)
+                    if hp[16, 3]:
+                        print(f"   owner latency loop (wg0, per posted job): wait for the answer {hp[16, 0] / hp[16, 3]:.0f}, answer in hand -> post {hp[16, 1] / hp[16, 3]:.0f}, post {hp[16, 2] / hp[16, 3]:.0f} cycles ({hp[16, 3]} jobs)")
                     if hp[0, 2]:
                         print(f"   first helper: producer {hp[0, 2]} jobs, per job: wait-for-slot {hp[0, 0] / hp[0, 2]:.0f}, scan+claim+fetch {hp[0, 1] / hp[0, 2]:.0f}, lost claims {hp[0, 3] / hp[0, 2]:.2f}; total {hp[0, 5] / hp[0, 2]:.0f} cycles/job")
                         for wv in range(1, 16):
