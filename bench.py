@@ -427,6 +427,80 @@ def single_process(args, w):
     print(json.dumps(line), flush=True)
 
 
+def measure_other(cfg_id, dev, device_index, lib, n=0, hours=0.0, tag=None):
+    """One timed pass of another BASELINE configuration inside the headline run (`other_configs` of the JSON line): its own context,
+    one short warm-up launch (code object, tables, mailboxes), then ONE launch of the full workload with inputs resident in HBM
+    (configs 3, 5 and the full-chip launch of configs[1]'s force model: nyx_hip_propagate_batch_device + the ensemble moments) or
+    through the host-buffer entry (config 4: nyx_hip_predict_until has no other), bracketed by synchronisations.  The driver's
+    clock is around all of it."""
+    t_all = time.perf_counter()
+    w = workload(cfg_id)
+    n = n or w["n"]
+    hours = hours or w["hours"]
+    compiled = w["prop"].compile(w["almanac"], w["central"], stm=w["stm"])
+    ctx = nx.GpuContext(compiled, device=device_index)
+    batch = w["batch"](n, seed=0)
+    dur_ns = int(round(hours * 3600)) * nx.NS_PER_S
+    stream = torch.cuda.current_stream(dev)
+    if not w["stm"]:
+        tin, sin = tensor_states(batch, dev)
+        tout, sout = tensor_states(batch, dev)
+        tst, sst = tensor_stats(n, dev)
+        mom = torch.zeros(55, dtype=torch.float64, device=dev)
+        x0 = np.concatenate([batch.rv()[0], [batch.cr[0], batch.cd[0], batch.prop_mass_kg[0]]]).astype(np.float64)
+
+        def go(d_ns):
+            rc = lib.nyx_hip_propagate_batch_device(ctx._h, C.byref(sin), d_ns, C.byref(sout), C.byref(sst), C.c_void_p(stream.cuda_stream))
+            if rc != 0:
+                raise RuntimeError(_abi.last_error())
+            rc = lib.nyx_hip_ensemble_moments_device(ctx._h, C.byref(sout), C.c_void_p(tst["status"].data_ptr()), x0.ctypes.data_as(_abi.c_double_p),
+                                                     C.c_void_p(mom.data_ptr()), C.c_void_p(stream.cuda_stream))
+            if rc != 0:
+                raise RuntimeError(_abi.last_error())
+        go(min(dur_ns, 1800 * nx.NS_PER_S))   # warm-up: the first half hour
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        go(dur_ns)
+        torch.cuda.synchronize(dev)
+        wall = time.perf_counter() - t0
+        k_ms = ctx.last_kernel_ms()
+        n_evals = int(tst["n_evals"].sum().item())
+        n_bad = int((tst["status"] != 0).sum().item())
+        helpers = ctx.last_coop_helpers()
+        per_wg = 64
+    else:
+        batch.stm = np.zeros((n, 81))
+        batch.reset_stm()
+        p0 = init_covar(n)
+        end_ns = int(batch.epoch_ns[0]) + dur_ns
+        nx.predict_until(ctx, batch, p0, int(batch.epoch_ns[0]) + 120 * nx.NS_PER_S, 60 * nx.NS_PER_S)   # warm-up: two updates
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        res = nx.predict_until(ctx, batch, p0, end_ns, 60 * nx.NS_PER_S)
+        torch.cuda.synchronize(dev)
+        wall = time.perf_counter() - t0
+        k_ms = res.kernel_ms
+        n_evals, n_bad = int(res.stats.n_evals.sum()), int((res.stats.status != 0).sum())
+        helpers = 0
+        per_wg = 16 if (n + 15) // 16 <= 2 * N_CU else 64
+    ctx.close()
+    if n_bad:
+        raise SystemExit(f"config {cfg_id}: {n_bad} trajectories failed")
+    achieved_tf = n_evals * w["flop"] / (k_ms * 1e-3) / 1e12
+    owners = (n + per_wg - 1) // per_wg
+    out = {"baseline_config": cfg_id, "workload": w["label"](n, hours), "metric": w["metric"], "value": n / wall, "unit": "trajectories/s",
+           "ms_per_step": wall * 1e3, "kernel_ms": k_ms, "value_device": n / (k_ms * 1e-3), "steps": 1, "force_evals_per_launch": n_evals,
+           "roofline": {"bound": "valu_fp64", "achieved": achieved_tf, "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                        "frac": achieved_tf / FP64_VECTOR_PEAK_TFLOPS, "algorithmic_flop_per_eval": w["flop"]},
+           "occupancy": {"owner_workgroups": owners, "helper_workgroups": helpers, "cus": N_CU, "cu_fraction": min(1.0, (owners + helpers) / N_CU)},
+           "inputs": "host buffers (nyx_hip_predict_until: PCIe-inclusive)" if w["stm"] else "resident in HBM",
+           "wall_s_with_setup": None, "fits_in_driver_run": True}
+    if tag:
+        out["tag"] = tag
+    out["wall_s_with_setup"] = time.perf_counter() - t_all
+    return out
+
+
 class ClockSampler:
     """Shader clock of the device WHILE the timed steps run (amdsmi through torch.cuda.clock_rate, 5 Hz from a side thread; best
     effort: None where the query is not available).  Diagnostic only - a box whose clock is capped shows up here, not as a regression."""
@@ -489,6 +563,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-dense-output", action="store_true", help="skip the extra launch with the trajectories recorded")
     ap.add_argument("--no-host-call", action="store_true", help="skip the PCIe-inclusive host-buffer call")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the one-pass measurements of configs 3, 4, 5 and of the full-chip launch that the headline run carries in `other_configs`")
     args = ap.parse_args()
 
     # ---- how many ranks, and who starts them.  Under torchrun (the driver's N > 1 launch) WORLD_SIZE is set and must agree
@@ -765,6 +841,13 @@ def main():
                                     "states_written": n_states, "bytes_written": n_states * 56,
                                     "note": "one launch of nyx_hip_propagate_batch_with_traj_device (until_epoch_with_traj of every run)"}
             del t_ep, t_st, t_len
+        if world == 1 and args.config == 2 and not args.no_other_configs and not args.n and not args.hours and args.degree is None:
+            # the other GPU configurations and the full-chip launch under the SAME driver clock, one timed pass each
+            others = {}
+            for key, kw in (("config3", dict(cfg_id=3)), ("config4", dict(cfg_id=4)), ("config5", dict(cfg_id=5)),
+                            ("fullchip", dict(cfg_id=2, n=16384, hours=3.0, tag="configs[1]'s force model on a full chip: 16 384 trajectories (256 workgroups, no helpers), 3 h"))):
+                others[key] = measure_other(dev=dev, device_index=device_index, lib=lib, **kw)
+            line["other_configs"] = others
         if not args.no_cpu_baseline and world == 1:
             if not w["stm"]:
                 cb, sample, ref, samp_h = cpu_baseline(shard, compiled, n, hours)
