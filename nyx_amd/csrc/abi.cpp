@@ -98,16 +98,17 @@ struct nyx_hip_ctx {
     int terms2 = 0;                // its table rows
     ColHdr *d_cols2 = nullptr;
     double *d_hyb = nullptr;  // the same table in the hybrid-feed layout (devcfg.h HYB_*)
-    // the helpers' columns as a stream of their own, every column at the head of a sixteen-row group (DevCfg.hyb_h): rebuilt when the
-    // helper schedule changes (build_schedule sets hyb_h_dirty), uploaded by launch() before a cooperative launch that streams in the helpers
+    // Run streams (DevCfg.rs_*): the table once more per column schedule - [0] SOLO, [1] PRIMARY, [2] the helpers' - with every RANGE of
+    // a wave starting a sixteen-row group of its own.  Rebuilt when a schedule changes (build_schedule sets rs_dirty), uploaded by
+    // launch() before a launch that streams the table.
     std::vector<HarmEntry> h_tab;  // host copy of the entry table (without its tail padding)
     std::vector<ColHdr> h_cols;
-    std::vector<double> h_hyb_h;   // (kept: the asynchronous upload reads it)
-    std::vector<ColHdr> h_cols_h;
-    double *d_hyb_h = nullptr;
-    size_t hyb_h_cap = 0;
-    ColHdr *d_cols_h = nullptr;
-    bool hyb_h_dirty = true;
+    std::vector<double> h_rs[3];   // (kept: the asynchronous upload reads them)
+    std::vector<ColHdr> h_rs_cols[3];
+    double *d_rs[3] = {nullptr, nullptr, nullptr};
+    size_t rs_cap[3] = {0, 0, 0};
+    ColHdr *d_rs_cols[3] = {nullptr, nullptr, nullptr};
+    bool rs_dirty = true;
     // experiment knobs of the helper dealing (environment, only with NYX_HIP_TUNING_ENV: tools/sweep.py)
     double coop_fast_weight = 4.0 / 3.0;  // speed of a helper column wave on a SIMD that hosts three of them (beside the producer / the answering wave)
     double coop_start_rows = 4.0;         // what the start of one more column on a helper wave is charged, in rows
@@ -414,26 +415,29 @@ static void build_hybrid(const std::vector<HarmEntry> &tab, std::vector<double> 
             }
 }
 
-// The helpers' columns as a stream of their own (DevCfg.hyb_h): every column of the helper schedules at the head of a sixteen-row
-// group, so that a helper wave - ONE column per range - starts its walk on the column's first row (in the common stream it starts at
-// the batch that holds it, with up to seven rows of the previous column in front).  `cols_h` = the headers with `start` moved.
-static void build_helper_stream(const nyx_hip_ctx *ctx, std::vector<double> &hyb, int64_t &vec_off, std::vector<ColHdr> &cols_h) {
-    cols_h = ctx->h_cols;
+// A run stream (DevCfg.rs_*): the rows of the schedules `ids`, every range of every wave laid out as one contiguous piece that
+// starts a sixteen-row group of its own - a wave's walk then begins on its range's first row (in the common stream it begins at the
+// batch that holds it, with up to seven rows of the previous column in front, through the recursion with a zero state: at 70x70
+// 3 % of an owner's rows, and most of a short range).  `cols_x` = the column headers with `start` pointing into this stream.
+// Same rows, same operations: bit-identical sums.
+static void build_run_stream(const nyx_hip_ctx *ctx, std::initializer_list<int> ids, std::vector<double> &hyb, int64_t &vec_off, std::vector<ColHdr> &cols_x) {
+    cols_x = ctx->h_cols;
     std::vector<HarmEntry> t;
     const HarmEntry z = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    std::vector<char> seen(cols_h.size(), 0);
-    for (int k : {DEV_SCHED_HELPER, DEV_SCHED_HELPER2}) {
+    std::vector<char> seen(cols_x.size(), 0);
+    for (int k : ids) {
         const DevSched &sd = ctx->host_cfg.sched[k];
         for (int w = 0; w < DEV_MAX_WAVES; ++w)
-            for (int r = 0; r < sd.n_ranges[w]; ++r)
+            for (int r = 0; r < sd.n_ranges[w]; ++r) {
+                t.resize((t.size() + 15) / 16 * 16, z);
                 for (int c = sd.range_c0[w][r]; c < sd.range_c0[w][r] + sd.range_cnt[w][r]; ++c) {
-                    if (c < 1 || c >= (int)cols_h.size() || seen[c]) continue;
+                    if (c < 1 || c >= (int)cols_x.size() || seen[c]) continue;
                     seen[c] = 1;
-                    t.resize((t.size() + 15) / 16 * 16, z);
                     const int32_t src = ctx->h_cols[c].start;
-                    cols_h[c].start = (int32_t)t.size();
+                    cols_x[c].start = (int32_t)t.size();
                     for (int q = 0; q < ctx->h_cols[c].rows; ++q) t.push_back(ctx->h_tab[(size_t)src + q]);
                 }
+            }
     }
     build_hybrid(t, hyb, vec_off);
 }
@@ -759,6 +763,7 @@ static void assign_roles(nyx_hip_ctx *ctx, int n_waves, bool fanout, double *hc)
 
 static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
     DevCfg &dc = ctx->host_cfg;
+    ctx->rs_dirty = true;  // (the run streams follow the schedules: rebuilt before the next launch that streams the table)
     const int nc = dc.n_cols;
     for (int k = 0; k < DEV_N_SCHED; ++k)
         for (int w = 0; w < DEV_MAX_WAVES; ++w) dc.sched[k].n_ranges[w] = 0;
@@ -901,7 +906,6 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
                 hs.range_c0[w][r] = mine[k]; hs.range_cnt[w][r] = 1;
             }
         }
-        ctx->hyb_h_dirty = true;  // (the helpers' own stream follows their schedule: rebuilt before the next cooperative launch)
         if (!help.empty() && !own.empty() && fill_schedule(ctx, dc.sched[DEV_SCHED_PRIMARY], n_waves, own, hc, false)) {
             dc.coop_ok = 1;
         } else {
@@ -1081,7 +1085,7 @@ extern "C" int32_t nyx_hip_debug_profile(nyx_hip_ctx *ctx, int64_t *out) {
 extern "C" void nyx_hip_ctx_destroy(nyx_hip_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
-    hipFree(ctx->d_cfg); hipFree(ctx->d_htab); hipFree(ctx->d_htab2); hipFree(ctx->d_cols2); hipFree(ctx->d_hyb); hipFree(ctx->d_hyb_h); hipFree(ctx->d_cols_h); hipFree(ctx->d_cols); hipFree(ctx->d_records);
+    hipFree(ctx->d_cfg); hipFree(ctx->d_htab); hipFree(ctx->d_htab2); hipFree(ctx->d_cols2); hipFree(ctx->d_hyb); for (int k = 0; k < 3; ++k) { hipFree(ctx->d_rs[k]); hipFree(ctx->d_rs_cols[k]); } hipFree(ctx->d_cols); hipFree(ctx->d_records);
     free_arrays(ctx->in);
     free_arrays(ctx->out);
     free_arrays(ctx->cal);
@@ -1749,30 +1753,38 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
             }
         }
     }
-    if (bt.coop_helpers > 0 && (ctx->host_cfg.harm_feed & 2) && !ctx->h_tab.empty()) {
-        // helpers that stream the table walk a stream of their own, one column per sixteen-row group (DevCfg.hyb_h; debug_flags
-        // 0x800000: the common stream, as in round 4 - same bits)
+    if (!ctx->h_tab.empty() && ctx->host_cfg.harm_feed != 0 && !(ctx->host_cfg.flags & NYX_HIP_FLAG_STM)) {
+        // workgroups that stream the table walk run streams: one per schedule, every range of a wave at the head of a sixteen-row
+        // group (DevCfg.rs_*; debug_flags 0x800000: the common stream, as in round 4 - same bits)
         const bool want = (ctx->tune.debug_flags & 0x800000) == 0;
-        if (want && ctx->hyb_h_dirty) {
-            int64_t vec_off = 0;
-            build_helper_stream(ctx, ctx->h_hyb_h, vec_off, ctx->h_cols_h);
-            if (ctx->h_hyb_h.size() > ctx->hyb_h_cap) {
-                if (ctx->launched) HIP_TRY(hipEventSynchronize(ctx->ev_done));
-                (void)hipFree(ctx->d_hyb_h);
-                ctx->d_hyb_h = nullptr; ctx->hyb_h_cap = 0;
-                HIP_TRY(hipMalloc(&ctx->d_hyb_h, ctx->h_hyb_h.size() * sizeof(double)));
-                ctx->hyb_h_cap = ctx->h_hyb_h.size();
+        if (want && ctx->rs_dirty) {
+            for (int k = 0; k < 3; ++k) {
+                const bool used = k == 0 ? (ctx->host_cfg.harm_feed & 1) != 0
+                                  : (ctx->host_cfg.coop_ok != 0 && (k == 1 ? (ctx->host_cfg.harm_feed & 1) != 0 : (ctx->host_cfg.harm_feed & 2) != 0));
+                ctx->host_cfg.rs_hyb[k] = 0;
+                if (!used) continue;
+                int64_t vec_off = 0;
+                if (k == 0) build_run_stream(ctx, {DEV_SCHED_SOLO}, ctx->h_rs[k], vec_off, ctx->h_rs_cols[k]);
+                else if (k == 1) build_run_stream(ctx, {DEV_SCHED_PRIMARY}, ctx->h_rs[k], vec_off, ctx->h_rs_cols[k]);
+                else build_run_stream(ctx, {DEV_SCHED_HELPER, DEV_SCHED_HELPER2}, ctx->h_rs[k], vec_off, ctx->h_rs_cols[k]);
+                if (ctx->h_rs[k].size() > ctx->rs_cap[k]) {
+                    if (ctx->launched) HIP_TRY(hipEventSynchronize(ctx->ev_done));
+                    (void)hipFree(ctx->d_rs[k]);
+                    ctx->d_rs[k] = nullptr; ctx->rs_cap[k] = 0;
+                    HIP_TRY(hipMalloc(&ctx->d_rs[k], ctx->h_rs[k].size() * sizeof(double)));
+                    ctx->rs_cap[k] = ctx->h_rs[k].size();
+                }
+                if (!ctx->d_rs_cols[k]) HIP_TRY(hipMalloc(&ctx->d_rs_cols[k], ctx->h_rs_cols[k].size() * sizeof(ColHdr)));
+                HIP_TRY(hipMemcpyAsync(ctx->d_rs[k], ctx->h_rs[k].data(), ctx->h_rs[k].size() * sizeof(double), hipMemcpyHostToDevice, stream));
+                HIP_TRY(hipMemcpyAsync(ctx->d_rs_cols[k], ctx->h_rs_cols[k].data(), ctx->h_rs_cols[k].size() * sizeof(ColHdr), hipMemcpyHostToDevice, stream));
+                ctx->host_cfg.rs_hyb[k] = (uint64_t)ctx->d_rs[k];
+                ctx->host_cfg.rs_hyb_v[k] = (uint64_t)(ctx->d_rs[k] + vec_off);
+                ctx->host_cfg.rs_cols[k] = (uint64_t)ctx->d_rs_cols[k];
             }
-            if (!ctx->d_cols_h) HIP_TRY(hipMalloc(&ctx->d_cols_h, ctx->h_cols_h.size() * sizeof(ColHdr)));
-            HIP_TRY(hipMemcpyAsync(ctx->d_hyb_h, ctx->h_hyb_h.data(), ctx->h_hyb_h.size() * sizeof(double), hipMemcpyHostToDevice, stream));
-            HIP_TRY(hipMemcpyAsync(ctx->d_cols_h, ctx->h_cols_h.data(), ctx->h_cols_h.size() * sizeof(ColHdr), hipMemcpyHostToDevice, stream));
-            ctx->host_cfg.hyb_h = (uint64_t)ctx->d_hyb_h;
-            ctx->host_cfg.hyb_h_v = (uint64_t)(ctx->d_hyb_h + vec_off);
-            ctx->host_cfg.cols_h = (uint64_t)ctx->d_cols_h;
-            ctx->hyb_h_dirty = false;
+            ctx->rs_dirty = false;
             HIP_TRY(hipMemcpyAsync(ctx->d_cfg, &ctx->host_cfg, sizeof(DevCfg), hipMemcpyHostToDevice, stream));
-        } else if (!want && ctx->host_cfg.hyb_h != 0) {
-            ctx->host_cfg.hyb_h = 0;
+        } else if (!want && (ctx->host_cfg.rs_hyb[0] | ctx->host_cfg.rs_hyb[1] | ctx->host_cfg.rs_hyb[2]) != 0) {
+            ctx->host_cfg.rs_hyb[0] = ctx->host_cfg.rs_hyb[1] = ctx->host_cfg.rs_hyb[2] = 0;
             HIP_TRY(hipMemcpyAsync(ctx->d_cfg, &ctx->host_cfg, sizeof(DevCfg), hipMemcpyHostToDevice, stream));
         }
     }

@@ -139,11 +139,12 @@ struct DevCfg {
                         * bit 1 = in the helpers (and the owner's fallback for a helper that does not answer) */
     uint64_t hyb;     /* device address of the hybrid-feed stream: scalar side (24 bytes per stream row) */
     uint64_t hyb_v;   /* its vector side (groups of sixteen stream rows, [t3..t6][16]) */
-    /* The helpers' columns once more, every column starting a sixteen-row group of its own (cooperative mode, harm_feed bit 1): a helper
-     * wave walks ONE column per range, and in the common stream it would begin inside a batch - up to seven rows of the previous column
-     * in front of it, through the recursion with a zero state, per column and job.  0 = not built: the common stream serves.  Same rows,
-     * same operations: bit-identical sums.  cols_h = the column headers with `start` pointing into this stream. */
-    uint64_t hyb_h, hyb_h_v, cols_h;
+    /* Run streams: the table once more per column schedule - [0] DEV_SCHED_SOLO, [1] DEV_SCHED_PRIMARY, [2] the helpers' schedules -,
+     * every RANGE of a wave starting a sixteen-row group of its own: in the common stream a range begins inside a batch, up to seven rows
+     * of the previous column in front of it (through the recursion with a zero state), per range and evaluation.  0 = not built: the
+     * common stream serves.  Same rows, same operations: bit-identical sums.  rs_cols = the column headers with `start` pointing into
+     * the stream. */
+    uint64_t rs_hyb[3], rs_hyb_v[3], rs_cols[3];
     int32_t coop_late, _pad_cl; /* pipelined loop: the helper's answer of stage i is collected behind B2(i), in phase C, instead of inside the window */
 };
 

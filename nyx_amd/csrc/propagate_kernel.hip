@@ -1110,9 +1110,12 @@ static __device__ __attribute__((noinline)) Partial4 harmonics_stream(uint64_t c
     const CAS DevSched &sd = cfg->sched[sched];
     const int nr = sd.n_ranges[wave];
     uint64_t hs0 = cfg->hyb, hv0 = cfg->hyb_v;
-    if ((sched == DEV_SCHED_HELPER || sched == DEV_SCHED_HELPER2) && cfg->hyb_h != 0) {  // (uniform) the helpers' columns, each at the head of a group of its own (DevCfg.hyb_h)
-        hs0 = cfg->hyb_h; hv0 = cfg->hyb_h_v;
-        cols = (ColPtr)cfg->cols_h;
+    {   // (uniform) the run stream of this schedule, every range at the head of a group of its own (DevCfg.rs_*)
+        const int rs = sched == DEV_SCHED_SOLO ? 0 : (sched == DEV_SCHED_PRIMARY ? 1 : ((sched == DEV_SCHED_HELPER || sched == DEV_SCHED_HELPER2) ? 2 : -1));
+        if (rs >= 0 && cfg->rs_hyb[rs >= 0 ? rs : 0] != 0) {
+            hs0 = cfg->rs_hyb[rs]; hv0 = cfg->rs_hyb_v[rs];
+            cols = (ColPtr)cfg->rs_cols[rs];
+        }
     }
     const int voff = (lane & 15) * 8;
     for (int q = 0; q < nr; ++q) {
@@ -2253,6 +2256,11 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     double *const kbuf = L.kbuf;
     double *const tabl = L.tabl;
     const int stages = cfg->stages;
+    // Markers for tools/kernel_roles.py: every instantiation of this function is inlined into one kernel, and which ROLE owns the
+    // scratch traffic of a code object cannot be told from its metadata.  `s_nop 13; s_nop <id>` opens a role's code, `s_nop 13; s_nop 15`
+    // closes it (two scalar no-ops per wave and launch); id = INTEG | ALMANAC << 1 | PERT << 2 | PIPE << 3 (the STM / quad layouts live in
+    // kernels of their own).
+    asm volatile("s_nop 13\n\ts_nop %0" ::"n"((INTEG ? 1 : 0) | (ALMANAC ? 2 : 0) | (PERT ? 4 : 0) | (PIPE ? 8 : 0)) : "memory");
 #ifdef NYX_ASSUME_SMALL
     // propagate_w8n.hip: the kernel of workgroups whose dynamics have no body-fixed model at all (point masses and SRP around a
     // two-body term: BASELINE config 3) - the four switches are compile-time constants there.  The general eight-wave kernel is 2.8 MB
@@ -3324,6 +3332,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
         if (bt.n_rej) bt.n_rej[gid] = c.n_rej;
         if (bt.n_evals) bt.n_evals[gid] = c.n_evals;
     }
+    asm volatile("s_nop 13\n\ts_nop 15" ::: "memory");
 }
 
 #undef coop_two

@@ -28,6 +28,13 @@ def kernels(lib):
             if r.returncode or not os.path.exists(co) or os.path.getsize(co) == 0:
                 continue
             notes = subprocess.run([f"{LLVM}/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout
+            # .text bytes of every function symbol of this code object (kernels and the out-of-line device functions they call)
+            sizes = {}
+            for ln in subprocess.run([f"{LLVM}/llvm-readelf", "-s", "-W", co], capture_output=True, text=True).stdout.splitlines():
+                f = ln.split()
+                if len(f) >= 8 and f[3] == "FUNC":
+                    sizes[f[7]] = int(f[2])
+            first = len(out)
             cur = {}
             for line in notes.splitlines():
                 m = re.match(r"\s*-?\s*\.(\w+):\s*(.*)", line)
@@ -42,12 +49,14 @@ def kernels(lib):
                     cur[key] = val
             if cur.get("name"):
                 out.append(cur)
+            for k in out[first:]:
+                k["text_bytes"] = str(sizes.get(k.get("name", ""), 0))
     return out
 
 
 if __name__ == "__main__":
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "nyx_amd", "libnyx_hip.so")
-    print(f"{'kernel':36s} {'wg':>5s} {'vgpr':>5s} {'agpr':>5s} {'sgpr':>5s} {'scratch B':>9s} {'sgpr spills':>11s} {'vgpr spills':>11s}")
+    print(f"{'kernel':36s} {'wg':>5s} {'vgpr':>5s} {'agpr':>5s} {'sgpr':>5s} {'scratch B':>9s} {'sgpr spills':>11s} {'vgpr spills':>11s} {'.text B':>9s}")
     for k in kernels(lib):
         print(f"{k.get('name', '?'):36s} {k.get('max_flat_workgroup_size', '?'):>5s} {k.get('vgpr_count', '?'):>5s} {k.get('agpr_count', '?'):>5s} "
-              f"{k.get('sgpr_count', '?'):>5s} {k.get('private_segment_fixed_size', '?'):>9s} {k.get('sgpr_spill_count', '?'):>11s} {k.get('vgpr_spill_count', '?'):>11s}")
+              f"{k.get('sgpr_count', '?'):>5s} {k.get('private_segment_fixed_size', '?'):>9s} {k.get('sgpr_spill_count', '?'):>11s} {k.get('vgpr_spill_count', '?'):>11s} {k.get('text_bytes', '?'):>9s}")
