@@ -1045,28 +1045,55 @@ class Traj:
 _ARRAY_DIGESTS: dict = {}
 
 
+def _array_sample(a: np.ndarray) -> bytes:
+    """A cheap fingerprint of a large array - its first and last KiB and a comb of 256 elements - to tell a buffer whose ADDRESS is
+    being reused by another table from the one a memoised digest belongs to."""
+    flat = a.reshape(-1) if a.flags.c_contiguous else np.ascontiguousarray(a).reshape(-1)
+    k = max(1, 1024 // max(flat.itemsize, 1))
+    comb = flat[:: max(1, flat.size // 256)][:256]
+    return hashlib.blake2b(flat[:k].tobytes() + flat[-k:].tobytes() + np.ascontiguousarray(comb).tobytes(), digest_size=8).digest()
+
+
 def _array_digest(a: np.ndarray) -> bytes:
     """Digest of an array's content (blake2b over the whole buffer: ~1 ms per megabyte).  The digest is memoised ONLY for
     arrays that cannot change under it - `a.flags.writeable == False` all the way down to the buffer's owner (freeze a table
-    with `arr.setflags(write=False)` to get the cached path) - keyed on (address, shape, strides, type).  A writable array is
-    hashed in full every time: an in-place edit of one Stokes coefficient must give a new context, never a stale one."""
-    def frozen(x):
+    with `arr.setflags(write=False)` to get the cached path) - keyed on (address, shape, strides, type) AND tied to the buffer's
+    owner: the entry holds a weak reference to the owning object and is dropped when that object dies, so a later table that the
+    allocator places at the same address (free JGM3, load another 70x70 field: the same shape, quite possibly the same address)
+    can never inherit it; where the owner cannot be weakly referenced, and as a second line in any case, a hit is revalidated
+    against a cheap sample of the content (first and last KiB + a comb of 256 elements).  A writable array is hashed in full every
+    time: an in-place edit of one Stokes coefficient must give a new context, never a stale one."""
+    import weakref
+
+    def owner_of(x):
+        frozen = True
         while isinstance(x, np.ndarray):
             if x.flags.writeable:
-                return False
+                frozen = False
+            if x.base is None:
+                break
             x = x.base
-        return True   # (the owner is read-only: nobody holds a writable view through numpy)
+        return x, frozen   # (owner read-only: nobody holds a writable view through numpy)
     key = (a.__array_interface__["data"][0], a.shape, a.strides, a.dtype.str)
-    if a.nbytes <= 4096 or not frozen(a):
+    owner, frozen = owner_of(a)
+    if a.nbytes <= 4096 or not frozen:
         _ARRAY_DIGESTS.pop(key, None)   # (a buffer seen writable may be edited before it is frozen again: forget what was known of it)
         return hashlib.blake2b(np.ascontiguousarray(a).tobytes(), digest_size=16).digest()
     hit = _ARRAY_DIGESTS.get(key)
     if hit is not None:
-        return hit
+        ref, digest, sample = hit
+        alive = ref is None or ref() is owner
+        if alive and sample == _array_sample(a):
+            return digest
+        _ARRAY_DIGESTS.pop(key, None)
     d = hashlib.blake2b(np.ascontiguousarray(a).tobytes(), digest_size=16).digest()
     if len(_ARRAY_DIGESTS) > 256:
         _ARRAY_DIGESTS.clear()
-    _ARRAY_DIGESTS[key] = d
+    try:
+        ref = weakref.ref(owner, lambda _r, k=key: _ARRAY_DIGESTS.pop(k, None))
+    except TypeError:
+        ref = None   # (bytes, mmap, ...: the sample check alone guards the entry)
+    _ARRAY_DIGESTS[key] = (ref, d, _array_sample(a))
     return d
 
 

@@ -45,3 +45,27 @@ def test_only_frozen_arrays_are_memoised():
     n = len(P._ARRAY_DIGESTS)
     P._array_digest(ro)
     assert len(P._ARRAY_DIGESTS) == n
+
+
+def test_a_freed_tables_digest_is_not_inherited_by_its_successor():
+    """free a frozen table, load another frozen table of the same shape - the allocator may well hand out the
+    same address - and the memo must NOT answer with the first table's digest: the entry dies with the owner, and a hit is
+    revalidated against a sample of the content."""
+    import gc
+    P._ARRAY_DIGESTS.clear()
+    a = np.random.default_rng(1).standard_normal(8192)
+    a.setflags(write=False)
+    da = P._array_digest(a)
+    assert len(P._ARRAY_DIGESTS) == 1
+    key = next(iter(P._ARRAY_DIGESTS))
+    del a
+    gc.collect()
+    assert not P._ARRAY_DIGESTS                       # the owner is gone: so is its entry
+    # the same address, shape and strides answering for other content (forced: a stale entry planted under the new array's key)
+    b = np.random.default_rng(2).standard_normal(8192)
+    b.setflags(write=False)
+    kb = (b.__array_interface__["data"][0], b.shape, b.strides, b.dtype.str)
+    P._ARRAY_DIGESTS[kb] = (None, da, b"stale___")     # (no owner reference: only the sample stands guard)
+    db = P._array_digest(b)
+    assert db != da and db == hashlib.blake2b(b.tobytes(), digest_size=16).digest()
+    assert key is not None
