@@ -389,7 +389,12 @@ int32_t nyx_hip_propagate_batch_device(nyx_hip_ctx *ctx, const nyx_hip_states_t 
  * Host arrays; `traj` arrays must hold capacity * n elements. */
 int32_t nyx_hip_propagate_batch_with_traj(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t duration_ns,
                                           nyx_hip_states_t *out, nyx_hip_step_stats_t *stats, nyx_hip_traj_t *traj);
-/* Device-pointer flavour (every pointer in in/out/stats/traj is a device pointer), asynchronous on `hip_stream`. */
+/* Device-pointer flavour (every pointer in in/out/stats/traj is a device pointer), asynchronous on `hip_stream`.
+ * Aliasing: the DEVICE entry points read `in` while they write `out`; `out` may alias `in` for a plain propagation (every workgroup
+ * reads its own trajectories' start states before it writes anything), but NOT together with dense output AND an integration-frame
+ * swap (config.state_frame_body): entry 0 of the dense output is then rewritten from `in` after the launch (instance.rs:319-321: the
+ * start state in the caller's frame), and an aliased `in` would hold the final states by then.  The host flavours stage through
+ * device blocks of their own and take any aliasing. */
 int32_t nyx_hip_propagate_batch_with_traj_device(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, int64_t duration_ns,
                                                  nyx_hip_states_t *out, nyx_hip_step_stats_t *stats, nyx_hip_traj_t *traj,
                                                  void *hip_stream);

@@ -1583,6 +1583,10 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
                                   coop_get(&b->in[par][2][0][lane], seq_c, v2) & coop_get(&b->in[par][3][0][lane], seq_c, v3) &
                                   coop_get(&b->in[par][4][0][lane], seq_c, v4);
                         }
+                        // the poll timed out: the inputs were never seen whole.  The job is NOT worked on - a tagged answer vouches for
+                        // the data it was computed from, and this one would be computed from torn or zero inputs; the owner gave up
+                        // waiting 2 ms in, walks these columns itself and never looks at the mailbox again
+                        if (!__all(got)) continue;
                         owner = owner_c;
                         seq = seq_c;
                         sub = part_c;
