@@ -313,7 +313,12 @@ typedef struct nyx_hip_config {
 
 /* flags */
 #define NYX_HIP_FLAG_STM 0x1u          /* states carry a 9x9 STM (Spacecraft.stm = Some) */
-#define NYX_HIP_FLAG_STM_TEXTBOOK 0x2u /* integrate dPhi/dt = A Phi instead of the reference's Phi_ctx*A (spacecraft.rs:214) */
+#define NYX_HIP_FLAG_STM_TEXTBOOK 0x2u /* (with NYX_HIP_FLAG_STM) the variational equations dPhi/dt = A(t) Phi, integrated with the state by the step's
+                                        * own tableau, instead of the reference's first-order Phi_{n+1} = Phi_n (I + h sum b_i A_i) (spacecraft.rs:208-224: the
+                                        * step-start STM right-multiplied).  No reference vector exists for this form; it is pinned as the derivative of the
+                                        * flow (tests/test_oracle_stm_textbook.py: 5e-7 of finite differences where the reference's form is 0.2 off) and device =
+                                        * oracle to rounding (tests/test_gpu_stm_textbook.py).  The states are the same bits either way.  64-lane dual
+                                        * layout only (tuning.stm_quad is ignored); through nyx_hip_predict_until as well. */
 
 /* Spacecraft batch, structure-of-arrays (one array per field, length n).
  * Mirrors Spacecraft::to_vector / set (cosmic/spacecraft.rs:451-497) plus the

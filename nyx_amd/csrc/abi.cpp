@@ -90,6 +90,8 @@ struct nyx_hip_ctx {
     int32_t swap_seg[4] = {0, 0, 0, 0};
     double swap_sign[4] = {0.0, 0.0, 0.0, 0.0};
     double *d_mom = nullptr;   // scratch of the ensemble-moments reduction: [MOM_BLOCKS][MOM_N] block sums, then MOM_N results (host flavour)
+    double *d_stm_hist = nullptr;  // NYX_HIP_FLAG_STM_TEXTBOOK: [16][12][stm_hist_cap] stage matrices of the attempt in flight (DevBatch.stm_hist)
+    int64_t stm_hist_cap = 0;
     double *d_swap = nullptr;  // six rows of swap_cap doubles: the translated copy of a batch's Cartesian state
     int64_t swap_cap = 0;
     int ed_reuse_fit = 0;  // fields of stage-0 epoch data an unchained pipelined loop may carry between attempts (LDS room)
@@ -923,6 +925,7 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
 static bool pick_quad(const nyx_hip_ctx *ctx, int64_t n) {
     if (!(ctx->host_cfg.flags & NYX_HIP_FLAG_STM)) return false;
     if (ctx->host_cfg.has_grav2) return false;  // (the second field's dual form is walked by the perturbation wave of the 64-lane layout only)
+    if (ctx->host_cfg.flags & NYX_HIP_FLAG_STM_TEXTBOOK) return false;  // (the variational equations are integrated by the 64-lane layout: one trajectory's k-buffer column per lane)
     if (ctx->forced_quad >= 0) return ctx->forced_quad != 0;
     if (ctx->tune.stm_quad >= 0) return ctx->tune.stm_quad != 0;
     // deterministic: the layout fixes the column split, hence the bits - it must not follow the batch size (a shard is a smaller batch)
@@ -1085,7 +1088,7 @@ extern "C" int32_t nyx_hip_debug_profile(nyx_hip_ctx *ctx, int64_t *out) {
 extern "C" void nyx_hip_ctx_destroy(nyx_hip_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
-    hipFree(ctx->d_cfg); hipFree(ctx->d_htab); hipFree(ctx->d_htab2); hipFree(ctx->d_cols2); hipFree(ctx->d_hyb); for (int k = 0; k < 3; ++k) { hipFree(ctx->d_rs[k]); hipFree(ctx->d_rs_cols[k]); } hipFree(ctx->d_cols); hipFree(ctx->d_records);
+    hipFree(ctx->d_cfg); hipFree(ctx->d_htab); hipFree(ctx->d_htab2); hipFree(ctx->d_cols2); hipFree(ctx->d_stm_hist); hipFree(ctx->d_hyb); for (int k = 0; k < 3; ++k) { hipFree(ctx->d_rs[k]); hipFree(ctx->d_rs_cols[k]); } hipFree(ctx->d_cols); hipFree(ctx->d_records);
     free_arrays(ctx->in);
     free_arrays(ctx->out);
     free_arrays(ctx->cal);
@@ -1108,7 +1111,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
         nyx_set_error("STM propagation on the device supports the RSSCartesianStep / RSSCartesianState error controls only");
         return NYX_HIP_RC_UNSUPPORTED;
     }
-    if (cfg->flags & NYX_HIP_FLAG_STM_TEXTBOOK) { nyx_set_error("textbook STM form (A Phi) is not implemented"); return NYX_HIP_RC_UNSUPPORTED; }
+    if ((cfg->flags & NYX_HIP_FLAG_STM_TEXTBOOK) && !(cfg->flags & NYX_HIP_FLAG_STM)) { nyx_set_error("NYX_HIP_FLAG_STM_TEXTBOOK without NYX_HIP_FLAG_STM"); return NYX_HIP_RC_BAD_ARG; }
     if (cfg->drag && (cfg->flags & NYX_HIP_FLAG_STM)) {  // PartialsUndefined in the reference too (drag.rs:286-294)
         nyx_set_error("drag has no partials: STM propagation with drag is undefined");
         return NYX_HIP_RC_UNSUPPORTED;
@@ -1653,6 +1656,18 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
     if (ctx->host_cfg.flags & NYX_HIP_FLAG_STM) {
         if (!in->stm || !out->stm) { nyx_set_error("STM context: in->stm and out->stm are mandatory"); return NYX_HIP_RC_BAD_ARG; }
         bt.stm = in->stm; bt.o_stm = out->stm;
+        if (ctx->host_cfg.flags & NYX_HIP_FLAG_STM_TEXTBOOK) {
+            if (ctx->stm_hist_cap < in->n) {
+                if (ctx->launched) HIP_TRY(hipEventSynchronize(ctx->ev_done));
+                (void)hipFree(ctx->d_stm_hist);
+                ctx->d_stm_hist = nullptr; ctx->stm_hist_cap = 0;
+                const int64_t cap = (in->n + 63) / 64 * 64;
+                HIP_TRY(hipMalloc(&ctx->d_stm_hist, (size_t)DEV_MAX_STAGES * 12 * (size_t)cap * sizeof(double)));
+                ctx->stm_hist_cap = cap;
+            }
+            bt.stm_hist = ctx->d_stm_hist;
+            bt.stm_hist_stride = ctx->stm_hist_cap;
+        }
     }
     bt.o_epoch_ns = out->epoch_ns;
     bt.o_x = out->x_km; bt.o_y = out->y_km; bt.o_z = out->z_km; bt.o_vx = out->vx_km_s; bt.o_vy = out->vy_km_s; bt.o_vz = out->vz_km_s;

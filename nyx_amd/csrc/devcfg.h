@@ -234,6 +234,9 @@ struct DevBatch { /* device pointers of one launch */
     const int64_t *dur_ns; /* optional per-trajectory duration (covariance-mapping segments); overrides duration_ns */
     const double *stm; /* [n][81] column-major per trajectory, or NULL */
     double *o_stm;
+    int64_t stm_hist_stride; /* elements between consecutive rows of stm_hist */
+    double *stm_hist; /* NYX_HIP_FLAG_STM_TEXTBOOK: [16 stages][12][n] the stage matrices of the current attempt - G_i (9, row-major), c_i (3) -
+                       * for the variational equations d(Phi)/dt = A Phi integrated at the accepted step (stm_update_textbook); else NULL */
     int64_t *o_epoch_ns;
     double *o_x, *o_y, *o_z, *o_vx, *o_vy, *o_vz, *o_cr, *o_cd, *o_mprop, *o_mdry, *o_mextra, *o_asrp, *o_adrag;
     int64_t *o_step;

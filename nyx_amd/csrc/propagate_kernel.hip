@@ -2252,6 +2252,65 @@ size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles, int stm, int reuse_fie
 #define BD_COEF(i) tabl[DEV_MAX_STAGES * DEV_MAX_STAGES + DEV_MAX_STAGES + (i)]
 #define C_COEF(i) tabl[DEV_MAX_STAGES * DEV_MAX_STAGES + 2 * DEV_MAX_STAGES + (i)]
 
+// NYX_HIP_FLAG_STM_TEXTBOOK: the variational equations d(Phi)/dt = A(t) Phi integrated by the step's own tableau (the form SURVEY 8a-11
+// asks to expose beside the reference's Phi_ctx * A).  A(t) does not depend on Phi and the error control does not look at Phi, so
+// integrating Phi "in the stage vector" is the same arithmetic as replaying the tableau over the stage matrices A_i of the ACCEPTED
+// attempt - which phase C left in `hist` ([stage][12][stride]: G_i row-major, c_i) - once the step is accepted: per column of Phi,
+//     Phi_s = Phi + h sum_{j<i} a_ij K_j,   K_i = A_i Phi_s,   Phi_next = Phi + sum_i (h b_i) K_i
+// with the oracle's operation order (oracle/nyx_oracle.c, sc_eom / derive: sums from 0.0 with ascending index, products unfused).
+// A = [[0 I 0], [G 0 c], [0 0 0]]: rows 0..2 of K are rows 3..5 of Phi_s, rows 3..5 are G Phi_s[0..2] + c Phi_s[6], rows 6..8 of Phi
+// never move.  The K_i of a column (16 x 6 per lane) live in the k-buffer, which the attempt no longer needs once it is accepted.
+// Out of line: the 64-lane dual kernel has no registers to spare at its call site.
+static __device__ __attribute__((noinline)) bool stm_update_textbook(double *phi, double h, const double *hist, int64_t stride, int64_t gid, double *kb,
+                                                                  const double *tabl, int stages_v, int lane) {
+    const int stages = __builtin_amdgcn_readfirstlane(stages_v);
+    bool nan = false;
+    for (int col = 0; col < 9; ++col) {
+        double p[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) p[e] = phi[e + 9 * col];
+        const double gam = phi[6 + 9 * col];
+        for (int i = 0; i < stages; ++i) {
+            double wi[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            for (int j = 0; j < i; ++j) {
+                const double a_ij = A_ROW(i, j);
+#pragma unroll
+                for (int e = 0; e < 6; ++e) wi[e] += a_ij * kb[(j * 6 + e) * DEV_LANES + lane];
+            }
+            double ps[6];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) ps[e] = p[e] + h * wi[e];
+            double g[12];
+#pragma unroll
+            for (int q = 0; q < 12; ++q) g[q] = hist[(int64_t)(i * 12 + q) * stride + gid];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                double s = g[3 * a + 0] * ps[0];
+                s += g[3 * a + 1] * ps[1];
+                s += g[3 * a + 2] * ps[2];
+                s += g[9 + a] * gam;
+                kb[(i * 6 + a) * DEV_LANES + lane] = ps[3 + a];
+                kb[(i * 6 + 3 + a) * DEV_LANES + lane] = s;
+            }
+        }
+        double nx[6];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) nx[e] = p[e];
+        for (int i = 0; i < stages; ++i) {
+            const double cb = h * B_COEF(i);
+#pragma unroll
+            for (int e = 0; e < 6; ++e) nx[e] += cb * kb[(i * 6 + e) * DEV_LANES + lane];
+        }
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+            nan = nan || (nx[e] != nx[e]);
+            phi[e + 9 * col] = nx[e];
+        }
+    }
+    return nan;
+}
+
+
 // One role (or a merged set of roles) of the workgroup.  Every instantiation executes the SAME sequence of
 // workgroup barriers; only the work between them differs, so that each role keeps just its own state live.
 template <bool INTEG, bool ALMANAC, bool PERT, bool STM, bool QUAD = false, bool PIPE = false>
@@ -3166,6 +3225,12 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     for (int q = 0; q < 9; ++q) L.sacc[q * DEV_LANES + lane] += b_i * G[q];
 #pragma unroll
                     for (int q = 0; q < 3; ++q) L.sacc[(9 + q) * DEV_LANES + lane] += b_i * cv[q];
+                    if (bt.stm_hist != nullptr && valid) {  // (uniform) the textbook form replays the tableau over the stage matrices at the accepted step
+#pragma unroll
+                        for (int q = 0; q < 9; ++q) bt.stm_hist[(int64_t)(i * 12 + q) * bt.stm_hist_stride + gid] = G[q];
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) bt.stm_hist[(int64_t)(i * 12 + 9 + q) * bt.stm_hist_stride + gid] = cv[q];
+                    }
                 }
                 if (!(STM && QUAD) && !(spec_now && i == 0 && keep_k0)) {
                     KB(i, 0) = ys[3]; KB(i, 1) = ys[4]; KB(i, 2) = ys[5];
@@ -3256,6 +3321,9 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 if (accept && STM && valid) {
                     double sumb = 0.0;
                     for (int q = 0; q < stages; ++q) sumb += B_COEF(q);
+                    if (!QUAD && bt.stm_hist != nullptr)
+                        stm_bad = stm_update_textbook(bt.o_stm + gid * 81, h_used, bt.stm_hist, bt.stm_hist_stride, gid, kbuf, tabl, stages, lane);
+                    else
                     stm_bad = QUAD ? stm_update_q(bt.o_stm + gid * 81, h_used, L.sacc, lane, ql, sumb)
                                    : stm_update(bt.o_stm + gid * 81, h_used, L.sacc, lane, sumb);
                 }

@@ -1162,10 +1162,12 @@ class Propagator:
         self.opts.set_min_step(step)
         self._ctx_cache.clear()
 
-    def compile(self, almanac: Almanac, central: Frame, stm: bool = False, state_frame: Optional[Frame] = None) -> CompiledConfig:
+    def compile(self, almanac: Almanac, central: Frame, stm: bool = False, state_frame: Optional[Frame] = None,
+                stm_textbook: bool = False) -> CompiledConfig:
         """`central`: the frame the dynamics integrate in; `state_frame`: the frame the states come in when it is another one
-        (`opts.integration_frame`, instance.rs:117-142: translated in at the start, back at the end)."""
-        return compile_config(self.dynamics, self.method, self.opts, almanac, central, stm=stm, state_frame=state_frame)
+        (`opts.integration_frame`, instance.rs:117-142: translated in at the start, back at the end).  `stm_textbook` (with `stm`):
+        the variational equations dPhi/dt = A Phi instead of the reference's Phi_ctx * A (NYX_HIP_FLAG_STM_TEXTBOOK)."""
+        return compile_config(self.dynamics, self.method, self.opts, almanac, central, stm=stm, stm_textbook=stm_textbook, state_frame=state_frame)
 
     def _context(self, almanac: Almanac, central: Frame, stm: bool) -> GpuContext:
         """Cached device context.  The key is a CONTENT fingerprint (dynamics, method, options, the full central frame, the

@@ -1062,6 +1062,20 @@ static int sc_eom(const prepared_t *p, int64_t ctx_epoch_ns, double dt_s, const 
         int st = dual_eom(p, et_s, y, sc, fx, grad);
         if (st) return st;
         for (int i = 0; i < 9; ++i) dy[i] = fx[i];
+        if (cfg->flags & NYX_HIP_FLAG_STM_TEXTBOOK) {
+            /* The textbook form SURVEY 8a-11 asks to expose beside the reference's: d(Phi)/dt = A(t) Phi, with Phi the STM of the STAGE
+             * vector (y[9..90), column-major) - the variational equations integrated by the same tableau as the state.  No reference
+             * line computes this (the reference right-multiplies the step-start STM, below); the definition here is the test's:
+             * entry (i, j) = sum_k grad[i][k] * Phi_stage[k][j], k ascending from 0.0. */
+            const double *ph = y + 9;
+            for (int j = 0; j < 9; ++j)
+                for (int i = 0; i < 9; ++i) {
+                    double s = 0.0;
+                    for (int k = 0; k < 9; ++k) s += grad[i + 9 * k] * ph[k + 9 * j];
+                    dy[9 + i + 9 * j] = s;
+                }
+            return NYX_HIP_OK;
+        }
         /* stm_dt = ctx.stm * grad  (spacecraft.rs:214), both column-major */
         for (int j = 0; j < 9; ++j)
             for (int i = 0; i < 9; ++i) {
