@@ -798,7 +798,9 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
     dc.ed_reuse = (dc.spec || dc.seg_mode) ? 0 : ctx->ed_reuse_fit;  // (chained attempts need no copy of the stage-0 epoch data: a rejected lane keeps its k_0)
     if (!dc.has_grav || nc == 0) return;
     // with enough column workers the integrator keeps its window free: its serial phases A / C gate every other wave
-    if (n_waves >= 8 && !any_nonzero(ctx->tune.role_duties, 3)) hc[0] = 1e9;
+    // (pipelined loop: the integrator wave walks NO columns at all - role_loop skips its walk -, whatever duties the caller states:
+    //  round 5 found tuning.role_duties handing it 57 rows that nobody then evaluated)
+    if (n_waves >= 8 && (dc.pipe || !any_nonzero(ctx->tune.role_duties, 3))) hc[0] = 1e9;
     std::vector<int> all;
     for (int c = 1; c <= nc; ++c) all.push_back(c);
     (void)fill_schedule(ctx, dc.sched[DEV_SCHED_SOLO], n_waves, all, hc, true);
