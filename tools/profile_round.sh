@@ -6,18 +6,21 @@ set -u
 export TMPDIR=/tmp
 CFG=${CFG:-2}
 STEPS=${STEPS:-3}
-OUT=gpurun_out/prof_cfg$CFG
+# TAG / EXTRA: another workload of the same configuration (round 5: TAG=fullchip EXTRA="--n 16384 --hours 3" = configs[1]'s force model on a full chip)
+TAG=${TAG:-cfg$CFG}
+EXTRA="${EXTRA:-} --no-other-configs"
+OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-if [ -z "${SKIP_BENCH:-}" ]; then timeout 900 python bench.py --config $CFG --steps $STEPS --warmup 1 > $OUT/bench.json 2> $OUT/bench.err; fi
+if [ -z "${SKIP_BENCH:-}" ]; then timeout 900 python bench.py --config $CFG --steps $STEPS --warmup 1 $EXTRA > $OUT/bench.json 2> $OUT/bench.err; fi
 tail -c 300 $OUT/bench.json; echo
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt --output-format rocpd -- python bench.py --config $CFG --steps $STEPS --warmup 1 --no-cpu-baseline --no-dense-output --no-host-call > $OUT/kt.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/kt --output-format rocpd -- python bench.py --config $CFG --steps $STEPS --warmup 1 --no-cpu-baseline --no-dense-output --no-host-call $EXTRA > $OUT/kt.log 2>&1
 DB=$(find $OUT/kt -name "*.db" | head -1)
 python tools/rocpd_summary.py "$DB" $OUT/kernel_trace_stats.md > /dev/null 2>&1 || echo "summary failed"
 head -6 $OUT/kernel_trace_stats.md
 [ -n "${SKIP_PMC:-}" ] && exit 0
 for C in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INSTS_SALU" "SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" "SQ_INSTS_FLAT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS"; do
-  TAG=$(echo $C | tr ' ' '_')
-  timeout 400 rocprofv3 --pmc $C -d $OUT/pmc_$TAG --output-format csv -- python bench.py --config $CFG --steps 1 --warmup 0 --no-cpu-baseline --no-dense-output --no-host-call > $OUT/pmc_$TAG.log 2>&1
+  PTAG=$(echo $C | tr ' ' '_')
+  timeout 400 rocprofv3 --pmc $C -d $OUT/pmc_$PTAG --output-format csv -- python bench.py --config $CFG --steps 1 --warmup 0 --no-cpu-baseline --no-dense-output --no-host-call $EXTRA > $OUT/pmc_$PTAG.log 2>&1
 done
 python - "$OUT" <<'PY'
 import csv, glob, collections, sys
