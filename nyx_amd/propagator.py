@@ -891,6 +891,21 @@ class Event:
     frame: Optional[Frame] = None           # until_nth_event's `event_frame` (event.rs:104-117): an IAU-oriented frame of the same centre
 
     @classmethod
+    def less_than(cls, scalar: int, value: float, **kw):
+        """`Condition::LessThan(value)`.  The closure of `until_nth_event` (event.rs:124-141) looks at SIGN CHANGES of the event's
+        value only (`y_prev * y_next < 0.0`, either direction) and the root search then finds where it vanishes: for a non-angle
+        scalar the propagation stops at the same crossing of `value` as `Equals(value)` - which is what this builds."""
+        if scalar in (_abi.EV_TRUE_ANOMALY_DEG, _abi.EV_LONGITUDE_DEG):
+            raise NotImplementedError("LessThan / GreaterThan on an angle: the wrapped difference has no such reading")
+        return cls(scalar, value, **kw)
+
+    greater_than = less_than   # (the same crossings: the counter does not see a direction)
+
+    @classmethod
+    def between(cls, scalar: int, lo: float, hi: float, **kw):
+        raise NotImplementedError("Condition::Between: two boundaries, two crossings per pass - refused on the device path (INTEGRATION.md)")
+
+    @classmethod
     def apoapsis(cls):
         return cls(_abi.EV_TRUE_ANOMALY_DEG, 180.0)
 

@@ -90,6 +90,25 @@ def test_non_angle_scalars_and_batches():
     assert (st.status == _abi.ERR_EVENT_NOT_FOUND).all() and (crossings == 0).all()
 
 
+def test_less_than_and_greater_than_stop_where_equals_stops():
+    """Condition::LessThan(v) / GreaterThan(v): until_nth_event's closure counts sign changes of the event's value in either direction
+    (event.rs:124-141), so on a non-angle scalar they are `Equals(v)` to the stop condition - which is what the mirror builds."""
+    import pytest
+    compiled, batch = setup(n=2)
+    p = period_ns(batch.rv()[0])
+    target = float(np.linalg.norm(batch.rv()[:, :3], axis=1).max() + 2.0)
+    ref = oracle_lib.propagate_until_event(compiled, batch, 2 * p, nx.Event(_abi.EV_RMAG_KM, target), trigger=2)
+    for make in (nx.Event.less_than, nx.Event.greater_than):
+        got = oracle_lib.propagate_until_event(compiled, batch, 2 * p, make(_abi.EV_RMAG_KM, target), trigger=2)
+        np.testing.assert_array_equal(got[0].rv(), ref[0].rv())
+        np.testing.assert_array_equal(got[0].epoch_ns, ref[0].epoch_ns)
+        np.testing.assert_array_equal(got[3], ref[3])
+    with pytest.raises(NotImplementedError):
+        nx.Event.less_than(_abi.EV_TRUE_ANOMALY_DEG, 10.0)
+    with pytest.raises(NotImplementedError):
+        nx.Event.between(_abi.EV_RMAG_KM, 7000.0, 7100.0)
+
+
 # ---- geometric scalars and the observer frame (tests/propagation/stopcond.rs:252-312) -------------------------------------
 EPOCH_2008_02_29_NOON_UTC_NS = (2981 * 86400) * nx.NS_PER_S + 65_184_000_000   # ET past J2000 (TT - UTC = 65.184 s in 2008)
 IAU_EARTH_SHAPED = nx.Frame(nx.EARTH, 398600.435436096, 6378.14, nx.IAU_EARTH_ROTATION, flattening=(6378.14 - 6356.75) / 6378.14)  # pck08 radii
