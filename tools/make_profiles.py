@@ -14,16 +14,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from kernel_stamp import kernel_source_stamp  # noqa: E402
 tag = sys.argv[1]
-cfgs = [int(x) for x in sys.argv[2:]] or [2, 3, 4, 5]
+# configurations by number, or "fullchip" (round 5: configs[1]'s force model on a full chip, 16 384 trajectories x 3 h: gpurun_out/prof_fullchip)
+items = sys.argv[2:] or ["2", "3", "4", "5"]
 CLOCK_HZ, SIMDS = 2.4e9, 1024
 degree_of = {2: 70, 3: 0, 4: 21, 5: 150}
-for cfg in cfgs:
-    src = os.path.join(ROOT, "gpurun_out", f"prof_cfg{cfg}")
+for item in items:
+    cfg = 2 if item == "fullchip" else int(item)
+    name = "fullchip" if item == "fullchip" else f"cfg{cfg}"
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{name}")
     if not os.path.isdir(src):
         continue
     line = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
-    bench_out = os.path.join(ROOT, "profiles", f"{tag}_cfg{cfg}_bench.json")
-    shutil.copy(os.path.join(src, "kernel_trace_stats.md"), os.path.join(ROOT, "profiles", f"{tag}_cfg{cfg}_kernel_trace_stats.md"))
+    bench_out = os.path.join(ROOT, "profiles", f"{tag}_{name}_bench.json")
+    shutil.copy(os.path.join(src, "kernel_trace_stats.md"), os.path.join(ROOT, "profiles", f"{tag}_{name}_kernel_trace_stats.md"))
+    if name == "cfg2" and os.path.exists(os.path.join(src, "bench_with_others.json")):   # the default run, `other_configs` included
+        full = json.loads(open(os.path.join(src, "bench_with_others.json")).read().strip().splitlines()[-1])
+        json.dump(full, open(os.path.join(ROOT, "profiles", f"{tag}_cfg2_bench_with_other_configs.json"), "w"), indent=1)
     per = collections.defaultdict(list)
     # (gpurun merges every pass of a configuration into the same scratch directory: the newest file of each counter set counts)
     newest = {}
@@ -44,8 +50,9 @@ for cfg in cfgs:
     simd_cycles = SIMDS * k_ms * 1e-3 * CLOCK_HZ
     fetch_b, write_b = c.get("FETCH_SIZE", 0.0) * 1024.0, c.get("WRITE_SIZE", 0.0) * 1024.0
     traffic = 2.0 * fetch_b + write_b   # MI355X_MICROARCH.md, HBM: FETCH_SIZE reports half of the bytes on gfx950; WRITE_SIZE as is
-    out = [f"# {tag}, BASELINE config {cfg}: PMC counters of the dominant kernel (rocprofv3 --pmc, one counter set per pass)", "",
-           f"command: `python bench.py --config {cfg} --steps 1 --warmup 0 --no-cpu-baseline --no-dense-output --no-host-call`; "
+    extra = " --n 16384 --hours 3" if name == "fullchip" else ""
+    out = [f"# {tag}, BASELINE config {cfg}{' on a full chip (16 384 trajectories, 3 h)' if name == 'fullchip' else ''}: PMC counters of the dominant kernel (rocprofv3 --pmc, one counter set per pass)", "",
+           f"command: `python bench.py --config {cfg} --steps 1 --warmup 0 --no-cpu-baseline --no-dense-output --no-host-call --no-other-configs{extra}`; "
            f"values per launch of `{'nyx_propagate_kernel_stmq' if cfg == 4 else 'nyx_propagate_kernel'}` "
            f"({'mean over the segment launches' if cfg == 4 else 'the timed launch: the largest dispatch of the command'}); "
            f"kernel time {k_ms:.3f} ms (bench line of the same build).", "",
@@ -73,20 +80,20 @@ for cfg in cfgs:
     out.append(f"* HBM: FETCH_SIZE {fetch_b / 1e6:.4g} MB (x2 on gfx950 per MI355X_MICROARCH.md) + WRITE_SIZE {write_b / 1e6:.4g} MB = "
                f"**{traffic / 1e6:.5g} MB per launch** = {traffic / (k_ms * 1e-3) / 1e9:.4g} GB/s = {traffic / (k_ms * 1e-3) / 8e12:.2e} of the 8 TB/s peak; "
                f"algorithmic: {line['config']['trajectories_per_gpu'] * 272 / 1e6:.3g} MB")
-    open(os.path.join(ROOT, "profiles", f"{tag}_cfg{cfg}_pmc.md"), "w").write("\n".join(out) + "\n")
+    open(os.path.join(ROOT, "profiles", f"{tag}_{name}_pmc.md"), "w").write("\n".join(out) + "\n")
     n = line["config"]["trajectories_per_gpu"]
     w = line["config"]["workload"]
-    hours = {2: 24.0, 3: 720.0, 4: 1.0, 5: 72.0}[cfg]
+    hours = 3.0 if name == "fullchip" else {2: 24.0, 3: 720.0, 4: 1.0, 5: 72.0}[cfg]
     degree = {2: 70, 3: 0, 4: 21, 5: 150}[cfg]
     json.dump({"config": cfg, "n": n, "hours": hours, "degree": degree, "hbm_bytes_per_launch": traffic * launches,
                "kernel_source_stamp": kernel_source_stamp(ROOT),
                "fetch_size_bytes_raw": fetch_b * launches, "write_size_bytes": write_b * launches,
                "note": "2 x FETCH_SIZE + WRITE_SIZE of the timed step (gfx950 correction of MI355X_MICROARCH.md), rocprofv3 --pmc, separate passes",
-               "workload": w}, open(os.path.join(ROOT, "profiles", f"{tag}_cfg{cfg}_hbm_traffic.json"), "w"), indent=1)
+               "workload": w}, open(os.path.join(ROOT, "profiles", f"{tag}_{name}_hbm_traffic.json"), "w"), indent=1)
     # the bench line was printed before the counter passes of this round existed: give it THIS round's traffic (same command, same build)
     line["roofline"]["traffic"] = traffic * launches
-    line["roofline"]["traffic_source"] = f"profiles/{tag}_cfg{cfg}_hbm_traffic.json"
+    line["roofline"]["traffic_source"] = f"profiles/{tag}_{name}_hbm_traffic.json"
     line["roofline"]["hbm"]["achieved"] = traffic * launches / (line["kernel_ms"] * 1e-3) / 1e9
     line["roofline"]["hbm"]["frac"] = line["roofline"]["hbm"]["achieved"] / line["roofline"]["hbm"]["peak"]
     json.dump(line, open(bench_out, "w"), indent=1)
-    print(f"config {cfg}: value {line['value']:.1f} {line['unit']}, kernel {line['kernel_ms']:.2f} ms, frac {line['roofline']['frac']:.4f}, traffic {traffic * launches / 1e6:.4g} MB")
+    print(f"{name}: value {line['value']:.1f} {line['unit']}, kernel {line['kernel_ms']:.2f} ms, frac {line['roofline']['frac']:.4f}, traffic {traffic * launches / 1e6:.4g} MB")
