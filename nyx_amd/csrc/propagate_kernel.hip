@@ -1477,6 +1477,9 @@ static __device__ __attribute__((noinline)) Partial4 coop_fallback(uint64_t cfg_
 // ~2 us each on uncached memory) overlap the arithmetic of its neighbours: a helper's job period is its longest
 // column, not column + latencies.  LDS words: ready[s] / answered[s] = 1 + number of the job last published /
 // answered in slot s, cnt[s] = column waves that have delivered.
+#ifndef COOP_AFFINITY
+#define COOP_AFFINITY 1  /* helpers take a job of their own first (see helper_body) */
+#endif
 #ifndef HELPER_SLOTS
 #define HELPER_SLOTS 2  /* jobs in flight inside a helper (see helper_body: three and four were measured, slower) */
 #endif
@@ -1541,7 +1544,21 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
                     // first candidate at or after a rotating start lane, so that the helpers of a set spread over the jobs
                     const unsigned rot = turn++ & 63u;
                     const uint64_t hi = cand >> rot;
-                    const int pick = hi ? (int)rot + __builtin_ctzll(hi) : __builtin_ctzll(cand);
+                    int pick = hi ? (int)rot + __builtin_ctzll(hi) : __builtin_ctzll(cand);
+#if COOP_AFFINITY
+                    // ... but a job has a PREFERRED helper - (owner slot + job number) mod the set's helpers, so that an owner's consecutive
+                    // jobs go round the set - and a helper takes one of its own first: two idle helpers of a set that see the same jobs no
+                    // longer go for the same one.  Round 5, 3 h of configs[1], same box, alternating: 82.6 / 83.3 ms without, 79.3 / 79.2 with
+                    // (lost claims per job 1.75 -> 1.3; the results are the same bits).  Measured and dropped: a static owner -> helper
+                    // preference (80.7-81.2), waiting one more scan for a job of its own (82.8-83.3: lost claims 0.55, but the wait is on the
+                    // job's path), every helper taking the waiting job NEAREST to its rank (83.1-84.3: it takes its neighbour's).
+                    {
+                        const int hs = (bt.coop_helpers - set + n_sets - 1) / n_sets;   // helpers watching this set
+                        const int rank = h / n_sets;
+                        const uint64_t pref = __ballot(has && (int32_t)(posted - claimed) > 0 && hs > 0 && (int)(((unsigned)lane + claimed) % (unsigned)hs) == rank);
+                        if (pref) pick = __builtin_ctzll(pref);
+                    }
+#endif
                     // jobs are taken in order, one at a time: an owner may have two outstanding (the pipelined loop posts
                     // stage i+1 before it has read the answer of stage i).  The five input rows of the job are fetched in the
                     // shadow of the compare-and-swap (they were complete before `posted` moved): one memory round trip, not two.
