@@ -306,8 +306,8 @@ typedef struct nyx_hip_config {
      * column waves - give it the larger field -, this one is evaluated in one piece by the perturbation wave beside them.  Either
      * may be the integration centre's or another body's (offset_body).  NULL => none.  With NYX_HIP_FLAG_STM the second field's
      * gradient (GravityField::gradient, gravity_field.rs:273-431: the same frame handling, duals on the translated and rotated
-     * radius, dcm * grad * dcm^T) is formed by the perturbation wave of the 64-lane dual layout - the quad layout (tuning.stm_quad)
-     * is not used with a second field; a non-central `gravity` takes either layout. */
+     * radius, dcm * grad * dcm^T) is formed by the perturbation wave, in either STM layout (round 5: the quad layout too, one partial
+     * per lane, bit-identical to the 64-lane form); a non-central `gravity` takes either layout as well. */
     const nyx_hip_gravity_field_t *gravity2;
 } nyx_hip_config_t;
 

@@ -926,7 +926,6 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
 // the chip without a workgroup, i.e. up to ~2 quad workgroups per CU.
 static bool pick_quad(const nyx_hip_ctx *ctx, int64_t n) {
     if (!(ctx->host_cfg.flags & NYX_HIP_FLAG_STM)) return false;
-    if (ctx->host_cfg.has_grav2) return false;  // (the second field's dual form is walked by the perturbation wave of the 64-lane layout only)
     if (ctx->host_cfg.flags & NYX_HIP_FLAG_STM_TEXTBOOK) return false;  // (the variational equations are integrated by the 64-lane layout: one trajectory's k-buffer column per lane)
     if (ctx->forced_quad >= 0) return ctx->forced_quad != 0;
     if (ctx->tune.stm_quad >= 0) return ctx->tune.stm_quad != 0;

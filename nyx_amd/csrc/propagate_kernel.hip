@@ -1305,6 +1305,51 @@ DEVFN int quad_or(int x) {
     return x;
 }
 
+// second_field_into_pertD for the QUAD layout (round 5: the quad layout used to be refused with a second field): the four lanes of a quad
+// walk every column of the second table on ONE-partial duals (lane k carries d/dx_k of the body-fixed position; lane 0 the value
+// alone), the epilogue is second_field_into_pertD's in D1 - every expression is that function's for the value and for one partial
+// slot, so value and gradient are bit-identical to the 64-lane layout -, and R^T G_bf R is formed with the quad exchange of phase_c_quad:
+// this lane's column (ql - 1) of G from the three partial lanes' rows.  Added to rows 0..2 (a) and 3..5 (this lane's column of G) of the
+// quad layout's perturbation block, i.e. to the point-mass share.  Returns the status of the field's own orientation.
+static __device__ __attribute__((noinline)) int second_field_into_pert_q(CfgPtr cfg, const double *records, const double *ed, int lane, int ql, int wave,
+                                                                        double et_s, const double *ys, double *pertq) {
+    double r[3] = {ys[0 * DEV_LANES + lane], ys[1 * DEV_LANES + lane], ys[2 * DEV_LANES + lane]};
+    if (cfg->g2_slot >= 0) {  // (uniform)
+        double pg[3];
+        ed_body(cfg, ed, lane, cfg->g2_slot, pg);
+        r[0] = r[0] - pg[0]; r[1] = r[1] - pg[1]; r[2] = r[2] - pg[2];
+    }
+    double m[9];
+    const int st = rotation_dcm(cfg, cfg->g2_rot, records, et_s, m);
+    const D1 x0 = d1seed(m[0] * r[0] + m[1] * r[1] + m[2] * r[2], 0, ql);
+    const D1 x1 = d1seed(m[3] * r[0] + m[4] * r[1] + m[5] * r[2], 1, ql);
+    const D1 x2 = d1seed(m[6] * r[0] + m[7] * r[1] + m[8] * r[2], 2, ql);
+    const D1 rD = d1norm(x0, x1, x2);
+    const D1 sD = d1div(x0, rD), tD = d1div(x1, rD), uD = d1div(x2, rD);
+    const D1 rhoD = d1div(d1c(cfg->g2_re), rD);
+    const D1 kD = d1div(d1div(d1c(cfg->g2_mu), rD), d1c(cfg->g2_re));
+    const D1 invD = rD * cfg->g2_inv_re;
+    CfgPtr cfg_s = (CfgPtr)uniform_u64((uint64_t)cfg);
+    Partial4T<D1> pd = harmonics_core<D1>(cfg_s, (HarmPtr)uniform_u64(cfg_s->htab2), (ColPtr)uniform_u64(cfg_s->cols2), __builtin_amdgcn_readfirstlane(wave),
+                                          DEV_SCHED_SECOND, rhoD * sD, rhoD * tD, rhoD * uD, rhoD, invD);
+    const D1 p0 = pd.x * kD, p1 = pd.y * kD, p2 = pd.z * kD, p3 = pd.w * kD;
+    const D1 al[3] = {p0 + p3 * sD, p1 + p3 * tD, p2 + p3 * uD};
+    double tmpc[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        pertq[a * DEV_LANES + lane] = pertq[a * DEV_LANES + lane] + (m[0 + a] * al[0].v + m[3 + a] * al[1].v + m[6 + a] * al[2].v);
+        tmpc[a] = m[0 + a] * al[0].d + m[3 + a] * al[1].d + m[6 + a] * al[2].d;
+    }
+    const int b = ql > 0 ? ql - 1 : 0;
+    const double mb0 = b == 0 ? m[0] : (b == 1 ? m[1] : m[2]), mb1 = b == 0 ? m[3] : (b == 1 ? m[4] : m[5]), mb2 = b == 0 ? m[6] : (b == 1 ? m[7] : m[8]);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double t0 = quad_bcast<1>(tmpc[a]), t1 = quad_bcast<2>(tmpc[a]), t2 = quad_bcast<3>(tmpc[a]);
+        pertq[(3 + a) * DEV_LANES + lane] = pertq[(3 + a) * DEV_LANES + lane] + (t0 * mb0 + t1 * mb1 + t2 * mb2);
+    }
+    return st;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Cooperative mode: idle CUs lend a hand.
 //
@@ -2359,7 +2404,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
 #else
     const bool has_tides = cfg->has_tides != 0;
 #endif
-    const bool has_grav2 = !QUAD && cfg->has_grav2 != 0;  // (plain kernel: value; 64-lane dual layout of the STM kernel: value and gradient; the quad layout is not launched with a second field)
+    const bool has_grav2 = cfg->has_grav2 != 0;  // (plain kernel: value; STM kernels: value and gradient, in either layout)
 #endif
     const bool need_almanac = has_grav || has_drag || has_tides || cfg->n_slots > 0;
     // role fan-out: this wave's share of the almanac / perturbation duties, and its status slot
@@ -2820,7 +2865,11 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 if (has_tides && !STM && do_pm) tides_into_pert(cfg, edc, lane, ysp, pertp);
                 if (has_grav2 && (do_pm || STM)) {  // a second gravity field (after the tides: the reference's model order does not reach the bits the parity bar looks at)
                     const int64_t ep2 = __double_as_longlong(L.step[lane]) + seconds_to_ns(C_COEF(i) * L.step[DEV_LANES + lane]);
-                    if (STM)
+                    if (STM && QUAD) {
+                        if (do_pm)   // (role fan-out: the wave with the point-mass share)
+                            L.pertst[(i & 1) * DEV_LANES + lane] =
+                                second_field_into_pert_q(cfg, rec_in_lds ? (const double *)L.rec : records, edc, lane, ql, wave, ns_to_seconds(ep2), ysp, pertp);
+                    } else if (STM)
                         L.pertst[(i & 1) * DEV_LANES + lane] =
                             second_field_into_pertD(cfg, rec_in_lds ? (const double *)L.rec : records, edc, lane, wave, ns_to_seconds(ep2), ysp, L.pertD);
                     else
@@ -3169,7 +3218,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     phase_c_quad((LdsCPtr)((pipe && (i & 1)) ? L.pert2 : L.pertD), (LdsCPtr)L.partD, (LdsCPtr)L.qpre,
                                  (LdsCPtr)((pipe && (i & 1)) ? L.ys2 : L.ys), (LdsPtr)L.sacc,
                                  (LdsPtr)(kbuf + (i * 6) * KB_STR + kb_li), KB_STR, B_COEF(i), nw,
-                                 ((has_pm || has_tides) ? PC_HAS_PM : 0) | (has_grav ? PC_HAS_GRAV : 0) | (has_srp ? PC_HAS_SRP : 0), lane, ql,
+                                 ((has_pm || has_tides || has_grav2) ? PC_HAS_PM : 0) | (has_grav ? PC_HAS_GRAV : 0) | (has_srp ? PC_HAS_SRP : 0), lane, ql,
                                  LCTL + 3, pipe ? i + 1 : 0, prof_on ? bt.prof + 16 * 8 : nullptr);
                 } else if (STM) {
                     // dual path (dual_eom, spacecraft.rs:312-363): f(x) and A = df/dx; the derivative written to k_i is

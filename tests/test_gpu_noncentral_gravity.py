@@ -123,11 +123,11 @@ def test_stm_with_a_non_central_field(layout):
     ctx.close()
 
 
-@pytest.mark.parametrize("centre", ["earth", "moon"])
-def test_stm_with_two_stacked_fields(centre):
+@pytest.mark.parametrize("centre,layout", [("earth", 0), ("moon", 0), ("earth", 1), ("moon", 1)])
+def test_stm_with_two_stacked_fields(centre, layout):
     """Earth 21x21 + Moon 20x20 in one OrbitalDynamics with the STM, around either body (the cislunar OD set-up): sixty 1-minute
     segments with Phi reset (od/process/mod.rs:466-483) against the oracle's twin - states to 1 mm, Phi element-wise to 1e-9 - and the
-    second field's gradient visibly in Phi.  The 64-lane dual layout (the quad layout is not launched with a second field)."""
+    second field's gradient visibly in Phi.  Both layouts: 64 lanes x three-partial duals, and (round 5) the quad layout."""
     prop, almanac, frame = nc.two_fields(centre, 21, 20)
     b = nc.batch(70, seed=8)
     if centre == "earth":
@@ -135,6 +135,7 @@ def test_stm_with_two_stacked_fields(centre):
     b = _stm_batch(b)
     compiled = prop.compile(almanac, frame, stm=True)
     ctx = nx.GpuContext(compiled)
+    ctx.set_stm_layout(layout)
     cur_d, cur_o = b, b
     worst = 0.0
     for seg in range(60):
@@ -247,3 +248,22 @@ def test_second_field_orientation_leaving_its_coverage_is_reported(stm):
     assert (rst2.status == _abi.ERR_EPHEM_RANGE).all()
     assert (st2.status == _abi.ERR_EPHEM_RANGE).all()
     ctx.close()
+
+
+def test_quad_and_64_lane_layouts_agree_bit_for_bit_with_a_second_field():
+    """The quad layout's second-field gradient is the 64-lane layout's expression per partial slot (second_field_into_pert_q): with
+    the column split of the first field fixed the two layouts return the same bits."""
+    prop, almanac, frame = nc.two_fields("moon", 8, 12)
+    b = _stm_batch(nc.batch(40, seed=3))
+    compiled = prop.compile(almanac, frame, stm=True)
+    outs = []
+    for layout in (0, 1):
+        ctx = nx.GpuContext(compiled)
+        ctx.set_stm_layout(layout)
+        ctx.set_column_waves(4)
+        out, st = ctx.propagate(b, 600 * nx.NS_PER_S)
+        assert (st.status == 0).all()
+        outs.append(out)
+        ctx.close()
+    np.testing.assert_array_equal(outs[0].rv(), outs[1].rv())
+    np.testing.assert_array_equal(outs[0].stm, outs[1].stm)
