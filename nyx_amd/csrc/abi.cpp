@@ -1075,9 +1075,9 @@ extern "C" double nyx_hip_last_kernel_ms(nyx_hip_ctx *ctx) {
 }
 
 // Cycle accounting of workgroup 0 of the last launch (NYX_HIP_PROFILE=1): out[17][8], see the kernel (row 16: mailbox counters).
-extern "C" int32_t nyx_hip_debug_profile_helper(nyx_hip_ctx *ctx, int64_t *out /* [17][8] */) {
+extern "C" int32_t nyx_hip_debug_profile_helper(nyx_hip_ctx *ctx, int64_t *out /* [19][8] */) {
     if (!ctx || !ctx->d_prof) return NYX_HIP_RC_BAD_ARG;
-    if (hipMemcpy(out, ctx->d_prof + 17 * 8, 17 * 8 * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return NYX_HIP_RC_HIP_ERROR;  // (row 16 of `out` = row 33: the owner's latency loop)
+    if (hipMemcpy(out, ctx->d_prof + 17 * 8, 19 * 8 * sizeof(int64_t), hipMemcpyDeviceToHost) != hipSuccess) return NYX_HIP_RC_HIP_ERROR;  // (row 16 of `out` = row 33: the owner's latency loop; rows 17-18 = the integrator's stage in pieces)
     return NYX_HIP_RC_OK;
 }
 extern "C" int32_t nyx_hip_debug_profile(nyx_hip_ctx *ctx, int64_t *out) {
@@ -1818,8 +1818,8 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
         }
     }
     if (ctx->tune.profile || calibrating) {
-        if (!ctx->d_prof) HIP_TRY(hipMalloc(&ctx->d_prof, 34 * 8 * sizeof(int64_t)));  // rows 0-15 owner workgroup 0, 16 mailbox counts, 17-32 the first helper workgroup
-        HIP_TRY(hipMemsetAsync(ctx->d_prof, 0, 34 * 8 * sizeof(int64_t), stream));
+        if (!ctx->d_prof) HIP_TRY(hipMalloc(&ctx->d_prof, 36 * 8 * sizeof(int64_t)));  // rows 0-15 owner workgroup 0, 16 mailbox counts, 17-32 the first helper workgroup
+        HIP_TRY(hipMemsetAsync(ctx->d_prof, 0, 36 * 8 * sizeof(int64_t), stream));
         bt.prof = ctx->d_prof;
     }
     if (time_it) HIP_TRY(hipEventRecord(ctx->ev0, stream));

@@ -52,6 +52,16 @@
 #define NYX_EMIT_STMQ8 16   /* quad layout, eight waves or fewer */
 #define NYX_EMIT_PLAIN16_P2 32 /* sixteen waves, cooperative launches whose hand-off has TWO parts (two helper workgroups per owner and evaluation) */
 #define NYX_EMIT_PLAIN8N 64   /* eight waves or fewer, dynamics WITHOUT a body-fixed model (no gravity field, drag, tides): NYX_ASSUME_SMALL */
+// The in-kernel accounting (tuning.profile / tuning.calibrate: cycle counters per wave and phase, the mailbox counts, the first
+// helper's rows) is loop-carried state and s_memtime reads in every role; switched off at run time it still costs the launch
+// (measured round 5: 1.3 % of the headline launch, 4.5 % of config 4, 7 % of config 3). Every propagation kernel is therefore
+// compiled TWICE from this source: the product kernel without the accounting (NYX_PROF 0) and a twin `<name>_prof` with it
+// (__graft_entry__.build compiles each propagate_*.hip a second time with -DNYX_PROF=1); nyx_launch_propagate picks the twin
+// when the batch carries a profile buffer. Same arithmetic, same bits.
+#ifndef NYX_PROF
+#define NYX_PROF 0
+#endif
+#define NYX_HOST_TU ((NYX_EMIT & NYX_EMIT_PLAIN16) && !NYX_PROF)  /* the one object that carries the host side: launch, LDS sizing, frame shift */
 // The two-part hand-off is a property of the TRANSLATION UNIT (NYX_COOP_TWO_PARTS, set by propagate_p2.hip), not a run-time branch:
 // the role code of the integrator is register-allocated around the mailbox calls, and the mere presence of the two-part calls in
 // the default kernel cost 3-5 % of the north-star run (8 h of propagation: 246.7 against 235.7 ms), whichever way they were folded.
@@ -195,7 +205,7 @@ struct FrameChain {
     int32_t n_chain, seg[4];
     double sign[4];
 };
-#if NYX_EMIT & NYX_EMIT_PLAIN16
+#if NYX_HOST_TU
 // opts.integration_frame (instance.rs:117-142, 211-220): x += dir * (state of the chain's body w.r.t. the integration centre at the
 // trajectory's epoch); dir = +1 into the integration frame, -1 back.  One thread per trajectory.
 __global__ __launch_bounds__(256) void nyx_frame_shift_kernel(const DevCfg *cfg_g, const double *records, FrameChain ch, int64_t n,
@@ -1522,6 +1532,9 @@ static __device__ __attribute__((noinline)) Partial4 coop_fallback(uint64_t cfg_
 // ~2 us each on uncached memory) overlap the arithmetic of its neighbours: a helper's job period is its longest
 // column, not column + latencies.  LDS words: ready[s] / answered[s] = 1 + number of the job last published /
 // answered in slot s, cnt[s] = column waves that have delivered.
+#ifndef NYX_SEG_PROF
+#define NYX_SEG_PROF 0  /* 1 adds the integrator's per-piece timers (rows 34-35); off in the product build, they cost registers */
+#endif
 #ifndef COOP_AFFINITY
 #define COOP_AFFINITY 1  /* helpers take a job of their own first (see helper_body) */
 #endif
@@ -1562,7 +1575,7 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
         const bool has = lane < COOP_SET && mine < n_own;
         const int widx = set * COOP_SET + lane;                       // its scan words
         unsigned turn = (unsigned)h;
-        const bool pprof = bt.prof != nullptr && (int)blockIdx.x == bt.coop_base;
+        const bool pprof = NYX_PROF && bt.prof != nullptr && (int)blockIdx.x == bt.coop_base;
         int64_t pp_slot = 0, pp_scan = 0, pp_jobs = 0, pp_lost = 0;
         const int64_t pp_start = pprof ? (int64_t)__builtin_readcyclecounter() : 0;
         for (int j = 0;; ++j) {
@@ -1687,7 +1700,7 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
         if (pr == 3) __builtin_amdgcn_s_setprio(3); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else if (pr == 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
     }
 #endif
-    const bool hprof = bt.prof != nullptr && (int)blockIdx.x == bt.coop_base;
+    const bool hprof = NYX_PROF && bt.prof != nullptr && (int)blockIdx.x == bt.coop_base;
     int64_t hp_busy = 0, hp_wait = 0, hp_jobs = 0;
     const int64_t hp_start = hprof ? (int64_t)__builtin_readcyclecounter() : 0;
     for (int j = 0;; ++j) {
@@ -2291,7 +2304,7 @@ DEVFN LdsMap carve_lds(char *smem, int n_waves, bool stm, int rec_lds_doubles, i
     return m;
 }
 
-#if !(NYX_EMIT & NYX_EMIT_PLAIN16)
+#if !NYX_HOST_TU
 static
 #else
 extern "C"
@@ -2417,7 +2430,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     const bool dbg_skip_harm = (cfg->flags & DBG_SKIP_HARMONICS) != 0;
     // optional cycle accounting (workgroup 0 only): [0] phase A, [1] window duty (almanac / pert), [2] harmonics,
     // [3] phase C, [4] step control, [5] total, [6] barrier waits, [7] realtime (100 MHz)
-    const bool prof_on = bt.prof != nullptr && blockIdx.x == 0;
+    const bool prof_on = NYX_PROF && bt.prof != nullptr && blockIdx.x == 0;
     int64_t prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const int64_t prof_start = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;
     const int64_t prof_rt0 = prof_on ? (int64_t)__builtin_amdgcn_s_memrealtime() : 0;
@@ -2541,7 +2554,14 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     for (int q = 0; q < 9; ++q) { m_cur[q] = 0.0; m_nx[q] = 0.0; }
     uint32_t seq_cur = 0, seq_nx = 0;   // mailbox sequence numbers of this stage / the next one
     unsigned long long dbg_answers = 0, dbg_fallbacks = 0, dbg_fb_seq = 0;  // (NYX_HIP_PROFILE: row 16 of the profile)
-    int64_t pl_tc = 0, pl_chain = 0, pl_wait = 0, pl_n = 0, pl_post = 0;  // (NYX_HIP_PROFILE, row 33: the latency loop of a cooperative owner - answer in hand -> next post)
+    int64_t pl_tc = 0, pl_chain = 0, pl_wait = 0, pl_n = 0, pl_post = 0;
+#if NYX_SEG_PROF
+    int64_t sg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sg_t = 0;  // (NYX_HIP_PROFILE, rows 34-35: the integrator's stage in eleven pieces)
+#define SEG(k) if (INTEG && prof_on) { const int64_t n_ = (int64_t)__builtin_readcyclecounter(); sg[k] += n_ - sg_t; sg_t = n_; }
+#else
+#define SEG(k)
+#endif
+    // (NYX_HIP_PROFILE, row 33: the latency loop of a cooperative owner - answer in hand -> next post)
     bool shared_cur = false, shared_nx = false;  // did the workers of this / the next stage leave columns to a helper?
 
     // start of a step: final-step test on integer epochs (instance.rs:149-186), then epoch and step published to the other waves
@@ -2628,6 +2648,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             double s_ = 0.0, t_ = 0.0, u_ = 0.0, kfac = 0.0;
             double ys[6];
             PROF_T0();
+            SEG(0)   /* loop back-edge */
             if (INTEG) {
                 // ---- Phase A: stage state  y + h * sum_j a_ij k_j   (instance.rs:376-394)
                 double *const ysb = (pipe && (i & 1)) ? L.ys2 : L.ys;
@@ -2758,6 +2779,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 }
             }
             PROF_ADD(0);
+            SEG(1)   /* phase A */
             if (!pipe || (i == 0 && !spec_now)) {
                 PROF_T0();
                 __syncthreads();  // B1: stage state and harmonics inputs published (pipelined: stage 0 only, and not when it was published speculatively)
@@ -2921,6 +2943,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     double *const inbn = ((i + 1) & 1) ? L.inb2 : L.inb;
 #pragma unroll
                     for (int e = 0; e < 3; ++e) ysn[e * DEV_LANES + lane] = nx_pos[e];
+                    SEG(2)   /* window: next position formed and stored */
                     if (has_grav) {  // (without a gravity field the position is all the next window needs: the perturbation waves read it after B2)
                     if (need_almanac) {  // the almanac wave writes the DCM of stage i+1 first thing in this window
                         // (bounded: a protocol error must end as a failed run, never as a hung GPU)
@@ -2932,6 +2955,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     const double *const edn = L.ed + ((i + 1) & 1) * ED_FIELDS * DEV_LANES;  // (its DCM: the flag is raised before the body positions are evaluated)
 #pragma unroll
                     for (int q = 0; q < 9; ++q) m_nx[q] = edn[q * DEV_LANES + lane];
+                    SEG(3)   /* DCM flag wait */
                     const double rb0 = m_nx[0] * nx_pos[0] + m_nx[1] * nx_pos[1] + m_nx[2] * nx_pos[2];
                     const double rb1 = m_nx[3] * nx_pos[0] + m_nx[4] * nx_pos[1] + m_nx[5] * nx_pos[2];
                     const double rb2 = m_nx[6] * nx_pos[0] + m_nx[7] * nx_pos[1] + m_nx[8] * nx_pos[2];
@@ -2950,6 +2974,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                         L.part[0 * DEV_LANES + lane] = nx_s; L.part[1 * DEV_LANES + lane] = nx_t; L.part[2 * DEV_LANES + lane] = nx_u; L.part[3 * DEV_LANES + lane] = nx_kfac;
                     }
                     }
+                    SEG(4)   /* rotate, norm, inputs to LDS */
                     shared_nx = coop_on;
                     if (lane == 0) L.ctl[1] = coop_on ? 1 : 0;  // the workers read it after B2(i), for stage i+1
                     if (coop_on) {
@@ -2962,6 +2987,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             };
             if (INTEG && fastp) {
                 publish_next(true);
+                SEG(5)   /* post */
                 // two-body term of this stage (orbital.rs:86-92)
                 {
                     const double rmag = norm3(ys[0], ys[1], ys[2]);
@@ -3089,6 +3115,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     for (int q = 0; q < 9; ++q) L.qpre[(14 + q) * DEV_LANES + lane] = edc[q * DEV_LANES + lane];
                 }
             }
+            SEG(6)   /* two-body + stage sums */
             if (prof_on) prof_acc[1] += (int64_t)__builtin_readcyclecounter() - ptw_;
             const int64_t pth_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;
             double px = 0.0, py = 0.0, pz = 0.0, pw = 0.0;
@@ -3159,6 +3186,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 __syncthreads();  // B2: partials / perturbations / next epoch data published
                 PROF_ADD(6);
             }
+            SEG(7)   /* barrier */
             if (spec_now && i == 0 && LCTL[0]) {  // every lane had finished: the exit, one window late
                 leave = true;
                 break;
@@ -3190,9 +3218,11 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         if (lane == 0) LCTL[3] = fold_base + i + 1;
                     }
+                    SEG(8)   /* phase C up to the fold */
                     if (pipe && cfg->coop_late != 0) {
                         const int64_t w0_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;
                         COOP_COLLECT()
+                        SEG(9)   /* the answer */
                         if (prof_on) { pl_tc = (int64_t)__builtin_readcyclecounter(); pl_wait += pl_tc - w0_; }
                     }
                     px += coop_x; py += coop_y; pz += coop_z; pw += coop_w;  // + the helper's columns (0 when working alone)
@@ -3303,6 +3333,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     KB(i, 3) = acc[0]; KB(i, 4) = acc[1]; KB(i, 5) = acc[2];
                 }
             }
+            SEG(10)  /* rest of phase C */
             if (prof_on) prof_acc[3] += (int64_t)__builtin_readcyclecounter() - ptc_;
         }
         if (leave) break;
@@ -3427,6 +3458,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             }
             cold_store(L.cs, lane, c);
         }
+        SEG(11)  /* step control */
         if (prof_on) prof_acc[4] += (int64_t)__builtin_readcyclecounter() - pts_;
         spec_now = spec;
         ++att;
@@ -3434,6 +3466,9 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     if (prof_on && lane == 0 && INTEG) {
         int64_t *row = bt.prof + 33 * 8;
         row[0] = pl_wait; row[1] = pl_chain; row[2] = pl_post; row[3] = pl_n;
+#if NYX_SEG_PROF
+        for (int q = 0; q < 12; ++q) bt.prof[34 * 8 + q] = sg[q];
+#endif
     }
     if (prof_on && lane == 0) {
         prof_acc[5] = (int64_t)__builtin_readcyclecounter() - prof_start;
@@ -3558,14 +3593,21 @@ DEVFN void propagate_body(const DevBatch &bt, const DevCfg *cfg_g, const HarmEnt
 // register budget follows __launch_bounds__ - 128 VGPRs for sixteen waves, 256 for eight or fewer - so the role code of the
 // small shapes (fan-out workgroups of dynamics without a gravity field, the quad STM layout on eight waves) is compiled without
 // the 128-VGPR cap that sixteen waves per workgroup impose, instead of one instantiation serving every shape.
-#define NYX_KERNEL(NAME, THREADS, ...)                                                                                        \
+#if NYX_PROF
+#define NYX_KN(NAME) NAME##_prof
+#else
+#define NYX_KN(NAME) NAME
+#endif
+#define NYX_KERNEL(NAME, THREADS, ...) NYX_KERNEL_(NYX_KN(NAME), THREADS, __VA_ARGS__)
+#define NYX_KERNEL_(NAME, THREADS, ...)                                                                                       \
     extern "C" __global__ void __launch_bounds__(THREADS)                                                                     \
         NAME(DevBatch bt, const DevCfg *cfg_g, const HarmEntry *htab_g, const ColHdr *cols_g, const double *__restrict__ records) { \
         extern __shared__ __attribute__((aligned(16))) char smem[];                                                           \
         propagate_body<__VA_ARGS__>(bt, cfg_g, htab_g, cols_g, records, smem);                                                \
     }
 #define NYX_KERNEL_DECL(NAME) \
-    extern "C" __global__ void NAME(DevBatch bt, const DevCfg *cfg_g, const HarmEntry *htab_g, const ColHdr *cols_g, const double *__restrict__ records);
+    extern "C" __global__ void NAME(DevBatch bt, const DevCfg *cfg_g, const HarmEntry *htab_g, const ColHdr *cols_g, const double *__restrict__ records); \
+    extern "C" __global__ void NAME##_prof(DevBatch bt, const DevCfg *cfg_g, const HarmEntry *htab_g, const ColHdr *cols_g, const double *__restrict__ records);
 #if NYX_EMIT & NYX_EMIT_PLAIN16
 NYX_KERNEL(nyx_propagate_kernel, DEV_MAX_WAVES *DEV_LANES, false)
 #endif
@@ -3588,7 +3630,8 @@ NYX_KERNEL(nyx_propagate_kernel_p2, DEV_MAX_WAVES *DEV_LANES, false)
 NYX_KERNEL(nyx_propagate_kernel_w8n, 8 * DEV_LANES, false, false, false)
 #endif
 
-#if NYX_EMIT & NYX_EMIT_PLAIN16
+#if NYX_HOST_TU
+NYX_KERNEL_DECL(nyx_propagate_kernel)
 NYX_KERNEL_DECL(nyx_propagate_kernel_w8)
 NYX_KERNEL_DECL(nyx_propagate_kernel_stm)
 NYX_KERNEL_DECL(nyx_propagate_kernel_stmq)
@@ -3610,13 +3653,17 @@ extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg
         (void)hipGetDevice(&devid);
         std::lock_guard<std::mutex> lk(attr_mu);
         if (devid < 0 || devid >= 64 || !attr_set[devid]) {
-            (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_stm, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_stmq, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_w8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_stmq_w8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_p2, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void *)nyx_propagate_kernel_w8n, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+#define NYX_LDS_ATTR(K)                                                                                             \
+    (void)hipFuncSetAttribute((const void *)K, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);               \
+    (void)hipFuncSetAttribute((const void *)K##_prof, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            NYX_LDS_ATTR(nyx_propagate_kernel)
+            NYX_LDS_ATTR(nyx_propagate_kernel_stm)
+            NYX_LDS_ATTR(nyx_propagate_kernel_stmq)
+            NYX_LDS_ATTR(nyx_propagate_kernel_w8)
+            NYX_LDS_ATTR(nyx_propagate_kernel_stmq_w8)
+            NYX_LDS_ATTR(nyx_propagate_kernel_p2)
+            NYX_LDS_ATTR(nyx_propagate_kernel_w8n)
+#undef NYX_LDS_ATTR
             if (devid >= 0 && devid < 64) attr_set[devid] = true;
         }
     }
@@ -3626,20 +3673,25 @@ extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg
     DevBatch btl = bt;
     btl.lds_bytes = (int32_t)lds;
     const bool small = n_waves <= 8;  // (helpers are sixteen-wave workgroups: cooperative launches never are)
+    // the kernel of the shape; with a profile buffer attached, its twin that carries the accounting (NYX_PROF)
+#define NYX_PICK(K) (bt.prof != nullptr ? K##_prof : K)
+    auto kern = NYX_PICK(nyx_propagate_kernel);
+    int64_t grid = blocks;
     if (stm && quad)
-        hipLaunchKernelGGL(small ? nyx_propagate_kernel_stmq_w8 : nyx_propagate_kernel_stmq, dim3((unsigned)blocks),
-                           dim3((unsigned)(n_waves * DEV_LANES)), lds, stream, btl, cfg, htab, cols, records);
+        kern = small ? NYX_PICK(nyx_propagate_kernel_stmq_w8) : NYX_PICK(nyx_propagate_kernel_stmq);
     else if (stm)
-        hipLaunchKernelGGL(nyx_propagate_kernel_stm, dim3((unsigned)blocks), dim3((unsigned)(n_waves * DEV_LANES)), lds, stream, btl, cfg,
-                           htab, cols, records);
+        kern = NYX_PICK(nyx_propagate_kernel_stm);
     else {
-        const int64_t grid = bt.coop_helpers > 0 ? (int64_t)bt.coop_base + bt.coop_helpers : blocks;
+        if (bt.coop_helpers > 0) grid = (int64_t)bt.coop_base + bt.coop_helpers;
         const bool two_parts = bt.coop_helpers > 0 && bt.coop_parts == 2 && bt.coop_out2 != nullptr;  // (its own kernel: NYX_COOP_TWO_PARTS)
         // (no_body_fixed: the host's statement that the configuration has no gravity field, drag or tides - propagate_w8n.hip)
-        hipLaunchKernelGGL((small && bt.coop_helpers == 0) ? (no_body_fixed ? nyx_propagate_kernel_w8n : nyx_propagate_kernel_w8)
-                                                             : (two_parts ? nyx_propagate_kernel_p2 : nyx_propagate_kernel), dim3((unsigned)grid),
-                           dim3((unsigned)(n_waves * DEV_LANES)), lds, stream, btl, cfg, htab, cols, records);
+        if (small && bt.coop_helpers == 0)
+            kern = no_body_fixed ? NYX_PICK(nyx_propagate_kernel_w8n) : NYX_PICK(nyx_propagate_kernel_w8);
+        else if (two_parts)
+            kern = NYX_PICK(nyx_propagate_kernel_p2);
     }
+#undef NYX_PICK
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)(n_waves * DEV_LANES)), lds, stream, btl, cfg, htab, cols, records);
     return hipGetLastError();
 }
-#endif  // NYX_EMIT & NYX_EMIT_PLAIN16
+#endif  // NYX_HOST_TU

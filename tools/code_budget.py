@@ -13,6 +13,7 @@ import kernel_roles  # noqa: E402
 
 PROPAGATION = ("nyx_propagate_kernel", "nyx_propagate_kernel_w8", "nyx_propagate_kernel_w8n", "nyx_propagate_kernel_stm", "nyx_propagate_kernel_stmq",
                "nyx_propagate_kernel_stmq_w8", "nyx_propagate_kernel_p2")
+PROPAGATION = PROPAGATION + tuple(k + "_prof" for k in PROPAGATION)   # the twins that carry the in-kernel accounting (NYX_PROF)
 ROLE_KERNELS = ("nyx_propagate_kernel", "nyx_propagate_kernel_stmq", "nyx_propagate_kernel_w8n")
 
 

@@ -88,11 +88,15 @@ for rep in range(reps):
                 for wv in range(16):
                     if p[wv, 5]:
                         print(f"    wave {wv:2d}: " + " ".join(f"{p[wv, q] / ne:8.0f}" for q in (0, 1, 2, 3, 4)) + f" | {p[wv, 5] / ne:8.0f} {p[wv, 6] / ne:8.0f}")
-            hb = (C.c_int64 * 136)()
+            hb = (C.c_int64 * 152)()
             if hasattr(ctx._lib, "nyx_hip_debug_profile_helper"):
                 ctx._lib.nyx_hip_debug_profile_helper.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
                 if ctx._lib.nyx_hip_debug_profile_helper(ctx._h, hb) == 0:
-                    hp = np.array(hb[:]).reshape(17, 8)
+                    hp = np.array(hb[:]).reshape(19, 8)
+                    sgv = hp[17:19].reshape(-1)[:12]
+                    if sgv.sum():
+                        names = ['back-edge', 'phase A', 'next position', 'DCM wait', 'rotate+inputs', 'post', 'two-body+sums', 'barrier', 'C to fold', 'answer', 'C rest', 'step ctl']
+                        print('   integrator per eval: ' + ', '.join(f'{n} {v / ne:.0f}' for n, v in zip(names, sgv)))
                     if hp[16, 3]:
                         print(f"   owner latency loop (wg0, per posted job): wait for the answer {hp[16, 0] / hp[16, 3]:.0f}, answer in hand -> post {hp[16, 1] / hp[16, 3]:.0f}, post {hp[16, 2] / hp[16, 3]:.0f} cycles ({hp[16, 3]} jobs)")
                     if hp[0, 2]:
