@@ -243,7 +243,7 @@ typedef struct nyx_hip_tuning {
     int32_t coop_mute;         /* test switch: helpers never answer (exercises the owner's fallback) */
     int32_t profile;           /* 1: in-kernel cycle accounting of workgroup 0 (nyx_hip_debug_profile) */
     int32_t debug_flags;       /* timing-only switches (0x100 skip the serial role work, 0x200 skip the harmonics): WRONG RESULTS;
-                                * 0x400 host trace; A/B switches with the SAME results: 0x800 no role offload, 0x1000 no segment-level almanac
+                                * 0x400 host trace; A/B switches with the SAME results: 0x800 role offload ON (off by default since round 5), 0x1000 no segment-level almanac
                                 * units on a single almanac wave, 0x2000 packed Chebyshev records; schedule switches (another summation order):
                                 * 0x8000 the two-ended column fill everywhere, 0x10000 one contiguous run of columns per wave whatever the feed,
                                 * 0x20000 owners / helpers rounded to multiples of eight, 0x40000 / 0x80000 two-part / one-part hand-off,

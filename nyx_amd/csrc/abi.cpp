@@ -134,6 +134,7 @@ struct nyx_hip_ctx {
     int coop_parts = 1;  // sub-jobs per evaluation of the schedules in host_cfg (1, or 2: two helper workgroups per owner and evaluation)
     int forced_quad = -1;  // STM layout: -1 = by ensemble size, 0 = 64 trajectories x D3 per workgroup, 1 = quad layout (16 x 4 lanes, D1)
     double role_handicap[3] = {0.0, 0.0, 0.0};  // integrator, almanac, perturbations (harmonics-term units)
+    int role_place[8] = {-1, -1, -1, -1, -1, -1, -1, -1}, role_place_sums = -1, role_place_twobody = -1;  // (tools only: ExpKnobs)
     DevArrays in, out;
     int64_t *d_prof = nullptr;
     CoopBox *d_coop = nullptr;  // cooperative-mode mailboxes, one per trajectory-owning workgroup, then the packed scan words
@@ -279,6 +280,8 @@ static double ns_to_seconds_host(int64_t ns) {  // Duration::to_seconds for |ns|
 struct ExpKnobs {  // experiment knobs of tools/sweep.py that have no field in nyx_hip_tuning_t (the helper dealing, round 5); < 0 / 0: unset
     double fast_weight = 0.0, start_rows = -1.0;
     int deal = -1;
+    int place[8] = {-1, -1, -1, -1, -1, -1, -1, -1};  // role fan-out: the wave of the k-th duty (duties heaviest first), assign_roles
+    int place_sums = -1, place_twobody = -1;         // ... and of the two offloaded integrator pieces
 };
 static nyx_hip_tuning_t resolve_tuning(const nyx_hip_tuning_t *t, ExpKnobs *xk = nullptr) {
     nyx_hip_tuning_t r = NYX_HIP_TUNING_DEFAULT;
@@ -288,6 +291,11 @@ static nyx_hip_tuning_t resolve_tuning(const nyx_hip_tuning_t *t, ExpKnobs *xk =
         if (const char *e = std::getenv("NYX_HIP_COOP_FASTW")) xk->fast_weight = std::atof(e);
         if (const char *e = std::getenv("NYX_HIP_COOP_START")) xk->start_rows = std::atof(e);
         if (const char *e = std::getenv("NYX_HIP_COOP_DEAL")) xk->deal = std::atoi(e);
+        if (const char *e = std::getenv("NYX_HIP_ROLE_PLACE")) {
+            const char *q = e;
+            for (int k = 0; k < 8 && *q; ++k) { xk->place[k] = (int)std::strtol(q, (char **)&q, 10); if (*q == ',') ++q; }
+        }
+        if (const char *e = std::getenv("NYX_HIP_ROLE_OFFLOAD")) (void)std::sscanf(e, "%d,%d", &xk->place_sums, &xk->place_twobody);
     }
     auto geti = [](const char *name, int32_t &dst) { if (const char *e = std::getenv(name)) dst = (int32_t)std::strtol(e, nullptr, 0); };
     auto getd = [](const char *name, double &dst) { if (const char *e = std::getenv(name)) dst = std::atof(e); };
@@ -697,6 +705,7 @@ static void assign_roles(nyx_hip_ctx *ctx, int n_waves, bool fanout, double *hc)
         bool taken[DEV_MAX_WAVES] = {true};
         std::sort(duties.begin(), duties.end(), [](const Duty &a, const Duty &b) { return a.cost > b.cost; });
         bool placed_all = true;
+        int duty_no = 0;
         for (const Duty &d : duties) {
             int best_w = -1;
             double best_load = 1e300;
@@ -705,15 +714,19 @@ static void assign_roles(nyx_hip_ctx *ctx, int n_waves, bool fanout, double *hc)
                 for (int k = sd; k < n_waves; k += 4) if (!taken[k]) { w = k; break; }
                 if (w >= 0 && simd_load[sd] < best_load) { best_load = simd_load[sd]; best_w = w; }
             }
+            if (duty_no < 8 && ctx->role_place[duty_no] > 0 && ctx->role_place[duty_no] < n_waves && !taken[ctx->role_place[duty_no]]) best_w = ctx->role_place[duty_no];  // (tools: NYX_HIP_ROLE_PLACE)
+            ++duty_no;
             if (best_w < 0) { placed_all = false; break; }
             taken[best_w] = true;
             simd_load[best_w % 4] += d.cost;
             dc.role_kind[best_w] = d.kind; dc.role_mask[best_w] = d.mask; dc.role_slot[best_w] = d.slot; hc[best_w] = d.cost;
         }
         if (placed_all) {
-            if (dc.pipe && !dc.has_grav && !stm && !(ctx->tune.debug_flags & 0x800)) {  // (0x800: A/B switch, same results)
-                // pipelined, no column waves: the integrator wave is the critical path; the two lightest almanac shares take the two-body
-                // term and the head of the stage sums off it (DevCfg.offload)
+            if (dc.pipe && !dc.has_grav && !stm && (ctx->tune.debug_flags & 0x800)) {  // (0x800: A/B switch, same results)
+                // pipelined, no column waves: the two lightest almanac shares take the two-body term and the head of the stage sums off
+                // the integrator wave (DevCfg.offload).  Rounds 3-4 default; OFF since round 5: the integrator's publish-first window
+                // (role_loop, `fastp`) is shorter than the offloaded one and the almanac SIMDs are the busiest of the workgroup
+                // (config 3: 46.7 -> 44.7 ms without it, same bits)
                 // (what an almanac wave has to spare depends on whom it shares its SIMD with: the integrator's SIMD last, then by the SIMD's load)
                 int w1 = -1, w2 = -1;
                 auto spare = [&](int w) { return (w % 4 == 0 ? 1e6 : 0.0) + simd_load[w % 4] + hc[w]; };
@@ -722,6 +735,8 @@ static void assign_roles(nyx_hip_ctx *ctx, int n_waves, bool fanout, double *hc)
                     if (w1 < 0 || spare(w) < spare(w1)) { w2 = w1; w1 = w; }
                     else if (w2 < 0 || spare(w) < spare(w2)) w2 = w;
                 }
+                if (ctx->role_place_sums > 0 && ctx->role_place_sums < n_waves && dc.role_kind[ctx->role_place_sums] == DEV_ROLE_ALMANAC) w1 = ctx->role_place_sums;  // (tools: NYX_HIP_ROLE_OFFLOAD)
+                if (ctx->role_place_twobody > 0 && ctx->role_place_twobody < n_waves && dc.role_kind[ctx->role_place_twobody] == DEV_ROLE_ALMANAC) w2 = ctx->role_place_twobody;
                 if (w1 >= 0) {
                     if (w2 < 0) w2 = w1;
                     dc.role_mask[w1] |= DEV_ROLE_SUMS; hc[w1] += 4.0;
@@ -998,6 +1013,15 @@ extern "C" int32_t nyx_hip_debug_layout(nyx_hip_ctx *ctx, int32_t *out) {
     return NYX_HIP_RC_OK;
 }
 
+// Roles of the last launch's workgroup shape (tools): out[w] = role_kind, out[16 + w] = role_mask of wave w.
+extern "C" int32_t nyx_hip_debug_roles(nyx_hip_ctx *ctx, int32_t *out) {
+    if (!ctx || !out) return NYX_HIP_RC_BAD_ARG;
+    CTX_LOCK(ctx);
+    const DevCfg &dc = ctx->host_cfg;
+    for (int w = 0; w < DEV_MAX_WAVES; ++w) { out[w] = dc.role_kind[w]; out[DEV_MAX_WAVES + w] = dc.role_mask[w]; }
+    return NYX_HIP_RC_OK;
+}
+
 // Calibration of the column weights: 1 = on the device, once per workgroup shape, 0 = the model's weights (tuning.schedule).
 extern "C" int32_t nyx_hip_debug_set_calibration(nyx_hip_ctx *ctx, int32_t mode) {
     if (!ctx || mode < 0 || mode > 1) return NYX_HIP_RC_BAD_ARG;
@@ -1169,6 +1193,8 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
     if (xk.fast_weight > 0.0) ctx->coop_fast_weight = xk.fast_weight;  // (experiment knobs of the tools, never of a caller: resolve_tuning)
     if (xk.start_rows >= 0.0) ctx->coop_start_rows = xk.start_rows;
     if (xk.deal >= 0) ctx->coop_deal = xk.deal;
+    for (int k = 0; k < 8; ++k) ctx->role_place[k] = xk.place[k];
+    ctx->role_place_sums = xk.place_sums; ctx->role_place_twobody = xk.place_twobody;
     DevCfg &dc = ctx->host_cfg;
     std::memset(&dc, 0, sizeof dc);
     const NyxTableau &tb = NYX_TABLEAUX[o.method];

@@ -166,15 +166,23 @@ emit("s_waitcnt vmcnt(0) lgkmcnt(0)")
 clob = [f"s{i}" for i in range(36, 102)] + [f"v{i}" for r in ((48, 56), (64, 72), (80, 88), (96, 104), (112, 120)) for i in range(*r)]
 clob += ["vcc", "scc", "memory"]
 
-with open(OUT, "w") as f:
-    f.write("// GENERATED by tools/gen_harm_stream.py - do not edit.  The hybrid-feed walk of one column range (see the generator's header).\n")
-    f.write("#define HARM_STREAM_ASM(e, vp, hp, voff, left, cols_left, first, low_half, sink, rho_u, rho2, rho, inv_rho, zr, zi, px, py, pz, pw, rc, ic) \\\n")
-    f.write("    asm volatile( \\\n")
-    for ln in lines:
-        f.write(f'        "{ln}\\n\\t" \\\n')
-    f.write('        : [left] "+s"(left), [cols_left] "+s"(cols_left), [first] "+s"(first), [sink] "=&s"(sink), \\\n')
-    f.write('          [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [pw] "+v"(pw), [rc] "+v"(rc), [ic] "+v"(ic) \\\n')
-    f.write('        : [e] "s"(e), [vp] "s"(vp), [hp] "s"(hp), [voff] "v"(voff), [low_half] "s"(low_half), \\\n')
-    f.write('          [rho_u] "v"(rho_u), [rho2] "v"(rho2), [rho] "v"(rho), [inv_rho] "v"(inv_rho), [zr] "v"(zr), [zi] "v"(zi) \\\n')
-    f.write("        : " + ", ".join(f'"{c}"' for c in clob) + ")\n")
+import io  # noqa: E402
+
+f = io.StringIO()
+f.write("// GENERATED by tools/gen_harm_stream.py - do not edit.  The hybrid-feed walk of one column range (see the generator's header).\n")
+f.write("#define HARM_STREAM_ASM(e, vp, hp, voff, left, cols_left, first, low_half, sink, rho_u, rho2, rho, inv_rho, zr, zi, px, py, pz, pw, rc, ic) \\\n")
+f.write("    asm volatile( \\\n")
+for ln in lines:
+    f.write(f'        "{ln}\\n\\t" \\\n')
+f.write('        : [left] "+s"(left), [cols_left] "+s"(cols_left), [first] "+s"(first), [sink] "=&s"(sink), \\\n')
+f.write('          [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [pw] "+v"(pw), [rc] "+v"(rc), [ic] "+v"(ic) \\\n')
+f.write('        : [e] "s"(e), [vp] "s"(vp), [hp] "s"(hp), [voff] "v"(voff), [low_half] "s"(low_half), \\\n')
+f.write('          [rho_u] "v"(rho_u), [rho2] "v"(rho2), [rho] "v"(rho), [inv_rho] "v"(inv_rho), [zr] "v"(zr), [zi] "v"(zi) \\\n')
+f.write("        : " + ", ".join(f'"{c}"' for c in clob) + ")\n")
+text = f.getvalue()
+# written only when the content changes: the header's mtime is a build dependency of every kernel object (__graft_entry__.build),
+# and tests/test_codegen.py imports this module on every run
+if not os.path.exists(OUT) or open(OUT).read() != text:
+    with open(OUT, "w") as out_f:
+        out_f.write(text)
 print(f"wrote {OUT}: {len(lines)} instructions / labels")

@@ -78,6 +78,12 @@ for rep in range(reps):
             for sc_id, nm in ((1, "owner"), (2, "helper")):
                 ctx._lib.nyx_hip_debug_schedule_rows(ctx._h, sc_id, rows, None)
                 print(f"   {nm} rows/wave " + " ".join(f"{x:4d}" for x in rows[:]) + f"  sum {sum(rows[:])}")
+        if show:
+            ro = (C.c_int32 * 32)()
+            if hasattr(ctx._lib, "nyx_hip_debug_roles"):
+                ctx._lib.nyx_hip_debug_roles.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+                ctx._lib.nyx_hip_debug_roles(ctx._h, ro)
+                print("   roles (kind:mask) " + " ".join(f"{ro[w]}:{ro[16 + w]:x}" for w in range(16)))
         if fields.get("profile"):
             buf = (C.c_int64 * 136)()
             ctx._lib.nyx_hip_debug_profile.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
