@@ -429,14 +429,9 @@ DEVFN int epoch_data(CfgPtr cfg, P records, int64_t epoch_ns, double *slot, int 
     }
     if (cfg->seg_mode) {  // (uniform) one distinct segment per unit: the chains are summed by the readers, ed_bp()
         const int nu = cfg->n_useg, base = cfg->ed_seg_base;
-        // (kernels of the small shapes, NYX_ASSUME_SMALL: the units as a ROLLED loop - the five almanac waves of a fan-out workgroup then
-        //  walk the same Chebyshev code instead of five unrolled copies of it; config 3: 44.8 -> 43.7 ms, same bits.  The sixteen-wave
-        //  kernels keep the unrolled form their profiles were taken with.)
-#ifdef NYX_ASSUME_SMALL
+        // (a ROLLED loop: the five almanac waves of a fan-out workgroup walk the same Chebyshev code instead of five unrolled copies of
+        //  it, a single almanac wave one copy four times; round 5, same bits: config 3 44.8 -> 43.7 ms, config 4 9.19 -> 9.08, configs[1] -0.8 %)
 #pragma unroll 1
-#else
-#pragma unroll
-#endif
         for (int u = 0; u < DEV_MAX_SEG; ++u) {
             if (u < nu && ((amask >> u) & 1)) {
                 double p[3];
