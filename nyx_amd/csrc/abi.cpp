@@ -10,7 +10,9 @@
 #include <cstdlib>
 #include <array>
 #include <cstring>
+#include <functional>
 #include <map>
+#include <set>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -130,6 +132,7 @@ struct nyx_hip_ctx {
     WKey last_key = WKey(0, 0, 0, 0);      // shape of the last launch
     DevArrays cal;                         // scratch outputs of the calibration launches
     bool block_schedule = true;  // one contiguous run of columns per wave where the owner streams the table (fill_schedule)
+    bool fit_partition = true;   // ... placed along the column list in a free wave order so that every wave meets its target (fill_schedule)
     bool block_force = false;
     int coop_parts = 1;  // sub-jobs per evaluation of the schedules in host_cfg (1, or 2: two helper workgroups per owner and evaluation)
     int forced_quad = -1;  // STM layout: -1 = by ensemble size, 0 = 64 trajectories x D3 per workgroup, 1 = quad layout (16 x 4 lanes, D1)
@@ -484,6 +487,7 @@ static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, con
     // the in-kernel cycle accounting and moves columns from the late waves to the early ones until the windows agree;
     // before that (and with calibration off) a structural guess by age class is used.
     double per_wave[DEV_MAX_WAVES];
+    bool fit = false;  // (the runs of a block schedule placed along the list in a free wave order: the cooperative 70x70 shape, see below)
     {
         const nyx_hip_ctx::WKey key(n_waves, (ctx->host_cfg.pipe && (!(ctx->host_cfg.flags & NYX_HIP_FLAG_STM) || ctx->sched_quad)) ? 1 : 0, ctx->sched_quad ? 1 : 0,
                                     all_columns ? -1 : (int)(ctx->host_cfg.coop_frac * 10.0 + 0.5));
@@ -506,9 +510,15 @@ static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, con
         static const double model_coop_blk[16] = {1.00, 1.413, 0.549, 1.946, 1.892, 1.523, 1.588, 1.292, 1.066, 0.828, 0.937, 0.692, 0.430, 0.347, 0.357, 0.142};
         static const double model_coop_big_blk[16] = {1.00, 1.755, 1.706, 1.802, 1.733, 1.22, 1.246, 1.181, 1.087, 0.672, 0.621, 0.604, 0.549, 0.279, 0.284, 0.255};
         static const double model_solo_blk[16] = {1.00, 1.612, 1.263, 1.906, 1.764, 1.346, 1.331, 1.198, 1.113, 0.757, 0.659, 0.568, 0.513, 0.398, 0.291, 0.27};
+        // Round 5, the cooperative 70x70 shape with its runs placed in a free wave order (`fit`, below): the column waves' weights as
+        // tools/tune_schedule.py settles on them with that partition (full day of configs[1]; the role waves keep the table's values -
+        // every row more on them costs the integrator's chain: 614 ms with these, 662 with ten rows more on each of the two).
+        // Same box, product kernel, 24 h: 625.0 ms linear partition, 617.0 free order with the old table, 614.0 with this one.
+        static const double model_coop_fit[16] = {1.00, 1.413, 0.549, 1.95, 1.83, 1.48, 1.40, 1.23, 1.04, 0.88, 0.85, 0.62, 0.50, 0.36, 0.34, 0.16};
         const bool blk = ctx->block_schedule && n_waves == DEV_MAX_WAVES && !ctx->sched_quad && ((ctx->host_cfg.harm_feed & 1) || ctx->block_force);
+        fit = blk && !all_columns && ctx->host_cfg.n_cols <= 96 && ctx->fit_partition;
         const double *model = ctx->sched_quad ? model_quad
-                              : (blk ? (all_columns ? model_solo_blk : (ctx->host_cfg.n_cols > 96 ? model_coop_big_blk : model_coop_blk))
+                              : (blk ? (all_columns ? model_solo_blk : (ctx->host_cfg.n_cols > 96 ? model_coop_big_blk : (fit ? model_coop_fit : model_coop_blk)))
                                      : (all_columns ? model_solo : model_coop));
         for (int w = 0; w < DEV_MAX_WAVES; ++w)
             per_wave[w] = it != ctx->weights.end() ? it->second[w] : (n_waves == 16 ? model[w] : 1.0);
@@ -546,6 +556,71 @@ static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, con
         std::vector<int> order;
         for (int w = 0; w < n_waves; ++w) order.push_back(w);
         std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return std::max(0.0, level * wgt(a) - hc[a]) > std::max(0.0, level * wgt(b) - hc[b]); });
+        if (fit) {
+            // Round 5, the same contiguous runs in a FREE wave order.  The linear partition above deals whole columns at the cumulative
+            // targets in descending target order, so a wave's load is off by up to half a column - +-25 rows of ~230 for the waves
+            // that hold the 50-row columns of a 70x70 owner, and a column wave is bound by its OWN issue rate (one VALU instruction per
+            // ~9 cycles and wave, tools/_exp/exec_rate.hip): the two or three waves rounded UP set the workgroup's period.  A run of j
+            // columns starting at length L sums to jL - j(j-1)/2: which sums exist depends on WHERE in the list a run sits, so the
+            // waves are placed along the list in whatever order lets every one of them meet its target - a depth-first search over
+            // (columns consumed, waves placed) for the smallest tolerance D with |load_w - target_w| <= D * weight_w for every wave
+            // (the weight is the wave's speed: the same TIME error everywhere).  A pure function of the configuration, like the rest.
+            std::vector<int> act;
+            for (int w : order) if (std::max(0.0, level * wgt(w) - hc[w]) > 0.0) act.push_back(w);
+            const int na = (int)act.size(), m = (int)list.size();
+            std::vector<double> pre(m + 1, 0.0), tg(na), wg(na);
+            for (int k = 0; k < m; ++k) pre[k + 1] = pre[k] + cost(list[k]);
+            for (int a = 0; a < na; ++a) { tg[a] = std::max(0.0, level * wgt(act[a]) - hc[act[a]]); wg[a] = std::max(wgt(act[a]), 1e-3); }
+            std::vector<int> seq_w, seq_k;   // the placement found: wave index (into act) and its first column, in list order
+            bool found = false;
+            if (na >= 2 && na <= 16 && m >= na) {
+                for (double D = 1.0; D <= 40.0 && !found; D += 1.0) {
+                    std::set<std::pair<int, int>> dead;
+                    seq_w.clear(); seq_k.clear();
+                    long budget = 400000;
+                    std::function<bool(int, int)> dfs = [&](int k, int mask) -> bool {
+                        if (mask == (1 << na) - 1) return k == m;
+                        if (--budget < 0) return false;
+                        if (dead.count({k, mask})) return false;
+                        const int left = na - __builtin_popcount((unsigned)mask);
+                        for (int a = 0; a < na; ++a) {
+                            if (mask & (1 << a)) continue;
+                            const double tol = D * wg[a];
+                            // run lengths whose load meets the target within the tolerance (the last wave takes what is left)
+                            for (int e = k + 1; e <= m - (left - 1); ++e) {
+                                const double load = pre[e] - pre[k];
+                                if (load > tg[a] + tol) break;
+                                if (load < tg[a] - tol) continue;
+                                if (left == 1 && e != m) continue;
+                                seq_w.push_back(a); seq_k.push_back(k);
+                                if (dfs(e, mask | (1 << a))) return true;
+                                seq_w.pop_back(); seq_k.pop_back();
+                            }
+                        }
+                        dead.insert({k, mask});
+                        return false;
+                    };
+                    found = dfs(0, 0);
+                }
+            }
+            if (found) {
+                for (size_t q = 0; q < seq_w.size(); ++q) {
+                    const int w = act[seq_w[q]];
+                    const size_t k0 = (size_t)seq_k[q], k1 = q + 1 < seq_w.size() ? (size_t)seq_k[q + 1] : list.size();
+                    int nr = 0;
+                    for (size_t a = k0; a < k1;) {
+                        size_t e = a + 1;
+                        while (e < k1 && list[e] == list[e - 1] + 1) ++e;
+                        if (nr >= DEV_MAX_RANGES) return false;
+                        sd.range_c0[w][nr] = list[a]; sd.range_cnt[w][nr] = (int)(e - a); ++nr;
+                        a = e;
+                    }
+                    sd.n_ranges[w] = nr;
+                }
+                return true;
+            }
+            // (no placement within the widest tolerance: the linear partition below)
+        }
         double cum_t = 0.0, cum_r = 0.0;
         size_t k = 0;
         for (size_t q = 0; q < order.size(); ++q) {
@@ -1189,6 +1264,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
     ctx->tune = resolve_tuning(cfg->tuning, &xk);
     ctx->block_schedule = (ctx->tune.debug_flags & 0x8000) == 0;  // (0x8000: the two-ended column fill of rounds 1-3 everywhere)
     ctx->block_force = (ctx->tune.debug_flags & 0x10000) != 0;    // (0x10000: contiguous runs whatever the feed - the A/B partner of the streamed walk)
+    ctx->fit_partition = (ctx->tune.debug_flags & 0x400000) == 0;  // (0x400000: the linear partition of round 4 for the cooperative 70x70 shape too, fill_schedule)
     ctx->coop_deal = (ctx->tune.debug_flags & 0x400000) ? 0 : 1;  // (0x400000: the helper dealing of rounds 1-4 - the longest columns, one per wave)
     if (xk.fast_weight > 0.0) ctx->coop_fast_weight = xk.fast_weight;  // (experiment knobs of the tools, never of a caller: resolve_tuning)
     if (xk.start_rows >= 0.0) ctx->coop_start_rows = xk.start_rows;
