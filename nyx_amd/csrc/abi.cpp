@@ -1264,7 +1264,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
     ctx->tune = resolve_tuning(cfg->tuning, &xk);
     ctx->block_schedule = (ctx->tune.debug_flags & 0x8000) == 0;  // (0x8000: the two-ended column fill of rounds 1-3 everywhere)
     ctx->block_force = (ctx->tune.debug_flags & 0x10000) != 0;    // (0x10000: contiguous runs whatever the feed - the A/B partner of the streamed walk)
-    ctx->fit_partition = (ctx->tune.debug_flags & 0x400000) == 0;  // (0x400000: the linear partition of round 4 for the cooperative 70x70 shape too, fill_schedule)
+    ctx->fit_partition = (ctx->tune.debug_flags & 0x2000000) == 0;  // (0x2000000: the linear partition of round 4 for the cooperative 70x70 shape too, fill_schedule)
     ctx->coop_deal = (ctx->tune.debug_flags & 0x400000) ? 0 : 1;  // (0x400000: the helper dealing of rounds 1-4 - the longest columns, one per wave)
     if (xk.fast_weight > 0.0) ctx->coop_fast_weight = xk.fast_weight;  // (experiment knobs of the tools, never of a caller: resolve_tuning)
     if (xk.start_rows >= 0.0) ctx->coop_start_rows = xk.start_rows;

@@ -15,7 +15,11 @@ S = nx.NS_PER_S
 
 
 @pytest.mark.parametrize("tuning", [dict(role_duties=[60.0, 600.0, 52.0]), dict(role_duties=[60.0, 600.0, 500.0], cooperative=0),
-                                    dict(coop_fraction=0.40), dict(coop_fraction=0.25, harmonics_feed=1)])
+                                    dict(coop_fraction=0.40), dict(coop_fraction=0.25, harmonics_feed=1),
+                                    # the owner's column runs: free wave order (default since round 5) and the linear partition of round 4,
+                                    # at the default share and at shares that move every target
+                                    dict(), dict(debug_flags=0x2000000), dict(coop_fraction=0.33), dict(coop_fraction=0.36, debug_flags=0x2000000),
+                                    dict(schedule=nx.SCHED_EXPLICIT, wave_weights=[1.0, 1.2, 0.7, 1.7, 1.9, 1.3, 1.5, 1.1, 1.0, 0.9, 0.8, 0.7, 0.5, 0.4, 0.3, 0.2])])
 def test_every_column_is_walked_whatever_the_tuning(tuning):
     prop, almanac, central = leo_full_setup(degree=70)
     compiled = prop.compile(almanac, central)
@@ -31,3 +35,28 @@ def test_every_column_is_walked_whatever_the_tuning(tuning):
     d = out.rv()[::10] - ref.rv()
     dr, dv = np.linalg.norm(d[:, :3], axis=1).max(), np.linalg.norm(d[:, 3:], axis=1).max()
     assert dr < 1e-3 and dv < 1e-6, (tuning, dr, dv)   # (a dropped column is tens of metres after twenty minutes)
+
+
+def test_free_order_partition_deals_every_row_once():
+    """The rows the owner's schedule holds (nyx_hip_debug_schedule_rows) are the same total under both partitions of its column runs,
+    and owner + helper rows are the whole 70x70 table (2 556 rows)."""
+    import ctypes as C
+    prop, almanac, central = leo_full_setup(degree=70)
+    compiled = prop.compile(almanac, central)
+    batch = dispersed_leo_batch(640, seed=17)
+    totals = []
+    for flags in (0, 0x2000000):
+        ctx = nx.GpuContext(compiled, tuning=nx.Tuning(debug_flags=flags))
+        ctx.propagate(batch, 60 * S)
+        assert ctx.last_coop_helpers() > 0
+        rows = (C.c_int32 * 16)()
+        ctx._lib.nyx_hip_debug_schedule_rows.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+        per = []
+        for sched in (1, 2):
+            assert ctx._lib.nyx_hip_debug_schedule_rows(ctx._h, sched, rows, None) == 0
+            per.append(list(rows[:]))
+        ctx.close()
+        assert per[0][0] == 0                       # the integrator wave of a pipelined workgroup walks no columns
+        assert sum(per[0]) + sum(per[1]) == 2556, per
+        totals.append(per[0])
+    assert totals[0] != totals[1]                   # (the two partitions do differ on this shape)
