@@ -132,6 +132,7 @@ struct nyx_hip_ctx {
     WKey last_key = WKey(0, 0, 0, 0);      // shape of the last launch
     DevArrays cal;                         // scratch outputs of the calibration launches
     bool block_schedule = true;  // one contiguous run of columns per wave where the owner streams the table (fill_schedule)
+    bool fit_big = false;        // (tools: NYX_HIP_FIT_BIG - the free-order placement for the large cooperative shape too)
     bool fit_partition = true;   // ... placed along the column list in a free wave order so that every wave meets its target (fill_schedule)
     bool block_force = false;
     int coop_parts = 1;  // sub-jobs per evaluation of the schedules in host_cfg (1, or 2: two helper workgroups per owner and evaluation)
@@ -516,7 +517,7 @@ static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, con
         // Same box, product kernel, 24 h: 625.0 ms linear partition, 617.0 free order with the old table, 614.0 with this one.
         static const double model_coop_fit[16] = {1.00, 1.413, 0.549, 1.95, 1.83, 1.48, 1.40, 1.23, 1.04, 0.88, 0.85, 0.62, 0.50, 0.36, 0.34, 0.16};
         const bool blk = ctx->block_schedule && n_waves == DEV_MAX_WAVES && !ctx->sched_quad && ((ctx->host_cfg.harm_feed & 1) || ctx->block_force);
-        fit = blk && !all_columns && ctx->host_cfg.n_cols <= 96 && ctx->fit_partition;
+        fit = blk && !all_columns && (ctx->host_cfg.n_cols <= 96 || ctx->fit_big) && ctx->fit_partition;
         const double *model = ctx->sched_quad ? model_quad
                               : (blk ? (all_columns ? model_solo_blk : (ctx->host_cfg.n_cols > 96 ? model_coop_big_blk : (fit ? model_coop_fit : model_coop_blk)))
                                      : (all_columns ? model_solo : model_coop));
@@ -1264,6 +1265,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
     ctx->tune = resolve_tuning(cfg->tuning, &xk);
     ctx->block_schedule = (ctx->tune.debug_flags & 0x8000) == 0;  // (0x8000: the two-ended column fill of rounds 1-3 everywhere)
     ctx->block_force = (ctx->tune.debug_flags & 0x10000) != 0;    // (0x10000: contiguous runs whatever the feed - the A/B partner of the streamed walk)
+    ctx->fit_big = std::getenv("NYX_HIP_TUNING_ENV") && std::getenv("NYX_HIP_FIT_BIG");
     ctx->fit_partition = (ctx->tune.debug_flags & 0x2000000) == 0;  // (0x2000000: the linear partition of round 4 for the cooperative 70x70 shape too, fill_schedule)
     ctx->coop_deal = (ctx->tune.debug_flags & 0x400000) ? 0 : 1;  // (0x400000: the helper dealing of rounds 1-4 - the longest columns, one per wave)
     if (xk.fast_weight > 0.0) ctx->coop_fast_weight = xk.fast_weight;  // (experiment knobs of the tools, never of a caller: resolve_tuning)

@@ -60,3 +60,38 @@ def test_free_order_partition_deals_every_row_once():
         assert sum(per[0]) + sum(per[1]) == 2556, per
         totals.append(per[0])
     assert totals[0] != totals[1]                   # (the two partitions do differ on this shape)
+
+
+@pytest.mark.parametrize("degree", [40, 47, 56, 64, 83, 95])
+def test_free_order_partition_at_other_degrees(degree):
+    """Every cooperative shape that streams the table in its owners (degree 40 ... 95) goes through the depth-first placement: the
+    context is built in bounded time, both partitions deal the same rows in total, and the run stays on the oracle."""
+    import ctypes as C
+    import time
+    prop, almanac, central = leo_full_setup(degree=degree)
+    compiled = prop.compile(almanac, central)
+    batch = dispersed_leo_batch(640, seed=23)
+    dur = 600 * S
+    sums, outs = [], []
+    for flags in (0, 0x2000000):
+        t0 = time.time()
+        ctx = nx.GpuContext(compiled, tuning=nx.Tuning(debug_flags=flags))
+        out, st = ctx.propagate(batch, dur)
+        assert time.time() - t0 < 20.0
+        assert (st.status == 0).all()
+        rows = (C.c_int32 * 16)()
+        ctx._lib.nyx_hip_debug_schedule_rows.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+        tot = 0
+        for sched in (1, 2):
+            assert ctx._lib.nyx_hip_debug_schedule_rows(ctx._h, sched, rows, None) == 0
+            tot += sum(rows[:])
+        helpers = ctx.last_coop_helpers()
+        ctx.close()
+        sums.append((tot, helpers))
+        outs.append(out.rv())
+    assert sums[0] == sums[1], sums
+    sub = batch.take(np.arange(0, 640, 40))
+    ref, rst = oracle_lib.propagate(compiled, sub, dur, n_threads=os.cpu_count() or 1)
+    for o in outs:
+        d = o[::40] - ref.rv()
+        assert np.linalg.norm(d[:, :3], axis=1).max() < 1e-3 and np.linalg.norm(d[:, 3:], axis=1).max() < 1e-6

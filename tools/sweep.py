@@ -75,7 +75,7 @@ for rep in range(reps):
         if show:
             rows = (C.c_int32 * 16)()
             ctx._lib.nyx_hip_debug_schedule_rows.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
-            for sc_id, nm in ((1, "owner"), (2, "helper")):
+            for sc_id, nm in ((0, "solo"), (1, "owner"), (2, "helper")):
                 ctx._lib.nyx_hip_debug_schedule_rows(ctx._h, sc_id, rows, None)
                 print(f"   {nm} rows/wave " + " ".join(f"{x:4d}" for x in rows[:]) + f"  sum {sum(rows[:])}")
         if show:
