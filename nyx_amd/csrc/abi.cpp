@@ -133,6 +133,7 @@ struct nyx_hip_ctx {
     DevArrays cal;                         // scratch outputs of the calibration launches
     bool block_schedule = true;  // one contiguous run of columns per wave where the owner streams the table (fill_schedule)
     bool fit_big = false;        // (tools: NYX_HIP_FIT_BIG - the free-order placement for the large cooperative shape too)
+    bool fit_quad = false;       // (NYX_HIP_FIT_QUAD / default, see ctx_create: ... and for the sixteen-wave quad STM shape)
     bool fit_partition = true;   // ... placed along the column list in a free wave order so that every wave meets its target (fill_schedule)
     bool block_force = false;
     int coop_parts = 1;  // sub-jobs per evaluation of the schedules in host_cfg (1, or 2: two helper workgroups per owner and evaluation)
@@ -500,7 +501,10 @@ static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, con
         // result - is the same in every context, process and rank.
         static const double model_coop[16] = {1.70, 1.66, 1.48, 2.14, 2.08, 1.70, 1.65, 1.67, 1.45, 0.97, 1.05, 1.02, 0.70, 0.53, 0.56, 0.55};
         static const double model_solo[16] = {1.41, 1.41, 1.26, 1.61, 1.59, 1.29, 1.375, 1.23, 1.06, 0.98, 0.98, 0.98, 0.77, 0.69, 0.70, 0.70};
-        static const double model_quad[16] = {0.70, 0.70, 0.70, 0.70, 1.26, 2.03, 1.78, 1.59, 1.58, 1.68, 0.96, 1.02, 0.875, 0.93, 0.86, 0.91};
+        // (quad table, round 5: re-fitted by hill-climbing the explicit weights on config 4 with the position-only pieces of phase C on
+        //  the DCM wave (assign_roles, DEV_ROLE_QPRE) - with the integrator's window shorter the column waves are the period again:
+        //  8.99 ms with the round-4 table {0.70 x 4, 1.26, 2.03, 1.78, 1.59, 1.58, 1.68, 0.96, 1.02, 0.875, 0.93, 0.86, 0.91}, 8.61 with this)
+        static const double model_quad[16] = {0.700, 0.700, 0.505, 0.876, 1.173, 1.490, 1.795, 2.380, 3.445, 2.528, 0.927, 1.020, 0.875, 0.930, 0.941, 1.124};
         // Round 4, the shapes that deal ONE contiguous run of columns per wave (below) and stream the table in the trajectory-owning
         // workgroups: fitted with tools/tune_schedule.py (windows of every wave -> rows that would equalise them -> weights, best
         // kernel time of 8-14 iterations, two boxes) on configs[1] at 10 000 (cooperative) and 16 384 trajectories (alone) and on
@@ -517,7 +521,7 @@ static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, con
         // Same box, product kernel, 24 h: 625.0 ms linear partition, 617.0 free order with the old table, 614.0 with this one.
         static const double model_coop_fit[16] = {1.00, 1.413, 0.549, 1.95, 1.83, 1.48, 1.40, 1.23, 1.04, 0.88, 0.85, 0.62, 0.50, 0.36, 0.34, 0.16};
         const bool blk = ctx->block_schedule && n_waves == DEV_MAX_WAVES && !ctx->sched_quad && ((ctx->host_cfg.harm_feed & 1) || ctx->block_force);
-        fit = blk && !all_columns && (ctx->host_cfg.n_cols <= 96 || ctx->fit_big) && ctx->fit_partition;
+        fit = (blk && !all_columns && (ctx->host_cfg.n_cols <= 96 || ctx->fit_big) && ctx->fit_partition) || (ctx->fit_quad && ctx->sched_quad && n_waves == DEV_MAX_WAVES);
         const double *model = ctx->sched_quad ? model_quad
                               : (blk ? (all_columns ? model_solo_blk : (ctx->host_cfg.n_cols > 96 ? model_coop_big_blk : (fit ? model_coop_fit : model_coop_blk)))
                                      : (all_columns ? model_solo : model_coop));
@@ -548,7 +552,7 @@ static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, con
             if (sum < terms) lo = level; else hi = level;
         }
     }
-    if (ctx->block_schedule && n_waves == DEV_MAX_WAVES && !ctx->sched_quad && ((ctx->host_cfg.harm_feed & 1) || ctx->block_force)) {
+    if ((ctx->block_schedule && n_waves == DEV_MAX_WAVES && !ctx->sched_quad && ((ctx->host_cfg.harm_feed & 1) || ctx->block_force)) || (fit && ctx->sched_quad)) {
         // ONE contiguous run of columns per wave (the hybrid stream walks a run as one piece of the table: every range START costs it a
         // pipeline fill, the complex power of the range and up to seven rows in front of the run - with two or three ranges per wave
         // and evaluation that is a third of a 70x70 owner's work).  Linear partition of the list (longest columns first) at the
@@ -736,6 +740,7 @@ static void assign_roles(nyx_hip_ctx *ctx, int n_waves, bool fanout, double *hc)
     dc.n_alm = 1;
     dc.seg_mode = 0;
     dc.offload = 0;
+    dc.qpre_off = 0;
     const double *rh = ctx->role_handicap;
     if (n_waves == 1) { dc.role_kind[0] = DEV_ROLE_ALL; dc.role_mask[0] = all_alm | all_pert; hc[0] = rh[0] + rh[1] + rh[2]; return; }
     dc.role_kind[0] = DEV_ROLE_INTEG; hc[0] = rh[0];
@@ -819,6 +824,20 @@ static void assign_roles(nyx_hip_ctx *ctx, int n_waves, bool fanout, double *hc)
                     dc.role_mask[w2] |= DEV_ROLE_TWOBODY; hc[w2] += 2.0;
                     dc.offload = 1;
                 }
+            }
+            if (stm && ctx->sched_quad && !(ctx->tune.debug_flags & 0x4000000)) {  // (0x4000000: A/B switch, same results)
+                // quad STM layout: the position-only pieces of phase C (quad_pre, 4-5 k cycles of the integrator's window per evaluation)
+                // go to the almanac wave with the most time to spare - the integrator's chain is what bounds such a workgroup
+                // (the wave that holds the DCM when there is one: in the sixteen-wave shape it walks no columns, the segment waves do)
+                int wq = -1;
+                for (int w = 1; w < n_waves; ++w)
+                    if (dc.role_kind[w] == DEV_ROLE_ALMANAC && (dc.role_mask[w] & DEV_ROLE_DCM)) wq = w;
+                if (wq < 0)
+                    for (int w = 1; w < n_waves; ++w) {
+                        if (dc.role_kind[w] != DEV_ROLE_ALMANAC) continue;
+                        if (wq < 0 || simd_load[w % 4] + hc[w] < simd_load[wq % 4] + hc[wq]) wq = w;
+                    }
+                if (wq >= 0) { dc.role_mask[wq] |= DEV_ROLE_QPRE; hc[wq] += 18.0; simd_load[wq % 4] += 18.0; dc.qpre_off = 1; }
             }
             if (segment_units_fit(dc)) {  // the almanac shares above are distinct segments: tell the kernel where their vectors live
                 dc.seg_mode = 1;
@@ -1266,6 +1285,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
     ctx->block_schedule = (ctx->tune.debug_flags & 0x8000) == 0;  // (0x8000: the two-ended column fill of rounds 1-3 everywhere)
     ctx->block_force = (ctx->tune.debug_flags & 0x10000) != 0;    // (0x10000: contiguous runs whatever the feed - the A/B partner of the streamed walk)
     ctx->fit_big = std::getenv("NYX_HIP_TUNING_ENV") && std::getenv("NYX_HIP_FIT_BIG");
+    ctx->fit_quad = std::getenv("NYX_HIP_TUNING_ENV") && std::getenv("NYX_HIP_FIT_QUAD");
     ctx->fit_partition = (ctx->tune.debug_flags & 0x2000000) == 0;  // (0x2000000: the linear partition of round 4 for the cooperative 70x70 shape too, fill_schedule)
     ctx->coop_deal = (ctx->tune.debug_flags & 0x400000) ? 0 : 1;  // (0x400000: the helper dealing of rounds 1-4 - the longest columns, one per wave)
     if (xk.fast_weight > 0.0) ctx->coop_fast_weight = xk.fast_weight;  // (experiment knobs of the tools, never of a caller: resolve_tuning)

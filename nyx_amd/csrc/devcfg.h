@@ -23,6 +23,7 @@ enum { DEV_ROLE_COLUMNS = 0, DEV_ROLE_ALL = 1, DEV_ROLE_INTEG = 2, DEV_ROLE_ALMA
 #define DEV_ROLE_DCM 0x100
 #define DEV_ROLE_SUMS 0x200    /* DevCfg.offload: the head of the next-but-one stage's sum_j a_ij k_j (see role_loop) */
 #define DEV_ROLE_TWOBODY 0x400 /* DevCfg.offload: the two-body term of the current stage */
+#define DEV_ROLE_QPRE 0x800    /* DevCfg.qpre_off (quad STM layout): the position-only pieces of phase C of the current stage (quad_pre) */
 #define DEV_PERT_PM 1  /* point masses + solid tides */
 #define DEV_PERT_SRP 2 /* solar radiation pressure + drag */
 
@@ -124,7 +125,7 @@ struct DevCfg {
                       * the stage sums off the integrator wave, which is the critical path there (role_mask bits DEV_ROLE_SUMS / _TWOBODY) */
     int32_t useg_seg[DEV_MAX_SEG];
     int32_t spec; /* speculative stage 0 of the next attempt (pipelined loop, see role_loop) */
-    int32_t dcm_incr, _pad_di; /* the body-fixed frame of the epoch data is a polynomial IAU orientation: its DCM is advanced from a base
+    int32_t dcm_incr, qpre_off; /* the body-fixed frame of the epoch data is a polynomial IAU orientation: its DCM is advanced from a base
                                 * epoch by angle addition (rotation_dcm_iau_poly) instead of three full-range sincos per stage */
 
     /* --- column schedules: wave w walks n_ranges[w] contiguous column ranges --- */

@@ -2164,6 +2164,48 @@ static __device__ __attribute__((noinline)) void phase_c_quad(LdsCPtr pertD, Lds
     if (pslot && lane == 0) pslot[6] += (int64_t)__builtin_readcyclecounter() - pc0;
 }
 
+// Quad layout: the position-only pieces of phase C - the two-body dual, the duals of s, t, u and (mu / r) / R_eq, the stage's DCM -
+// formed inside the window and left in L.qpre for phase C.  By the integrator wave, or (DevCfg.qpre_off, round 5) by the almanac wave
+// that holds DEV_ROLE_QPRE: the integrator's chain - phase C, phase A, window - is what bounds a quad workgroup's period, and this is
+// 4-5 k cycles of its window that need nothing but the published position and the stage's epoch data.  Same operations on the same
+// operands in the same lanes: same bits.
+DEVFN void quad_pre(CfgPtr cfg, const double *edc, double y0, double y1, double y2, int ql, int lane, double *qpre, bool has_grav) {
+    double q_acc[3], q_gc[3];
+    D1 q_aux[4] = {d1c(0.0), d1c(0.0), d1c(0.0), d1c(0.0)};
+    const D1 rad[3] = {d1seed(y0, 0, ql), d1seed(y1, 1, ql), d1seed(y2, 2, ql)};
+    const D1 fac = d1div(d1c(-cfg->mu_central), d1cube(d1norm(rad[0], rad[1], rad[2])));
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const D1 a = rad[q] * fac;
+        q_acc[q] = a.v; q_gc[q] = a.d;
+    }
+    if (has_grav) {
+        double m[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) m[q] = edc[q * DEV_LANES + lane];
+        double rq[3] = {y0, y1, y2};
+        if (cfg->g_slot >= 0) {  // (uniform; plain stage loop then: edc is this stage's data)
+            double pg[3];
+            ed_body(cfg, edc, lane, cfg->g_slot, pg);
+            rq[0] = y0 - pg[0]; rq[1] = y1 - pg[1]; rq[2] = y2 - pg[2];
+        }
+        const D1 x0 = d1seed(m[0] * rq[0] + m[1] * rq[1] + m[2] * rq[2], 0, ql);
+        const D1 x1 = d1seed(m[3] * rq[0] + m[4] * rq[1] + m[5] * rq[2], 1, ql);
+        const D1 x2 = d1seed(m[6] * rq[0] + m[7] * rq[1] + m[8] * rq[2], 2, ql);
+        const D1 rD = d1norm(x0, x1, x2);
+        q_aux[0] = d1div(x0, rD); q_aux[1] = d1div(x1, rD); q_aux[2] = d1div(x2, rD);
+        q_aux[3] = d1div(d1div(d1c(cfg->g_mu), rD), d1c(cfg->g_re));
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) { qpre[q * DEV_LANES + lane] = q_acc[q]; qpre[(3 + q) * DEV_LANES + lane] = q_gc[q]; }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { qpre[(6 + 2 * q) * DEV_LANES + lane] = q_aux[q].v; qpre[(7 + 2 * q) * DEV_LANES + lane] = q_aux[q].d; }
+    if (has_grav) {  // the DCM of this stage, for phase C (its LDS buffer is recycled by the almanac wave in the pipelined loop)
+#pragma unroll
+        for (int q = 0; q < 9; ++q) qpre[(14 + q) * DEV_LANES + lane] = edc[q * DEV_LANES + lane];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // The kernel
 // ---------------------------------------------------------------------------------------------
@@ -2547,6 +2589,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     // its LDS.  The exit is seen one (wasted) window late.
     const bool spec = pipe && !STM && cfg->spec != 0;
     const bool offl = PIPE && !STM && cfg->offload != 0;  // (uniform) see DevCfg.offload
+    const bool qoff = STM && QUAD && cfg->qpre_off != 0;   // (uniform) quad layout: the position-only pieces of phase C formed by an almanac wave (quad_pre)
     bool spec_now = false;  // stage 0 of the attempt being started was published in the previous attempt's last window
     bool keep_k0 = false;   // (integrator, per lane) the previous attempt was rejected: k_0 stands
     int att = 0;            // attempts started by this workgroup
@@ -2636,7 +2679,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             }
         }
         if (!spec_now) {
-        if (INTEG && lane == 0) { L.ctl[2] = 0; L.ctl[3] = 0; L.ctl[4] = 0; }
+        if (INTEG && lane == 0) { L.ctl[2] = 0; L.ctl[3] = 0; L.ctl[4] = 0; L.ctl[6] = 0; }
         __syncthreads();  // Bp
         }
         const int fold_base = spec ? att * stages : 0;  // ctl[3] counts the folds of the whole launch when the attempts are chained
@@ -2844,6 +2887,18 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
 #pragma unroll
                     for (int e = 0; e < 6; ++e) qb[e * DEV_LANES + lane] = q6[e];
                 }
+            }
+            if (ALMANAC && STM && QUAD && qoff && (amask & DEV_ROLE_QPRE)) {
+                // (after this wave's epoch data of the NEXT stage - the integrator's window is waiting for that DCM.  The rows are read
+                //  by phase C of THIS stage, behind B2; phase C of the previous stage may still be reading the previous contents: ctl[6]
+                //  = stages whose phase C is done, bounded spin)
+                if (i > 0) {
+                    int spin = 0;
+                    while (LCTL[6] < i && ++spin < 4000000) __builtin_amdgcn_s_sleep(2);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                }
+                const double *const ysq = (pipe && (i & 1)) ? L.ys2 : L.ys;
+                quad_pre(cfg, edc, ysq[0 * DEV_LANES + lane], ysq[1 * DEV_LANES + lane], ysq[2 * DEV_LANES + lane], ql, lane, L.qpre, has_grav);
             }
             if (PERT && (has_pm || has_srp || has_drag || has_tides || has_grav2)) {
                 // position-dependent third-body and SRP terms of THIS stage
@@ -3081,42 +3136,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             }
             // quad layout: the position-only parts of phase C (two-body dual, the duals of s, t, u and (mu / r) / R_eq) are formed
             // HERE, inside the window, where the integrator wave has nothing else to do (after the next stage's inputs: those gate the column waves)
-            if (INTEG && STM && QUAD) {
-                double q_acc[3], q_gc[3];
-                D1 q_aux[4] = {d1c(0.0), d1c(0.0), d1c(0.0), d1c(0.0)};
-                const D1 rad[3] = {d1seed(ys[0], 0, ql), d1seed(ys[1], 1, ql), d1seed(ys[2], 2, ql)};
-                const D1 fac = d1div(d1c(-cfg->mu_central), d1cube(d1norm(rad[0], rad[1], rad[2])));
-#pragma unroll
-                for (int q = 0; q < 3; ++q) {
-                    const D1 a = rad[q] * fac;
-                    q_acc[q] = a.v; q_gc[q] = a.d;
-                }
-                if (has_grav) {
-                    double m[9];
-#pragma unroll
-                    for (int q = 0; q < 9; ++q) m[q] = edc[q * DEV_LANES + lane];
-                    double rq[3] = {ys[0], ys[1], ys[2]};
-                    if (cfg->g_slot >= 0) {  // (uniform; plain stage loop then: edc is this stage's data)
-                        double pg[3];
-                        ed_body(cfg, edc, lane, cfg->g_slot, pg);
-                        rq[0] = ys[0] - pg[0]; rq[1] = ys[1] - pg[1]; rq[2] = ys[2] - pg[2];
-                    }
-                    const D1 x0 = d1seed(m[0] * rq[0] + m[1] * rq[1] + m[2] * rq[2], 0, ql);
-                    const D1 x1 = d1seed(m[3] * rq[0] + m[4] * rq[1] + m[5] * rq[2], 1, ql);
-                    const D1 x2 = d1seed(m[6] * rq[0] + m[7] * rq[1] + m[8] * rq[2], 2, ql);
-                    const D1 rD = d1norm(x0, x1, x2);
-                    q_aux[0] = d1div(x0, rD); q_aux[1] = d1div(x1, rD); q_aux[2] = d1div(x2, rD);
-                    q_aux[3] = d1div(d1div(d1c(cfg->g_mu), rD), d1c(cfg->g_re));
-                }
-#pragma unroll
-                for (int q = 0; q < 3; ++q) { L.qpre[q * DEV_LANES + lane] = q_acc[q]; L.qpre[(3 + q) * DEV_LANES + lane] = q_gc[q]; }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { L.qpre[(6 + 2 * q) * DEV_LANES + lane] = q_aux[q].v; L.qpre[(7 + 2 * q) * DEV_LANES + lane] = q_aux[q].d; }
-                if (has_grav) {  // the DCM of this stage, for phase C (its LDS buffer is recycled by the almanac wave in the pipelined loop)
-#pragma unroll
-                    for (int q = 0; q < 9; ++q) L.qpre[(14 + q) * DEV_LANES + lane] = edc[q * DEV_LANES + lane];
-                }
-            }
+            if (INTEG && STM && QUAD && !qoff) quad_pre(cfg, edc, ys[0], ys[1], ys[2], ql, lane, L.qpre, has_grav);
             SEG(6)   /* two-body + stage sums */
             if (prof_on) prof_acc[1] += (int64_t)__builtin_readcyclecounter() - ptw_;
             const int64_t pth_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;
@@ -3252,6 +3272,10 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                                  (LdsPtr)(kbuf + (i * 6) * KB_STR + kb_li), KB_STR, B_COEF(i), nw,
                                  ((has_pm || has_tides || has_grav2) ? PC_HAS_PM : 0) | (has_grav ? PC_HAS_GRAV : 0) | (has_srp ? PC_HAS_SRP : 0), lane, ql,
                                  LCTL + 3, pipe ? i + 1 : 0, prof_on ? bt.prof + 16 * 8 : nullptr);
+                    if (qoff) {  // L.qpre of this stage has been read: the wave that forms it may write the next stage's
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) LCTL[6] = i + 1;
+                    }
                 } else if (STM) {
                     // dual path (dual_eom, spacecraft.rs:312-363): f(x) and A = df/dx; the derivative written to k_i is
                     // the dual path's real part, as in the reference's STM branch (spacecraft.rs:208-224)
