@@ -287,6 +287,7 @@ struct ExpKnobs {  // experiment knobs of tools/sweep.py that have no field in n
     int deal = -1;
     int place[8] = {-1, -1, -1, -1, -1, -1, -1, -1};  // role fan-out: the wave of the k-th duty (duties heaviest first), assign_roles
     int place_sums = -1, place_twobody = -1;         // ... and of the two offloaded integrator pieces
+    bool fit_big = false, fit_quad = false;          // the free-order column placement for the large cooperative / the quad STM shape too
 };
 static nyx_hip_tuning_t resolve_tuning(const nyx_hip_tuning_t *t, ExpKnobs *xk = nullptr) {
     nyx_hip_tuning_t r = NYX_HIP_TUNING_DEFAULT;
@@ -301,6 +302,8 @@ static nyx_hip_tuning_t resolve_tuning(const nyx_hip_tuning_t *t, ExpKnobs *xk =
             for (int k = 0; k < 8 && *q; ++k) { xk->place[k] = (int)std::strtol(q, (char **)&q, 10); if (*q == ',') ++q; }
         }
         if (const char *e = std::getenv("NYX_HIP_ROLE_OFFLOAD")) (void)std::sscanf(e, "%d,%d", &xk->place_sums, &xk->place_twobody);
+        xk->fit_big = std::getenv("NYX_HIP_FIT_BIG") != nullptr;
+        xk->fit_quad = std::getenv("NYX_HIP_FIT_QUAD") != nullptr;
     }
     auto geti = [](const char *name, int32_t &dst) { if (const char *e = std::getenv(name)) dst = (int32_t)std::strtol(e, nullptr, 0); };
     auto getd = [](const char *name, double &dst) { if (const char *e = std::getenv(name)) dst = std::atof(e); };
@@ -991,6 +994,26 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
             if (part >= parts) continue;
             std::vector<int> mine;
             for (size_t k = 0; k < help.size(); ++k) if ((int)(k % (size_t)parts) == part) mine.push_back(help[k]);
+            if (ctx->coop_deal >= 2 && parts_cfg == 1 && max_cols == col_waves) {
+                // EXPERIMENT (tools only: NYX_HIP_COOP_DEAL=2 / 3), measured in round 5 and LOST: two waves per SIMD, each with a pair of
+                // columns of equal sum (k-th longest + k-th shortest of the helper's set) - on the microbenchmark two waves saturate a
+                // SIMD's issue, so four one-column waves that finish at 8 / 10 / 13 / 16-17 k cycles looked like oldest-first skew a pair
+                // of two-column waves would avoid.  They do not: a column walk is a dependent chain per row (108 cycles per row and wave
+                // whatever the SIMD's load), 129 rows on one wave are 15.6 k cycles - 95.4 ms per 3 h of configs[1] against 77.4 (scalar
+                // feed), 102.3 against 77.0 (streamed).  One column per wave on fourteen waves stays.
+                static const int pair_waves[12] = {1, 2, 4, 3, 5, 6, 8, 7, 9, 10, 12, 11};
+                const int nm = (int)mine.size();
+                const int use = ctx->coop_deal == 3 ? 12 : 8;   // (3: three waves per SIMD, for comparison)
+                int q = 0;
+                for (int a = 0, b = nm - 1; a <= b; ++a, --b, ++q) {
+                    const int w = pair_waves[q % use];
+                    if (hs.n_ranges[w] + 2 > DEV_MAX_RANGES) break;
+                    int r = hs.n_ranges[w]++;
+                    hs.range_c0[w][r] = mine[a]; hs.range_cnt[w][r] = 1;
+                    if (b > a) { r = hs.n_ranges[w]++; hs.range_c0[w][r] = mine[b]; hs.range_cnt[w][r] = 1; }
+                }
+                continue;
+            }
             if (balanced) {
                 // longest column first onto the wave that would finish it soonest: load / speed, speed = coop_fast_weight on the SIMDs with
                 // three column waves (waves 4 8 12 beside the producer, 3 7 11 beside the answering wave)
@@ -1284,8 +1307,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
     ctx->tune = resolve_tuning(cfg->tuning, &xk);
     ctx->block_schedule = (ctx->tune.debug_flags & 0x8000) == 0;  // (0x8000: the two-ended column fill of rounds 1-3 everywhere)
     ctx->block_force = (ctx->tune.debug_flags & 0x10000) != 0;    // (0x10000: contiguous runs whatever the feed - the A/B partner of the streamed walk)
-    ctx->fit_big = std::getenv("NYX_HIP_TUNING_ENV") && std::getenv("NYX_HIP_FIT_BIG");
-    ctx->fit_quad = std::getenv("NYX_HIP_TUNING_ENV") && std::getenv("NYX_HIP_FIT_QUAD");
+    ctx->fit_big = xk.fit_big; ctx->fit_quad = xk.fit_quad;
     ctx->fit_partition = (ctx->tune.debug_flags & 0x2000000) == 0;  // (0x2000000: the linear partition of round 4 for the cooperative 70x70 shape too, fill_schedule)
     ctx->coop_deal = (ctx->tune.debug_flags & 0x400000) ? 0 : 1;  // (0x400000: the helper dealing of rounds 1-4 - the longest columns, one per wave)
     if (xk.fast_weight > 0.0) ctx->coop_fast_weight = xk.fast_weight;  // (experiment knobs of the tools, never of a caller: resolve_tuning)
