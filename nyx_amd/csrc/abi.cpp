@@ -133,7 +133,8 @@ struct nyx_hip_ctx {
     DevArrays cal;                         // scratch outputs of the calibration launches
     bool block_schedule = true;  // one contiguous run of columns per wave where the owner streams the table (fill_schedule)
     bool fit_big = false;        // (tools: NYX_HIP_FIT_BIG - the free-order placement for the large cooperative shape too)
-    bool fit_quad = false;       // (NYX_HIP_FIT_QUAD / default, see ctx_create: ... and for the sixteen-wave quad STM shape)
+    bool fit_quad = false;       // (tools: NYX_HIP_FIT_QUAD - ... and for the sixteen-wave quad STM shape)
+    bool fit_solo = false;       // (tools: NYX_HIP_FIT_SOLO - ... and for workgroups that walk every column themselves)
     bool fit_partition = true;   // ... placed along the column list in a free wave order so that every wave meets its target (fill_schedule)
     bool block_force = false;
     int coop_parts = 1;  // sub-jobs per evaluation of the schedules in host_cfg (1, or 2: two helper workgroups per owner and evaluation)
@@ -287,7 +288,7 @@ struct ExpKnobs {  // experiment knobs of tools/sweep.py that have no field in n
     int deal = -1;
     int place[8] = {-1, -1, -1, -1, -1, -1, -1, -1};  // role fan-out: the wave of the k-th duty (duties heaviest first), assign_roles
     int place_sums = -1, place_twobody = -1;         // ... and of the two offloaded integrator pieces
-    bool fit_big = false, fit_quad = false;          // the free-order column placement for the large cooperative / the quad STM shape too
+    bool fit_big = false, fit_quad = false, fit_solo = false;  // the free-order column placement for the large cooperative / the quad STM / the solo shape too
 };
 static nyx_hip_tuning_t resolve_tuning(const nyx_hip_tuning_t *t, ExpKnobs *xk = nullptr) {
     nyx_hip_tuning_t r = NYX_HIP_TUNING_DEFAULT;
@@ -304,6 +305,7 @@ static nyx_hip_tuning_t resolve_tuning(const nyx_hip_tuning_t *t, ExpKnobs *xk =
         if (const char *e = std::getenv("NYX_HIP_ROLE_OFFLOAD")) (void)std::sscanf(e, "%d,%d", &xk->place_sums, &xk->place_twobody);
         xk->fit_big = std::getenv("NYX_HIP_FIT_BIG") != nullptr;
         xk->fit_quad = std::getenv("NYX_HIP_FIT_QUAD") != nullptr;
+        xk->fit_solo = std::getenv("NYX_HIP_FIT_SOLO") != nullptr;
     }
     auto geti = [](const char *name, int32_t &dst) { if (const char *e = std::getenv(name)) dst = (int32_t)std::strtol(e, nullptr, 0); };
     auto getd = [](const char *name, double &dst) { if (const char *e = std::getenv(name)) dst = std::atof(e); };
@@ -524,7 +526,7 @@ static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, con
         // Same box, product kernel, 24 h: 625.0 ms linear partition, 617.0 free order with the old table, 614.0 with this one.
         static const double model_coop_fit[16] = {1.00, 1.413, 0.549, 1.95, 1.83, 1.48, 1.40, 1.23, 1.04, 0.88, 0.85, 0.62, 0.50, 0.36, 0.34, 0.16};
         const bool blk = ctx->block_schedule && n_waves == DEV_MAX_WAVES && !ctx->sched_quad && ((ctx->host_cfg.harm_feed & 1) || ctx->block_force);
-        fit = (blk && !all_columns && (ctx->host_cfg.n_cols <= 96 || ctx->fit_big) && ctx->fit_partition) || (ctx->fit_quad && ctx->sched_quad && n_waves == DEV_MAX_WAVES);
+        fit = (blk && (!all_columns || ctx->fit_solo) && (ctx->host_cfg.n_cols <= 96 || ctx->fit_big) && ctx->fit_partition) || (ctx->fit_quad && ctx->sched_quad && n_waves == DEV_MAX_WAVES);
         const double *model = ctx->sched_quad ? model_quad
                               : (blk ? (all_columns ? model_solo_blk : (ctx->host_cfg.n_cols > 96 ? model_coop_big_blk : (fit ? model_coop_fit : model_coop_blk)))
                                      : (all_columns ? model_solo : model_coop));
@@ -1307,7 +1309,7 @@ extern "C" int32_t nyx_hip_ctx_create(const nyx_hip_config_t *cfg, int32_t devic
     ctx->tune = resolve_tuning(cfg->tuning, &xk);
     ctx->block_schedule = (ctx->tune.debug_flags & 0x8000) == 0;  // (0x8000: the two-ended column fill of rounds 1-3 everywhere)
     ctx->block_force = (ctx->tune.debug_flags & 0x10000) != 0;    // (0x10000: contiguous runs whatever the feed - the A/B partner of the streamed walk)
-    ctx->fit_big = xk.fit_big; ctx->fit_quad = xk.fit_quad;
+    ctx->fit_big = xk.fit_big; ctx->fit_quad = xk.fit_quad; ctx->fit_solo = xk.fit_solo;
     ctx->fit_partition = (ctx->tune.debug_flags & 0x2000000) == 0;  // (0x2000000: the linear partition of round 4 for the cooperative 70x70 shape too, fill_schedule)
     ctx->coop_deal = (ctx->tune.debug_flags & 0x400000) ? 0 : 1;  // (0x400000: the helper dealing of rounds 1-4 - the longest columns, one per wave)
     if (xk.fast_weight > 0.0) ctx->coop_fast_weight = xk.fast_weight;  // (experiment knobs of the tools, never of a caller: resolve_tuning)
