@@ -10,9 +10,7 @@
 #include <cstdlib>
 #include <array>
 #include <cstring>
-#include <functional>
 #include <map>
-#include <set>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -22,6 +20,7 @@
 #include "../../include/nyx_hip.h"
 #include "butcher.h"
 #include "devcfg.h"
+#include "col_partition.h"
 #include "predict_args.h"
 #include "traj_args.h"
 #include "moments_args.h"
@@ -574,45 +573,14 @@ static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, con
             // columns starting at length L sums to jL - j(j-1)/2: which sums exist depends on WHERE in the list a run sits, so the
             // waves are placed along the list in whatever order lets every one of them meet its target - a depth-first search over
             // (columns consumed, waves placed) for the smallest tolerance D with |load_w - target_w| <= D * weight_w for every wave
-            // (the weight is the wave's speed: the same TIME error everywhere).  A pure function of the configuration, like the rest.
+            // (the weight is the wave's speed: the same TIME error everywhere; col_partition.h).  A pure function of the configuration, like the rest.
             std::vector<int> act;
             for (int w : order) if (std::max(0.0, level * wgt(w) - hc[w]) > 0.0) act.push_back(w);
-            const int na = (int)act.size(), m = (int)list.size();
-            std::vector<double> pre(m + 1, 0.0), tg(na), wg(na);
-            for (int k = 0; k < m; ++k) pre[k + 1] = pre[k] + cost(list[k]);
-            for (int a = 0; a < na; ++a) { tg[a] = std::max(0.0, level * wgt(act[a]) - hc[act[a]]); wg[a] = std::max(wgt(act[a]), 1e-3); }
+            std::vector<double> cst, tg, wg;
+            for (int c : list) cst.push_back(cost(c));
+            for (int w : act) { tg.push_back(std::max(0.0, level * wgt(w) - hc[w])); wg.push_back(wgt(w)); }
             std::vector<int> seq_w, seq_k;   // the placement found: wave index (into act) and its first column, in list order
-            bool found = false;
-            if (na >= 2 && na <= 16 && m >= na) {
-                for (double D = 1.0; D <= 40.0 && !found; D += 1.0) {
-                    std::set<std::pair<int, int>> dead;
-                    seq_w.clear(); seq_k.clear();
-                    long budget = 400000;
-                    std::function<bool(int, int)> dfs = [&](int k, int mask) -> bool {
-                        if (mask == (1 << na) - 1) return k == m;
-                        if (--budget < 0) return false;
-                        if (dead.count({k, mask})) return false;
-                        const int left = na - __builtin_popcount((unsigned)mask);
-                        for (int a = 0; a < na; ++a) {
-                            if (mask & (1 << a)) continue;
-                            const double tol = D * wg[a];
-                            // run lengths whose load meets the target within the tolerance (the last wave takes what is left)
-                            for (int e = k + 1; e <= m - (left - 1); ++e) {
-                                const double load = pre[e] - pre[k];
-                                if (load > tg[a] + tol) break;
-                                if (load < tg[a] - tol) continue;
-                                if (left == 1 && e != m) continue;
-                                seq_w.push_back(a); seq_k.push_back(k);
-                                if (dfs(e, mask | (1 << a))) return true;
-                                seq_w.pop_back(); seq_k.pop_back();
-                            }
-                        }
-                        dead.insert({k, mask});
-                        return false;
-                    };
-                    found = dfs(0, 0);
-                }
-            }
+            const bool found = nyx_place_runs(cst, tg, wg, seq_w, seq_k);
             if (found) {
                 for (size_t q = 0; q < seq_w.size(); ++q) {
                     const int w = act[seq_w[q]];
