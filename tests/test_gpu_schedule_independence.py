@@ -107,3 +107,46 @@ def test_config5_full_ensemble_does_not_depend_on_the_hand_off():
             worst[(names[a], names[b])] = (dr.max(), np.median(dr), dv.max())
             assert dr.max() < 20.0 and dv.max() < 0.02, (names[a], names[b], dr.max(), dv.max())
     print("hand-off independence over 6 250 x 72 h (max dr mm, median dr mm, max dv mm/s):", worst)
+
+
+def test_config4_full_ensemble_across_layouts_and_column_splits():
+    """BASELINE config 4 at its full size - 1 000 GEO states, 21x21 + Sun/Moon + SRP (Cr estimated), the 9x9 STM, sixty one-minute
+    covariance-mapping segments.  The quad layout deals the dual column work by a weight table; its sums are folded in a fixed order,
+    so the table must not reach the bits: the default (round-5 table, the position-only pieces of phase C on the DCM wave), the same
+    pieces on the integrator wave (`debug_flags 0x4000000`) and the round-4 table (explicit weights) give the SAME Phi, states and mapped
+    covariances on every trajectory and update, bit for bit.  The 64-lane D3 layout (`stm_quad = 0`: another workgroup shape, another
+    column split) agrees with them to 1e-9 of an element's scale (SURVEY 8d's bar for Phi against the oracle)."""
+    from bench import geo_batch, init_covar
+    prop, almanac, central = sc.leo_full_setup(degree=21)
+    compiled = prop.compile(almanac, central, stm=True)
+    n = 1_000
+    p0 = init_covar(n)
+    r4_table = [0.70, 0.70, 0.70, 0.70, 1.26, 2.03, 1.78, 1.59, 1.58, 1.68, 0.96, 1.02, 0.875, 0.93, 0.86, 0.91]
+    res = {}
+    for name, tuning in (("default", {}), ("phase C pieces on the integrator", dict(debug_flags=0x4000000)),
+                         ("round-4 table", dict(schedule=nx.SCHED_EXPLICIT, wave_weights=r4_table)), ("D3 layout", dict(stm_quad=0))):
+        ctx = nx.GpuContext(compiled, tuning=nx.Tuning(**tuning))
+        b = geo_batch(n, seed=0)
+        b.stm = np.zeros((n, 81))
+        b.reset_stm()
+        end = int(b.epoch_ns[0]) + 3600 * S
+        got = nx.predict_until(ctx, b, p0, end, 60 * S, history=60)
+        ctx.close()
+        assert (got.stats.status == 0).all() and (got.n_updates == 60).all(), name
+        res[name] = (got.states.rv().copy(), np.array(got.stm).copy(), np.array(got.covar_history).copy())
+    ref = res["default"]
+    for name in ("phase C pieces on the integrator", "round-4 table"):
+        for a, r in zip(res[name], ref):
+            assert a.tobytes() == r.tobytes(), name
+
+    def rel(a, r):
+        scale = np.maximum(np.abs(r), 1e-6 * np.abs(r).max(axis=(-2, -1), keepdims=True))
+        return float((np.abs(a - r) / scale).max())
+
+    d3 = res["D3 layout"]
+    d = d3[0] - ref[0]
+    dr, dv = np.linalg.norm(d[:, :3], axis=1).max(), np.linalg.norm(d[:, 3:], axis=1).max()
+    e_phi, e_p = rel(d3[1], ref[1]), rel(d3[2], ref[2])
+    print(f"config 4, quad against D3 layout over {n} x 60 updates: dr {dr * 1e6:.2e} mm, dv {dv * 1e6:.2e} mm/s, Phi {e_phi:.2e}, Pbar {e_p:.2e}")
+    assert dr < 1e-6 and dv < 1e-9
+    assert e_phi < 1e-9 and e_p < 1e-9
