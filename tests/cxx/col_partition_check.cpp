@@ -1,6 +1,7 @@
 // col_partition_check.cpp - CPU check of nyx_place_runs (nyx_amd/csrc/col_partition.h), the free-order placement of the owner's column
 // runs.  Built and run by tests/test_col_partition.py with g++ (no HIP, no GPU).  Prints one line per case; exit code 0 = all good.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <numeric>
@@ -117,6 +118,25 @@ int main() {
         CHECK(!nyx_place_runs({5, 4, 3}, {6, 6}, {1.0}, sw, sk), "weight vector of the wrong size accepted");
         // targets nothing can meet inside the widest tolerance: no placement, empty result
         CHECK(!nyx_place_runs({100, 100, 100}, {1, 299}, {0.01, 0.01}, sw, sk) && sw.empty() && sk.empty(), "impossible targets placed");
+    }
+    // 4. host time: a sixteen-wave shape with NO placement at any tolerance walks the whole budget of every D - the worst
+    //    case fill_schedule can meet inside a launch - and must stay well under a second; asked again, it is a memo hit
+    {
+        std::vector<double> cost, tg, wg;
+        for (int k = 0; k < 120; ++k) cost.push_back(120 - k);
+        const double total = std::accumulate(cost.begin(), cost.end(), 0.0);
+        for (int a = 0; a < 16; ++a) { wg.push_back(1.0); tg.push_back((total - 900.0) / 16.0 + 3.0 * a); }   // (every prefix fits, the last wave never does)
+        std::vector<int> sw, sk;
+        const auto t0 = std::chrono::steady_clock::now();
+        const bool f1 = nyx_place_runs(cost, tg, wg, sw, sk);
+        const double s1 = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const auto t1 = std::chrono::steady_clock::now();
+        const bool f2 = nyx_place_runs(cost, tg, wg, sw, sk);
+        const double s2 = std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+        std::printf("worst case (16 waves, 120 columns, found %d): %.3f s, again (memo): %.6f s\n", (int)f1, s1, s2);
+        CHECK(f1 == f2, "memo changed the answer");
+        CHECK(s1 < 1.5, "search took %.2f s", s1);
+        CHECK(s2 < 0.01, "memo hit took %.4f s", s2);
     }
     std::printf("%s\n", failures ? "FAILED" : "ok");
     return failures ? 1 : 0;
