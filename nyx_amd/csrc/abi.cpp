@@ -867,7 +867,9 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
     const bool stm_cfg = (dc.flags & NYX_HIP_FLAG_STM) != 0;
     // (not with a non-central gravity field: its inputs need the body's position of the stage, which the almanac waves write late in the window)
     dc.pipe = (!dc.merge_roles && ctx->tune.pipelined != 0 && !(dc.has_grav && dc.g_slot >= 0) &&
-               ((n_waves == DEV_MAX_WAVES && dc.has_grav) || (!dc.has_grav && !stm_cfg && n_waves >= 2))) ? 1 : 0;
+               ((n_waves == DEV_MAX_WAVES && dc.has_grav) || (!dc.has_grav && !stm_cfg && n_waves >= 2 && n_waves <= 8))) ? 1 : 0;
+    // (a workgroup of more than eight waves WITHOUT a gravity field exists only when the caller forces it - nyx_hip_ctx_set_column_waves -
+    //  and runs the plain loop: the pipelined integrator of the sixteen-wave kernels is compiled for the gravity-field shape, INTEG_OOL)
     // roles of this workgroup shape and their serial duties (merged roles when there are fewer than three waves)
     double hc[DEV_MAX_WAVES] = {0};
     assign_roles(ctx, n_waves, want_fanout(ctx, quad), hc);

@@ -405,8 +405,10 @@ template <typename P>
 // needs only that to form the next stage's recursion inputs, the body positions are for the next window.
 // `amask`: the share of this almanac wave when the duty is dealt over several (role fan-out, DEV_ROLE_DCM = the DCM, bit s =
 // body slot s); every wave writes only its own rows of `slot`.
+// `gate` / `gate_val` (INTEG_OOL): the DCM rows of `slot` still hold the orientation of two stages ago, which the integrator's phase C
+// reads late (behind the stage barrier, see integ_back) - they are not overwritten before *gate >= gate_val (the fold counter).
 DEVFN int epoch_data(CfgPtr cfg, P records, int64_t epoch_ns, double *slot, int lane, int amask, LdsFlagPtr dcm_flag = nullptr, int dcm_val = 0,
-                     RotBase *rbase = nullptr) {
+                     RotBase *rbase = nullptr, LdsFlagPtr gate = nullptr, int gate_val = 0) {
     const double et = ns_to_seconds(epoch_ns);
     int status = NYX_HIP_OK;
     if ((amask & DEV_ROLE_DCM) && (cfg->has_grav || cfg->has_drag || cfg->has_tides)) {  // (ctx_create requires these body-fixed frames to coincide)
@@ -420,6 +422,11 @@ DEVFN int epoch_data(CfgPtr cfg, P records, int64_t epoch_ns, double *slot, int 
         else if (cfg->has_drag) st = rotation_dcm(cfg, cfg->d_rot, records, et, m);
         else st = rotation_dcm(cfg, cfg->t_rot, records, et, m);
         if (st) status = st;
+        if (gate) {  // (bounded: a protocol error must end as a failed run, never as a hung GPU)
+            int spin = 0;
+            while (*gate < gate_val && ++spin < 4000000) __builtin_amdgcn_s_sleep(1);
+            if (spin >= 4000000) status = NYX_HIP_ERR_NAN;
+        }
 #pragma unroll
         for (int q = 0; q < 9; ++q) slot[q * DEV_LANES + lane] = m[q];
     }
@@ -1425,6 +1432,15 @@ DEVFN bool coop_get(const uint64_t *g, uint32_t seq, double &v) {
 #else
 #define COOP_FN static __device__ __attribute__((noinline))
 #endif
+// (`mult`: what the scan words count - sub-jobs: 1 per evaluation, or 2 with the two-part hand-off)
+DEVFN void coop_post_inl(CoopBox *box, uint32_t *posted, int lane, uint32_t seq, LdsCPtr inb, uint32_t mult) {
+    double v[5];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) v[q] = inb[q * DEV_LANES + lane];
+#pragma unroll
+    for (int q = 0; q < 5; ++q) coop_put(&box->in[seq & 1u][q][0][lane], v[q], seq);
+    if (lane == 0) coop_store(posted, mult * seq);
+}
 COOP_FN void coop_post(CoopBox *box, uint32_t *posted, int lane, uint32_t seq, LdsCPtr inb) {
     double v[5];
 #pragma unroll
@@ -1448,31 +1464,38 @@ struct CoopAnswer {
 };
 // The answer needs no flag: every lane polls the LAST granule the helper writes for it, and when all of them carry this
 // evaluation's tag the other seven are read and checked the same way (they were stored earlier, but nothing orders them).
-COOP_FN CoopAnswer coop_wait(CoopBox *box, int lane, uint32_t seq) {
+DEVFN CoopAnswer coop_wait_inl(CoopBox *box, int lane, uint32_t seq) {
     CoopAnswer a = {0.0, 0.0, 0.0, 0.0, 0};
     const int64_t t0 = (int64_t)__builtin_amdgcn_s_memrealtime();
     const unsigned par = seq & 1u;
-    // (poll ONE granule - lane 0's last one, a single request - until it carries the tag: the traffic of 157 polling owners is
-    //  not free, the exchange is faster with less of it; then every lane checks its own)
+    // Round 6: the answer is read OPTIMISTICALLY first - all eight granules of every lane in one batch of loads, one round trip.  With the
+    // late collection (phase C, behind the stage barrier) the answer is almost always in the mailbox by the time the integrator asks
+    // (in-kernel accounting, round 5: "wait for the answer" 3.6 k cycles = exactly the three SERIAL uncached loads this function used to
+    // make - poll lane 0's last granule, every lane's last granule, then the eight - with nothing to wait for), and this wave's
+    // chain answer -> next post is what bounds a cooperative owner's period.  Only when the optimistic read misses does it fall back to
+    // the light poll (ONE granule, one request: the traffic of 157 polling owners is not free) and then reads again.
+    {
+        const bool ok = coop_get(&box->out[par][0][0][lane], seq, a.x) & coop_get(&box->out[par][1][0][lane], seq, a.y) &
+                        coop_get(&box->out[par][2][0][lane], seq, a.z) & coop_get(&box->out[par][3][0][lane], seq, a.w);
+        if (__all(ok)) { a.ok = 1; return a; }
+    }
     while ((uint32_t)(coop_loadu(&box->out[par][3][1][0]) >> 32) != seq) {
-        if ((int64_t)__builtin_amdgcn_s_memrealtime() - t0 > COOP_TIMEOUT_TICKS) return a;
+        if ((int64_t)__builtin_amdgcn_s_memrealtime() - t0 > COOP_TIMEOUT_TICKS) { a.x = a.y = a.z = a.w = 0.0; return a; }
         __builtin_amdgcn_s_sleep(1);
     }
     for (;;) {
-        const uint64_t last = coop_loadu(&box->out[par][3][1][lane]);
-        if (__all((uint32_t)(last >> 32) == seq)) {
-            const bool ok = coop_get(&box->out[par][0][0][lane], seq, a.x) & coop_get(&box->out[par][1][0][lane], seq, a.y) &
-                            coop_get(&box->out[par][2][0][lane], seq, a.z) & coop_get(&box->out[par][3][0][lane], seq, a.w);
-            if (__all(ok)) break;
-        }
+        const bool ok = coop_get(&box->out[par][0][0][lane], seq, a.x) & coop_get(&box->out[par][1][0][lane], seq, a.y) &
+                        coop_get(&box->out[par][2][0][lane], seq, a.z) & coop_get(&box->out[par][3][0][lane], seq, a.w);
+        if (__all(ok)) break;
         if ((int64_t)__builtin_amdgcn_s_memrealtime() - t0 > COOP_TIMEOUT_TICKS) { a.x = a.y = a.z = a.w = 0.0; return a; }
         __builtin_amdgcn_s_sleep(1);
     }
     a.ok = 1;
     return a;
 }
+COOP_FN CoopAnswer coop_wait(CoopBox *box, int lane, uint32_t seq) { return coop_wait_inl(box, lane, seq); }
 // two parts: part 0 from the mailbox, part 1 from the array of second answers, added in that order whichever helper answered first
-static __device__ __attribute__((noinline)) CoopAnswer coop_wait2(CoopBox *box, CoopOut *out2, int lane, uint32_t seq) {
+DEVFN CoopAnswer coop_wait2_inl(CoopBox *box, CoopOut *out2, int lane, uint32_t seq) {
     CoopAnswer a = {0.0, 0.0, 0.0, 0.0, 0};
     const int64_t t0 = (int64_t)__builtin_amdgcn_s_memrealtime();
     const unsigned par = seq & 1u;
@@ -1499,6 +1522,7 @@ static __device__ __attribute__((noinline)) CoopAnswer coop_wait2(CoopBox *box, 
     a.ok = 1;
     return a;
 }
+static __device__ __attribute__((noinline)) CoopAnswer coop_wait2(CoopBox *box, CoopOut *out2, int lane, uint32_t seq) { return coop_wait2_inl(box, out2, lane, seq); }
 
 // What the owner does when no helper answers: the helper's sixteen wave slots one after the other, summed in the
 // helper's fold order, i.e. bit for bit the answer it did not get.  Out of line: a rare path must not cost the
@@ -2292,6 +2316,7 @@ struct LdsMap {
     double *rec;    // [rec_doubles]
     // pipelined stage loop (non-STM): buffers of odd stages
     double *ys2, *inb2, *pert2;
+    double *ixs;    // [4][64]  s, t, u, (mu / r) / R_eq of the ODD stages (the even ones: wave 0's slot of `part`), see INTEG_OOL
     // epoch data carried between attempts (cfg->ed_reuse fields per lane), behind the ephemeris records
     double *ed0;         // [ed_reuse][64]  stage-0 data of the current attempt (what a rejected attempt starts from again)
     long long *ed0_ep;   // [64]            its epoch
@@ -2331,10 +2356,12 @@ DEVFN LdsMap carve_lds(char *smem, int n_waves, bool stm, int rec_lds_doubles, i
         m.pert = p; p += 9 * DEV_LANES;
     }
     m.ys2 = m.ys; m.inb2 = m.inb; m.pert2 = m.pert;
+    m.ixs = m.part;
     if (!stm) {
         m.ys2 = p; p += 6 * DEV_LANES;
         m.inb2 = p; p += NIN * DEV_LANES;
         m.pert2 = p; p += 9 * DEV_LANES;
+        m.ixs = p; p += 4 * DEV_LANES;
     } else if (quad) {  // pipelined stage loop of the quad layout: second set of the dual buffers
         m.ys2 = p; p += 6 * DEV_LANES;
         m.inb2 = p; p += 10 * DEV_LANES;
@@ -2358,7 +2385,7 @@ size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles, int stm, int reuse_fie
     size_t d = (size_t)DEV_MAX_STAGES * 6 * (quad ? DEV_LANES / 4 : DEV_LANES) + DEV_MAX_STAGES * DEV_MAX_STAGES + 3 * DEV_MAX_STAGES + 6 * DEV_LANES +
                2 * ED_FIELDS * DEV_LANES + 2 * DEV_LANES + CS_FIELDS * DEV_LANES + (size_t)(quad ? DEV_MAX_WAVES * QSLOT : DEV_MAX_WAVES * 4 * DEV_LANES) + DEV_MAX_ALM * DEV_LANES +
                DEV_LANES + 8 + (size_t)rec_doubles;
-    d += quad ? (size_t)(10 + 15 + 6 + QPRE_ROWS + 6 + 10 + 15) * DEV_LANES : (stm ? (size_t)(20 + 27 + 12) * DEV_LANES : (size_t)(NIN + 9 + 6 + NIN + 9) * DEV_LANES);
+    d += quad ? (size_t)(10 + 15 + 6 + QPRE_ROWS + 6 + 10 + 15) * DEV_LANES : (stm ? (size_t)(20 + 27 + 12) * DEV_LANES : (size_t)(NIN + 9 + 6 + NIN + 9 + 4) * DEV_LANES);
     (void)n_waves;
     if (reuse_fields > 0) d += (size_t)reuse_fields * DEV_LANES + 2 * DEV_LANES + DEV_LANES / 2;
     return d * sizeof(double) + 64;
@@ -2429,6 +2456,309 @@ static __device__ __attribute__((noinline)) bool stm_update_textbook(double *phi
     return nan;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// INTEG_OOL (round 6): the integrator wave of the sixteen-wave plain kernels, out of line.
+//
+// In the pipelined stage loop the integrator wave is a serial, latency-bound chain - phase C of stage i - 1 (fold, the helper's answer,
+// assembly of k), phase A of stage i, position and recursion inputs of stage i + 1, the mailbox post - and in a cooperative launch the
+// two ends of that chain (answer in, post out) close the loop that bounds the owner's period.  Inlined into role_loop at the 128-VGPR
+// budget of sixteen waves it kept ~30 doubles live across its three calls per stage (coop_post, fold_partials, coop_wait; the ABI
+// preserves 24): 115 scratch loads, 122 stores and 475 SGPR-spill lane moves per stage loop (tests/golden/code_budget.json, round 5),
+// every reload a trip to L2 on the critical path, and every scratch reload behind a post also waits for the post's uncached stores
+// (loads and stores share vmcnt on gfx9).  Here the chain is TWO functions with register files of their own that talk through LDS -
+// the treatment phase_c_quad got in round 4 -:
+//   integ_front(i): phase A of stage i (velocity of the stage state; the position was published a window earlier), then position,
+//                   DCM rotation, recursion inputs of stage i + 1 into LDS and the mailbox post;
+//   integ_back(i):  phase C of stage i behind the stage barrier: fold of the fifteen partial sums, the helper's answer, s / t / u /
+//                   (mu / r) / R_eq and the stage's DCM read HERE (not carried from phase A), assembly of the acceleration, k_i.
+// What role_loop keeps across the two calls is the velocity part of the next stage sum and the position part of the one after (six
+// doubles) - inside the callee-saved set.  Two protocol consequences: (1) s, t, u, (mu / r) / R_eq of stage i + 1 are written in window
+// i and read in phase C(i + 1), AFTER window i + 1 has written those of stage i + 2: two row sets by stage parity (wave 0's slot of the
+// partial sums and LdsMap.ixs); (2) phase C(i) reads the DCM of stage i from the epoch data behind B2(i), when the almanac wave is
+// about to write the DCM of stage i + 2 over it: the almanac wave holds that write until the fold counter (ctl[3]) says phase C(i) has
+// its operands (epoch_data `gate`; the column waves wait on the same word before they overwrite their partial sums).
+// Same operations on the same operands in the same order as the inline code: bit-identical results (digests in tests/).
+// ---------------------------------------------------------------------------------------------
+#ifndef INTEG_OOL
+#define INTEG_OOL ((NYX_EMIT & (NYX_EMIT_PLAIN16 | NYX_EMIT_PLAIN16_P2)) ? 1 : 0)
+#endif
+#if INTEG_OOL
+#define IX_HOT 1       /* phase A from the position the previous window published (else: the caller did phase A, v3..5 are the stage velocity) */
+#define IX_SPEC_NOW 2  /* stage 0 of this attempt was published speculatively */
+#define IX_COOP 4      /* this workgroup shares its columns with the helpers */
+#define IX_PROF 8
+#define IX_SHARED 16   /* integ_back: the column waves of THIS stage left columns to a helper */
+#define IXR_ANSWER 0x10000
+#define IXR_FALLBACK 0x20000
+DEVFN char *lds_from_u32(uint32_t a) { return (char *)(__attribute__((address_space(3))) char *)(uintptr_t)a; }
+// An LDS array's row base for this lane as ONE address register the optimiser cannot take apart: the carve's offsets are constants
+// beyond the 16-bit offset field of the ds instructions, and folded into every access they cost an address VGPR per row (the first
+// cut of integ_back: sixty of them, all 48 callee-saved VGPRs saved and restored per call).  Rows are then base[row * DEV_LANES].
+DEVFN LdsPtr ix_rows(const double *arr, int lane) {
+    uint32_t a = (uint32_t)(uintptr_t)(LdsCPtr)arr + (uint32_t)lane * 8u;
+    asm volatile("" : "+v"(a));
+    return (LdsPtr)(uintptr_t)a;
+}
+DEVFN void ix_stamp(LdsFlagPtr ctl, int k) {  // (accounting twin only) a 64-bit cycle stamp in two control words
+    const int64_t t = (int64_t)__builtin_readcyclecounter();
+    ctl[8 + 2 * k] = (int)(uint32_t)t; ctl[9 + 2 * k] = (int)(uint32_t)(t >> 32);
+}
+// kbuf / tabl / L in scope: the KB / A_ROW / B_COEF / CS_Y macros of role_loop
+#define IX_PROLOGUE                                                                                                        \
+    CfgPtr cfg = (CfgPtr)uniform_u64(cfg_u);                                                                               \
+    const LdsMap L = carve_lds(lds_from_u32(__builtin_amdgcn_readfirstlane(lds_v)), 0, false, cfg->rec_in_lds ? cfg->rec_doubles : 0, cfg->ed_reuse, false); \
+    double *const kbuf = L.kbuf;                                                                                           \
+    double *const tabl = L.tabl;                                                                                           \
+    constexpr int KB_STR = DEV_LANES;                                                                                      \
+    const int kb_li = lane;                                                                                                \
+    const int i = __builtin_amdgcn_readfirstlane(i_v);                                                                     \
+    const int flags = __builtin_amdgcn_readfirstlane(flags_v);                                                             \
+    const int stages = cfg->stages;
+
+static __device__ __attribute__((noinline)) int integ_front(uint32_t lds_v, uint64_t cfg_u, int i_v, int flags_v, int lane, double h,
+                                                           double v3, double v4, double v5, double p0, double p1, double p2,
+                                                           uint64_t cbox_u, uint64_t posted_u, uint32_t seq_nx_v, int keep_k0) {
+    IX_PROLOGUE
+    const bool has_grav = cfg->has_grav != 0;
+    const bool need_almanac = has_grav || cfg->has_drag != 0 || cfg->has_tides != 0 || cfg->n_slots > 0;
+    const bool spec = cfg->spec != 0;
+    int st = NYX_HIP_OK;
+    double vel[3] = {v3, v4, v5};
+    if (flags & IX_HOT) {
+        // ---- Phase A: the velocity of the stage state (instance.rs:376-394); its position was published in the previous window
+        double *const ysb = (i & 1) ? L.ys2 : L.ys;
+        if (i == 0) {
+            // speculative stage 0: the state step control has just stored (accepted lanes: its position IS the published one, bit for
+            // bit; rejected lanes: the result of this stage is dropped, k_0 stands)
+#pragma unroll
+            for (int e = 0; e < 3; ++e) vel[e] = CS_Y(3 + e);
+        } else {
+            const double a_last = A_ROW(i, i - 1);
+            const double w[3] = {v3, v4, v5};   // (the velocity part of sum_{j < i-1} a_ij k_j, accumulated in the previous window)
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                const double wi = w[e] + a_last * KB(i - 1, 3 + e);
+                vel[e] = CS_Y(3 + e) + h * wi;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 3; ++e) ysb[(3 + e) * DEV_LANES + lane] = vel[e];
+        if (cfg->has_drag) {  // the perturbation wave is already in this stage's window; drag is the one term that wants the velocity
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) LCTL[4] = i + 1;
+        }
+        // (the almanac wave finished this stage's data before the barrier this wave has just passed)
+        if (need_almanac && !(i == 0 && keep_k0)) {  // (a rejected lane's stage 0 is not evaluated: its epoch data at t + h does not count)
+            const int n_alm = cfg->n_alm;
+            for (int a = 0; a < n_alm; ++a) {
+                const int es = L.edst[(2 * a + (i & 1)) * DEV_LANES + lane];
+                if (es) st = es;
+            }
+        }
+    }
+    if (i + 1 < stages || spec) {
+        // ---- position and recursion inputs of stage i+1, published inside the window of stage i.
+        // k_i[0..2] is this stage's velocity, so  y + h (pre + a_{i+1,i} k_i)  is complete for the position
+        double nx_pos[3];
+        const double pre[3] = {p0, p1, p2};
+        if (i + 1 < stages) {
+            const double a_nl = A_ROW(i + 1, i);
+#pragma unroll
+            for (int e = 0; e < 3; ++e) {
+                const double wi = pre[e] + a_nl * vel[e];
+                nx_pos[e] = CS_Y(e) + h * wi;
+            }
+        } else {
+            // last window: stage 0 of the next attempt, should this one be accepted - the position step control will form
+            // (next[e] = y[e]; next[e] += (h b_j) k_j[e], j ascending: y + the terms j < i were added up in the previous window)
+            const double cb = h * B_COEF(i);
+#pragma unroll
+            for (int e = 0; e < 3; ++e) nx_pos[e] = pre[e] + cb * vel[e];
+        }
+        double *const ysn = ((i + 1) & 1) ? L.ys2 : L.ys;
+        double *const inbn = ((i + 1) & 1) ? L.inb2 : L.inb;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) ysn[e * DEV_LANES + lane] = nx_pos[e];
+        if (has_grav) {  // (without a gravity field the position is all the next window needs)
+            if (need_almanac) {  // the almanac wave writes the DCM of stage i+1 first thing in this window
+                int spin = 0;
+                while (LCTL[2] != i + 1 && ++spin < 4000000) __builtin_amdgcn_s_sleep(4);
+                if (spin >= 4000000) st = NYX_HIP_ERR_NAN;  // (bounded: a protocol error must end as a failed run, never as a hung GPU)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+            const double *const edn = L.ed + ((i + 1) & 1) * ED_FIELDS * DEV_LANES;  // (its DCM: the flag is raised before the body positions are evaluated)
+            double m_nx[9];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) m_nx[q] = edn[q * DEV_LANES + lane];
+            const double rb0 = m_nx[0] * nx_pos[0] + m_nx[1] * nx_pos[1] + m_nx[2] * nx_pos[2];
+            const double rb1 = m_nx[3] * nx_pos[0] + m_nx[4] * nx_pos[1] + m_nx[5] * nx_pos[2];
+            const double rb2 = m_nx[6] * nx_pos[0] + m_nx[7] * nx_pos[1] + m_nx[8] * nx_pos[2];
+            const double r_ = norm3(rb0, rb1, rb2);
+            const double inv_r = 1.0 / r_;
+            const double nx_s = rb0 * inv_r, nx_t = rb1 * inv_r, nx_u = rb2 * inv_r;
+            const double rho = cfg->g_re * inv_r;
+            const double nx_kfac = (cfg->g_mu * inv_r) * cfg->g_inv_re;
+            inbn[0 * DEV_LANES + lane] = rho * nx_s;
+            inbn[1 * DEV_LANES + lane] = rho * nx_t;
+            inbn[2 * DEV_LANES + lane] = rho * nx_u;
+            inbn[3 * DEV_LANES + lane] = rho;
+            inbn[4 * DEV_LANES + lane] = r_ * cfg->g_inv_re;
+            double *const sx = ((i + 1) & 1) ? L.ixs : L.part;  // (read back in phase C of stage i + 1: integ_back)
+            sx[0 * DEV_LANES + lane] = nx_s; sx[1 * DEV_LANES + lane] = nx_t; sx[2 * DEV_LANES + lane] = nx_u; sx[3 * DEV_LANES + lane] = nx_kfac;
+        }
+        if (lane == 0) L.ctl[1] = (flags & IX_COOP) ? 1 : 0;  // the workers read it after B2(i), for stage i+1
+        if ((flags & IX_COOP) && has_grav) {
+            CoopBox *const cbox = (CoopBox *)uniform_u64(cbox_u);
+            uint32_t *const posted = (uint32_t *)uniform_u64(posted_u);
+            const uint32_t seq_nx = (uint32_t)__builtin_amdgcn_readfirstlane((int)seq_nx_v);
+            if (flags & IX_PROF) ix_stamp(LCTL, 1);
+            coop_post_inl(cbox, posted, lane, seq_nx, (LdsCPtr)inbn, COOP_PARTS_HERE);  // (inline: this function stays a leaf)
+            if (flags & IX_PROF) ix_stamp(LCTL, 2);
+        }
+    }
+    return st;
+}
+
+// Phase C of stage i (orbital.rs:80-114, spacecraft.rs:227-243), behind the stage barrier.  (a0, a1, a2): the two-body term formed in the
+// window.  A LEAF like integ_front (a function that keeps values live across calls of its own has to save the callee-saved registers it
+// uses in its prologue - fifty scratch stores and loads per call, measured on the first cut of this function): the wait for the helper's
+// answer is inlined, and the one thing that needs a call - walking the helper's columns here when no answer comes, coop_fallback - is
+// left to the caller: the function then returns IXR_NEED_FB with its own fifteen-slot fold in (px..pw) and the caller finishes the
+// stage through integ_back_slow.  `ret`: status of the second field's orientation (low 16 bits) | IXR_ANSWER (a helper answered) |
+// IXR_NEED_FB.  skip_k (per lane): a rejected lane's speculative stage 0 (nothing of it is kept).
+struct IxBack {
+    double px, py, pz, pw;
+    int ret;
+};
+#define IXR_NEED_FB 0x40000
+DEVFN void ix_assemble(CfgPtr cfg, const LdsMap &L, int i, int lane, double (&acc)[3], double px, double py, double pz, double pw,
+                       const double (&m_cur)[9], double s_, double t_, double u_, double kfac, int skip_k) {
+    const LdsPtr pertc = ix_rows((i & 1) ? L.pert2 : L.pert, lane);
+    const LdsPtr ysb = ix_rows((i & 1) ? L.ys2 : L.ys, lane);
+    const LdsPtr kb = ix_rows(L.kbuf + i * 6 * DEV_LANES, lane);
+    if (cfg->has_grav) {
+        px *= kfac; py *= kfac; pz *= kfac; pw *= kfac;
+        const double al0 = px + pw * s_, al1 = py + pw * t_, al2 = pz + pw * u_;
+        acc[0] += m_cur[0] * al0 + m_cur[3] * al1 + m_cur[6] * al2;
+        acc[1] += m_cur[1] * al0 + m_cur[4] * al1 + m_cur[7] * al2;
+        acc[2] += m_cur[2] * al0 + m_cur[5] * al1 + m_cur[8] * al2;
+    }
+    if (cfg->has_srp) {
+        acc[0] += pertc[3 * DEV_LANES]; acc[1] += pertc[4 * DEV_LANES]; acc[2] += pertc[5 * DEV_LANES];
+    }
+    if (cfg->has_drag) {
+        acc[0] += pertc[6 * DEV_LANES]; acc[1] += pertc[7 * DEV_LANES]; acc[2] += pertc[8 * DEV_LANES];
+    }
+    if (!skip_k) {
+        // k_i = [velocity of the stage state, f(x)]
+        kb[0 * DEV_LANES] = ysb[3 * DEV_LANES]; kb[1 * DEV_LANES] = ysb[4 * DEV_LANES]; kb[2 * DEV_LANES] = ysb[5 * DEV_LANES];
+        kb[3 * DEV_LANES] = acc[0]; kb[4 * DEV_LANES] = acc[1]; kb[5 * DEV_LANES] = acc[2];
+    }
+}
+static __device__ __attribute__((noinline)) IxBack integ_back(uint32_t lds_v, uint64_t cfg_u, int i_v, int flags_v, int lane, double a0, double a1,
+                                                             double a2, double px, double py, double pz, double pw, uint32_t seq_cur_v, int fold_val_v,
+                                                             uint64_t cbox_u, uint64_t out2_u, int skip_k) {
+    IX_PROLOGUE
+    (void)stages; (void)tabl; (void)kbuf; (void)kb_li; (void)KB_STR;
+    const bool has_grav = cfg->has_grav != 0, has_grav2 = cfg->has_grav2 != 0;
+#ifdef NYX_NO_TIDES
+    const bool has_tides = false;
+#else
+    const bool has_tides = cfg->has_tides != 0;
+#endif
+    const bool has_pm = cfg->n_pm > 0;
+    IxBack out = {0.0, 0.0, 0.0, 0.0, 0};
+    double acc[3] = {a0, a1, a2};
+    {
+        const LdsPtr pertc = ix_rows((i & 1) ? L.pert2 : L.pert, lane);
+        if (has_pm || has_tides || has_grav2) {
+            acc[0] += pertc[0 * DEV_LANES]; acc[1] += pertc[1 * DEV_LANES]; acc[2] += pertc[2 * DEV_LANES];
+        }
+    }
+    if (has_grav2 && !skip_k) {  // the second field's orientation status of THIS stage (a rejected lane's speculative stage 0 does not count)
+        const int es = L.pertst[(i & 1) * DEV_LANES + lane];
+        if (es) out.ret = es & 0xffff;
+    }
+    // (px..pw: the fold of the fifteen partial sums, made by the caller through fold_partials - sixty reads that want a register file of
+    //  their own: inlined here they pushed this function into the callee-saved registers)
+    double m_cur[9] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    double s_ = 0.0, t_ = 0.0, u_ = 0.0, kfac = 0.0;
+    if (has_grav) {
+        // the operands phase C keeps from the stage's own data: its DCM (the almanac wave overwrites those rows once ctl[3] moves) and
+        // s, t, u, (mu / r) / R_eq from the rows the publishing window left them in
+        const LdsPtr edc = ix_rows(L.ed + (i & 1) * ED_FIELDS * DEV_LANES, lane);
+        const LdsPtr sx = ix_rows((i & 1) ? L.ixs : L.part, lane);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) m_cur[q] = edc[q * DEV_LANES];
+        s_ = sx[0 * DEV_LANES]; t_ = sx[1 * DEV_LANES]; u_ = sx[2 * DEV_LANES]; kfac = sx[3 * DEV_LANES];
+        {   // the partial sums of stage i and the DCM are in registers: the workers may overwrite their slots, the almanac wave its rows
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) LCTL[3] = __builtin_amdgcn_readfirstlane(fold_val_v);
+        }
+        if (flags & IX_SHARED) {
+            if (flags & IX_PROF) ix_stamp(LCTL, 3);
+            CoopAnswer ans = {0.0, 0.0, 0.0, 0.0, 0};
+            if (flags & IX_COOP) {
+                CoopBox *const cbox = (CoopBox *)uniform_u64(cbox_u);
+                const uint32_t seq_cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)seq_cur_v);
+#if COOP_PARTS_HERE == 2
+                ans = coop_wait2_inl(cbox, (CoopOut *)uniform_u64(out2_u), lane, seq_cur);
+#else
+                ans = coop_wait_inl(cbox, lane, seq_cur);
+#endif
+            }
+            if (flags & IX_PROF) ix_stamp(LCTL, 0);
+            if (!ans.ok) {  // (uniform) no answer in time: the caller walks the helper's columns and finishes the stage (integ_back_slow)
+                out.px = px; out.py = py; out.pz = pz; out.pw = pw;
+                out.ret |= IXR_NEED_FB;
+                return out;
+            }
+            px += ans.x; py += ans.y; pz += ans.z; pw += ans.w;  // + the helper's columns
+            out.ret |= IXR_ANSWER;
+        } else {
+            px += 0.0; py += 0.0; pz += 0.0; pw += 0.0;  // (the inline code adds the helper's share unconditionally: 0.0 when working alone)
+        }
+    }
+    ix_assemble(cfg, L, i, lane, acc, px, py, pz, pw, m_cur, s_, t_, u_, kfac, skip_k);
+    return out;
+}
+// The rare other half of integ_back: the helper did not answer, the caller has walked its columns (fx..fw) on top of the fold (px..pw).
+// The stage's DCM is no longer in LDS (the almanac wave was told it may overwrite those rows) and is evaluated again - the same
+// function of the stage epoch the almanac wave evaluates, bit for bit (rotation_dcm_iau_poly's base depends on the lane's epoch alone).
+static __device__ __attribute__((noinline)) void integ_back_slow(uint32_t lds_v, uint64_t cfg_u, uint64_t rec_u, int i_v, int lane, double a0, double a1, double a2,
+                                                                double px, double py, double pz, double pw, double fx, double fy, double fz, double fw, int skip_k) {
+    const int flags_v = 0;
+    IX_PROLOGUE
+    (void)stages; (void)flags; (void)kbuf; (void)kb_li; (void)KB_STR;
+    double acc[3] = {a0, a1, a2};
+    const double *const pertc = (i & 1) ? L.pert2 : L.pert;
+#ifdef NYX_NO_TIDES
+    const bool has_tides = false;
+#else
+    const bool has_tides = cfg->has_tides != 0;
+#endif
+    if (cfg->n_pm > 0 || has_tides || cfg->has_grav2 != 0) {
+        acc[0] += pertc[0 * DEV_LANES + lane]; acc[1] += pertc[1 * DEV_LANES + lane]; acc[2] += pertc[2 * DEV_LANES + lane];
+    }
+    const int64_t ep = __double_as_longlong(L.step[lane]) + seconds_to_ns(C_COEF(i) * L.step[DEV_LANES + lane]);
+    double m_cur[9];
+    if (cfg->dcm_incr) {
+        RotBase rb;
+        rb.ep = INT64_MIN;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { rb.sn[q] = 0.0; rb.cs[q] = 1.0; }
+        rotation_dcm_iau_poly(cfg->g_rot, ep, rb, m_cur);
+    } else {
+        const double *records = cfg->rec_in_lds ? (const double *)L.rec : (const double *)uniform_u64(rec_u);
+        (void)rotation_dcm(cfg, cfg->g_rot, records, ns_to_seconds(ep), m_cur);
+    }
+    const double *const sx = (i & 1) ? L.ixs : L.part;
+    const double s_ = sx[0 * DEV_LANES + lane], t_ = sx[1 * DEV_LANES + lane], u_ = sx[2 * DEV_LANES + lane], kfac = sx[3 * DEV_LANES + lane];
+    px += fx; py += fy; pz += fz; pw += fw;
+    ix_assemble(cfg, L, i, lane, acc, px, py, pz, pw, m_cur, s_, t_, u_, kfac, skip_k);
+}
+#endif  // INTEG_OOL
 
 // One role (or a merged set of roles) of the workgroup.  Every instantiation executes the SAME sequence of
 // workgroup barriers; only the work between them differs, so that each role keeps just its own state live.
@@ -2588,8 +2918,17 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     // carried between attempts (no copy of the stage-0 data is needed: nothing is evaluated at a rejected attempt's start) and
     // its LDS.  The exit is seen one (wasted) window late.
     const bool spec = pipe && !STM && cfg->spec != 0;
-    const bool offl = PIPE && !STM && cfg->offload != 0;  // (uniform) see DevCfg.offload
+    const bool offl = PIPE && !STM && !INTEG_OOL && cfg->offload != 0;  // (uniform) see DevCfg.offload (shapes without a gravity field: never the sixteen-wave kernels)
     const bool qoff = STM && QUAD && cfg->qpre_off != 0;   // (uniform) quad layout: the position-only pieces of phase C formed by an almanac wave (quad_pre)
+    // (uniform) the integrator's chain out of line (integ_front / integ_back, see INTEG_OOL): the sixteen-wave plain kernels, pipelined loop, a
+    // central gravity field.  The almanac wave with the DCM share holds its write of the next-but-one DCM for the fold counter then.
+#if INTEG_OOL
+    constexpr bool ool = PIPE && !STM;   // (a compile-time property of these kernels: the host pipelines a sixteen-wave workgroup only with a gravity field, build_schedule)
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(LdsPtr)L.kbuf;   // (the carve starts at the k-buffer)
+#define IX_STAMP(k) (int64_t)(((uint64_t)(uint32_t)LCTL[9 + 2 * (k)] << 32) | (uint64_t)(uint32_t)LCTL[8 + 2 * (k)])
+#else
+    constexpr bool ool = false;
+#endif
     bool spec_now = false;  // stage 0 of the attempt being started was published in the previous attempt's last window
     bool keep_k0 = false;   // (integrator, per lane) the previous attempt was rejected: k_0 stands
     int att = 0;            // attempts started by this workgroup
@@ -2698,7 +3037,11 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 // ---- Phase A: stage state  y + h * sum_j a_ij k_j   (instance.rs:376-394)
                 double *const ysb = (pipe && (i & 1)) ? L.ys2 : L.ys;
                 double *const inbb = (pipe && (i & 1)) ? L.inb2 : L.inb;
-                if (pipe && (i > 0 || spec_now)) {
+                if (ool && pipe && (i > 0 || spec_now)) {
+                    // (phase A of this stage is the head of integ_front, called from the window below)
+                    seq_cur = seq_nx; shared_cur = shared_nx;
+                } else
+                if (!ool && pipe && (i > 0 || spec_now)) {
                     // position and inputs of this stage were published in the previous window: only the velocity is left
                     if (i == 0) {
                         // speculative stage 0: the state step control has just stored (accepted lanes: its position IS the published
@@ -2821,6 +3164,9 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     shared_cur = coop_on;
                     if (lane == 0) L.ctl[1] = coop_on ? 1 : 0;
                 }
+                if (ool) {  // (integ_back reads s, t, u, (mu / r) / R_eq of a stage from its parity's rows: stage 0 here)
+                    L.part[0 * DEV_LANES + lane] = s_; L.part[1 * DEV_LANES + lane] = t_; L.part[2 * DEV_LANES + lane] = u_; L.part[3 * DEV_LANES + lane] = kfac;
+                }
                 }
             }
             PROF_ADD(0);
@@ -2854,8 +3200,10 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 if (!dbg_skip_serial || i == 0)  // (timing switch: reuse the data of stages 0/1)
                 {
                     const LdsFlagPtr fl = (pipe && (!last_stage || spec) && (amask & DEV_ROLE_DCM)) ? LCTL + 2 : nullptr;
-                    st = rec_in_lds ? epoch_data(cfg, (const double *)L.rec, ep, edn, lane, amask, fl, i + 1, &rot_base)
-                                    : epoch_data(cfg, records, ep, edn, lane, amask, fl, i + 1, &rot_base);
+                    // (INTEG_OOL: the DCM rows of `edn` are those of stage i - 1 until its phase C has read them - fold counter >= fold_base + i)
+                    const LdsFlagPtr gt = ool ? LCTL + 3 : nullptr;
+                    st = rec_in_lds ? epoch_data(cfg, (const double *)L.rec, ep, edn, lane, amask, fl, i + 1, &rot_base, gt, fold_base + i)
+                                    : epoch_data(cfg, records, ep, edn, lane, amask, fl, i + 1, &rot_base, gt, fold_base + i);
                 }
                 my_edst[((i + 1) & 1) * DEV_LANES + lane] = st;
                 if (pipe && (!last_stage || spec) && (amask & DEV_ROLE_DCM)) {  // tell the integrator wave (which publishes the inputs of stage i+1 inside this window)
@@ -2892,13 +3240,19 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 // (after this wave's epoch data of the NEXT stage - the integrator's window is waiting for that DCM.  The rows are read
                 //  by phase C of THIS stage, behind B2; phase C of the previous stage may still be reading the previous contents: ctl[6]
                 //  = stages whose phase C is done, bounded spin)
+                bool expired = false;
                 if (i > 0) {
                     int spin = 0;
                     while (LCTL[6] < i && ++spin < 4000000) __builtin_amdgcn_s_sleep(2);
+                    expired = spin >= 4000000;
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 }
+                // (a protocol error ends as a FAILED run, like the other bounded spins: the rows are left alone - phase C of the previous stage
+                //  may still be reading them - and every lane's status row of the next stage carries the error, which the integrator's phase A
+                //  turns into the attempt's status)
+                if (expired) my_edst[((i + 1) & 1) * DEV_LANES + lane] = NYX_HIP_ERR_NAN;
                 const double *const ysq = (pipe && (i & 1)) ? L.ys2 : L.ys;
-                quad_pre(cfg, edc, ysq[0 * DEV_LANES + lane], ysq[1 * DEV_LANES + lane], ysq[2 * DEV_LANES + lane], ql, lane, L.qpre, has_grav);
+                if (!expired) quad_pre(cfg, edc, ysq[0 * DEV_LANES + lane], ysq[1 * DEV_LANES + lane], ysq[2 * DEV_LANES + lane], ql, lane, L.qpre, has_grav);
             }
             if (PERT && (has_pm || has_srp || has_drag || has_tides || has_grav2)) {
                 // position-dependent third-body and SRP terms of THIS stage
@@ -3042,7 +3396,84 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     }
                 }
             };
-            if (INTEG && fastp) {
+#if INTEG_OOL
+            if (INTEG && fastp && ool) {
+                const bool hot = i > 0 || spec_now;
+                const bool pub = i + 1 < stages || spec;
+                uint32_t sq = 0;
+                if (pub && coop_on) sq = ++coop_seq;
+                const int st1 = integ_front(lds_base, (uint64_t)cfg, i, (hot ? IX_HOT : 0) | (spec_now ? IX_SPEC_NOW : 0) | (coop_on ? IX_COOP : 0) | (prof_on ? IX_PROF : 0),
+                                            lane, h, hot ? wpre[3] : ys[3], hot ? wpre[4] : ys[4], hot ? wpre[5] : ys[5], pre_wr[0], pre_wr[1], pre_wr[2],
+                                            (uint64_t)cbox, (uint64_t)(bt.coop_posted + coop_widx), sq, keep_k0 ? 1 : 0);
+                if (st1) st_att = st1;
+                if (pub) {
+                    shared_nx = coop_on;
+                    if (coop_on) {
+                        seq_nx = sq;
+                        if (prof_on && pl_tc != 0) { const int64_t p0_ = IX_STAMP(1), now_ = IX_STAMP(2); pl_chain += p0_ - pl_tc; pl_post += now_ - p0_; ++pl_n; pl_tc = 0; }
+                    }
+                }
+                // the stage state, back from the rows phase A completed (position: published a window ago; a speculative stage 0 starts from
+                // the state step control stored, as the inline code does - rejected lanes drop this stage anyway)
+                {
+                    const double *const ysb = (i & 1) ? L.ys2 : L.ys;
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) ys[e] = ysb[e * DEV_LANES + lane];
+                    if (hot && i == 0) {
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) ys[e] = CS_Y(e);
+                    }
+                }
+                // two-body term of this stage (orbital.rs:86-92)
+                {
+                    const double rmag = norm3(ys[0], ys[1], ys[2]);
+                    const double f = -cfg->mu_central / cube(rmag);
+                    acc[0] = f * ys[0]; acc[1] = f * ys[1]; acc[2] = f * ys[2];
+                }
+                // velocity part of sum_{j<i} a_{i+1,j} k_j (phase A of the next stage adds the newest term)
+#pragma unroll
+                for (int e = 0; e < 6; ++e) wpre[e] = 0.0;
+                if (i + 1 < stages) {
+#pragma unroll
+                    for (int j = 0; j < DEV_MAX_STAGES - 2; ++j) {
+                        if (j < i) {  // uniform
+                            const double a_nj = A_ROW(i + 1, j);
+#pragma unroll
+                            for (int e = 3; e < 6; ++e) wpre[e] += a_nj * KB(j, e);
+                        }
+                    }
+                }
+                // position part of the stage sum the NEXT window publishes from (j ascending from 0.0, the newest term last)
+                if (i + 2 < stages) {
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) pre_wr[e] = 0.0;
+#pragma unroll
+                    for (int j = 0; j < DEV_MAX_STAGES - 2; ++j) {
+                        if (j < i) {  // uniform
+                            const double a_nj = A_ROW(i + 2, j);
+#pragma unroll
+                            for (int e = 0; e < 3; ++e) pre_wr[e] += a_nj * KB(j, e);
+                        }
+                    }
+                    const double a_ni = A_ROW(i + 2, i);
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) pre_wr[e] += a_ni * ys[3 + e];
+                } else if (i + 2 == stages && spec) {
+                    // the next window is the last: it publishes stage 0 of the next attempt, y + sum_j (h b_j) k_j
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) pre_wr[e] = CS_Y(e);
+                    for (int j = 0; j < i; ++j) {
+                        const double cb = h * B_COEF(j);
+#pragma unroll
+                        for (int e = 0; e < 3; ++e) pre_wr[e] += cb * KB(j, e);
+                    }
+                    const double cbi = h * B_COEF(i);
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) pre_wr[e] += cbi * ys[3 + e];
+                }
+            } else
+#endif
+            if (INTEG && fastp && !ool) {
                 publish_next(true);
                 SEG(5)   /* post */
                 // two-body term of this stage (orbital.rs:86-92)
@@ -3197,7 +3628,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             // C(i) -> A(i + 1) -> the inputs of stage i + 2, which has ~12 k cycles to spare before the column waves ask for them.  The
             // deadline of a job moves out by that much: the helpers can be loaded further.  (The inputs of this stage in LDS - the
             // fallback's operands - are not overwritten before window i + 1 publishes stage i + 2 into the same parity: behind this point.)
-            if (!pipe || cfg->coop_late == 0) {
+            if ((!pipe || cfg->coop_late == 0) && !ool) {  // (INTEG_OOL: always collected in phase C)
                 const int64_t w0_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;
                 COOP_COLLECT()
                 if (prof_on && INTEG) { pl_tc = (int64_t)__builtin_readcyclecounter(); pl_wait += pl_tc - w0_; }
@@ -3215,6 +3646,27 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             }
             const int64_t ptc_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;
 
+#if INTEG_OOL
+            if (INTEG && ool) {
+                // ---- Phase C, out of line (integ_back)
+                const int skip_k = (spec_now && i == 0 && keep_k0) ? 1 : 0;
+                // fixed wave order; all 15 slots are read unconditionally (slots of absent waves hold an exact 0.0); this wave walks no columns: 0.0
+                const Partial4 f4 = fold_partials((LdsCPtr)L.part, lane, 0.0, 0.0, 0.0, 0.0);
+                const IxBack rb_ = integ_back(lds_base, (uint64_t)cfg, i, (shared_cur ? IX_SHARED : 0) | (coop_on ? IX_COOP : 0) | (prof_on ? IX_PROF : 0), lane,
+                                              acc[0], acc[1], acc[2], f4.x, f4.y, f4.z, f4.w, seq_cur, fold_base + i + 1, (uint64_t)cbox,
+                                              (uint64_t)(bt.coop_out2 + blockIdx.x), skip_k);
+                if (rb_.ret & 0xffff) st_att = rb_.ret & 0xffff;
+                if (rb_.ret & IXR_ANSWER) ++dbg_answers;
+                if (rb_.ret & IXR_NEED_FB) {  // (uniform) no answer in time: do the helper's columns here, then carry on alone
+                    if (coop_on) { ++dbg_fallbacks; dbg_fb_seq = seq_cur; }
+                    const Partial4 fb = coop_fallback((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, (i & 1) ? L.inb2 : L.inb, lane | (coop_two ? 0x100 : 0));
+                    integ_back_slow(lds_base, (uint64_t)cfg, (uint64_t)records, i, lane, acc[0], acc[1], acc[2], rb_.px, rb_.py, rb_.pz, rb_.pw, fb.x, fb.y, fb.z, fb.w, skip_k);
+                    coop_on = false;  // (pipelined: ctl[1] is rewritten for every stage, nothing to undo)
+                    if (lane == 0) coop_store(bt.coop_finished + coop_widx, 1u);
+                }
+                if (prof_on && shared_cur) { pl_tc = IX_STAMP(0); pl_wait += pl_tc - IX_STAMP(3); }
+            } else
+#endif
             if (INTEG) {
                 // ---- Phase C: assemble the derivative in the reference's order (orbital.rs:80-114, spacecraft.rs:227-243)
                 const double *const pertc = (pipe && (i & 1)) ? L.pert2 : L.pert;

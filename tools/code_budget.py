@@ -38,6 +38,19 @@ def measure(lib):
     return out
 
 
+def toolchain():
+    """The compiler the figures belong to: budgets are register-allocation outcomes of ONE hipcc (tests/test_code_budget.py skips under another)."""
+    import subprocess
+    try:
+        out = subprocess.run(["hipcc", "--version"], capture_output=True, text=True).stdout
+    except OSError:
+        return None
+    for line in out.splitlines():
+        if line.startswith("HIP version:"):
+            return line.split(":", 1)[1].strip()
+    return None
+
+
 if __name__ == "__main__":
     lib = os.path.join(ROOT, "nyx_amd", "libnyx_hip.so")
     m = measure(lib)
@@ -46,6 +59,7 @@ if __name__ == "__main__":
         slack = float(sys.argv[i + 1]) if len(sys.argv) > i + 1 else 0.08
         up = lambda v: int(v * (1.0 + slack)) + (4 if v else 0)
         b = {"note": "budgets = the figures of the build they were written from x (1 + slack); see tests/test_code_budget.py", "slack": slack,
+             "hipcc": toolchain(),
              "kernels": {k: {f: (v if f == "vgprs" else up(v)) for f, v in d.items()} for k, d in m["kernels"].items()},
              "roles": {k: {f: up(v) for f, v in d.items()} for k, d in m["roles"].items()}}
         json.dump(b, open(os.path.join(ROOT, "tests", "golden", "code_budget.json"), "w"), indent=1, sort_keys=True)
