@@ -136,7 +136,8 @@ struct nyx_hip_ctx {
     bool fit_solo = false;       // (tools: NYX_HIP_FIT_SOLO - ... and for workgroups that walk every column themselves)
     bool fit_partition = true;   // ... placed along the column list in a free wave order so that every wave meets its target (fill_schedule)
     bool block_force = false;
-    int coop_parts = 1;  // sub-jobs per evaluation of the schedules in host_cfg (1, or 2: two helper workgroups per owner and evaluation)
+    int coop_parts = 1;  // sub-jobs per evaluation of the schedules in host_cfg (1, or 2: two helper workgroups per owner and evaluation; fan-out: 2 .. DEV_FAN_MAX)
+    bool coop_fan = false;  // the schedules in host_cfg are those of the fan-out mode: coop_parts DEDICATED helper workgroups per owner (small shards, see launch())
     int forced_quad = -1;  // STM layout: -1 = by ensemble size, 0 = 64 trajectories x D3 per workgroup, 1 = quad layout (16 x 4 lanes, D1)
     double role_handicap[3] = {0.0, 0.0, 0.0};  // integrator, almanac, perturbations (harmonics-term units)
     int role_place[8] = {-1, -1, -1, -1, -1, -1, -1, -1}, role_place_sums = -1, role_place_twobody = -1;  // (tools only: ExpKnobs)
@@ -625,10 +626,14 @@ static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, con
     }
     int lo = 0, hi = (int)list.size() - 1;  // indices into `list`
     // plain column workers first (highest wave index), role waves last so they take what is left
-    for (int w = n_waves - 1; w >= 0; --w) {
+    // (round 6: what is left goes to the last wave that WALKS columns - the integrator wave of a pipelined workgroup walks none (hc = 1e9),
+    //  and a list of two or three short columns, the owner's share in the fan-out mode of a field below degree 40, is all "left over":
+    //  dealt to wave 0 it was never evaluated - 59 m after two hours, tests/test_gpu_rotation.py)
+    const int last_w = (hc[0] >= 1e8 && n_waves > 1) ? 1 : 0;
+    for (int w = n_waves - 1; w >= last_w; --w) {
         const double tgt = std::max(0.0, level * wgt(w) - hc[w]);
         std::vector<int> mine;
-        if (w == 0) {
+        if (w == last_w) {
             for (int k = lo; k <= hi; ++k) mine.push_back(list[k]);
             lo = hi + 1;
         } else {
@@ -648,7 +653,7 @@ static bool fill_schedule(const nyx_hip_ctx *ctx, DevSched &sd, int n_waves, con
             k = e;
         }
         sd.n_ranges[w] = nr;
-        if (w == 0) break;
+        if (w == last_w) break;
     }
     return true;
 }
@@ -877,7 +882,7 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
     // then leaves the buffers of stage parity 0 free for the epoch data of t + h)
     // (with a gravity field: one almanac wave; without: any fan-out, almanac and perturbation duties in waves of their own)
     dc.spec = (dc.pipe && !(dc.flags & NYX_HIP_FLAG_STM) && dc.stages % 2 == 0 &&
-               (dc.has_grav ? dc.n_alm == 1 : (n_waves >= 3 && dc.role_kind[1] != DEV_ROLE_ALMANAC_PERT && (dc.n_slots > 0 || dc.has_drag || dc.has_tides))) &&
+               (dc.has_grav ? (dc.n_alm == 1 || (ctx->tune.debug_flags & 0x10000000) != 0) : (n_waves >= 3 && dc.role_kind[1] != DEV_ROLE_ALMANAC_PERT && (dc.n_slots > 0 || dc.has_drag || dc.has_tides))) &&
                !dc.has_grav2 &&  // (the second field's wave reads the attempt's epoch at stage 0: it would have to wait for step control)
                ctx->tune.chained_attempts != 0) ? 1 : 0;
     dc.ed_reuse = (dc.spec || dc.seg_mode) ? 0 : ctx->ed_reuse_fit;  // (chained attempts need no copy of the stage-0 epoch data: a rejected lane keeps its k_0)
@@ -893,6 +898,36 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
     // time is then one long column (~18 batches), which is within 17 % of the ideal x * terms / 16 for x <= 0.35, and the
     // owner keeps the many short columns that let it balance its fifteen waves.  (Interleaving the two sets column by
     // column was measured 10-25 % slower: the helper's waves then hold a long AND a short column each.)
+    if (n_waves == DEV_MAX_WAVES && nc >= 8 && ctx->coop_fan) {
+        // FAN-OUT mode (launch(): the idle CUs outnumber the owners at least two to one - a shard of an ensemble, a small Monte Carlo).
+        // Every owner has K = coop_parts dedicated helper workgroups (propagate_kernel.hip, helper_body under NYX_COOP_FAN); the owner's
+        // period is then bounded by its integrator's chain, not by column work, so the helpers take everything but the shortest columns:
+        // the K * cpp longest, dealt round-robin over the parts (every part a mix of long and short: equal jobs), one column per wave,
+        // the waves of a part taken round-robin over the SIMDs (eight columns = two waves per SIMD, which finish in ~10 k cycles where
+        // four per SIMD need ~17 k).  The owner keeps at least two columns (its PRIMARY schedule must not be empty).
+        const int K = std::min(std::max(ctx->coop_parts, 2), DEV_FAN_MAX);
+        const int col_waves = DEV_MAX_WAVES - 2;
+        int cpp = std::min(col_waves, (nc - 2 + K - 1) / K);
+        if (ctx->tune.coop_max_columns > 0) cpp = std::max(1, std::min(cpp, (int)ctx->tune.coop_max_columns / K));
+        const int n_help = std::min(nc - 2, K * cpp);
+        std::vector<int> own;
+        for (int c = n_help + 1; c <= nc; ++c) own.push_back(c);
+        for (int k = 0; k < n_help; ++k) {
+            const int part = k % K, pos = k / K;       // (ascending column number = descending length)
+            const int w = 1 + pos;                      // waves 1 .. 14 sit on SIMDs 1 2 3 0 1 2 3 0 ...: any prefix is balanced
+            DevSched &hs = dc.sched[DEV_SCHED_FAN0 + part];
+            const int r = hs.n_ranges[w]++;
+            hs.range_c0[w][r] = 1 + k; hs.range_cnt[w][r] = 1;
+        }
+        if (n_help > 0 && !own.empty() && fill_schedule(ctx, dc.sched[DEV_SCHED_PRIMARY], n_waves, own, hc, false)) {
+            dc.coop_ok = 1;
+        } else {
+            dc.coop_ok = 0;
+            for (int k = 0; k < DEV_N_SCHED; ++k)
+                if (k == DEV_SCHED_PRIMARY || k >= DEV_SCHED_FAN0)
+                    for (int w = 0; w < DEV_MAX_WAVES; ++w) dc.sched[k].n_ranges[w] = 0;
+        }
+    } else
     if (n_waves == DEV_MAX_WAVES && nc >= 8) {
         double terms = 0.0, given = 0.0;
         for (int c = 1; c <= nc; ++c) terms += ctx->col_len[c];
@@ -1829,18 +1864,28 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
             int parts = (ctx->host_cfg.n_cols > 96 && 4 * free_cus >= 5 * n_own) ? 2 : 1;
             if (ctx->tune.debug_flags & 0x40000) parts = 2;
             if (ctx->tune.debug_flags & 0x80000) parts = 1;
+            // Fan-out mode (round 6): when the idle CUs outnumber the owners at least two to one - what a rank runs when ONE ensemble is
+            // cut over the GPUs of a node (configs[1] over 2 / 4 / 8 ranks: 79 / 40 / 20 owners), or a small Monte Carlo - every owner gets
+            // K = idle CUs / owners (<= DEV_FAN_MAX) DEDICATED helper workgroups and hands them all but its shortest columns.  Measured
+            // before it existed (round 6, profiles/round06_shard_sizes_before.log): 5 000 / 2 500 / 1 250 trajectories x 24 h ran
+            // 648 / 642 / 639 ms against 615 for 10 000 - a rank of 8 was no faster than one GPU alone.  Fields up to degree 95 (larger
+            // ones keep the two-part claim mode, whose jobs hold several columns per wave).  debug_flags 0x8000000 switches it off.
+            bool fan = ctx->host_cfg.n_cols <= 96 && free_cus >= 2 * n_own && n_own >= 1 && !(ctx->tune.debug_flags & 0x8000000) &&
+                       !(ctx->tune.debug_flags & (0x40000 | 0x80000)) && !(ctx->tune.coop_helper_ratio > 0.0);
+            if (fan) parts = (int)std::min<int64_t>(DEV_FAN_MAX, free_cus / n_own);
             double h_ratio = parts == 2 ? 2.0 : 1.0;
             if (ctx->tune.coop_helper_ratio > 0.0) h_ratio = std::min(3.0, std::max(0.25, ctx->tune.coop_helper_ratio));
-            const int64_t helpers = std::min<int64_t>((int64_t)((double)n_own * h_ratio), free_cus);
-            if (parts != ctx->coop_parts) {
+            const int64_t helpers = fan ? n_own * parts : std::min<int64_t>((int64_t)((double)n_own * h_ratio), free_cus);
+            if (parts != ctx->coop_parts || fan != ctx->coop_fan) {
                 ctx->coop_parts = parts;
+                ctx->coop_fan = fan;
                 build_schedule(ctx, nw, false);
                 HIP_TRY(hipMemcpyAsync(ctx->d_cfg, &ctx->host_cfg, sizeof(DevCfg), hipMemcpyHostToDevice, stream));
             }
-            if (helpers >= 8 && 4 * helpers >= n_own) {
+            if (fan ? (ctx->host_cfg.coop_ok != 0) : (helpers >= 8 && 4 * helpers >= n_own)) {
                 // share of the terms the helpers take: owners keep (1 - x), each helper does x * owners / helpers jobs' worth
                 // per evaluation period, plus its hand-off overhead: x ~ 0.95 r / (1 + r) with r = helpers / owners
-                if (!(ctx->tune.coop_fraction > 0.0)) {
+                if (!fan && !(ctx->tune.coop_fraction > 0.0)) {
                     const double r = (double)helpers / (double)n_own;
                     // (two parts, measured on configs[4] with 158 helpers for 98 owners: 0.55 / 0.60 / 0.65 / 0.70 / 0.75 of the terms ->
                     //  98.1 / 97.9 / 93.4 / 92.9 / 102.6 ms per hour of the ensemble - half a job per helper takes the knee further out)
@@ -1874,8 +1919,12 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
                     HIP_TRY(hipMemsetAsync(ctx->d_coop, 0, (size_t)n_own * sizeof(CoopBox), stream));
                     HIP_TRY(hipMemsetAsync(ctx->d_coop + ctx->coop_cap, 0, 3 * (size_t)(ctx->coop_cap + 64) * sizeof(uint32_t), stream));
                     CoopOut *out2 = (CoopOut *)((char *)(ctx->d_coop + ctx->coop_cap) + 3 * (size_t)(ctx->coop_cap + 64) * sizeof(uint32_t));
-                    if (ctx->coop_parts == 2) HIP_TRY(hipMemsetAsync(out2, 0, (size_t)n_own * sizeof(CoopOut), stream));
-                    bt.coop_out2 = ctx->coop_parts == 2 ? out2 : nullptr;
+                    // (the array behind the scan words holds coop_cap >= 256 answer blocks: part-1 answers of the two-part claim mode, one per
+                    //  owner; in the fan-out mode the answers of every (owner, part), owners * parts <= idle CUs < 256)
+                    if (ctx->coop_fan) HIP_TRY(hipMemsetAsync(out2, 0, (size_t)std::min<int64_t>(n_own * ctx->coop_parts, ctx->coop_cap) * sizeof(CoopOut), stream));
+                    else if (ctx->coop_parts == 2) HIP_TRY(hipMemsetAsync(out2, 0, (size_t)n_own * sizeof(CoopOut), stream));
+                    bt.coop_out2 = (ctx->coop_parts == 2 || ctx->coop_fan) ? out2 : nullptr;
+                    bt.coop_fan = ctx->coop_fan ? 1 : 0;
                     bt.coop_helpers = (int32_t)helpers; bt.coop_base = (int32_t)base; bt.coop_box = ctx->d_coop;
                     uint32_t *words = (uint32_t *)(ctx->d_coop + ctx->coop_cap);
                     bt.coop_posted = words; bt.coop_claimed = words + (ctx->coop_cap + 64); bt.coop_finished = words + 2 * (ctx->coop_cap + 64);

@@ -50,7 +50,9 @@ struct DevSched {
  * propagate_kernel.hip): PRIMARY = the columns the trajectory-owning workgroup keeps, HELPER = the columns a helper
  * workgroup on another CU evaluates (the owner walks that schedule itself, wave slot by wave slot, if no helper
  * answers). */
-enum { DEV_SCHED_SOLO = 0, DEV_SCHED_PRIMARY = 1, DEV_SCHED_HELPER = 2, DEV_SCHED_SECOND = 3, DEV_SCHED_HELPER2 = 4, DEV_N_SCHED = 5 };
+#define DEV_FAN_MAX 8 /* dedicated helper workgroups per owner in the fan-out mode (DevBatch.coop_fan) */
+enum { DEV_SCHED_SOLO = 0, DEV_SCHED_PRIMARY = 1, DEV_SCHED_HELPER = 2, DEV_SCHED_SECOND = 3, DEV_SCHED_HELPER2 = 4, DEV_SCHED_FAN0 = 5, DEV_N_SCHED = 5 + DEV_FAN_MAX };
+/* FAN0 + p: the columns of part p of the fan-out mode (small shards: every owner has coop_parts DEDICATED helper workgroups, see helper_body). */
 /* SECOND: every column of the second field, for whichever wave walks it.  HELPER2: the second PART of an evaluation's hand-off when the
  * helpers' columns travel as two sub-jobs claimed by two different helper workgroups (DevBatch.coop_parts = 2, see propagate_kernel.hip). */
 #define DEV_COOP_PARTS 2
@@ -229,6 +231,8 @@ struct DevBatch { /* device pointers of one launch */
     int32_t coop_helpers, coop_base;
     int32_t lds_bytes, coop_parts; /* dynamic LDS of the launch: zeroed by every workgroup before use (see propagate_body); coop_parts: sub-jobs per evaluation (1 or 2) */
     int32_t coop_mute, coop_sets; /* coop_sets: owners are dealt into this many sets of <= 16, each watched by its own helpers */ /* test switch (NYX_HIP_COOP_MUTE): helpers exit at once, as if they had never become resident */
+    int32_t coop_fan, _pad_fan; /* 1: fan-out mode - helper h is DEDICATED to owner h % owners, part h / owners of coop_parts (no claims); answers of the parts
+                                 * 1.. go to coop_out2[owner * coop_parts + part], the part-0 helper adds them to its own and answers the owner's mailbox */
     struct CoopBox *coop_box; /* one mailbox per trajectory-owning workgroup, zeroed before the launch */
     struct CoopOut *coop_out2; /* [owners] answers of part 1 (coop_parts == 2), else NULL */
     uint32_t *coop_posted, *coop_claimed, *coop_finished; /* [owners] packed scan words, zeroed before the launch */

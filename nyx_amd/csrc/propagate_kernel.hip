@@ -52,6 +52,7 @@
 #define NYX_EMIT_STMQ8 16   /* quad layout, eight waves or fewer */
 #define NYX_EMIT_PLAIN16_P2 32 /* sixteen waves, cooperative launches whose hand-off has TWO parts (two helper workgroups per owner and evaluation) */
 #define NYX_EMIT_PLAIN8N 64   /* eight waves or fewer, dynamics WITHOUT a body-fixed model (no gravity field, drag, tides): NYX_ASSUME_SMALL */
+#define NYX_EMIT_PLAIN16_FAN 128 /* sixteen waves, cooperative launches in the FAN-OUT mode (small shards: several dedicated helper workgroups per owner, NYX_COOP_FAN) */
 // The in-kernel accounting (tuning.profile / tuning.calibrate: cycle counters per wave and phase, the mailbox counts, the first
 // helper's rows) is loop-carried state and s_memtime reads in every role; switched off at run time it still costs the launch
 // (measured round 5: 1.3 % of the headline launch, 4.5 % of config 4, 7 % of config 3). Every propagation kernel is therefore
@@ -1528,12 +1529,20 @@ static __device__ __attribute__((noinline)) CoopAnswer coop_wait2(CoopBox *box, 
 // helper's fold order, i.e. bit for bit the answer it did not get.  Out of line: a rare path must not cost the
 // integrator role registers.
 static __device__ __attribute__((noinline)) Partial4 coop_fallback(uint64_t cfg_u, uint64_t htab_u, uint64_t cols_u, const double *inb, int lane_p) {
+#ifdef NYX_COOP_FAN
+    const int lane = lane_p & 0xff, parts = (lane_p >> 8) & 0xf;   // (bits 8-11 of the lane argument: the parts of the fan-out)
+#else
     const int lane = lane_p & 0xff, parts = (lane_p & 0x100) ? 2 : 1;  // (bit 8 of the lane argument: two parts)
+#endif
     const double v0 = inb[0 * DEV_LANES + lane], v1 = inb[1 * DEV_LANES + lane], v2 = inb[2 * DEV_LANES + lane],
                  v3 = inb[3 * DEV_LANES + lane], v4 = inb[4 * DEV_LANES + lane];
     Partial4 tot = {0.0, 0.0, 0.0, 0.0};
     for (int part = 0; part < parts; ++part) {  // (every part summed on its own, then added in part order: what coop_wait does with the answers)
+#ifdef NYX_COOP_FAN
+        const int sched = DEV_SCHED_FAN0 + part;
+#else
         const int sched = part ? DEV_SCHED_HELPER2 : DEV_SCHED_HELPER;
+#endif
         Partial4 o = {0.0, 0.0, 0.0, 0.0};
         for (int hw = 0; hw < DEV_MAX_WAVES; ++hw) {
             const Partial4 p = (((CfgPtr)uniform_u64(cfg_u))->harm_feed & 2) ? harmonics_stream(cfg_u, cols_u, hw, sched, v0, v1, v2, v3, v4)
@@ -1592,6 +1601,63 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
         }
     }
     __syncthreads();
+#ifdef NYX_COOP_FAN
+    // FAN-OUT mode (small shards: the idle CUs outnumber the owners at least two to one).  Helper h is DEDICATED to owner h % owners and
+    // evaluates part h / owners of that owner's hand-off - no scan words, no claim, no lost race: its producer polls the tag of the
+    // owner's input rows (the poll is half of the fetch) and the columns of an evaluation are dealt over coop_parts helper workgroups,
+    // so a job is a fraction of a column set (two waves per SIMD or fewer finish in ~10 k cycles where fourteen need ~17 k) and the
+    // owner keeps next to nothing.  The owner's side is the single-part protocol unchanged - one post, one answer in its mailbox -:
+    // the helpers of the parts 1.. write their sums to coop_out2[owner * parts + part], the part-0 helper (the LEAD) waits for them,
+    // adds them to its own in part order and answers.  That hop is on no critical path: the owner asks for the answer ~1.5 periods
+    // after the post.  Nothing assumes residency: a part that never answers makes the lead give up, the owner time out after 2 ms and
+    // walk every part's columns itself (coop_fallback: the same sums in the same order).
+    const int fan_h = (int)blockIdx.x - bt.coop_base;
+    const int fan_own_n = (int)((bt.n + DEV_LANES - 1) / DEV_LANES);
+    const int fan_owner = fan_h % fan_own_n, fan_part = fan_h / fan_own_n;
+    const int fan_parts = bt.coop_parts;
+    if (fan_part >= fan_parts) return;
+    if (wave == 0) {
+        const int fan_widx = bt.coop_sets > 0 ? (fan_owner % bt.coop_sets) * COOP_SET + fan_owner / bt.coop_sets : 0;  // (the owner's coop_widx)
+        const CoopBox *b = bt.coop_box + fan_owner;
+        for (int j = 0;; ++j) {
+            const int s = j % NS;
+            const uint32_t seq = (uint32_t)j + 1u;   // the owner's evaluations, in order: every one of them is this helper's job
+            const unsigned par = seq & 1u;
+            int owner = fan_owner;
+            const int64_t t0 = (int64_t)__builtin_amdgcn_s_memrealtime();
+            bool slot_free = j < NS;
+            double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0, v4 = 0.0;
+            for (int it = 0;; ++it) {
+                if ((int64_t)__builtin_amdgcn_s_memrealtime() - t0 > 5000 * COOP_TIMEOUT_TICKS) { owner = -1; break; }  // 10 s: never spin forever
+                if (!slot_free) {  // the job that used this slot NS rounds ago has been answered
+                    slot_free = answered[s] == j - (NS - 1);
+                    if (!slot_free) { __builtin_amdgcn_s_sleep(4); continue; }
+                }
+                // one request: the last granule the owner writes for lane 0 (the owner stores its rows in order, nothing orders them in
+                // memory: the fetch below checks every tag)
+                if ((uint32_t)(coop_loadu(&b->in[par][4][1][0]) >> 32) == seq) {
+                    const bool got = coop_get(&b->in[par][0][0][lane], seq, v0) & coop_get(&b->in[par][1][0][lane], seq, v1) &
+                                     coop_get(&b->in[par][2][0][lane], seq, v2) & coop_get(&b->in[par][3][0][lane], seq, v3) &
+                                     coop_get(&b->in[par][4][0][lane], seq, v4);
+                    if (__all(got)) break;
+                    continue;
+                }
+                if ((it & 7) == 7 && coop_load(bt.coop_finished + fan_widx) != 0u) { owner = -1; break; }  // the owner is done (or carries on alone)
+                __builtin_amdgcn_s_sleep(2);
+            }
+            if (owner >= 0) {
+                double *il = inl + s * 5 * DEV_LANES;
+                il[0 * DEV_LANES + lane] = v0; il[1 * DEV_LANES + lane] = v1; il[2 * DEV_LANES + lane] = v2;
+                il[3 * DEV_LANES + lane] = v3; il[4 * DEV_LANES + lane] = v4;
+            }
+            if (lane == 0) { jown[s] = owner; jseq[s] = (int)seq; jpart[s] = fan_part; }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            if (lane == 0) ready[s] = j + 1;
+            if (owner < 0) break;
+        }
+        return;
+    }
+#else
     if (wave == 0) {
         const int h = (int)blockIdx.x - bt.coop_base;
         const int64_t n_own = (bt.n + DEV_LANES - 1) / DEV_LANES;
@@ -1715,6 +1781,7 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
         }
         return;
     }
+#endif  // NYX_COOP_FAN
     // optional accounting of the FIRST helper workgroup (NYX_HIP_PROFILE; rows 17.. of the profile, one per wave): [0] cycles in the
     // column walk, [1] cycles waiting for a job, [2] jobs, [3] cycles from a job's publication in LDS to this wave's delivery, [5] total
 #ifdef HELPER_PRIO
@@ -1751,7 +1818,11 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
             const double *il = inl + s * 5 * DEV_LANES;
             const double v0 = il[0 * DEV_LANES + lane], v1 = il[1 * DEV_LANES + lane], v2 = il[2 * DEV_LANES + lane],
                          v3 = il[3 * DEV_LANES + lane], v4 = il[4 * DEV_LANES + lane];
+#ifdef NYX_COOP_FAN
+            const int hsched = DEV_SCHED_FAN0 + sub;
+#else
             const int hsched = sub ? DEV_SCHED_HELPER2 : DEV_SCHED_HELPER;
+#endif
             const Partial4 pr = (cfg->harm_feed & 2) ? harmonics_stream((uint64_t)cfg, (uint64_t)cols, wave, hsched, v0, v1, v2, v3, v4)
                                                : harmonics_partial((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, hsched, v0, v1, v2, v3, v4);
             double *pp = ps + wave * 4 * DEV_LANES;
@@ -1778,11 +1849,36 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
 #pragma unroll
             for (int q = 0; q < 4; ++q) o[q] += ps[(w * 4 + q) * DEV_LANES + lane];
         }
+#ifdef NYX_COOP_FAN
+        bool fan_ok = true;
+        if (sub == 0) {
+            // the lead: the sums of the parts 1.., in part order (what coop_fallback adds up when the owner walks the parts itself)
+            const int64_t tl = (int64_t)__builtin_amdgcn_s_memrealtime();
+            for (int pq = 1; pq < fan_parts && fan_ok; ++pq) {
+                const uint64_t *o2 = &bt.coop_out2[owner * fan_parts + pq].out[par][0][0][0];
+                double x = 0.0, y = 0.0, z = 0.0, w = 0.0;
+                for (;;) {
+                    const bool got = coop_get(o2 + 0 * 2 * DEV_LANES + lane, seq, x) & coop_get(o2 + 1 * 2 * DEV_LANES + lane, seq, y) &
+                                     coop_get(o2 + 2 * 2 * DEV_LANES + lane, seq, z) & coop_get(o2 + 3 * 2 * DEV_LANES + lane, seq, w);
+                    if (__all(got)) break;
+                    if ((int64_t)__builtin_amdgcn_s_memrealtime() - tl > COOP_TIMEOUT_TICKS) { fan_ok = false; break; }  // (the owner gives up at the same age)
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                o[0] += x; o[1] += y; o[2] += z; o[3] += w;
+            }
+        }
+        if (fan_ok) {
+            uint64_t *og = sub ? &bt.coop_out2[owner * fan_parts + sub].out[par][0][0][0] : &b->out[par][0][0][0];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) coop_put(og + q * 2 * DEV_LANES + lane, o[q], seq);
+        }
+#else
         {
             uint64_t *og = (sub && bt.coop_out2) ? &bt.coop_out2[owner].out[par][0][0][0] : &b->out[par][0][0][0];
 #pragma unroll
             for (int q = 0; q < 4; ++q) coop_put(og + q * 2 * DEV_LANES + lane, o[q], seq);  // tagged granules: no drain, no flag (the owner polls the last one)
         }
+#endif
         if (lane == 0) __hip_atomic_store(cnt + s, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) answered[s] = j + 1;  // the slot may be refilled: its partial sums are in registers
@@ -2481,7 +2577,10 @@ static __device__ __attribute__((noinline)) bool stm_update_textbook(double *phi
 // Same operations on the same operands in the same order as the inline code: bit-identical results (digests in tests/).
 // ---------------------------------------------------------------------------------------------
 #ifndef INTEG_OOL
-#define INTEG_OOL ((NYX_EMIT & (NYX_EMIT_PLAIN16 | NYX_EMIT_PLAIN16_P2)) ? 1 : 0)
+#define INTEG_OOL ((NYX_EMIT & (NYX_EMIT_PLAIN16 | NYX_EMIT_PLAIN16_P2 | NYX_EMIT_PLAIN16_FAN)) ? 1 : 0)
+#endif
+#ifndef IX_SUMS_OOL
+#define IX_SUMS_OOL 0   /* 1: the window's two stage sums out of line too (integ_sums) - built and measured in round 6, same box, 24 h of configs[1]: 610 ms against 598.5 inline (fan-out shard of 1 250: 399 against 392): branch-free, it issues five times the VALU instructions of the branchy inline loops on the SIMD that also hosts three column waves */
 #endif
 #if INTEG_OOL
 #define IX_HOT 1       /* phase A from the position the previous window published (else: the caller did phase A, v3..5 are the stage velocity) */
@@ -2618,6 +2717,72 @@ static __device__ __attribute__((noinline)) int integ_front(uint32_t lds_v, uint
         }
     }
     return st;
+}
+
+// The two stage sums the integrator's window forms beside the column walk, out of line as well (round 6): the velocity part of
+// sum_{j<i} a_{i+1,j} k_j (phase A of the next stage adds the newest term) and the position part of the sum the NEXT window publishes
+// from (stage i + 2: j < i, then this stage's velocity; or, when the next window is the last of a chained attempt, y + sum (h b_j) k_j).
+// Inline in role_loop these were two loops of up to fourteen iterations with a uniform branch and an LDS round trip each - ~7 k cycles
+// of the integrator's ~19 k busy per evaluation, which is the owner's whole period once dedicated helpers carry its columns (fan-out
+// mode).  Here: the tableau rows as scalar loads from DevCfg (the same doubles propagate_body staged into LDS), the k rows in two
+// branch-free batches of seven stages (absent stages select +0.0 operands: +0.0 * +0.0 added to a sum that started from +0.0 leaves
+// its bits alone), the additions in the same ascending order: bit-identical sums.  A leaf inside the caller-saved registers.
+struct IxSums {
+    double w3, w4, w5, p0, p1, p2;
+};
+template <int COMP0>
+DEVFN void ix_sum_rows(const LdsPtr kb0, const CAS double *coef, double scale, bool scaled, int i, double (&acc)[3]) {
+    // acc[e] += c_j * k_j[COMP0 + e], j = 0 .. i - 1 ascending; c_j = coef[j], or scale * coef[j] (the h b_j of step control's sum)
+#pragma unroll
+    for (int j0 = 0; j0 < DEV_MAX_STAGES - 2; j0 += 7) {
+        if (j0 < i) {  // (uniform)
+            double c[7], k[7][3];
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+                const int j = j0 + q;
+                const bool on = j < i;  // (uniform)
+                const double cj = coef[on ? j : 0];
+                c[q] = on ? (scaled ? scale * cj : cj) : 0.0;
+#pragma unroll
+                for (int e = 0; e < 3; ++e) {
+                    const double kv = kb0[(j * 6 + COMP0 + e) * DEV_LANES];
+                    k[q][e] = on ? kv : 0.0;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 7; ++q) {
+#pragma unroll
+                for (int e = 0; e < 3; ++e) acc[e] += c[q] * k[q][e];
+            }
+        }
+    }
+}
+static __device__ __attribute__((noinline)) IxSums integ_sums(uint32_t lds_v, uint64_t cfg_u, int i_v, int lane, double h, double v3, double v4, double v5) {
+    const int flags_v = 0;
+    IX_PROLOGUE
+    (void)flags; (void)kbuf; (void)kb_li; (void)KB_STR; (void)tabl;
+    const bool spec = cfg->spec != 0;
+    const LdsPtr kb0 = ix_rows(L.kbuf, lane);
+    const double vel[3] = {v3, v4, v5};
+    double w[3] = {0.0, 0.0, 0.0}, p[3] = {0.0, 0.0, 0.0};
+    if (i + 1 < stages) ix_sum_rows<3>(kb0, cfg->a + (i + 1) * i / 2, 0.0, false, i, w);
+    if (i + 2 < stages) {
+        const CAS double *row = cfg->a + (i + 2) * (i + 1) / 2;
+        ix_sum_rows<0>(kb0, row, 0.0, false, i, p);
+        const double a_ni = row[i];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) p[e] += a_ni * vel[e];
+    } else if (i + 2 == stages && spec) {
+        // the next window is the last: it publishes stage 0 of the next attempt, y + sum_j (h b_j) k_j
+#pragma unroll
+        for (int e = 0; e < 3; ++e) p[e] = CS_Y(e);
+        ix_sum_rows<0>(kb0, cfg->b, h, true, i, p);
+        const double cbi = h * cfg->b[i];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) p[e] += cbi * vel[e];
+    }
+    IxSums r = {w[0], w[1], w[2], p[0], p[1], p[2]};
+    return r;
 }
 
 // Phase C of stage i (orbital.rs:80-114, spacecraft.rs:227-243), behind the stage barrier.  (a0, a1, a2): the two-body term formed in the
@@ -2876,6 +3041,11 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     CoopBox *const cbox = bt.coop_box + blockIdx.x;
     const int coop_widx = bt.coop_sets > 0 ? ((int)blockIdx.x % bt.coop_sets) * COOP_SET + (int)blockIdx.x / bt.coop_sets : 0;
 #define coop_two (COOP_PARTS_HERE == 2) /* (compile-time: see NYX_COOP_TWO_PARTS) */
+#ifdef NYX_COOP_FAN
+#define COOP_FB_PARTS ((bt.coop_parts & 0xf) << 8) /* coop_fallback: the parts of the fan-out */
+#else
+#define COOP_FB_PARTS (coop_two ? 0x100 : 0)
+#endif
     bool coop_on = !STM && LCTL[1] != 0;
     const bool coop_started = coop_on;
     uint32_t coop_seq = 0;
@@ -3402,9 +3572,11 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 const bool pub = i + 1 < stages || spec;
                 uint32_t sq = 0;
                 if (pub && coop_on) sq = ++coop_seq;
+                const int64_t pf0_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;   // (accounting twin: slot 0 = integ_front, slot 1 = the whole window)
                 const int st1 = integ_front(lds_base, (uint64_t)cfg, i, (hot ? IX_HOT : 0) | (spec_now ? IX_SPEC_NOW : 0) | (coop_on ? IX_COOP : 0) | (prof_on ? IX_PROF : 0),
                                             lane, h, hot ? wpre[3] : ys[3], hot ? wpre[4] : ys[4], hot ? wpre[5] : ys[5], pre_wr[0], pre_wr[1], pre_wr[2],
                                             (uint64_t)cbox, (uint64_t)(bt.coop_posted + coop_widx), sq, keep_k0 ? 1 : 0);
+                if (prof_on) prof_acc[0] += (int64_t)__builtin_readcyclecounter() - pf0_;
                 if (st1) st_att = st1;
                 if (pub) {
                     shared_nx = coop_on;
@@ -3430,7 +3602,16 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     const double f = -cfg->mu_central / cube(rmag);
                     acc[0] = f * ys[0]; acc[1] = f * ys[1]; acc[2] = f * ys[2];
                 }
-                // velocity part of sum_{j<i} a_{i+1,j} k_j (phase A of the next stage adds the newest term)
+                // the two stage sums (integ_sums): velocity part of the next stage's, position part of the one the NEXT window publishes from
+#if IX_SUMS_OOL
+                {
+                    const IxSums sm = integ_sums(lds_base, (uint64_t)cfg, i, lane, h, ys[3], ys[4], ys[5]);
+                    wpre[0] = wpre[1] = wpre[2] = 0.0;
+                    wpre[3] = sm.w3; wpre[4] = sm.w4; wpre[5] = sm.w5;
+                    if (i + 2 < stages || (i + 2 == stages && spec)) { pre_wr[0] = sm.p0; pre_wr[1] = sm.p1; pre_wr[2] = sm.p2; }
+                }
+#else
+                // (A/B switch: the sums inline, as the first cut of the out-of-line integrator had them)
 #pragma unroll
                 for (int e = 0; e < 6; ++e) wpre[e] = 0.0;
                 if (i + 1 < stages) {
@@ -3443,7 +3624,6 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                         }
                     }
                 }
-                // position part of the stage sum the NEXT window publishes from (j ascending from 0.0, the newest term last)
                 if (i + 2 < stages) {
 #pragma unroll
                     for (int e = 0; e < 3; ++e) pre_wr[e] = 0.0;
@@ -3459,7 +3639,6 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
 #pragma unroll
                     for (int e = 0; e < 3; ++e) pre_wr[e] += a_ni * ys[3 + e];
                 } else if (i + 2 == stages && spec) {
-                    // the next window is the last: it publishes stage 0 of the next attempt, y + sum_j (h b_j) k_j
 #pragma unroll
                     for (int e = 0; e < 3; ++e) pre_wr[e] = CS_Y(e);
                     for (int j = 0; j < i; ++j) {
@@ -3471,6 +3650,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
 #pragma unroll
                     for (int e = 0; e < 3; ++e) pre_wr[e] += cbi * ys[3 + e];
                 }
+#endif
             } else
 #endif
             if (INTEG && fastp && !ool) {
@@ -3615,7 +3795,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     ++dbg_answers;                                                                                                                \
                 } else {                                                                                                                          \
                     if (coop_on) { ++dbg_fallbacks; dbg_fb_seq = seq_cur; }  /* no answer in time: do the helper's columns here, then carry on alone */ \
-                    const Partial4 fb = coop_fallback((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, (pipe && (i & 1)) ? L.inb2 : L.inb, lane | (coop_two ? 0x100 : 0)); \
+                    const Partial4 fb = coop_fallback((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, (pipe && (i & 1)) ? L.inb2 : L.inb, lane | COOP_FB_PARTS); \
                     coop_x = fb.x; coop_y = fb.y; coop_z = fb.z; coop_w = fb.w;                                                                   \
                     coop_on = false;                                                                                                              \
                     coop_drop = !pipe;  /* (pipelined: ctl[1] is rewritten for every stage, nothing to undo) */                                   \
@@ -3659,7 +3839,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 if (rb_.ret & IXR_ANSWER) ++dbg_answers;
                 if (rb_.ret & IXR_NEED_FB) {  // (uniform) no answer in time: do the helper's columns here, then carry on alone
                     if (coop_on) { ++dbg_fallbacks; dbg_fb_seq = seq_cur; }
-                    const Partial4 fb = coop_fallback((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, (i & 1) ? L.inb2 : L.inb, lane | (coop_two ? 0x100 : 0));
+                    const Partial4 fb = coop_fallback((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, (i & 1) ? L.inb2 : L.inb, lane | COOP_FB_PARTS);
                     integ_back_slow(lds_base, (uint64_t)cfg, (uint64_t)records, i, lane, acc[0], acc[1], acc[2], rb_.px, rb_.py, rb_.pz, rb_.pw, fb.x, fb.y, fb.z, fb.w, skip_k);
                     coop_on = false;  // (pipelined: ctl[1] is rewritten for every stage, nothing to undo)
                     if (lane == 0) coop_store(bt.coop_finished + coop_widx, 1u);
@@ -3987,6 +4167,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
 }
 
 #undef coop_two
+#undef COOP_FB_PARTS
 
 template <bool STM, bool QUAD = false, bool W16 = true>  // W16: sixteen-wave workgroups (the shape whose pipelined stage loop serves the column waves)
 DEVFN void propagate_body(const DevBatch &bt, const DevCfg *cfg_g, const HarmEntry *htab_g, const ColHdr *cols_g,
@@ -4107,6 +4288,9 @@ NYX_KERNEL(nyx_propagate_kernel_p2, DEV_MAX_WAVES *DEV_LANES, false)
 #if NYX_EMIT & NYX_EMIT_PLAIN8N
 NYX_KERNEL(nyx_propagate_kernel_w8n, 8 * DEV_LANES, false, false, false)
 #endif
+#if NYX_EMIT & NYX_EMIT_PLAIN16_FAN
+NYX_KERNEL(nyx_propagate_kernel_fan, DEV_MAX_WAVES *DEV_LANES, false)
+#endif
 
 #if NYX_HOST_TU
 NYX_KERNEL_DECL(nyx_propagate_kernel)
@@ -4116,6 +4300,7 @@ NYX_KERNEL_DECL(nyx_propagate_kernel_stmq)
 NYX_KERNEL_DECL(nyx_propagate_kernel_stmq_w8)
 NYX_KERNEL_DECL(nyx_propagate_kernel_p2)
 NYX_KERNEL_DECL(nyx_propagate_kernel_w8n)
+NYX_KERNEL_DECL(nyx_propagate_kernel_fan)
 extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg, const HarmEntry *htab,
                                            const ColHdr *cols, const double *records, int n_waves, int rec_lds_doubles,
                                            int reuse_fields, hipStream_t stream, int quad, int no_body_fixed) {
@@ -4141,6 +4326,7 @@ extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg
             NYX_LDS_ATTR(nyx_propagate_kernel_stmq_w8)
             NYX_LDS_ATTR(nyx_propagate_kernel_p2)
             NYX_LDS_ATTR(nyx_propagate_kernel_w8n)
+            NYX_LDS_ATTR(nyx_propagate_kernel_fan)
 #undef NYX_LDS_ATTR
             if (devid >= 0 && devid < 64) attr_set[devid] = true;
         }
@@ -4161,10 +4347,12 @@ extern "C" hipError_t nyx_launch_propagate(const DevBatch &bt, const DevCfg *cfg
         kern = NYX_PICK(nyx_propagate_kernel_stm);
     else {
         if (bt.coop_helpers > 0) grid = (int64_t)bt.coop_base + bt.coop_helpers;
-        const bool two_parts = bt.coop_helpers > 0 && bt.coop_parts == 2 && bt.coop_out2 != nullptr;  // (its own kernel: NYX_COOP_TWO_PARTS)
+        const bool two_parts = bt.coop_helpers > 0 && bt.coop_parts == 2 && bt.coop_out2 != nullptr && bt.coop_fan == 0;  // (its own kernel: NYX_COOP_TWO_PARTS)
         // (no_body_fixed: the host's statement that the configuration has no gravity field, drag or tides - propagate_w8n.hip)
         if (small && bt.coop_helpers == 0)
             kern = no_body_fixed ? NYX_PICK(nyx_propagate_kernel_w8n) : NYX_PICK(nyx_propagate_kernel_w8);
+        else if (bt.coop_helpers > 0 && bt.coop_fan != 0)   // (its own kernel: NYX_COOP_FAN)
+            kern = NYX_PICK(nyx_propagate_kernel_fan);
         else if (two_parts)
             kern = NYX_PICK(nyx_propagate_kernel_p2);
     }

@@ -205,7 +205,9 @@ def test_two_stacked_fields_vs_oracle(centre, deg_earth, deg_moon, n, waves):
           f"dv {dv.max() * 1e6:.3e} mm/s; the second field moves the orbit by {effect * 1e3:.3e} m")
     assert dr.max() < 1e-6 and dv.max() < 1e-9
     assert effect > 20 * dr.max()          # the term is there (and far above the agreement)
-    assert (helpers > 0) == (n >= 1000)
+    # cooperative launches: sixteen-wave workgroups of a central first field that leave CUs idle - since round 6 (fan-out mode: dedicated
+    # helpers for small batches) whatever the batch size; the eight-wave shapes and non-central first fields never
+    assert (helpers > 0) == (n >= 1000 or (waves == 16 and centre == "moon"))
     if centre == "moon":
         # step for step (round 4): around the Moon the error estimate is not rounding noise (130 steps per 2 h), so the device and the
         # oracle must make the SAME accept / reject decisions - equal accepted / rejected / evaluation counts (the step sizes differ in the

@@ -533,8 +533,8 @@ def test_pipelined_stage_loop_is_bit_identical(n, drag):
     """The pipelined stage loop (the next stage's position is published inside the current window), the epoch data carried
     between attempts and the plain two-barrier loop do the same arithmetic in the same order: bit-identical states and step
     counts once both walk the same column schedule (by default the two loops use differently calibrated per-wave weights,
-    i.e. a different summation order of the harmonics partial sums).  256 trajectories run alone, 512 (with drag) and
-    2 048 in cooperative mode (one helper per owner: same column split in both loops)."""
+    i.e. a different summation order of the harmonics partial sums).  256 and 512 (with drag) trajectories run in the fan-out mode
+    (eight dedicated helpers per owner), 2 048 with seven (32 owners, 224 idle CUs): same column split in all the loops."""
     prop, almanac, central = leo_full_setup(degree=70, drag=drag) if drag else leo_full_setup(degree=70)
     compiled = prop.compile(almanac, central)
     b = dispersed_leo_batch(n, seed=11)
@@ -550,7 +550,7 @@ def test_pipelined_stage_loop_is_bit_identical(n, drag):
         ctx = nx.GpuContext(compiled, tuning=tun)   # (these switches are fixed when the context is built)
         out, st = ctx.propagate(b, dur)
         assert (st.status == 0).all()
-        assert (ctx.last_coop_helpers() > 0) == (n >= 512)   # cooperative mode needs at least 8 owners
+        assert ctx.last_coop_helpers() > 0   # (every one of these is a cooperative launch since round 6: 4 / 8 owners in the fan-out mode, 32 in the claim mode)
         res[(pipe, reuse, spec)] = (out.rv().copy(), out.epoch_ns.copy(), st.n_evals.copy(), st.n_rejected.copy())
         ctx.close()
     ref = res[("0", "0", "0")]

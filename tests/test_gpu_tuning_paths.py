@@ -45,7 +45,7 @@ def test_free_order_partition_deals_every_row_once():
     compiled = prop.compile(almanac, central)
     batch = dispersed_leo_batch(640, seed=17)
     totals = []
-    for flags in (0, 0x2000000):
+    for flags in (0x8000000, 0x8000000 | 0x2000000):   # (0x8000000: the claim mode, whose owner share the two partitions deal; the fan-out mode below)
         ctx = nx.GpuContext(compiled, tuning=nx.Tuning(debug_flags=flags))
         ctx.propagate(batch, 60 * S)
         assert ctx.last_coop_helpers() > 0
@@ -95,3 +95,35 @@ def test_free_order_partition_at_other_degrees(degree):
     for o in outs:
         d = o[::40] - ref.rv()
         assert np.linalg.norm(d[:, :3], axis=1).max() < 1e-3 and np.linalg.norm(d[:, 3:], axis=1).max() < 1e-6
+
+
+@pytest.mark.parametrize("degree, n", [(70, 640), (30, 70), (24, 200), (95, 1280)])
+def test_fan_out_schedules_deal_every_row_once(degree, n):
+    """Fan-out mode (round 6): the owner's rows (schedule 1) and those of the dedicated helpers' parts (schedules 5 ...) are the whole
+    table whatever the field's size - a field below degree 40 leaves the owner two or three rows, which the two-ended fill once handed to
+    the integrator wave (which walks none) - and no part is dealt to the integrator wave."""
+    import ctypes as C
+    from scenarios import kaula_field
+    prop, almanac, central = leo_full_setup(degree=degree if degree == 70 else 0)
+    if degree != 70:
+        from scenarios import iau_earth_frame
+        prop = nx.Propagator(nx.SpacecraftDynamics(nx.OrbitalDynamics([nx.PointMasses([nx.SUN, nx.MOON]), kaula_field(degree, seed=3, frame=iau_earth_frame())]), []),
+                             prop.method, prop.opts)
+    compiled = prop.compile(almanac, central)
+    batch = dispersed_leo_batch(n, seed=17)
+    ctx = nx.GpuContext(compiled)
+    out, st = ctx.propagate(batch, 600 * S)
+    assert (st.status == 0).all() and ctx.last_coop_helpers() > 0
+    rows = (C.c_int32 * 16)()
+    ctx._lib.nyx_hip_debug_schedule_rows.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    tot = 0
+    for sched in [1] + list(range(5, 13)):
+        assert ctx._lib.nyx_hip_debug_schedule_rows(ctx._h, sched, rows, None) == 0
+        assert rows[0] == 0 and (sched == 1 or rows[15] == 0)      # the integrator wave / a helper's answering wave walk nothing
+        tot += sum(rows[:])
+    ctx.close()
+    assert tot == (degree + 1) * (degree + 2) // 2, (degree, tot)
+    sub = batch.take(np.arange(0, n, max(1, n // 16))[:16])
+    ref, rst = oracle_lib.propagate(compiled, sub, 600 * S, n_threads=os.cpu_count() or 1)
+    d = out.rv()[np.arange(0, n, max(1, n // 16))[:16]] - ref.rv()
+    assert np.linalg.norm(d[:, :3], axis=1).max() < 1e-3

@@ -12,7 +12,7 @@ import kernel_meta  # noqa: E402
 import kernel_roles  # noqa: E402
 
 PROPAGATION = ("nyx_propagate_kernel", "nyx_propagate_kernel_w8", "nyx_propagate_kernel_w8n", "nyx_propagate_kernel_stm", "nyx_propagate_kernel_stmq",
-               "nyx_propagate_kernel_stmq_w8", "nyx_propagate_kernel_p2")
+               "nyx_propagate_kernel_stmq_w8", "nyx_propagate_kernel_p2", "nyx_propagate_kernel_fan")
 PROPAGATION = PROPAGATION + tuple(k + "_prof" for k in PROPAGATION)   # the twins that carry the in-kernel accounting (NYX_PROF)
 ROLE_KERNELS = ("nyx_propagate_kernel", "nyx_propagate_kernel_stmq", "nyx_propagate_kernel_w8n")
 
