@@ -137,6 +137,7 @@ struct nyx_hip_ctx {
     bool fit_partition = true;   // ... placed along the column list in a free wave order so that every wave meets its target (fill_schedule)
     bool block_force = false;
     int coop_parts = 1;  // sub-jobs per evaluation of the schedules in host_cfg (1, or 2: two helper workgroups per owner and evaluation; fan-out: 2 .. DEV_FAN_MAX)
+    const PredictArgs *fused_pred = nullptr;  // set around the ONE launch of a fused covariance-mapping loop (nyx_hip_predict_until): DEVICE copy of its arguments
     bool coop_fan = false;  // the schedules in host_cfg are those of the fan-out mode: coop_parts DEDICATED helper workgroups per owner (small shards, see launch())
     int forced_quad = -1;  // STM layout: -1 = by ensemble size, 0 = 64 trajectories x D3 per workgroup, 1 = quad layout (16 x 4 lanes, D1)
     double role_handicap[3] = {0.0, 0.0, 0.0};  // integrator, almanac, perturbations (harmonics-term units)
@@ -1803,6 +1804,7 @@ static int launch(nyx_hip_ctx *ctx, const nyx_hip_states_t *in, nyx_hip_states_t
     bt.cr = in->cr; bt.cd = in->cd; bt.mprop = in->prop_mass_kg; bt.mdry = in->dry_mass_kg; bt.mextra = in->extra_mass_kg;
     bt.asrp = in->srp_area_m2; bt.adrag = in->drag_area_m2; bt.step_in = in->step_ns;
     bt.dur_ns = dur_ns;
+    bt.pred = ctx->fused_pred;
     if (ev) {  // stop condition: only the ev_* fields of `ev` are read
         bt.ev_on = 1; bt.ev = ev->ev; bt.ev_mu = ev->ev_mu;
         bt.ev_prev = ev->ev_prev; bt.ev_count = ev->ev_count; bt.ev_found = ev->ev_found;
@@ -2634,6 +2636,28 @@ extern "C" int32_t nyx_hip_predict_until(nyx_hip_ctx *ctx, const nyx_hip_states_
         }
     }
     a.stm = sg.dout.stm;
+    // Round 6: the whole loop in ONE launch - the workgroups stay resident, the integrator wave performs the time updates of its
+    // trajectories at every segment boundary (propagate_kernel.hip, segment_update; DevBatch.pred = a device copy of `a`).  A segment
+    // launch cost ~30 us beyond its force evaluations (tools/seg_cost.py), a fifth of BASELINE config 4's loop.  The launch-per-segment
+    // loop of rounds 2-5 stays for the integration-frame swap (translated in and out per segment, od/process/mod.rs:453-468) and as
+    // the A/B reference (debug_flags 0x20000000): same states, STMs and covariances.
+    DevBuf pa_dev;
+    // (quad layout only: sixteen waves share sixteen trajectories' updates; the 64-lane layout - four waves, sixty-four trajectories per
+    //  workgroup - is the large-ensemble shape, where the per-launch cost is a small share and sixteen serial updates per wave cost more:
+    //  measured 26.2 ms fused against 24.3 ms per segment at n = 1 000)
+    const bool fused = ctx->swap_n_chain == 0 && !(ctx->tune.debug_flags & 0x20000000) && pick_quad(ctx, n);
+    if (fused) {
+        if (int rc = pa_dev.alloc(sizeof(PredictArgs))) return rc;
+        HIP_TRY(hipMemcpyAsync(pa_dev.p, &a, sizeof(PredictArgs), hipMemcpyHostToDevice, stream));
+        ctx->fused_pred = (const PredictArgs *)pa_dev.p;
+        const int rc = launch(ctx, &sg.din, &sg.dout, &sg.dst, 0, 0, 0, stream, false, nullptr, a.dur);
+        ctx->fused_pred = nullptr;
+        if (rc) return rc;
+        // the kernel's counters run over the whole loop
+        HIP_TRY(hipMemcpyAsync(a.acc_n_acc, sg.dst.n_accepted, (size_t)n * 8, hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(a.acc_n_rej, sg.dst.n_rejected, (size_t)n * 8, hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(a.acc_n_evals, sg.dst.n_evals, (size_t)n * 8, hipMemcpyDeviceToDevice, stream));
+    } else
     for (int64_t s = 0; s < n_seg; ++s) {
         const nyx_hip_states_t *src = s == 0 ? &sg.din : &sg.dout;
         if (int rc = launch(ctx, src, &sg.dout, &sg.dst, 0, 0, 0, stream, false, nullptr, a.dur)) return rc;

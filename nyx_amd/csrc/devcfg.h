@@ -255,6 +255,9 @@ struct DevBatch { /* device pointers of one launch */
     double *t_state[6];
     int32_t *t_len;
     int64_t *prof; /* optional [16][8] cycle counters written by workgroup 0 (NYX_HIP_PROFILE) */
+    const struct PredictArgs *pred; /* STM kernels, optional: the covariance-mapping loop of nyx_hip_predict_until in ONE launch - DEVICE copy of the
+                                     * loop's arguments (predict_args.h); the integrator wave performs the Kalman time update of its trajectories at
+                                     * every segment boundary and re-arms them (propagate_kernel.hip, segment_update) */
 };
 
 #endif

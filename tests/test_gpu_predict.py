@@ -178,3 +178,39 @@ def test_config4_full_size_one_hour():
     print(f"config 4 full size: 60 updates x {n} trajectories in {got.kernel_ms:.1f} ms of device time "
           f"({got.kernel_ms / 60:.2f} ms per update)")
     ctx.close()
+
+
+@pytest.mark.parametrize("frame", [None, "RIC"])
+def test_one_launch_loop_equals_the_launch_per_segment_loop(frame):
+    """Round 6: the whole covariance-mapping loop runs in ONE launch (quad layout; the integrator workgroup stays resident and every wave
+    takes a share of the Kalman time updates at a segment boundary, propagate_kernel.hip segment_update) instead of a segment launch + a
+    time-update launch per segment (rounds 2-5, debug_flags 0x20000000; od/process/mod.rs:440-486, od/kalman/filtering.rs:59-99).  Same
+    arithmetic on the same operands: final states, covariances, deviations, the whole history (epochs, states, STMs, covariances),
+    update counts and step counters are bit-identical - ragged start epochs (trajectories leave the loop at different segments), a
+    partial last workgroup, process noise with decay in a local frame."""
+    prop, almanac, central = leo_full_setup(degree=21)
+    compiled = prop.compile(almanac, central, stm=True)
+    n = 40
+    b = geo_batch(n, 13)
+    b.epoch_ns[:] = EPOCH0_NS + (np.arange(n) % 4) * 45 * S        # ragged: 8 to 10 updates to the common end epoch
+    b.stm = np.zeros((n, 81)); b.reset_stm()
+    end = EPOCH0_NS + 600 * S
+    pn = [nx.ProcessNoise3D(diag=(1e-12, 2e-12, 3e-12), disable_time_ns=3600 * S, decay_s=(1e-4, 2e-4, 0.0) if frame else None, local_frame=frame)]
+    dev0 = np.random.default_rng(3).standard_normal((n, 9)) * 1e-3
+    res = {}
+    for name, flags in (("one launch", 0), ("per segment", 0x20000000)):
+        ctx = nx.GpuContext(compiled, tuning=nx.Tuning(debug_flags=flags))
+        res[name] = nx.predict_until(ctx, b, init_covar(n, 2), end, 60 * S, process_noise=pn, deviation_tracking=True, state_deviation=dev0, history=12)
+        ctx.close()
+    a, r = res["one launch"], res["per segment"]
+    assert (a.stats.status == 0).all() and a.n_updates.min() == 8 and a.n_updates.max() == 10
+    np.testing.assert_array_equal(a.n_updates, r.n_updates)
+    np.testing.assert_array_equal(a.states.rv(), r.states.rv())
+    np.testing.assert_array_equal(a.states.epoch_ns, r.states.epoch_ns)
+    np.testing.assert_array_equal(a.states.stm, r.states.stm)
+    np.testing.assert_array_equal(a.covar, r.covar)
+    np.testing.assert_array_equal(a.state_deviation, r.state_deviation)
+    for f in ("epochs_ns", "nominal", "covar_history", "deviation_history", "stm"):
+        np.testing.assert_array_equal(getattr(a, f), getattr(r, f), err_msg=f)
+    for f in ("n_accepted", "n_rejected", "n_evals"):
+        np.testing.assert_array_equal(getattr(a.stats, f), getattr(r.stats, f), err_msg=f)
