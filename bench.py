@@ -201,13 +201,14 @@ def host_threads():
 CPU_BASELINE_MIN_WALL_S = 12.0   # the timed CPU wall of every configuration: >= 10 s, so that thread start-up and scheduling noise are < 1 %
 
 
-def cpu_baseline(shard, compiled, n_per_gpu, hours):
+def cpu_baseline(shard, compiled, n_per_gpu, hours, min_wall=None):
     """The oracle (CPU restatement of the reference, kind = "port") timed on this box's host on a bounded sample of the SAME
     workload: one pthread per hardware thread over trajectories (rayon par_iter analogue).  Rounds of `threads` trajectories -
     the head of this rank's shard first (the states the device propagated, not a re-draw), cycling through the shard when it
     is exhausted - are propagated until the timed wall reaches CPU_BASELINE_MIN_WALL_S; full-length trajectories when one round
     fits the budget, otherwise the head of the propagation (stated in `sample`, the rate scaled by the fraction)."""
     import oracle_lib
+    min_wall = CPU_BASELINE_MIN_WALL_S if min_wall is None else min_wall
     threads, phys = host_threads()
     probe = shard.slice(0, min(threads, shard.n))
     probe_h = min(0.5, hours)
@@ -215,13 +216,13 @@ def cpu_baseline(shard, compiled, n_per_gpu, hours):
     oracle_lib.propagate(compiled, probe, int(probe_h * 3600) * nx.NS_PER_S, n_threads=threads)
     per_hour = (time.time() - t0) / probe_h  # wall seconds per hour of propagation of one round (`threads` trajectories)
     samp_h = hours
-    if per_hour * hours > 1.5 * CPU_BASELINE_MIN_WALL_S:  # a full-length round is too long: time the first `samp_h` hours instead
-        samp_h = max(probe_h, min(hours, float(int(1.2 * CPU_BASELINE_MIN_WALL_S / per_hour * 4) / 4.0)))
+    if per_hour * hours > 1.5 * min_wall:  # a full-length round is too long: time the first `samp_h` hours instead
+        samp_h = max(probe_h, min(hours, float(int(1.2 * min_wall / per_hour * 4) / 4.0)))
     span = int(samp_h * 3600) * nx.NS_PER_S
     n1 = min(threads, shard.n)
     dt, n, evals, rounds, lo = 0.0, 0, 0.0, 0, 0
     sample = out = None
-    while dt < CPU_BASELINE_MIN_WALL_S and rounds < 400:
+    while dt < min_wall and rounds < 400:
         if lo + n1 > shard.n:
             lo = 0   # (the shard is exhausted: the same states again - the cost does not depend on who propagates them)
         chunk = shard.slice(lo, lo + n1)
@@ -244,7 +245,7 @@ def cpu_baseline(shard, compiled, n_per_gpu, hours):
             "wall_s": dt, "evals_per_s": evals / dt}, sample, out, samp_h
 
 
-def cpu_baseline_predict(shard, compiled, p0, end_ns, n_per_gpu, hours):
+def cpu_baseline_predict(shard, compiled, p0, end_ns, n_per_gpu, hours, min_wall=None):
     """Config 4: the oracle's predict_until twin over independent estimates.  One OD process is sequential, but the workload
     is 1 000 independent ones, which the reference would par_iter: every hardware thread maps its own chunk of 16 estimates
     again and again (the C call releases the GIL; its arguments are prepared once per thread) until the timed wall reaches
@@ -259,7 +260,7 @@ def cpu_baseline_predict(shard, compiled, p0, end_ns, n_per_gpu, hours):
     t1 = time.time()
     oracle_lib.predict_until(compiled, shard.slice(0, chunk), p0[:chunk], end_ns, step)
     one_chunk_s = time.time() - t1
-    reps = max(2, int(np.ceil(CPU_BASELINE_MIN_WALL_S / max(one_chunk_s, 1e-3))))
+    reps = max(2, int(np.ceil((CPU_BASELINE_MIN_WALL_S if min_wall is None else min_wall) / max(one_chunk_s, 1e-3))))
     gate = threading.Barrier(threads + 1)
     done = [0] * threads
 
@@ -427,7 +428,10 @@ def single_process(args, w):
     print(json.dumps(line), flush=True)
 
 
-def measure_other(cfg_id, dev, device_index, lib, n=0, hours=0.0, tag=None):
+OTHER_CPU_WALL_S = 6.0   # timed CPU wall of the baselines the other configurations carry (the headline's own: CPU_BASELINE_MIN_WALL_S)
+
+
+def measure_other(cfg_id, dev, device_index, lib, n=0, hours=0.0, tag=None, cpu=False):
     """One timed pass of another BASELINE configuration inside the headline run (`other_configs` of the JSON line): its own context,
     one short warm-up launch (code object, tables, mailboxes), then ONE launch of the full workload with inputs resident in HBM
     (configs 3, 5 and the full-chip launch of configs[1]'s force model: nyx_hip_propagate_batch_device + the ensemble moments) or
@@ -486,6 +490,15 @@ def measure_other(cfg_id, dev, device_index, lib, n=0, hours=0.0, tag=None):
     ctx.close()
     if n_bad:
         raise SystemExit(f"config {cfg_id}: {n_bad} trajectories failed")
+    cb = None
+    if cpu:
+        # VERDICT r5, Weak 9: the CPU oracle on this box's host threads for THIS configuration too (a bounded sample, OTHER_CPU_WALL_S
+        # of timed wall): context for "is this path worth a GPU at this ensemble size", not a target
+        if not w["stm"]:
+            cb, _, _, _ = cpu_baseline(batch, compiled, n, hours, min_wall=OTHER_CPU_WALL_S)
+        else:
+            cb, _, _ = cpu_baseline_predict(batch, compiled, p0, end_ns, n, hours, min_wall=OTHER_CPU_WALL_S)
+        cb["gpu_over_cpu"] = (n / wall) / cb["value"]
     achieved_tf = n_evals * w["flop"] / (k_ms * 1e-3) / 1e12
     owners = (n + per_wg - 1) // per_wg
     out = {"baseline_config": cfg_id, "workload": w["label"](n, hours), "metric": w["metric"], "value": n / wall, "unit": "trajectories/s",
@@ -497,6 +510,8 @@ def measure_other(cfg_id, dev, device_index, lib, n=0, hours=0.0, tag=None):
            "wall_s_with_setup": None, "fits_in_driver_run": True}
     if tag:
         out["tag"] = tag
+    if cb is not None:
+        out["cpu_baseline"] = cb
     out["wall_s_with_setup"] = time.perf_counter() - t_all
     return out
 
@@ -844,10 +859,34 @@ def main():
         if world == 1 and args.config == 2 and not args.no_other_configs and not args.n and not args.hours and args.degree is None:
             # the other GPU configurations and the full-chip launch under the SAME driver clock, one timed pass each
             others = {}
-            for key, kw in (("config3", dict(cfg_id=3)), ("config4", dict(cfg_id=4)), ("config5", dict(cfg_id=5)),
+            for key, kw in (("config3", dict(cfg_id=3, cpu=True)), ("config4", dict(cfg_id=4, cpu=True)), ("config5", dict(cfg_id=5, cpu=True)),
                             ("fullchip", dict(cfg_id=2, n=16384, hours=3.0, tag="configs[1]'s force model on a full chip: 16 384 trajectories (256 workgroups, no helpers), 3 h"))):
                 others[key] = measure_other(dev=dev, device_index=device_index, lib=lib, **kw)
+            # what ONE rank runs when the 10 000-trajectory ensemble of the metric is CUT over 2 / 4 / 8 GPUs (--scaling
+            # strong), measured on this one GPU, one timed pass each of the full day (and config 3 at an eighth): since round 6 such a shard
+            # runs in the fan-out mode (dedicated helper workgroups on the idle CUs).  The projection below is max rank time = shard time
+            # (equal shards) + the step's collectives; it is NOT the headline `value`, which at N > 1 is weak scaling (10 000 per GPU).
+            for key, kw in (("shard_5000", dict(cfg_id=2, n=5000)), ("shard_2500", dict(cfg_id=2, n=2500)), ("shard_1250", dict(cfg_id=2, n=1250)),
+                            ("config3_shard_625", dict(cfg_id=3, n=625))):
+                others[key] = measure_other(dev=dev, device_index=device_index, lib=lib,
+                                            tag=f"what one of {10000 // kw['n'] if kw['cfg_id'] == 2 else 8} ranks runs under --scaling strong", **kw)
             line["other_configs"] = others
+            coll_ms = gather_ms if gather_ms is not None else 0.0
+            one = line["ms_per_step"]
+            proj = {}
+            for g, key in ((2, "shard_5000"), (4, "shard_2500"), (8, "shard_1250")):
+                t = others[key]["ms_per_step"] + coll_ms
+                proj[str(g)] = {"rank_ms": others[key]["ms_per_step"], "collectives_ms": coll_ms, "speedup_over_1_gpu": one / t,
+                                "value_trajectories_per_s": 10000.0 / (t * 1e-3)}
+            line["strong_scaling_projection"] = {
+                "what": "configs[1]'s ONE 10 000-trajectory ensemble cut over N GPUs: time of a rank's shard measured on this GPU (equal shards: max over ranks = one "
+                        "shard) + the collectives of a step; 1 GPU = this line's ms_per_step",
+                "collectives": ("measured in this run (--force-collectives)" if gather_ms is not None else
+                                "not in this run (0 ms assumed: one all-gather of n x 7 f64 per rank + one all-reduce of 55 f64, latency-bound; bench.py --force-collectives measures them)"),
+                "n_gpus": proj,
+                "config3_cut_8_ways_ms": others["config3_shard_625"]["ms_per_step"],
+                "headline_value_at_n_gt_1": "weak scaling: every rank propagates its own 10 000-trajectory ensemble (the task's contract for a path that shards: per-GPU work fixed); "
+                                            "--scaling strong cuts ONE ensemble N ways"}
         if not args.no_cpu_baseline and world == 1:
             if not w["stm"]:
                 cb, sample, ref, samp_h = cpu_baseline(shard, compiled, n, hours)
