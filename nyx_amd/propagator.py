@@ -894,7 +894,9 @@ class Event:
     def less_than(cls, scalar: int, value: float, **kw):
         """`Condition::LessThan(value)`.  The closure of `until_nth_event` (event.rs:124-141) looks at SIGN CHANGES of the event's
         value only (`y_prev * y_next < 0.0`, either direction) and the root search then finds where it vanishes: for a non-angle
-        scalar the propagation stops at the same crossing of `value` as `Equals(value)` - which is what this builds."""
+        scalar the propagation stops at the same crossing of `value` as `Equals(value)` - which is what this builds.
+        UNVERIFIED against the reference: `Event::eval` for this condition is in the anise crate (not in the reference tree); see
+        INTEGRATION.md, "Stop conditions"."""
         if scalar in (_abi.EV_TRUE_ANOMALY_DEG, _abi.EV_LONGITUDE_DEG):
             raise NotImplementedError("LessThan / GreaterThan on an angle: the wrapped difference has no such reading")
         return cls(scalar, value, **kw)
