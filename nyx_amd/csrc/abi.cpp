@@ -899,6 +899,7 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
     // time is then one long column (~18 batches), which is within 17 % of the ideal x * terms / 16 for x <= 0.35, and the
     // owner keeps the many short columns that let it balance its fifteen waves.  (Interleaving the two sets column by
     // column was measured 10-25 % slower: the helper's waves then hold a long AND a short column each.)
+    dc.sums_wave1 = 0;
     if (n_waves == DEV_MAX_WAVES && nc >= 8 && ctx->coop_fan) {
         // FAN-OUT mode (launch(): the idle CUs outnumber the owners at least two to one - a shard of an ensemble, a small Monte Carlo).
         // Every owner has K = coop_parts dedicated helper workgroups (propagate_kernel.hip, helper_body under NYX_COOP_FAN); the owner's
@@ -922,6 +923,14 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
         }
         if (n_help > 0 && !own.empty() && fill_schedule(ctx, dc.sched[DEV_SCHED_PRIMARY], n_waves, own, hc, false)) {
             dc.coop_ok = 1;
+            // The sums wave (round 6, fan_sums): the owner's period is its integrator's chain, of which the two stage sums of a window are
+            // ~40 %; a column wave that holds no column of the PRIMARY schedule forms them beside it - on a SIMD that hosts no role wave
+            // when there is one (waves 3, 7, 11, 15).  debug_flags 0x40000000: the integrator forms them itself (A/B, same bits).
+            if (dc.pipe && !(ctx->tune.debug_flags & 0x40000000)) {
+                static const int order[] = {15, 11, 7, 3, 14, 13, 12, 10, 9, 8, 6, 5, 4};
+                for (int w : order)
+                    if (dc.role_kind[w] == DEV_ROLE_COLUMNS && dc.sched[DEV_SCHED_PRIMARY].n_ranges[w] == 0) { dc.sums_wave1 = w + 1; break; }
+            }
         } else {
             dc.coop_ok = 0;
             for (int k = 0; k < DEV_N_SCHED; ++k)

@@ -148,7 +148,8 @@ struct DevCfg {
      * common stream serves.  Same rows, same operations: bit-identical sums.  rs_cols = the column headers with `start` pointing into
      * the stream. */
     uint64_t rs_hyb[3], rs_hyb_v[3], rs_cols[3];
-    int32_t coop_late, _pad_cl; /* pipelined loop: the helper's answer of stage i is collected behind B2(i), in phase C, instead of inside the window */
+    int32_t coop_late;  /* pipelined loop: the helper's answer of stage i is collected behind B2(i), in phase C, instead of inside the window */
+    int32_t sums_wave1; /* fan-out mode (round 6): 1 + the column wave of an owner that forms the integrator's two stage sums beside it (fan_sums); 0 = the integrator forms them itself */
 };
 
 /* Column header (32 B = one s_load_dwordx8): rows of column c start at htab[start]: `nb & 0xffff` batches of HARM_BATCH

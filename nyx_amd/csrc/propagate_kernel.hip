@@ -1159,6 +1159,120 @@ static __device__ __attribute__((noinline)) Partial4 harmonics_stream(uint64_t c
     return r;
 }
 
+// The start of a walk, taken out of the stage loop (round 6).  harmonics_stream finds its first range through three levels of
+// dependent scalar loads - the schedule's range in DevCfg, the column header, then the table itself - and forms the complex power in
+// between: ~2 k cycles in which the wave issues nothing, at the start of EVERY stage, on all four waves of a SIMD at once (they leave
+// the stage barrier together), and the scalar cache does not keep those lines across a stage (the column waves of a workgroup stream
+// 40 KB of table rows through its 16 KB in between).  None of it depends on the stage: a pure column wave of the pipelined loop keeps
+// the descriptor of its FIRST range (stream addresses, header address, rows to skip, columns, first column, ranges) in registers across
+// the stages (harm_stream_setup once per schedule, role_loop), and harmonics_stream_d starts from it: it touches the first lines of
+// both sides of the table, forms the complex power under those loads, and enters the generated loop, whose own loads then hit.  The
+// further ranges of a wave (schedules other than the owner's one-run-per-wave deal) go the old way.  Same loop, same operands, same
+// order: bit-identical sums.
+#ifndef HS_DESC
+#define HS_DESC 0   /* built and measured in round 6, same box, three interleaved pairs: 24 h of configs[1] 605.0 ms with it against 597.9 without, the full-chip launch 107.4 against 106.0 - the start of a walk is not where a column wave's time goes (the compiled-out code and the generated macro stay as the record) */
+#endif
+struct HsDesc {
+    uint64_t e, vp, hp;
+    int pack;  // left (3 bits) | low_half << 3 | cols_left << 4 (12 bits) | c0 << 16 (8 bits) | n_ranges << 24
+};
+DEVFN void hs_locate(CfgPtr cfg, int sched, ColPtr &cols, uint64_t &hs0, uint64_t &hv0) {
+    hs0 = cfg->hyb; hv0 = cfg->hyb_v;
+    // (uniform) the run stream of this schedule, every range at the head of a group of its own (DevCfg.rs_*)
+    const int rs = sched == DEV_SCHED_SOLO ? 0 : (sched == DEV_SCHED_PRIMARY ? 1 : ((sched == DEV_SCHED_HELPER || sched == DEV_SCHED_HELPER2) ? 2 : -1));
+    if (rs >= 0 && cfg->rs_hyb[rs >= 0 ? rs : 0] != 0) {
+        hs0 = cfg->rs_hyb[rs]; hv0 = cfg->rs_hyb_v[rs];
+        cols = (ColPtr)cfg->rs_cols[rs];
+    }
+}
+static __device__ __attribute__((noinline)) HsDesc harm_stream_setup(uint64_t cfg_u, uint64_t cols_u, int wave_v, int sched_v) {
+    CfgPtr cfg = (CfgPtr)uniform_u64(cfg_u);
+    ColPtr cols = (ColPtr)uniform_u64(cols_u);
+    const int wave = __builtin_amdgcn_readfirstlane(wave_v);
+    const int sched = __builtin_amdgcn_readfirstlane(sched_v);
+    const CAS DevSched &sd = cfg->sched[sched];
+    const int nr = sd.n_ranges[wave];
+    uint64_t hs0, hv0;
+    hs_locate(cfg, sched, cols, hs0, hv0);
+    HsDesc d = {0, 0, 0, 0};
+    if (nr > 0) {
+        const int c0 = sd.range_c0[wave][0];
+        const int cols_left = sd.range_cnt[wave][0];
+        const int srow = cols[c0].start;
+        d.e = hs0 + (uint64_t)(srow & ~7) * (HYB_KS * 8);
+        d.vp = hv0 + (uint64_t)(srow >> 4) * (HYB_GROUP * 8);
+        d.hp = (uint64_t)cols + (uint64_t)c0 * sizeof(ColHdr);
+        d.pack = (srow & 7) | (((srow & 8) == 0 ? 1 : 0) << 3) | (cols_left << 4) | (c0 << 16);
+    }
+    d.pack |= nr << 24;
+    return d;
+}
+static __device__ __attribute__((noinline)) Partial4 harmonics_stream_d(uint64_t cfg_u, uint64_t cols_u, int wave_v, int sched_v, uint64_t e0_v, uint64_t vp0_v,
+                                                                      uint64_t hp0_v, int pack_v, double zr, double zi, double rho_u, double rho,
+                                                                      double inv_rho) {
+    const uint64_t e0 = uniform_u64(e0_v), vp0 = uniform_u64(vp0_v), hp0 = uniform_u64(hp0_v);
+    const int pack = __builtin_amdgcn_readfirstlane(pack_v);
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int voff = (lane & 15) * 8;
+    double px = 0.0, py = 0.0, pz = 0.0, pw = 0.0;
+    const double rho2 = rho * rho;
+    const int nr = pack >> 24;
+    if (nr > 0) {
+        int left = pack & 7, first = 1, sink = 0, vsink = 0;
+        const int low_half = (pack >> 3) & 1;
+        int cols_left = (pack >> 4) & 0xfff;
+        const int c0 = (pack >> 16) & 0xff;
+        // the first lines of both sides of the table (three scalar lines of the first batch, eight vector lines of the first two
+        // groups): in flight under the complex power; the generated loop's first waits cover them (its loads of the same lines hit)
+        asm volatile(
+            "s_load_dword %0, %2, 0x0\n\t"
+            "s_load_dword %0, %2, 0x40\n\t"
+            "s_load_dword %0, %2, 0x80\n\t"
+            "s_load_dword %0, %4, 0x0\n\t"
+            "global_load_dword %1, %5, %3\n\t"
+            "global_load_dword %1, %5, %3 offset:128\n\t"
+            "global_load_dword %1, %5, %3 offset:256\n\t"
+            "global_load_dword %1, %5, %3 offset:384\n\t"
+            "global_load_dword %1, %5, %3 offset:512\n\t"
+            "global_load_dword %1, %5, %3 offset:640\n\t"
+            "global_load_dword %1, %5, %3 offset:768\n\t"
+            "global_load_dword %1, %5, %3 offset:896"
+            : "+&s"(sink), "+&v"(vsink)
+            : "s"(e0), "s"(vp0), "s"(hp0), "v"(voff)
+            : "memory");
+        double rc, ic;
+        cpow_uniform(zr, zi, c0 - 1, rc, ic);
+        const uint64_t e = e0, vp = vp0, hp = hp0;  // (the macro's operand names)
+        HARM_STREAM_ASM_T(e, vp, hp, voff, left, cols_left, first, low_half, sink, vsink, rho_u, rho2, rho, inv_rho, zr, zi, px, py, pz, pw, rc, ic);
+        (void)sink; (void)vsink;
+    }
+    if (nr > 1) {  // (uniform) the further ranges of this wave: located as harmonics_stream locates them
+        CfgPtr cfg = (CfgPtr)uniform_u64(cfg_u);
+        ColPtr cols = (ColPtr)uniform_u64(cols_u);
+        const int wave = __builtin_amdgcn_readfirstlane(wave_v);
+        const int sched = __builtin_amdgcn_readfirstlane(sched_v);
+        const CAS DevSched &sd = cfg->sched[sched];
+        uint64_t hs0, hv0;
+        hs_locate(cfg, sched, cols, hs0, hv0);
+        for (int q = 1; q < nr; ++q) {
+            const int c0 = sd.range_c0[wave][q];
+            int cols_left = sd.range_cnt[wave][q];
+            const int srow = cols[c0].start;
+            const uint64_t e = hs0 + (uint64_t)(srow & ~7) * (HYB_KS * 8);
+            const uint64_t vp = hv0 + (uint64_t)(srow >> 4) * (HYB_GROUP * 8);
+            const uint64_t hp = (uint64_t)cols + (uint64_t)c0 * sizeof(ColHdr);
+            double rc, ic;
+            cpow_uniform(zr, zi, c0 - 1, rc, ic);
+            int left = srow & 7, first = 1, sink;
+            const int low_half = (srow & 8) == 0 ? 1 : 0;
+            HARM_STREAM_ASM(e, vp, hp, voff, left, cols_left, first, low_half, sink, rho_u, rho2, rho, inv_rho, zr, zi, px, py, pz, pw, rc, ic);
+            (void)sink;
+        }
+    }
+    Partial4 r = {px, py, pz, pw};
+    return r;
+}
+
 static __device__ __attribute__((noinline)) Partial4 harmonics_partial(uint64_t cfg_u, uint64_t htab_u, uint64_t cols_u, int wave_v,
                                                                      int sched_v, double zr, double zi, double rho_u, double rho,
                                                                      double inv_rho) {
@@ -1570,6 +1684,19 @@ static __device__ __attribute__((noinline)) Partial4 coop_fallback(uint64_t cfg_
 // answered in slot s, cnt[s] = column waves that have delivered.
 #ifndef NYX_SEG_PROF
 #define NYX_SEG_PROF 0  /* 1 adds the integrator's per-piece timers (rows 34-35); off in the product build, they cost registers */
+#endif
+#ifndef STEP_ONE_POW
+#define STEP_ONE_POW 1      /* step control: one pow in front of the accept / reject branches (round 6) */
+#endif
+#ifndef STEP_OOL
+#ifdef NYX_COOP_FAN
+#define STEP_OOL 1          /* step control out of line (integ_step, round 6): the fan-out kernel, whose period IS the integrator's chain (1 250 x 24 h: 391 -> 382.5 ms) */
+#else
+#define STEP_OOL 0          /* the other INTEG_OOL kernels keep it inline: measured same box, 24 h of configs[1]: 601.9 ms out of line against 597.9 inline (three interleaved pairs; step control 19 k -> 11.9 k cycles per attempt either way, but the period there is the column waves') */
+#endif
+#endif
+#ifndef STEP_SUMS_UNROLL
+#define STEP_SUMS_UNROLL 0  /* step control: unroll factor of the loop over the stages of its two sums (0: as the compiler leaves it) */
 #endif
 #ifndef COOP_AFFINITY
 #define COOP_AFFINITY 1  /* helpers take a job of their own first (see helper_body) */
@@ -2370,7 +2497,8 @@ struct ColdState {
     bool done, fresh, is_final, fixed, prev_kind, backprop, massless;
 };
 #define CS_I64(f) __double_as_longlong(cs[(f)*DEV_LANES + lane])
-DEVFN void cold_load(const double *cs, int lane, ColdState &c) {
+template <typename P>
+DEVFN void cold_load(P cs, int lane, ColdState &c) {
     c.epoch = CS_I64(0); c.stop = CS_I64(1); c.step_size = CS_I64(2); c.prev_step = CS_I64(3);
     c.det_step = CS_I64(4); c.n_acc = CS_I64(5); c.n_rej = CS_I64(6); c.n_evals = CS_I64(7);
 #pragma unroll
@@ -2382,7 +2510,8 @@ DEVFN void cold_load(const double *cs, int lane, ColdState &c) {
     c.done = b & 1; c.fresh = b & 2; c.is_final = b & 4; c.fixed = b & 8; c.prev_kind = b & 16; c.backprop = b & 32; c.massless = b & 64;
 }
 #define CS_SET_I64(f, v) cs[(f)*DEV_LANES + lane] = __longlong_as_double(v)
-DEVFN void cold_store(double *cs, int lane, const ColdState &c) {
+template <typename P>
+DEVFN void cold_store(P cs, int lane, const ColdState &c) {
     CS_SET_I64(0, c.epoch); CS_SET_I64(1, c.stop); CS_SET_I64(2, c.step_size); CS_SET_I64(3, c.prev_step);
     CS_SET_I64(4, c.det_step); CS_SET_I64(5, c.n_acc); CS_SET_I64(6, c.n_rej); CS_SET_I64(7, c.n_evals);
 #pragma unroll
@@ -2414,6 +2543,7 @@ struct LdsMap {
     // pipelined stage loop (non-STM): buffers of odd stages
     double *ys2, *inb2, *pert2;
     double *ixs;    // [4][64]  s, t, u, (mu / r) / R_eq of the ODD stages (the even ones: wave 0's slot of `part`), see INTEG_OOL
+    double *sums;   // [6][64]  fan-out mode: the velocity part of the next stage's sum and the position part of the one after, formed by the sums wave (fan_sums)
     // epoch data carried between attempts (cfg->ed_reuse fields per lane), behind the ephemeris records
     double *ed0;         // [ed_reuse][64]  stage-0 data of the current attempt (what a rejected attempt starts from again)
     long long *ed0_ep;   // [64]            its epoch
@@ -2454,11 +2584,13 @@ DEVFN LdsMap carve_lds(char *smem, int n_waves, bool stm, int rec_lds_doubles, i
     }
     m.ys2 = m.ys; m.inb2 = m.inb; m.pert2 = m.pert;
     m.ixs = m.part;
+    m.sums = m.part;
     if (!stm) {
         m.ys2 = p; p += 6 * DEV_LANES;
         m.inb2 = p; p += NIN * DEV_LANES;
         m.pert2 = p; p += 9 * DEV_LANES;
         m.ixs = p; p += 4 * DEV_LANES;
+        m.sums = p; p += 6 * DEV_LANES;
     } else if (quad) {  // pipelined stage loop of the quad layout: second set of the dual buffers
         m.ys2 = p; p += 6 * DEV_LANES;
         m.inb2 = p; p += 10 * DEV_LANES;
@@ -2482,10 +2614,36 @@ size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles, int stm, int reuse_fie
     size_t d = (size_t)DEV_MAX_STAGES * 6 * (quad ? DEV_LANES / 4 : DEV_LANES) + DEV_MAX_STAGES * DEV_MAX_STAGES + 3 * DEV_MAX_STAGES + 6 * DEV_LANES +
                2 * ED_FIELDS * DEV_LANES + 2 * DEV_LANES + CS_FIELDS * DEV_LANES + (size_t)(quad ? DEV_MAX_WAVES * QSLOT : DEV_MAX_WAVES * 4 * DEV_LANES) + DEV_MAX_ALM * DEV_LANES +
                DEV_LANES + 8 + (size_t)rec_doubles;
-    d += quad ? (size_t)(10 + 15 + 6 + QPRE_ROWS + 6 + 10 + 15) * DEV_LANES : (stm ? (size_t)(20 + 27 + 12) * DEV_LANES : (size_t)(NIN + 9 + 6 + NIN + 9 + 4) * DEV_LANES);
+    d += quad ? (size_t)(10 + 15 + 6 + QPRE_ROWS + 6 + 10 + 15) * DEV_LANES : (stm ? (size_t)(20 + 27 + 12) * DEV_LANES : (size_t)(NIN + 9 + 6 + NIN + 9 + 4 + 6) * DEV_LANES);
     (void)n_waves;
     if (reuse_fields > 0) d += (size_t)reuse_fields * DEV_LANES + 2 * DEV_LANES + DEV_LANES / 2;
     return d * sizeof(double) + 64;
+}
+
+// start of a step: final-step test on integer epochs (instance.rs:149-186), then epoch and step published to the other waves
+DEVFN void begin_attempt_fn(const LdsMap &L, int lane, ColdState &c) {
+    if (!c.done && c.fresh) {
+        if ((!c.backprop && c.epoch + c.step_size > c.stop) || (c.backprop && c.epoch + c.step_size <= c.stop)) {
+            if (c.stop == c.epoch) {
+                c.done = true;
+            } else {
+                c.prev_step = c.step_size;
+                c.prev_kind = c.fixed;
+                c.step_size = c.stop - c.epoch;
+                c.fixed = true;
+                c.is_final = true;
+            }
+        }
+        c.attempts = 1;
+        c.h = ns_to_seconds(c.step_size);
+        c.fresh = false;
+    }
+    if (!c.done && c.massless) { c.status = NYX_HIP_ERR_MASSLESS; c.done = true; }
+    L.step[lane] = __longlong_as_double(c.epoch);
+    L.step[DEV_LANES + lane] = c.h;
+    if (!__any(!c.done)) {
+        if (lane == 0) L.ctl[0] = 1;
+    }
 }
 
 #define PROF_T0() const int64_t pt0_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0
@@ -2644,7 +2802,11 @@ static __device__ __attribute__((noinline)) int integ_front(uint32_t lds_v, uint
         }
 #pragma unroll
         for (int e = 0; e < 3; ++e) ysb[(3 + e) * DEV_LANES + lane] = vel[e];
+#ifdef NYX_COOP_FAN
+        if (cfg->has_drag || cfg->sums_wave1 != 0) {  // (... and the sums wave, which adds this stage's velocity term last: fan_sums)
+#else
         if (cfg->has_drag) {  // the perturbation wave is already in this stage's window; drag is the one term that wants the velocity
+#endif
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             if (lane == 0) LCTL[4] = i + 1;
         }
@@ -2887,6 +3049,12 @@ static __device__ __attribute__((noinline)) IxBack integ_back(uint32_t lds_v, ui
         }
     }
     ix_assemble(cfg, L, i, lane, acc, px, py, pz, pw, m_cur, s_, t_, u_, kfac, skip_k);
+#ifdef NYX_COOP_FAN
+    if (cfg->sums_wave1 != 0) {  // k_i is written: the sums wave may add its term (fan_sums; ctl[6] counts like the fold counter)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) LCTL[6] = __builtin_amdgcn_readfirstlane(fold_val_v);
+    }
+#endif
     return out;
 }
 // The rare other half of integ_back: the helper did not answer, the caller has walked its columns (fx..fw) on top of the fold (px..pw).
@@ -2924,6 +3092,247 @@ static __device__ __attribute__((noinline)) void integ_back_slow(uint32_t lds_v,
     px += fx; py += fy; pz += fz; pw += fw;
     ix_assemble(cfg, L, i, lane, acc, px, py, pz, pw, m_cur, s_, t_, u_, kfac, skip_k);
 }
+
+// Step control out of line (round 6): error estimate, accept / reject, the next step size, the accepted state and - chained attempts -
+// the next attempt opened (derive(), instance.rs:401-493).  Inline in role_loop it ran on what the stage loop's carried values left of
+// the 128 VGPRs (59 scratch loads in the integrator's tail) and took ~20 k cycles per attempt, all of them between the last stage's
+// phase C and the first window of the next attempt - the one place where the column waves wait for the integrator (they walk the
+// speculative stage 0 in ~26 k cycles; phase C + step control + the first window's post took ~31 k).  Here: a leaf with a register
+// file of its own, the cold state and the k-buffer through one address register each, the tableau's b / b - b* as scalar loads from
+// DevCfg (the doubles propagate_body staged into LDS), the k rows of four stages loaded together.  Same operations on the same
+// operands in the same order: bit-identical results.  Not here: stop conditions (a call: role_loop keeps its inline step control for
+// launches with an event) and the dense output (the caller writes it from the cold state this function stored).
+#define IXS_ACCEPT 1
+#define IXS_KEEP_K0 2
+#define IXS_CHAIN 1   /* flags: chained attempts - open the next attempt and publish it (ctl[5]) */
+struct IxStep {
+    double h_next;
+    int ret;
+};
+static __device__ __attribute__((noinline)) IxStep integ_step(uint32_t lds_v, uint64_t cfg_u, int lane, double h, int st_att, int att_v, int flags_v) {
+    const int i_v = 0;
+    IX_PROLOGUE
+    (void)i; (void)kbuf; (void)tabl; (void)kb_li; (void)KB_STR;
+    const LdsPtr cs = ix_rows(L.cs, lane);
+    const LdsPtr kb0 = ix_rows(L.kbuf, lane);
+    ColdState c;
+    cold_load(cs, 0, c);
+    double *const y = c.y;
+    if (!c.done) c.n_evals += stages;
+    // ---- next state and error estimate (instance.rs:401-414).  d(Cr, Cd, prop mass)/dt = 0.
+    double next[9], err[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) { next[e] = y[e]; err[e] = 0.0; }
+    int j0 = 0;
+    for (; j0 + 4 <= stages; j0 += 4) {  // (uniform) four stages per batch: the loads first, the additions in ascending stage order
+        double ce[4], cb[4], kv[4][6];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            ce[q] = h * cfg->bdiff[j0 + q];
+            cb[q] = h * cfg->b[j0 + q];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) kv[q][e] = kb0[((j0 + q) * 6 + e) * DEV_LANES];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int e = 0; e < 6; ++e) {
+                err[e] += ce[q] * kv[q][e];
+                next[e] += cb[q] * kv[q][e];
+            }
+        }
+    }
+    for (; j0 < stages; ++j0) {
+        const double ce = h * cfg->bdiff[j0];
+        const double cb = h * cfg->b[j0];
+#pragma unroll
+        for (int e = 0; e < 6; ++e) {
+            const double kv = kb0[(j0 * 6 + e) * DEV_LANES];
+            err[e] += ce * kv;
+            next[e] += cb * kv;
+        }
+    }
+    bool accept = false, keep = false;
+    // the error estimate, the accept test and the controller's power for every lane at once, in front of the branches (STEP_ONE_POW)
+    double de = c.det_error, pw = 0.0;
+    bool take = false;
+    if (__any(!c.done && st_att == NYX_HIP_OK && !c.fixed)) {  // (uniform)
+        de = error_estimate(cfg->error_ctrl, err, next, y);
+        take = de <= cfg->tol || h <= cfg->min_step_s || c.attempts >= cfg->attempts;
+        pw = pow(cfg->tol / de, take ? cfg->inv_order : cfg->inv_order_m1);
+    }
+    if (!c.done) {
+        if (st_att != NYX_HIP_OK) {
+            c.status = st_att;
+            c.done = true;
+        } else if (c.fixed) {
+            c.det_step = c.step_size;
+            accept = true;
+        } else {
+            c.det_error = de;
+            if (take) {
+                bool nan = false;
+#pragma unroll
+                for (int e = 0; e < 9; ++e) nan = nan || (next[e] != next[e]);
+                if (nan) {
+                    c.status = NYX_HIP_ERR_NAN;
+                    c.done = true;
+                } else {
+                    c.det_step = seconds_to_ns(h);
+                    if (c.det_error < cfg->tol) {
+                        const double prop = 0.9 * h * pw;
+                        h = (fabs(prop) > fabs(cfg->max_step_s)) ? cfg->max_step_s * copysign(1.0, prop) : prop;
+                    }
+                    c.step_size = seconds_to_ns(h);
+                    const int64_t ab = c.step_size < 0 ? -c.step_size : c.step_size;
+                    if (ab < cfg->min_step_ns) c.step_size = (c.step_size < 0) ? -cfg->min_step_ns : cfg->min_step_ns;
+                    accept = true;
+                }
+            } else {
+                c.attempts += 1;
+                c.n_rej += 1;
+                const double prop = 0.9 * h * pw;
+                h = (prop < cfg->min_step_s) ? cfg->min_step_s : prop;
+                keep = true;
+            }
+        }
+        if (accept) {
+            // single_step(): state.set(c.epoch + t, vec) with the Cr clamp, then finally()
+            c.epoch += c.det_step;
+#pragma unroll
+            for (int e = 0; e < 9; ++e) y[e] = next[e];
+            y[6] = clamp02(y[6]);
+            c.n_acc += 1;
+            c.det_attempts = c.attempts;
+            if (y[8] < 0.0) { c.status = NYX_HIP_ERR_FUEL_EXHAUSTED; c.done = true; }
+            if (c.is_final) {
+                c.step_size = c.prev_step;
+                c.fixed = c.prev_kind;
+                if (c.backprop) c.step_size = -c.step_size;
+                c.is_final = false;
+                c.done = true;
+            }
+            c.fresh = true;
+        }
+    }
+    c.h = h;
+    IxStep out = {0.0, (accept ? IXS_ACCEPT : 0) | (keep ? IXS_KEEP_K0 : 0)};
+    if (flags & IXS_CHAIN) {
+        // with chained attempts the next one is opened first (all lanes together: the exit test is a wave vote), the other waves
+        // are waiting for its epoch and step
+        begin_attempt_fn(L, lane, c);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) LCTL[5] = __builtin_amdgcn_readfirstlane(att_v) + 1;  // the almanac wave waits for this word before it reads the new epoch and step
+        out.h_next = c.h;
+    }
+    cold_store(cs, 0, c);
+    return out;
+}
+
+#ifdef NYX_COOP_FAN
+// FAN-OUT mode: the integrator's two stage sums on a wave of their own (round 6).  With dedicated helpers an owner's period IS its
+// integrator's chain (~19 k cycles per evaluation: integ_front 4.4 k, read-back + two-body + the two sums 8.3 k, fold + integ_back 5.3 k,
+// step control 0.7 k), while thirteen column waves of the workgroup hold three rows between them.  One of them (DevCfg.sums_wave1)
+// forms, in the window of stage i, what the integrator's window formed behind its post:
+//     W = sum_{j<i} a_{i+1,j} k_j[3..5]                          (phase A of stage i + 1 adds the newest term)
+//     P = sum_{j<i} a_{i+2,j} k_j[0..2] + a_{i+2,i} v_i          (the position part the NEXT window publishes from;
+//         or, when that window is the last of a chained attempt,  y + sum_{j<i} (h b_j) k_j[0..2] + (h b_i) v_i)
+// - the terms j <= i - 2 at once (their k rows were complete before the barrier this window starts behind), the term j = i - 1 when
+// the integrator's phase C of stage i - 1 has written k_{i-1} (ctl[6], raised by integ_back), the velocity term when integ_front has
+// stored v_i (ctl[4]) - and leaves the six values in LdsMap.sums, which the integrator reads behind the stage barrier, in front of the
+// next integ_front.  The same additions in the same order as the inline sums: bit-identical results.  Every spin is bounded; a wait
+// that expires leaves NaNs, which end the step as NYX_HIP_ERR_NAN.
+static __device__ __attribute__((noinline)) void fan_sums(uint32_t lds_v, uint64_t cfg_u, int i_v, int lane, int flags_v, int kdone_v) {
+    IX_PROLOGUE
+    (void)kbuf; (void)kb_li; (void)KB_STR;
+    const bool spec = cfg->spec != 0;
+    const LdsPtr kb0 = ix_rows(L.kbuf, lane);
+    const LdsPtr ysb = ix_rows((i & 1) ? L.ys2 : L.ys, lane);
+    const LdsPtr out = ix_rows(L.sums, lane);
+    const bool need_w = i + 1 < stages, need_p = i + 2 < stages, need_b = !need_p && i + 2 == stages && spec;  // (uniform)
+    // the tableau from its LDS copy (uniform addresses: broadcast reads that queue with the k rows; scalar loads would drain the LDS queue
+    // at every wait): rows i + 1 and i + 2 of A, or h b for the last window of a chained attempt
+    const LdsCPtr row_w = (LdsCPtr)tabl + (need_w ? (i + 1) * DEV_MAX_STAGES : 0);
+    const LdsCPtr row_p = (LdsCPtr)tabl + (need_p ? (i + 2) * DEV_MAX_STAGES : DEV_MAX_STAGES * DEV_MAX_STAGES);
+    double w[3] = {0.0, 0.0, 0.0}, p[3] = {0.0, 0.0, 0.0};
+    double hh = 1.0;
+    bool bad = false;
+    if (need_b) {
+        hh = L.step[DEV_LANES + lane];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) p[e] = CS_Y(e);
+    }
+    const bool any_p = need_p || need_b;
+    // one term: w += a_{i+1,j} k_j[3..5];  p += a_{i+2,j} k_j[0..2]  (or (h b_j) k_j[0..2])
+    auto term = [&](const int j) __attribute__((always_inline)) {
+        if (need_w) {
+            const double a_nj = row_w[j];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) w[e] += a_nj * kb0[(j * 6 + 3 + e) * DEV_LANES];
+        }
+        if (any_p) {
+            const double c_nj = need_b ? hh * row_p[j] : row_p[j];
+#pragma unroll
+            for (int e = 0; e < 3; ++e) p[e] += c_nj * kb0[(j * 6 + e) * DEV_LANES];
+        }
+    };
+    if (need_w || any_p) {
+        const int nh = i - 1;  // the terms j < i - 1: their k rows were complete before the barrier this window starts behind
+        int j = 0;
+        for (; j + 4 <= nh; j += 4) {  // four terms per batch: the loads together, the additions in ascending j
+            double cw[4], cp[4], kv[4][6];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                cw[q] = row_w[j + q];
+                cp[q] = row_p[j + q];
+#pragma unroll
+                for (int e = 0; e < 6; ++e) kv[q][e] = kb0[((j + q) * 6 + e) * DEV_LANES];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (need_w) {
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) w[e] += cw[q] * kv[q][3 + e];
+                }
+                if (any_p) {
+                    const double c_nj = need_b ? hh * cp[q] : cp[q];
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) p[e] += c_nj * kv[q][e];
+                }
+            }
+        }
+        for (; j < nh; ++j) term(j);
+        if (i >= 1) {
+            const int want = __builtin_amdgcn_readfirstlane(kdone_v);
+            int spin = 0;
+            while (LCTL[6] < want && ++spin < 4000000) __builtin_amdgcn_s_sleep(1);
+            if (spin >= 4000000) bad = true;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            term(i - 1);
+        }
+    }
+    // (always behind the velocity flag of this window: the integrator reads the previous window's six values in front of integ_front,
+    //  which raises it - the rows are free then)
+    if (flags & 1) {  // (a stage whose velocity integ_front forms in this window; else: stage 0 of an attempt opened behind barriers)
+        int spin = 0;
+        while (LCTL[4] != i + 1 && ++spin < 4000000) __builtin_amdgcn_s_sleep(1);
+        if (spin >= 4000000) bad = true;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    if (any_p) {
+        const double cv = need_b ? hh * row_p[i] : row_p[i];
+#pragma unroll
+        for (int e = 0; e < 3; ++e) p[e] += cv * ysb[(3 + e) * DEV_LANES];
+    }
+    if (bad) {
+        const double qn = __longlong_as_double(0x7ff8000000000000LL);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) { w[e] = qn; p[e] = qn; }
+    }
+#pragma unroll
+    for (int e = 0; e < 3; ++e) { out[e * DEV_LANES] = w[e]; out[(3 + e) * DEV_LANES] = p[e]; }
+}
+#endif
 #endif  // INTEG_OOL
 
 // ---------------------------------------------------------------------------------------------
@@ -3253,10 +3662,18 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     // central gravity field.  The almanac wave with the DCM share holds its write of the next-but-one DCM for the fold counter then.
 #if INTEG_OOL
     constexpr bool ool = PIPE && !STM;   // (a compile-time property of these kernels: the host pipelines a sixteen-wave workgroup only with a gravity field, build_schedule)
+#ifdef NYX_COOP_FAN
+    // (uniform) fan-out mode: the integrator's two stage sums are formed by a column wave of their own (fan_sums)
+    const bool sums_on = ool && cfg->sums_wave1 != 0;
+    const bool sums_me = sums_on && !INTEG && !ALMANAC && !PERT && cfg->sums_wave1 == wave + 1;
+#else
+    constexpr bool sums_on = false;
+#endif
     const uint32_t lds_base = (uint32_t)(uintptr_t)(LdsPtr)L.kbuf;   // (the carve starts at the k-buffer)
 #define IX_STAMP(k) (int64_t)(((uint64_t)(uint32_t)LCTL[9 + 2 * (k)] << 32) | (uint64_t)(uint32_t)LCTL[8 + 2 * (k)])
 #else
     constexpr bool ool = false;
+    constexpr bool sums_on = false;
 #endif
     bool spec_now = false;  // stage 0 of the attempt being started was published in the previous attempt's last window
     bool keep_k0 = false;   // (integrator, per lane) the previous attempt was rejected: k_0 stands
@@ -3269,7 +3686,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     unsigned long long dbg_answers = 0, dbg_fallbacks = 0, dbg_fb_seq = 0;  // (NYX_HIP_PROFILE: row 16 of the profile)
     int64_t pl_tc = 0, pl_chain = 0, pl_wait = 0, pl_n = 0, pl_post = 0;
 #if NYX_SEG_PROF
-    int64_t sg[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sg_t = 0;  // (NYX_HIP_PROFILE, rows 34-35: the integrator's stage in eleven pieces)
+    int64_t sg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sg_t = 0;  // (NYX_HIP_PROFILE, rows 34-35: the integrator's stage in eleven pieces, step control in five: 12 cold state, 13 the two sums, 14 error estimate and decision, 15 next attempt opened, 11 the rest)
 #define SEG(k) if (INTEG && prof_on) { const int64_t n_ = (int64_t)__builtin_readcyclecounter(); sg[k] += n_ - sg_t; sg_t = n_; }
 #else
 #define SEG(k)
@@ -3277,32 +3694,10 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     // (NYX_HIP_PROFILE, row 33: the latency loop of a cooperative owner - answer in hand -> next post)
     bool shared_cur = false, shared_nx = false;  // did the workers of this / the next stage leave columns to a helper?
 
-    // start of a step: final-step test on integer epochs (instance.rs:149-186), then epoch and step published to the other waves
-    auto begin_attempt = [&](ColdState &c) {
-        if (!c.done && c.fresh) {
-            if ((!c.backprop && c.epoch + c.step_size > c.stop) || (c.backprop && c.epoch + c.step_size <= c.stop)) {
-                if (c.stop == c.epoch) {
-                    c.done = true;
-                } else {
-                    c.prev_step = c.step_size;
-                    c.prev_kind = c.fixed;
-                    c.step_size = c.stop - c.epoch;
-                    c.fixed = true;
-                    c.is_final = true;
-                }
-            }
-            c.attempts = 1;
-            c.h = ns_to_seconds(c.step_size);
-            c.fresh = false;
-        }
-        if (!c.done && c.massless) { c.status = NYX_HIP_ERR_MASSLESS; c.done = true; }
-        L.step[lane] = __longlong_as_double(c.epoch);
-        L.step[DEV_LANES + lane] = c.h;
-        if (!__any(!c.done)) {
-            if (lane == 0) L.ctl[0] = 1;
-        }
-    };
+    auto begin_attempt = [&](ColdState &c) __attribute__((always_inline)) { begin_attempt_fn(L, lane, c); };
     double h_next = 0.0;  // (chained attempts: the step of the attempt step control has just opened)
+    HsDesc hsd = {0, 0, 0, 0};  // (column waves) the start of this wave's walk under schedule hsd_sched, see harm_stream_setup
+    int hsd_sched = -1;
 
     for (;;) {  // one iteration = one RK attempt for every live lane (derive(), instance.rs:368-414)
         double h = h_next;
@@ -3668,6 +4063,9 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                             second_field_into_pert(cfg, rec_in_lds ? (const double *)L.rec : records, edc, lane, wave, ns_to_seconds(ep2), ysp, pertp);
                 }
             }
+#ifdef NYX_COOP_FAN
+            if (sums_me) fan_sums(lds_base, (uint64_t)cfg, i, lane, (i > 0 || spec_now) ? 1 : 0, fold_base + i);
+#endif
             double acc[3] = {0.0, 0.0, 0.0};
             // The integrator's window.  Round 5: in the pipelined plain loop the position and the recursion inputs of the next stage are
             // formed and POSTED first, everything else (two-body term, the velocity part of the next stage sum, the position part of the
@@ -3758,6 +4156,10 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             if (INTEG && fastp && ool) {
                 const bool hot = i > 0 || spec_now;
                 const bool pub = i + 1 < stages || spec;
+                if (sums_on && i > 0) {  // the two sums the sums wave formed in the previous window (behind the stage barrier: complete)
+#pragma unroll
+                    for (int e = 0; e < 3; ++e) { wpre[3 + e] = L.sums[e * DEV_LANES + lane]; pre_wr[e] = L.sums[(3 + e) * DEV_LANES + lane]; }
+                }
                 uint32_t sq = 0;
                 if (pub && coop_on) sq = ++coop_seq;
                 const int64_t pf0_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;   // (accounting twin: slot 0 = integ_front, slot 1 = the whole window)
@@ -3765,6 +4167,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                                             lane, h, hot ? wpre[3] : ys[3], hot ? wpre[4] : ys[4], hot ? wpre[5] : ys[5], pre_wr[0], pre_wr[1], pre_wr[2],
                                             (uint64_t)cbox, (uint64_t)(bt.coop_posted + coop_widx), sq, keep_k0 ? 1 : 0);
                 if (prof_on) prof_acc[0] += (int64_t)__builtin_readcyclecounter() - pf0_;
+                SEG(5)   /* integ_front: phase A, next position, DCM wait, rotate, inputs, post */
                 if (st1) st_att = st1;
                 if (pub) {
                     shared_nx = coop_on;
@@ -3800,6 +4203,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 }
 #else
                 // (A/B switch: the sums inline, as the first cut of the out-of-line integrator had them)
+                if (!sums_on) {
 #pragma unroll
                 for (int e = 0; e < 6; ++e) wpre[e] = 0.0;
                 if (i + 1 < stages) {
@@ -3837,6 +4241,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     const double cbi = h * B_COEF(i);
 #pragma unroll
                     for (int e = 0; e < 3; ++e) pre_wr[e] += cbi * ys[3 + e];
+                }
                 }
 #endif
             } else
@@ -3961,6 +4366,14 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 if (!(pipe && INTEG)) {
                     const double v0 = inbw[0 * DEV_LANES + lane], v1 = inbw[1 * DEV_LANES + lane], v2 = inbw[2 * DEV_LANES + lane],
                                  v3 = inbw[3 * DEV_LANES + lane], v4 = inbw[4 * DEV_LANES + lane];
+                    if (HS_DESC && PIPE && !INTEG && !ALMANAC && !PERT && (cfg->harm_feed & 1)) {
+                        // (a pure column wave of the pipelined loop: the start of its walk is kept across the stages, see harm_stream_setup)
+                        if (sched != hsd_sched) {  // (uniform) the first stage, or the workgroup has started / stopped sharing its columns
+                            hsd = harm_stream_setup((uint64_t)cfg, (uint64_t)cols, wave, sched);
+                            hsd_sched = sched;
+                        }
+                        pr = harmonics_stream_d((uint64_t)cfg, (uint64_t)cols, wave, sched, hsd.e, hsd.vp, hsd.hp, hsd.pack, v0, v1, v2, v3, v4);
+                    } else
                     pr = (cfg->harm_feed & 1) ? harmonics_stream((uint64_t)cfg, (uint64_t)cols, wave, sched, v0, v1, v2, v3, v4)
                                         : harmonics_partial((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, sched, v0, v1, v2, v3, v4);
                 }
@@ -4029,6 +4442,10 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     if (coop_on) { ++dbg_fallbacks; dbg_fb_seq = seq_cur; }
                     const Partial4 fb = coop_fallback((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, (i & 1) ? L.inb2 : L.inb, lane | COOP_FB_PARTS);
                     integ_back_slow(lds_base, (uint64_t)cfg, (uint64_t)records, i, lane, acc[0], acc[1], acc[2], rb_.px, rb_.py, rb_.pz, rb_.pw, fb.x, fb.y, fb.z, fb.w, skip_k);
+                    if (sums_on) {  // (k_i is written: see integ_back)
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) LCTL[6] = fold_base + i + 1;
+                    }
                     coop_on = false;  // (pipelined: ctl[1] is rewritten for every stage, nothing to undo)
                     if (lane == 0) coop_store(bt.coop_finished + coop_widx, 1u);
                 }
@@ -4186,15 +4603,37 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
 
         const int64_t pts_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;
         keep_k0 = false;
+#if INTEG_OOL && STEP_OOL
+        if (INTEG && ool && !bt.ev_on) {
+            // ---- step control, out of line (integ_step)
+            const IxStep sr = integ_step(lds_base, (uint64_t)cfg, lane, h, st_att, att, spec ? IXS_CHAIN : 0);
+            keep_k0 = (sr.ret & IXS_KEEP_K0) != 0;
+            if (spec) h_next = sr.h_next;
+            if ((sr.ret & IXS_ACCEPT) && bt.traj_cap > 0 && wr) {  // chan.send(self.state) after every accepted step, final one included
+                const int64_t acc_n = __double_as_longlong(L.cs[5 * DEV_LANES + lane]);
+                if (acc_n < bt.traj_cap) {
+                    const int64_t at = acc_n * bt.n + gid;
+                    bt.t_epoch[at] = __double_as_longlong(L.cs[0 * DEV_LANES + lane]);
+#pragma unroll
+                    for (int e = 0; e < 6; ++e) bt.t_state[e][at] = CS_Y(e);
+                }
+                bt.t_len[gid] = (int32_t)(acc_n + 1);
+            }
+        } else
+#endif
         if (INTEG) {
             ColdState c;
             cold_load(L.cs, lane, c);
             double *const y = c.y;
             if (!c.done) c.n_evals += stages;
+            SEG(12)  /* cold state */
             // ---- next state and error estimate (instance.rs:401-414).  d(Cr, Cd, prop mass)/dt = 0.
             double next[9], err[9];
 #pragma unroll
             for (int e = 0; e < 9; ++e) { next[e] = y[e]; err[e] = 0.0; }
+#if STEP_SUMS_UNROLL
+#pragma unroll STEP_SUMS_UNROLL
+#endif
             for (int i = 0; i < stages; ++i) {
                 const double ce = h * BD_COEF(i);
                 const double cb = h * B_COEF(i);
@@ -4205,8 +4644,21 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     next[e] += cb * kv;
                 }
             }
+            SEG(13)  /* the two sums */
             const double h_used = h;
             bool accept = false, ev_hit = false;
+#if STEP_ONE_POW
+            // The error estimate, the accept test and the controller's power for every lane at once, in front of the branches: an attempt
+            // of configs[1] is rejected on 18 % of the lanes, so a wave nearly always walked BOTH branches below, each with its own inlined
+            // pow (the two differ in the exponent only).  The same function of the same arguments: the same bits.
+            double de = c.det_error, pw = 0.0;
+            bool take = false;
+            if (__any(!c.done && st_att == NYX_HIP_OK && !c.fixed)) {  // (uniform)
+                de = error_estimate(cfg->error_ctrl, err, next, y);
+                take = de <= cfg->tol || h <= cfg->min_step_s || c.attempts >= cfg->attempts;
+                pw = pow(cfg->tol / de, take ? cfg->inv_order : cfg->inv_order_m1);
+            }
+#endif
             if (!c.done) {
                 if (st_att != NYX_HIP_OK) {
                     c.status = st_att;
@@ -4215,8 +4667,13 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     c.det_step = c.step_size;
                     accept = true;
                 } else {
+#if STEP_ONE_POW
+                    c.det_error = de;
+                    if (take) {
+#else
                     c.det_error = error_estimate(cfg->error_ctrl, err, next, y);
                     if (c.det_error <= cfg->tol || h <= cfg->min_step_s || c.attempts >= cfg->attempts) {
+#endif
                         bool nan = false;
 #pragma unroll
                         for (int e = 0; e < 9; ++e) nan = nan || (next[e] != next[e]);
@@ -4226,7 +4683,11 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                         } else {
                             c.det_step = seconds_to_ns(h);
                             if (c.det_error < cfg->tol) {
+#if STEP_ONE_POW
+                                const double prop = 0.9 * h * pw;
+#else
                                 const double prop = 0.9 * h * pow(cfg->tol / c.det_error, cfg->inv_order);
+#endif
                                 h = (fabs(prop) > fabs(cfg->max_step_s)) ? cfg->max_step_s * copysign(1.0, prop) : prop;
                             }
                             c.step_size = seconds_to_ns(h);
@@ -4237,7 +4698,11 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                     } else {
                         c.attempts += 1;
                         c.n_rej += 1;
+#if STEP_ONE_POW
+                        const double prop = 0.9 * h * pw;
+#else
                         const double prop = 0.9 * h * pow(cfg->tol / c.det_error, cfg->inv_order_m1);
+#endif
                         h = (prop < cfg->min_step_s) ? cfg->min_step_s : prop;
                         keep_k0 = true;
                     }
@@ -4284,6 +4749,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 }
             }
             c.h = h;
+            SEG(14)  /* error estimate, decision, state update */
             // what is left of an accepted step only writes results: with chained attempts the next one is opened first (all lanes
             // together: the exit test is a wave vote), the other waves are waiting for its epoch and step
             const int64_t acc_n = c.n_acc, acc_epoch = c.epoch;
@@ -4293,6 +4759,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 if (lane == 0) LCTL[5] = att + 1;  // the almanac wave waits for this word before it reads the new epoch and step
                 h_next = c.h;
             }
+            SEG(15)  /* next attempt opened */
             if (accept && bt.traj_cap > 0 && wr && !ev_hit) {  // chan.send(self.state) after every accepted step, final one included
                 if (acc_n < bt.traj_cap) {
                     const int64_t at = acc_n * bt.n + gid;
@@ -4313,7 +4780,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
         int64_t *row = bt.prof + 33 * 8;
         row[0] = pl_wait; row[1] = pl_chain; row[2] = pl_post; row[3] = pl_n;
 #if NYX_SEG_PROF
-        for (int q = 0; q < 12; ++q) bt.prof[34 * 8 + q] = sg[q];
+        for (int q = 0; q < 16; ++q) bt.prof[34 * 8 + q] = sg[q];
 #endif
     }
     if (prof_on && lane == 0) {

@@ -99,9 +99,9 @@ for rep in range(reps):
                 ctx._lib.nyx_hip_debug_profile_helper.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
                 if ctx._lib.nyx_hip_debug_profile_helper(ctx._h, hb) == 0:
                     hp = np.array(hb[:]).reshape(19, 8)
-                    sgv = hp[17:19].reshape(-1)[:12]
+                    sgv = hp[17:19].reshape(-1)[:16]
                     if sgv.sum():
-                        names = ['back-edge', 'phase A', 'next position', 'DCM wait', 'rotate+inputs', 'post', 'two-body+sums', 'barrier', 'C to fold', 'answer', 'C rest', 'step ctl']
+                        names = ['back-edge', 'phase A', 'next position', 'DCM wait', 'rotate+inputs', 'post', 'two-body+sums', 'barrier', 'C to fold', 'answer', 'C rest', 'step ctl (rest)', 'sc cold state', 'sc sums', 'sc decide', 'sc open next']
                         print('   integrator per eval: ' + ', '.join(f'{n} {v / ne:.0f}' for n, v in zip(names, sgv)))
                     if hp[16, 3]:
                         print(f"   owner latency loop (wg0, per posted job): wait for the answer {hp[16, 0] / hp[16, 3]:.0f}, answer in hand -> post {hp[16, 1] / hp[16, 3]:.0f}, post {hp[16, 2] / hp[16, 3]:.0f} cycles ({hp[16, 3]} jobs)")
