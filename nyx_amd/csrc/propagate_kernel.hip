@@ -1686,7 +1686,17 @@ static __device__ __attribute__((noinline)) Partial4 coop_fallback(uint64_t cfg_
 #define NYX_SEG_PROF 0  /* 1 adds the integrator's per-piece timers (rows 34-35); off in the product build, they cost registers */
 #endif
 #ifndef STEP_ONE_POW
-#define STEP_ONE_POW 1      /* step control: one pow in front of the accept / reject branches (round 6) */
+/* step control: one pow in front of the accept / reject branches (round 6).  The sixteen-wave plain kernels only - measured same box,
+ * three interleaved pairs each: 24 h of configs[1] 595.1 -> 592.1 ms (the decision 13.0 k -> 10.7 k cycles per attempt); the eight-wave
+ * kernel of config 3, whose integrator shares its SIMD with one almanac wave, 46.8 ms with two pows against 47.2 with one */
+#define STEP_ONE_POW ((NYX_EMIT & (NYX_EMIT_PLAIN16 | NYX_EMIT_PLAIN16_P2 | NYX_EMIT_PLAIN16_FAN)) ? 1 : 0)
+#endif
+#ifndef FAN_SUMS
+#ifdef NYX_FAN_SUMS
+#define FAN_SUMS 1
+#else
+#define FAN_SUMS 0  /* fan-out mode: the integrator's two stage sums formed by a column wave of their own (fan_sums, DevCfg.sums_wave1).  Built, bit-identical, and measured in round 6 (1 250 x 24 h, same box): 412.7 ms with it against 419.4 / 416.6 without - the integrator's window shrinks from 12.7 k to 7.7 k cycles per evaluation, but the almanac wave (18.6 k busy) then bounds the period; with the almanac duty fanned out as well (role_fanout + chained attempts) the integrator's phase C and the helpers' turnaround do (20.1 k).  Off: its six LDS rows (3 KB) pushed config 3's padded ephemeris records out of LDS (43.9 -> 47.1 ms) */
+#endif
 #endif
 #ifndef STEP_OOL
 #ifdef NYX_COOP_FAN
@@ -2590,7 +2600,9 @@ DEVFN LdsMap carve_lds(char *smem, int n_waves, bool stm, int rec_lds_doubles, i
         m.inb2 = p; p += NIN * DEV_LANES;
         m.pert2 = p; p += 9 * DEV_LANES;
         m.ixs = p; p += 4 * DEV_LANES;
+#if FAN_SUMS
         m.sums = p; p += 6 * DEV_LANES;
+#endif
     } else if (quad) {  // pipelined stage loop of the quad layout: second set of the dual buffers
         m.ys2 = p; p += 6 * DEV_LANES;
         m.inb2 = p; p += 10 * DEV_LANES;
@@ -2614,7 +2626,7 @@ size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles, int stm, int reuse_fie
     size_t d = (size_t)DEV_MAX_STAGES * 6 * (quad ? DEV_LANES / 4 : DEV_LANES) + DEV_MAX_STAGES * DEV_MAX_STAGES + 3 * DEV_MAX_STAGES + 6 * DEV_LANES +
                2 * ED_FIELDS * DEV_LANES + 2 * DEV_LANES + CS_FIELDS * DEV_LANES + (size_t)(quad ? DEV_MAX_WAVES * QSLOT : DEV_MAX_WAVES * 4 * DEV_LANES) + DEV_MAX_ALM * DEV_LANES +
                DEV_LANES + 8 + (size_t)rec_doubles;
-    d += quad ? (size_t)(10 + 15 + 6 + QPRE_ROWS + 6 + 10 + 15) * DEV_LANES : (stm ? (size_t)(20 + 27 + 12) * DEV_LANES : (size_t)(NIN + 9 + 6 + NIN + 9 + 4 + 6) * DEV_LANES);
+    d += quad ? (size_t)(10 + 15 + 6 + QPRE_ROWS + 6 + 10 + 15) * DEV_LANES : (stm ? (size_t)(20 + 27 + 12) * DEV_LANES : (size_t)(NIN + 9 + 6 + NIN + 9 + 4 + (FAN_SUMS ? 6 : 0)) * DEV_LANES);
     (void)n_waves;
     if (reuse_fields > 0) d += (size_t)reuse_fields * DEV_LANES + 2 * DEV_LANES + DEV_LANES / 2;
     return d * sizeof(double) + 64;
@@ -2802,7 +2814,7 @@ static __device__ __attribute__((noinline)) int integ_front(uint32_t lds_v, uint
         }
 #pragma unroll
         for (int e = 0; e < 3; ++e) ysb[(3 + e) * DEV_LANES + lane] = vel[e];
-#ifdef NYX_COOP_FAN
+#if defined(NYX_COOP_FAN) && FAN_SUMS
         if (cfg->has_drag || cfg->sums_wave1 != 0) {  // (... and the sums wave, which adds this stage's velocity term last: fan_sums)
 #else
         if (cfg->has_drag) {  // the perturbation wave is already in this stage's window; drag is the one term that wants the velocity
@@ -3049,7 +3061,7 @@ static __device__ __attribute__((noinline)) IxBack integ_back(uint32_t lds_v, ui
         }
     }
     ix_assemble(cfg, L, i, lane, acc, px, py, pz, pw, m_cur, s_, t_, u_, kfac, skip_k);
-#ifdef NYX_COOP_FAN
+#if defined(NYX_COOP_FAN) && FAN_SUMS
     if (cfg->sums_wave1 != 0) {  // k_i is written: the sums wave may add its term (fan_sums; ctl[6] counts like the fold counter)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) LCTL[6] = __builtin_amdgcn_readfirstlane(fold_val_v);
@@ -3229,7 +3241,7 @@ static __device__ __attribute__((noinline)) IxStep integ_step(uint32_t lds_v, ui
     return out;
 }
 
-#ifdef NYX_COOP_FAN
+#if defined(NYX_COOP_FAN) && FAN_SUMS
 // FAN-OUT mode: the integrator's two stage sums on a wave of their own (round 6).  With dedicated helpers an owner's period IS its
 // integrator's chain (~19 k cycles per evaluation: integ_front 4.4 k, read-back + two-body + the two sums 8.3 k, fold + integ_back 5.3 k,
 // step control 0.7 k), while thirteen column waves of the workgroup hold three rows between them.  One of them (DevCfg.sums_wave1)
@@ -3662,7 +3674,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
     // central gravity field.  The almanac wave with the DCM share holds its write of the next-but-one DCM for the fold counter then.
 #if INTEG_OOL
     constexpr bool ool = PIPE && !STM;   // (a compile-time property of these kernels: the host pipelines a sixteen-wave workgroup only with a gravity field, build_schedule)
-#ifdef NYX_COOP_FAN
+#if defined(NYX_COOP_FAN) && FAN_SUMS
     // (uniform) fan-out mode: the integrator's two stage sums are formed by a column wave of their own (fan_sums)
     const bool sums_on = ool && cfg->sums_wave1 != 0;
     const bool sums_me = sums_on && !INTEG && !ALMANAC && !PERT && cfg->sums_wave1 == wave + 1;
@@ -4063,7 +4075,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                             second_field_into_pert(cfg, rec_in_lds ? (const double *)L.rec : records, edc, lane, wave, ns_to_seconds(ep2), ysp, pertp);
                 }
             }
-#ifdef NYX_COOP_FAN
+#if defined(NYX_COOP_FAN) && FAN_SUMS
             if (sums_me) fan_sums(lds_base, (uint64_t)cfg, i, lane, (i > 0 || spec_now) ? 1 : 0, fold_base + i);
 #endif
             double acc[3] = {0.0, 0.0, 0.0};
