@@ -1159,120 +1159,6 @@ static __device__ __attribute__((noinline)) Partial4 harmonics_stream(uint64_t c
     return r;
 }
 
-// The start of a walk, taken out of the stage loop (round 6).  harmonics_stream finds its first range through three levels of
-// dependent scalar loads - the schedule's range in DevCfg, the column header, then the table itself - and forms the complex power in
-// between: ~2 k cycles in which the wave issues nothing, at the start of EVERY stage, on all four waves of a SIMD at once (they leave
-// the stage barrier together), and the scalar cache does not keep those lines across a stage (the column waves of a workgroup stream
-// 40 KB of table rows through its 16 KB in between).  None of it depends on the stage: a pure column wave of the pipelined loop keeps
-// the descriptor of its FIRST range (stream addresses, header address, rows to skip, columns, first column, ranges) in registers across
-// the stages (harm_stream_setup once per schedule, role_loop), and harmonics_stream_d starts from it: it touches the first lines of
-// both sides of the table, forms the complex power under those loads, and enters the generated loop, whose own loads then hit.  The
-// further ranges of a wave (schedules other than the owner's one-run-per-wave deal) go the old way.  Same loop, same operands, same
-// order: bit-identical sums.
-#ifndef HS_DESC
-#define HS_DESC 0   /* built and measured in round 6, same box, three interleaved pairs: 24 h of configs[1] 605.0 ms with it against 597.9 without, the full-chip launch 107.4 against 106.0 - the start of a walk is not where a column wave's time goes (the compiled-out code and the generated macro stay as the record) */
-#endif
-struct HsDesc {
-    uint64_t e, vp, hp;
-    int pack;  // left (3 bits) | low_half << 3 | cols_left << 4 (12 bits) | c0 << 16 (8 bits) | n_ranges << 24
-};
-DEVFN void hs_locate(CfgPtr cfg, int sched, ColPtr &cols, uint64_t &hs0, uint64_t &hv0) {
-    hs0 = cfg->hyb; hv0 = cfg->hyb_v;
-    // (uniform) the run stream of this schedule, every range at the head of a group of its own (DevCfg.rs_*)
-    const int rs = sched == DEV_SCHED_SOLO ? 0 : (sched == DEV_SCHED_PRIMARY ? 1 : ((sched == DEV_SCHED_HELPER || sched == DEV_SCHED_HELPER2) ? 2 : -1));
-    if (rs >= 0 && cfg->rs_hyb[rs >= 0 ? rs : 0] != 0) {
-        hs0 = cfg->rs_hyb[rs]; hv0 = cfg->rs_hyb_v[rs];
-        cols = (ColPtr)cfg->rs_cols[rs];
-    }
-}
-static __device__ __attribute__((noinline)) HsDesc harm_stream_setup(uint64_t cfg_u, uint64_t cols_u, int wave_v, int sched_v) {
-    CfgPtr cfg = (CfgPtr)uniform_u64(cfg_u);
-    ColPtr cols = (ColPtr)uniform_u64(cols_u);
-    const int wave = __builtin_amdgcn_readfirstlane(wave_v);
-    const int sched = __builtin_amdgcn_readfirstlane(sched_v);
-    const CAS DevSched &sd = cfg->sched[sched];
-    const int nr = sd.n_ranges[wave];
-    uint64_t hs0, hv0;
-    hs_locate(cfg, sched, cols, hs0, hv0);
-    HsDesc d = {0, 0, 0, 0};
-    if (nr > 0) {
-        const int c0 = sd.range_c0[wave][0];
-        const int cols_left = sd.range_cnt[wave][0];
-        const int srow = cols[c0].start;
-        d.e = hs0 + (uint64_t)(srow & ~7) * (HYB_KS * 8);
-        d.vp = hv0 + (uint64_t)(srow >> 4) * (HYB_GROUP * 8);
-        d.hp = (uint64_t)cols + (uint64_t)c0 * sizeof(ColHdr);
-        d.pack = (srow & 7) | (((srow & 8) == 0 ? 1 : 0) << 3) | (cols_left << 4) | (c0 << 16);
-    }
-    d.pack |= nr << 24;
-    return d;
-}
-static __device__ __attribute__((noinline)) Partial4 harmonics_stream_d(uint64_t cfg_u, uint64_t cols_u, int wave_v, int sched_v, uint64_t e0_v, uint64_t vp0_v,
-                                                                      uint64_t hp0_v, int pack_v, double zr, double zi, double rho_u, double rho,
-                                                                      double inv_rho) {
-    const uint64_t e0 = uniform_u64(e0_v), vp0 = uniform_u64(vp0_v), hp0 = uniform_u64(hp0_v);
-    const int pack = __builtin_amdgcn_readfirstlane(pack_v);
-    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const int voff = (lane & 15) * 8;
-    double px = 0.0, py = 0.0, pz = 0.0, pw = 0.0;
-    const double rho2 = rho * rho;
-    const int nr = pack >> 24;
-    if (nr > 0) {
-        int left = pack & 7, first = 1, sink = 0, vsink = 0;
-        const int low_half = (pack >> 3) & 1;
-        int cols_left = (pack >> 4) & 0xfff;
-        const int c0 = (pack >> 16) & 0xff;
-        // the first lines of both sides of the table (three scalar lines of the first batch, eight vector lines of the first two
-        // groups): in flight under the complex power; the generated loop's first waits cover them (its loads of the same lines hit)
-        asm volatile(
-            "s_load_dword %0, %2, 0x0\n\t"
-            "s_load_dword %0, %2, 0x40\n\t"
-            "s_load_dword %0, %2, 0x80\n\t"
-            "s_load_dword %0, %4, 0x0\n\t"
-            "global_load_dword %1, %5, %3\n\t"
-            "global_load_dword %1, %5, %3 offset:128\n\t"
-            "global_load_dword %1, %5, %3 offset:256\n\t"
-            "global_load_dword %1, %5, %3 offset:384\n\t"
-            "global_load_dword %1, %5, %3 offset:512\n\t"
-            "global_load_dword %1, %5, %3 offset:640\n\t"
-            "global_load_dword %1, %5, %3 offset:768\n\t"
-            "global_load_dword %1, %5, %3 offset:896"
-            : "+&s"(sink), "+&v"(vsink)
-            : "s"(e0), "s"(vp0), "s"(hp0), "v"(voff)
-            : "memory");
-        double rc, ic;
-        cpow_uniform(zr, zi, c0 - 1, rc, ic);
-        const uint64_t e = e0, vp = vp0, hp = hp0;  // (the macro's operand names)
-        HARM_STREAM_ASM_T(e, vp, hp, voff, left, cols_left, first, low_half, sink, vsink, rho_u, rho2, rho, inv_rho, zr, zi, px, py, pz, pw, rc, ic);
-        (void)sink; (void)vsink;
-    }
-    if (nr > 1) {  // (uniform) the further ranges of this wave: located as harmonics_stream locates them
-        CfgPtr cfg = (CfgPtr)uniform_u64(cfg_u);
-        ColPtr cols = (ColPtr)uniform_u64(cols_u);
-        const int wave = __builtin_amdgcn_readfirstlane(wave_v);
-        const int sched = __builtin_amdgcn_readfirstlane(sched_v);
-        const CAS DevSched &sd = cfg->sched[sched];
-        uint64_t hs0, hv0;
-        hs_locate(cfg, sched, cols, hs0, hv0);
-        for (int q = 1; q < nr; ++q) {
-            const int c0 = sd.range_c0[wave][q];
-            int cols_left = sd.range_cnt[wave][q];
-            const int srow = cols[c0].start;
-            const uint64_t e = hs0 + (uint64_t)(srow & ~7) * (HYB_KS * 8);
-            const uint64_t vp = hv0 + (uint64_t)(srow >> 4) * (HYB_GROUP * 8);
-            const uint64_t hp = (uint64_t)cols + (uint64_t)c0 * sizeof(ColHdr);
-            double rc, ic;
-            cpow_uniform(zr, zi, c0 - 1, rc, ic);
-            int left = srow & 7, first = 1, sink;
-            const int low_half = (srow & 8) == 0 ? 1 : 0;
-            HARM_STREAM_ASM(e, vp, hp, voff, left, cols_left, first, low_half, sink, rho_u, rho2, rho, inv_rho, zr, zi, px, py, pz, pw, rc, ic);
-            (void)sink;
-        }
-    }
-    Partial4 r = {px, py, pz, pw};
-    return r;
-}
-
 static __device__ __attribute__((noinline)) Partial4 harmonics_partial(uint64_t cfg_u, uint64_t htab_u, uint64_t cols_u, int wave_v,
                                                                      int sched_v, double zr, double zi, double rho_u, double rho,
                                                                      double inv_rho) {
@@ -3700,16 +3586,19 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
 #if NYX_SEG_PROF
     int64_t sg[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sg_t = 0;  // (NYX_HIP_PROFILE, rows 34-35: the integrator's stage in eleven pieces, step control in five: 12 cold state, 13 the two sums, 14 error estimate and decision, 15 next attempt opened, 11 the rest)
 #define SEG(k) if (INTEG && prof_on) { const int64_t n_ = (int64_t)__builtin_readcyclecounter(); sg[k] += n_ - sg_t; sg_t = n_; }
+    // (STM kernels, row 18 of the profile: the attempt / segment boundary of the integrator wave in pieces - 0 step control, 1 the next attempt opened,
+    //  2 barrier B0, 3 the time updates of a segment boundary, 4 re-arming, 5 stage-0 epoch data + Bp, 6 phase A of stage 0 + B1)
+    int64_t sb[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sb_t = 0;
+#define SBD(k) if (INTEG && STM && prof_on) { const int64_t n_ = (int64_t)__builtin_readcyclecounter(); if (sb_t) sb[k] += n_ - sb_t; sb_t = n_; }
 #else
 #define SEG(k)
+#define SBD(k)
 #endif
     // (NYX_HIP_PROFILE, row 33: the latency loop of a cooperative owner - answer in hand -> next post)
     bool shared_cur = false, shared_nx = false;  // did the workers of this / the next stage leave columns to a helper?
 
     auto begin_attempt = [&](ColdState &c) __attribute__((always_inline)) { begin_attempt_fn(L, lane, c); };
     double h_next = 0.0;  // (chained attempts: the step of the attempt step control has just opened)
-    HsDesc hsd = {0, 0, 0, 0};  // (column waves) the start of this wave's walk under schedule hsd_sched, see harm_stream_setup
-    int hsd_sched = -1;
 
     for (;;) {  // one iteration = one RK attempt for every live lane (derive(), instance.rs:368-414)
         double h = h_next;
@@ -3731,12 +3620,15 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 for (int q = 0; q < (QUAD ? 6 : 12); ++q) L.sacc[q * DEV_LANES + lane] = 0.0;
             }
         }
+        SBD(1)
         if (!spec_now) {
         __syncthreads();  // B0: attempt published (or exit requested)
+        SBD(2)
         if (STM && bt.pred != nullptr && LCTL[7] != 0) {  // (uniform) a segment boundary of the covariance-mapping loop, see segment_update
             segment_update(bt.pred, bt.o_stm, L.cs, L.part + wave * (QUAD ? QSLOT : (STM ? 16 * DEV_LANES : 4 * DEV_LANES)), L.pertst, lane, QUAD ? 1 : 0,
                            (int64_t)blockIdx.x * (QUAD ? DEV_LANES / 4 : DEV_LANES), bt.n, wave, nw);
             __syncthreads();
+            SBD(3)
             if (INTEG) {
                 // the next segment for the trajectories that have not reached the end epoch: the state, the step size and the counters carry
                 // over as the reference's propagator instance carries them (od/process/mod.rs:466-483)
@@ -3754,6 +3646,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 h = c.h;
             }
             __syncthreads();
+            SBD(4)
         }
         if (LCTL[0]) break;
         }
@@ -3785,6 +3678,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
         if (!spec_now) {
         if (INTEG && lane == 0) { L.ctl[2] = 0; L.ctl[3] = 0; L.ctl[4] = 0; L.ctl[6] = 0; }
         __syncthreads();  // Bp
+        SBD(5)
         }
         const int fold_base = spec ? att * stages : 0;  // ctl[3] counts the folds of the whole launch when the attempts are chained
         bool leave = false;
@@ -3941,6 +3835,10 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 __syncthreads();  // B1: stage state and harmonics inputs published (pipelined: stage 0 only, and not when it was published speculatively)
                 PROF_ADD(6);
             }
+#if NYX_SEG_PROF
+            if (i == 0) { SBD(6) }
+            if (i == 1) sb_t = 0;  /* (the pieces are measured from the end of the stage loop to B1 of stage 0) */
+#endif
             const int64_t ptw_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;
 
             // ---- window --------------------------------------------------------------------------
@@ -4378,14 +4276,6 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 if (!(pipe && INTEG)) {
                     const double v0 = inbw[0 * DEV_LANES + lane], v1 = inbw[1 * DEV_LANES + lane], v2 = inbw[2 * DEV_LANES + lane],
                                  v3 = inbw[3 * DEV_LANES + lane], v4 = inbw[4 * DEV_LANES + lane];
-                    if (HS_DESC && PIPE && !INTEG && !ALMANAC && !PERT && (cfg->harm_feed & 1)) {
-                        // (a pure column wave of the pipelined loop: the start of its walk is kept across the stages, see harm_stream_setup)
-                        if (sched != hsd_sched) {  // (uniform) the first stage, or the workgroup has started / stopped sharing its columns
-                            hsd = harm_stream_setup((uint64_t)cfg, (uint64_t)cols, wave, sched);
-                            hsd_sched = sched;
-                        }
-                        pr = harmonics_stream_d((uint64_t)cfg, (uint64_t)cols, wave, sched, hsd.e, hsd.vp, hsd.hp, hsd.pack, v0, v1, v2, v3, v4);
-                    } else
                     pr = (cfg->harm_feed & 1) ? harmonics_stream((uint64_t)cfg, (uint64_t)cols, wave, sched, v0, v1, v2, v3, v4)
                                         : harmonics_partial((uint64_t)cfg, (uint64_t)htab, (uint64_t)cols, wave, sched, v0, v1, v2, v3, v4);
                 }
@@ -4614,6 +4504,9 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
         if (leave) break;
 
         const int64_t pts_ = prof_on ? (int64_t)__builtin_readcyclecounter() : 0;
+#if NYX_SEG_PROF
+        if (INTEG && STM && prof_on) sb_t = (int64_t)__builtin_readcyclecounter();
+#endif
         keep_k0 = false;
 #if INTEG_OOL && STEP_OOL
         if (INTEG && ool && !bt.ev_on) {
@@ -4784,6 +4677,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
             cold_store(L.cs, lane, c);
         }
         SEG(11)  /* step control */
+        SBD(0)
         if (prof_on) prof_acc[4] += (int64_t)__builtin_readcyclecounter() - pts_;
         spec_now = spec;
         ++att;
@@ -4793,6 +4687,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
         row[0] = pl_wait; row[1] = pl_chain; row[2] = pl_post; row[3] = pl_n;
 #if NYX_SEG_PROF
         for (int q = 0; q < 16; ++q) bt.prof[34 * 8 + q] = sg[q];
+        if (STM) { for (int q = 0; q < 8; ++q) bt.prof[18 * 8 + q] = sb[q]; }
 #endif
     }
     if (prof_on && lane == 0) {

@@ -179,17 +179,6 @@ f.write('          [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [pw] "+v"(pw), [
 f.write('        : [e] "s"(e), [vp] "s"(vp), [hp] "s"(hp), [voff] "v"(voff), [low_half] "s"(low_half), \\\n')
 f.write('          [rho_u] "v"(rho_u), [rho2] "v"(rho2), [rho] "v"(rho), [inv_rho] "v"(inv_rho), [zr] "v"(zr), [zi] "v"(zi) \\\n')
 f.write("        : " + ", ".join(f'"{c}"' for c in clob) + ")\n")
-# the same walk behind touches of its first lines (harmonics_stream_d): the two sink registers stay reserved until the loop's own waits
-f.write("// the same loop for a caller that has touched the walk's first lines itself: `sink` / `vsink` carry loads in flight into the statement\n")
-f.write("#define HARM_STREAM_ASM_T(e, vp, hp, voff, left, cols_left, first, low_half, sink, vsink, rho_u, rho2, rho, inv_rho, zr, zi, px, py, pz, pw, rc, ic) \\\n")
-f.write("    asm volatile( \\\n")
-for ln in lines:
-    f.write(f'        "{ln}\\n\\t" \\\n')
-f.write('        : [left] "+s"(left), [cols_left] "+s"(cols_left), [first] "+s"(first), [sink] "+&s"(sink), [vsink] "+v"(vsink), \\\n')
-f.write('          [px] "+v"(px), [py] "+v"(py), [pz] "+v"(pz), [pw] "+v"(pw), [rc] "+v"(rc), [ic] "+v"(ic) \\\n')
-f.write('        : [e] "s"(e), [vp] "s"(vp), [hp] "s"(hp), [voff] "v"(voff), [low_half] "s"(low_half), \\\n')
-f.write('          [rho_u] "v"(rho_u), [rho2] "v"(rho2), [rho] "v"(rho), [inv_rho] "v"(inv_rho), [zr] "v"(zr), [zi] "v"(zi) \\\n')
-f.write("        : " + ", ".join(f'"{c}"' for c in clob) + ")\n")
 text = f.getvalue()
 # written only when the content changes: the header's mtime is a build dependency of every kernel object (__graft_entry__.build),
 # and tests/test_codegen.py imports this module on every run

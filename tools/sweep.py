@@ -103,6 +103,9 @@ for rep in range(reps):
                     if sgv.sum():
                         names = ['back-edge', 'phase A', 'next position', 'DCM wait', 'rotate+inputs', 'post', 'two-body+sums', 'barrier', 'C to fold', 'answer', 'C rest', 'step ctl (rest)', 'sc cold state', 'sc sums', 'sc decide', 'sc open next']
                         print('   integrator per eval: ' + ', '.join(f'{n} {v / ne:.0f}' for n, v in zip(names, sgv)))
+                    if w["stm"] and hp[1].sum():
+                        segs = max(1, int(st.n_evals[:16].max()) // ne)
+                        print('   integrator boundary per segment: ' + ', '.join(f'{n} {v / segs:.0f}' for n, v in zip(['step control', 'open next', 'B0', 'time updates', 're-arm', 'epoch data + Bp', 'phase A + B1'], hp[1, :7])) + f'  ({segs} segments)')
                     if hp[16, 3]:
                         print(f"   owner latency loop (wg0, per posted job): wait for the answer {hp[16, 0] / hp[16, 3]:.0f}, answer in hand -> post {hp[16, 1] / hp[16, 3]:.0f}, post {hp[16, 2] / hp[16, 3]:.0f} cycles ({hp[16, 3]} jobs)")
                     if hp[0, 2]:
