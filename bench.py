@@ -830,7 +830,7 @@ def main():
             else:
                 host_call = {"ms": elapsed / args.steps * 1e3, "value": value, "unit": "trajectories/s", "kernel_ms": k_ms,
                              "note": "nyx_hip_predict_until takes host buffers: the timed steps ARE PCIe-inclusive; kernel_ms = the "
-                                     "device time of the segment + time-update launches"}
+                                     "device time of the loop (round 6: ONE launch of the quad STM kernel for all sixty time updates)"}
             line["host_call"] = host_call
         if world == 1 and not args.no_dense_output and not w["stm"] and args.config == 2:
             # The reference's Monte Carlo runs `until_epoch_with_traj` (mc/montecarlo.rs:236-239): the same launch with the

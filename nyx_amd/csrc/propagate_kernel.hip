@@ -3269,7 +3269,17 @@ static __device__ __attribute__((noinline)) void segment_update(const PredictArg
     for (int tj = wave; tj < per_wg; tj += nw) {
         const int64_t i = gid0 + tj;
         if (i >= n) break;  // (uniform)
-        if (ld_l2(&a.dur[i]) == 0) continue;  // (uniform) finished or failed earlier
+        // every load of this trajectory that does not depend on another, at once (one round trip past the L1 instead of three one
+        // behind the other: the whole workgroup waits for the slowest wave of this function); a finished trajectory's are dropped
+        const int64_t dur_i = ld_l2(&a.dur[i]);
+        const int64_t prev_ep = ld_l2(&a.prev_epoch[i]);
+        const int32_t u = ld_l2(&a.hist.n_updates[i]);
+        // 81 elements over 64 lanes: t = lane, and t = lane + 64 for the first 17
+        const double phi_a = ld_l2(&o_stm[i * 81 + lane]), p_a = ld_l2(&a.covar[i * 81 + lane]);
+        double phi_b = 0.0, p_b = 0.0, dev_v = 0.0;
+        if (lane < 17) { phi_b = ld_l2(&o_stm[i * 81 + 64 + lane]); p_b = ld_l2(&a.covar[i * 81 + 64 + lane]); }
+        if (lane < 9 && a.state_dev) dev_v = ld_l2(&a.state_dev[i * 9 + lane]);
+        if (dur_i == 0) continue;  // (uniform) finished or failed earlier
         const int ln = quad ? 4 * tj : tj;  // the lane that owns trajectory tj's cold state
         const int64_t epoch = __double_as_longlong(cs[0 * DEV_LANES + ln]);
         const int st = (int)((__double_as_longlong(cs[19 * DEV_LANES + ln]) >> 32) & 0xffff);
@@ -3277,12 +3287,10 @@ static __device__ __attribute__((noinline)) void segment_update(const PredictArg
             if (lane == 0) { a.status[i] = st; a.dur[i] = 0; }
             continue;
         }
-        const int64_t delta_ns = epoch - ld_l2(&a.prev_epoch[i]);
-        const int32_t u = ld_l2(&a.hist.n_updates[i]);
-        // 81 elements over 64 lanes: t = lane, and t = lane + 64 for the first 17
-        phi[lane] = ld_l2(&o_stm[i * 81 + lane]); p[lane] = ld_l2(&a.covar[i * 81 + lane]);
-        if (lane < 17) { phi[64 + lane] = ld_l2(&o_stm[i * 81 + 64 + lane]); p[64 + lane] = ld_l2(&a.covar[i * 81 + 64 + lane]); }
-        if (lane < 9) dev[lane] = a.state_dev ? ld_l2(&a.state_dev[i * 9 + lane]) : 0.0;
+        const int64_t delta_ns = epoch - prev_ep;
+        phi[lane] = phi_a; p[lane] = p_a;
+        if (lane < 17) { phi[64 + lane] = phi_b; p[64 + lane] = p_b; }
+        if (lane < 9) dev[lane] = dev_v;
         int snc_q = -1;
         {
             // the process noise that applies: last applicable entry (filtering.rs:64-80), its diagonal at this epoch

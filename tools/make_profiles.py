@@ -43,9 +43,12 @@ for item in items:
                 per[r["Counter_Name"]].append(float(r["Counter_Value"]))
     # the dominant dispatch of the command = the timed launch (the short calibration launches of a fresh context are the others);
     # config 4 launches one segment kernel per time update: all alike, take the mean
-    pick = (lambda v: sum(v) / len(v)) if cfg == 4 else max
+    # (rounds 2-5: config 4 launched one segment kernel per time update - all alike, the mean was taken; round 6: the covariance-mapping
+    #  loop is ONE launch of the quad STM kernel, the largest dispatch like everywhere else.  PER_SEGMENT=1 restores the old reading)
+    per_segment = cfg == 4 and os.environ.get("PER_SEGMENT") == "1"
+    pick = (lambda v: sum(v) / len(v)) if per_segment else max
     c = {k: pick(v) for k, v in per.items()}
-    launches = 60 if cfg == 4 else 1
+    launches = 60 if per_segment else 1
     k_ms = line["kernel_ms"] / launches
     simd_cycles = SIMDS * k_ms * 1e-3 * CLOCK_HZ
     fetch_b, write_b = c.get("FETCH_SIZE", 0.0) * 1024.0, c.get("WRITE_SIZE", 0.0) * 1024.0
@@ -54,7 +57,7 @@ for item in items:
     out = [f"# {tag}, BASELINE config {cfg}{' on a full chip (16 384 trajectories, 3 h)' if name == 'fullchip' else ''}: PMC counters of the dominant kernel (rocprofv3 --pmc, one counter set per pass)", "",
            f"command: `python bench.py --config {cfg} --steps 1 --warmup 0 --no-cpu-baseline --no-dense-output --no-host-call --no-other-configs{extra}`; "
            f"values per launch of `{'nyx_propagate_kernel_stmq' if cfg == 4 else 'nyx_propagate_kernel'}` "
-           f"({'mean over the segment launches' if cfg == 4 else 'the timed launch: the largest dispatch of the command'}); "
+           f"({'mean over the segment launches' if per_segment else 'the timed launch: the largest dispatch of the command'}); "
            f"kernel time {k_ms:.3f} ms (bench line of the same build).", "",
            "| counter | per launch |", "|---|---:|"]
     for k in sorted(c):
