@@ -58,7 +58,7 @@ for rep in range(reps):
         if w["stm"]:
             for _ in range(2):
                 res = nx.predict_until(ctx, b, bench.init_covar(n), int(b.epoch_ns[0]) + dur, 60 * nx.NS_PER_S)
-            ms, st, arrs, ne = res.kernel_ms, res.stats, [res.states.rv(), res.covar], 16
+            ms, st, arrs, ne = res.kernel_ms, res.stats, [res.states.rv(), res.covar], int(st_max) if (st_max := res.stats.n_evals[:16].max()) else 16   # (the accounting sums over every segment of the loop)
         else:
             for _ in range(2):
                 out, st = ctx.propagate(b, dur)
@@ -104,7 +104,7 @@ for rep in range(reps):
                         names = ['back-edge', 'phase A', 'next position', 'DCM wait', 'rotate+inputs', 'post', 'two-body+sums', 'barrier', 'C to fold', 'answer', 'C rest', 'step ctl (rest)', 'sc cold state', 'sc sums', 'sc decide', 'sc open next']
                         print('   integrator per eval: ' + ', '.join(f'{n} {v / ne:.0f}' for n, v in zip(names, sgv)))
                     if w["stm"] and hp[1].sum():
-                        segs = max(1, int(st.n_evals[:16].max()) // ne)
+                        segs = max(1, int(st.n_evals[:16].max()) // 16)
                         print('   integrator boundary per segment: ' + ', '.join(f'{n} {v / segs:.0f}' for n, v in zip(['step control', 'open next', 'B0', 'time updates', 're-arm', 'epoch data + Bp', 'phase A + B1'], hp[1, :7])) + f'  ({segs} segments)')
                     if hp[16, 3]:
                         print(f"   owner latency loop (wg0, per posted job): wait for the answer {hp[16, 0] / hp[16, 3]:.0f}, answer in hand -> post {hp[16, 1] / hp[16, 3]:.0f}, post {hp[16, 2] / hp[16, 3]:.0f} cycles ({hp[16, 3]} jobs)")
