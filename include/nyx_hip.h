@@ -249,7 +249,7 @@ typedef struct nyx_hip_tuning {
                                 * 0x20000 owners / helpers rounded to multiples of eight, 0x40000 / 0x80000 two-part / one-part hand-off,
                                 * 0x100000 no mailbox pool (allocate and free per context), 0x200000 helpers fetch a job's inputs before they
                                 * know they won its claim (rounds 1-3), 0x400000 the helper dealing of rounds 1-4, 0x800000 the common table stream for every
-                                * schedule (no run streams), 0x1000000 the helper's answer collected inside the window (rounds 1-4; no effect in the sixteen-wave plain kernels since round 6, whose integrator always collects it in phase C), 0x8000000 no fan-out mode (small shards keep the claim mode of rounds 1-5: one helper workgroup per owner), 0x10000000 chained attempts also with the almanac duty fanned out over several waves of a gravity-field workgroup (tools), 0x20000000 nyx_hip_predict_until as one segment launch + one time-update launch per segment (rounds 2-5) instead of ONE launch for the whole loop, 0x4000000 quad STM layout: the position-only pieces of phase C formed by the integrator wave (rounds 3-4; since round 5 by an almanac wave), 0x2000000 the linear column partition of round 4 for the cooperative
+                                * schedule (no run streams), 0x1000000 the helper's answer collected inside the window (rounds 1-4; no effect in the sixteen-wave plain kernels since round 6, whose integrator always collects it in phase C), 0x8000000 no fan-out mode (small shards keep the claim mode of rounds 1-5: one helper workgroup per owner), 0x10000000 chained attempts also with the almanac duty fanned out over several waves of a gravity-field workgroup (tools), 0x40000000 fan-out mode: the integrator forms its two stage sums itself (A/B of the sums wave, which only exists in builds with -DNYX_FAN_SUMS: measured in round 6, no gain, compiled out), 0x20000000 nyx_hip_predict_until as one segment launch + one time-update launch per segment (rounds 2-5) instead of ONE launch for the whole loop, 0x4000000 quad STM layout: the position-only pieces of phase C formed by the integrator wave (rounds 3-4; since round 5 by an almanac wave), 0x2000000 the linear column partition of round 4 for the cooperative
                                 * 70x70 shape too (default since round 5: its runs placed in a free wave order); 0x4000 full-range sincos for a polynomial
                                 * IAU orientation every stage (results differ by the rounding of the large argument) */
     double coop_fraction;      /* 0 auto: share of the harmonics terms a helper takes */
