@@ -217,6 +217,8 @@ typedef struct nyx_hip_solid_tides {
  *                                  own first steps (it SYNCHRONISES the stream and copies a few hundred bytes back: not
  *                                  graph-capturable) and deals the columns by the measured cycle counts: a few percent
  *                                  faster, and context-dependent in the last bits (~0.05 mm after 45 min).
+ *                                  The calibration launches run the accounting twin of the kernel (its in-kernel counters
+ *                                  are the measurement): the weights are that build's, 1-7 % off the product kernel's timing.
  *   NYX_HIP_SCHED_EXPLICIT         wave_weights[] / role_duties[] as given.
  * `deterministic` = 1 additionally makes every trajectory's bits independent of the BATCH it is launched in (batch size,
  * position in the batch, rank-sharding): the cooperative mode - whose column split follows the ratio of idle CUs to
