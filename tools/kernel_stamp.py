@@ -8,7 +8,8 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNEL_SOURCES = [
-    "nyx_amd/csrc/propagate_kernel.hip", "nyx_amd/csrc/propagate_w8.hip", "nyx_amd/csrc/propagate_stm.hip", "nyx_amd/csrc/propagate_stmq.hip",
+    "nyx_amd/csrc/propagate_kernel.hip", "nyx_amd/csrc/pk_epoch_data.h", "nyx_amd/csrc/pk_force_models.h", "nyx_amd/csrc/pk_harmonics.h", "nyx_amd/csrc/pk_cooperative.h", "nyx_amd/csrc/pk_error_stm.h", "nyx_amd/csrc/pk_state_lds.h", "nyx_amd/csrc/pk_integrator_ool.h", "nyx_amd/csrc/pk_segment_update.h",
+    "nyx_amd/csrc/propagate_w8.hip", "nyx_amd/csrc/propagate_stm.hip", "nyx_amd/csrc/propagate_stmq.hip",
     "nyx_amd/csrc/propagate_stmq_w8.hip", "nyx_amd/csrc/propagate_p2.hip", "nyx_amd/csrc/propagate_w8n.hip", "nyx_amd/csrc/propagate_fan.hip", "nyx_amd/csrc/harm_stream_asm.h", "nyx_amd/csrc/devcfg.h", "nyx_amd/csrc/butcher.h",
     "nyx_amd/csrc/hifitime_dev.h", "nyx_amd/csrc/event_dev.h", "nyx_amd/csrc/predict_kernel.hip", "nyx_amd/csrc/predict_args.h",
     "nyx_amd/csrc/moments_kernel.hip", "nyx_amd/csrc/abi.cpp", "nyx_amd/csrc/col_partition.h", "include/nyx_hip.h",
