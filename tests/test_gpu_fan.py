@@ -92,3 +92,38 @@ def test_fan_out_is_reproducible_and_follows_the_batch_size():
     ctx.close()
     assert (h1, h2, h3) == (160, 99, 160)
     np.testing.assert_array_equal(a.rv(), b.rv())
+
+
+def test_fan_out_step_control_out_of_line_is_the_inline_one_and_records_the_same_trajectory():
+    """Round 6: the fan-out kernel's step control is a leaf function (integ_step, pk_integrator_ool.h) and the caller writes the dense
+    output from the cold state it stored; a launch with a stop condition keeps the INLINE step control of the same kernel (event_step
+    is a call).  Same kernel, same column schedule, same sums: a stop condition that never fires must leave every bit where the
+    out-of-line step control leaves it - final states, epochs, counters and every recorded state of every run."""
+    from nyx_amd import _abi
+    compiled = _setup()
+    batch = dispersed_leo_batch(128, seed=5)
+    dur = 45 * 60 * S
+    ctx = nx.GpuContext(compiled)
+    out_p, st_p = ctx.propagate(batch, dur)
+    assert ctx.last_coop_helpers() == 16           # two owners x eight dedicated helpers: the fan-out kernel
+    out_a, st_a, tr_a = ctx.propagate_with_traj(batch, dur, 512)
+    never = nx.Event(_abi.EV_RMAG_KM, 1.0e6)      # |r| = 1e6 km: no sign change in 45 min of a LEO
+    out_b, st_b, tr_b, crossings = ctx.propagate_until_event(batch, dur, never, trigger=1, capacity=512)
+    ctx.close()
+    assert (st_p.status == 0).all() and (st_a.status == 0).all()
+    assert (st_b.status == _abi.ERR_EVENT_NOT_FOUND).all() and (crossings == 0).all()
+    for o in (out_a, out_b):
+        np.testing.assert_array_equal(o.rv(), out_p.rv())
+        np.testing.assert_array_equal(o.epoch_ns, out_p.epoch_ns)
+    for s in (st_a, st_b):
+        np.testing.assert_array_equal(s.n_accepted, st_p.n_accepted)
+        np.testing.assert_array_equal(s.n_rejected, st_p.n_rejected)
+        np.testing.assert_array_equal(s.n_evals, st_p.n_evals)
+    assert (st_p.n_rejected > 0).any()             # (both branches of the controller were walked)
+    np.testing.assert_array_equal(tr_a.len, st_p.n_accepted + 1)
+    for i in range(0, 128, 7):
+        m = int(tr_a.len[i])
+        np.testing.assert_array_equal(tr_a.epoch_ns[:m, i], tr_b.epoch_ns[:m, i])
+        np.testing.assert_array_equal(tr_a.state[:, :m, i], tr_b.state[:, :m, i])
+        np.testing.assert_array_equal(tr_a.state[:, m - 1, i], out_p.rv()[i])
+        assert tr_a.epoch_ns[m - 1, i] == out_p.epoch_ns[i]
