@@ -926,8 +926,8 @@ static void build_schedule(nyx_hip_ctx *ctx, int n_waves, bool quad = false) {
             // The sums wave (round 6, fan_sums): the owner's period is its integrator's chain, of which the two stage sums of a window are
             // ~40 %; a column wave that holds no column of the PRIMARY schedule forms them beside it - on a SIMD that hosts no role wave
             // when there is one (waves 3, 7, 11, 15).  debug_flags 0x40000000: the integrator forms them itself (A/B, same bits).
-#ifdef NYX_FAN_SUMS  /* (compiled out with the kernel side, FAN_SUMS in propagate_kernel.hip: measured, no gain; build every object with -DNYX_FAN_SUMS to take it up again) */
-            if (dc.pipe && !(ctx->tune.debug_flags & 0x40000000)) {
+#if NYX_FAN_SUMS
+            if (dc.pipe && !dc.has_drag && !(ctx->tune.debug_flags & 0x40000000)) {  // (the six values live in the drag rows of the perturbation buffers)
                 static const int order[] = {15, 11, 7, 3, 14, 13, 12, 10, 9, 8, 6, 5, 4};
                 for (int w : order)
                     if (dc.role_kind[w] == DEV_ROLE_COLUMNS && dc.sched[DEV_SCHED_PRIMARY].n_ranges[w] == 0) { dc.sums_wave1 = w + 1; break; }

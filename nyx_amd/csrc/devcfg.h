@@ -50,6 +50,9 @@ struct DevSched {
  * propagate_kernel.hip): PRIMARY = the columns the trajectory-owning workgroup keeps, HELPER = the columns a helper
  * workgroup on another CU evaluates (the owner walks that schedule itself, wave slot by wave slot, if no helper
  * answers). */
+#ifndef NYX_FAN_SUMS
+#define NYX_FAN_SUMS 0 /* 1: fan-out mode, a column wave of an owner forms the integrator's two stage sums beside it (host: DevCfg.sums_wave1; kernel: fan_sums; its six values live in the drag rows of the perturbation buffers: no LDS of its own).  Bit-identical; measured in round 6 on the final fan-out kernel, 1 250 / 2 500 / 5 000 trajectories x 24 h: 374.0-378.6 / 393.6 / 439.9 ms with it against 369.9-372.0 / 387.8 / 439.4 without - the integrator's window shrinks 13.5 k -> 8.0 k cycles per evaluation and it then waits 3 k for the helpers' answer: the turnaround of a job (a 71-row column on one wave + five uncached hops) bounds the period */
+#endif
 #define DEV_FAN_MAX 8 /* dedicated helper workgroups per owner in the fan-out mode (DevBatch.coop_fan) */
 enum { DEV_SCHED_SOLO = 0, DEV_SCHED_PRIMARY = 1, DEV_SCHED_HELPER = 2, DEV_SCHED_SECOND = 3, DEV_SCHED_HELPER2 = 4, DEV_SCHED_FAN0 = 5, DEV_N_SCHED = 5 + DEV_FAN_MAX };
 /* FAN0 + p: the columns of part p of the fan-out mode (small shards: every owner has coop_parts DEDICATED helper workgroups, see helper_body). */

@@ -205,12 +205,14 @@ static __device__ __attribute__((noinline)) Partial4 coop_fallback(uint64_t cfg_
  * kernel of config 3, whose integrator shares its SIMD with one almanac wave, 46.8 ms with two pows against 47.2 with one */
 #define STEP_ONE_POW ((NYX_EMIT & (NYX_EMIT_PLAIN16 | NYX_EMIT_PLAIN16_P2 | NYX_EMIT_PLAIN16_FAN)) ? 1 : 0)
 #endif
-#ifndef FAN_SUMS
-#ifdef NYX_FAN_SUMS
-#define FAN_SUMS 1
-#else
-#define FAN_SUMS 0  /* fan-out mode: the integrator's two stage sums formed by a column wave of their own (fan_sums, DevCfg.sums_wave1).  Built, bit-identical, and measured in round 6 (1 250 x 24 h, same box): 412.7 ms with it against 419.4 / 416.6 without - the integrator's window shrinks from 12.7 k to 7.7 k cycles per evaluation, but the almanac wave (18.6 k busy) then bounds the period; with the almanac duty fanned out as well (role_fanout + chained attempts) the integrator's phase C and the helpers' turnaround do (20.1 k).  Off: its six LDS rows (3 KB) pushed config 3's padded ephemeris records out of LDS (43.9 -> 47.1 ms) */
+#ifndef FAN_POLL_FETCH
+#define FAN_POLL_FETCH 0  /* 1: the fan-out producer's poll fetches all ten granules (one round trip from post to inputs instead of two); measured neutral, round 6: 1 250 x 24 h 357.2-359.9 ms against 357.7-359.5 */
 #endif
+#ifndef FAN_SKIP
+#define FAN_SKIP 1  /* fan-out kernel: a wave without columns under the schedule in force skips its walk (five LDS reads, a call, the schedule lookup) */
+#endif
+#ifndef FAN_SUMS
+#define FAN_SUMS NYX_FAN_SUMS  /* devcfg.h: fan-out mode, the integrator's two stage sums formed by a column wave of their own (fan_sums, DevCfg.sums_wave1) */
 #endif
 #ifndef STEP_OOL
 #ifdef NYX_COOP_FAN
@@ -285,14 +287,21 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
                     slot_free = answered[s] == j - (NS - 1);
                     if (!slot_free) { __builtin_amdgcn_s_sleep(4); continue; }
                 }
-                // one request: the last granule the owner writes for lane 0 (the owner stores its rows in order, nothing orders them in
-                // memory: the fetch below checks every tag)
+                // the poll IS the fetch (FAN_POLL_FETCH): all ten granules of this lane every time, accepted when every tag of every lane
+                // carries the sequence number - one uncached round trip from the owner's post to the inputs in hand instead of two (a poll of
+                // one granule, then the fetch), on the turnaround that bounds the owner's period in this mode
+#if FAN_POLL_FETCH
+                {
+#else
                 if ((uint32_t)(coop_loadu(&b->in[par][4][1][0]) >> 32) == seq) {
+#endif
                     const bool got = coop_get(&b->in[par][0][0][lane], seq, v0) & coop_get(&b->in[par][1][0][lane], seq, v1) &
                                      coop_get(&b->in[par][2][0][lane], seq, v2) & coop_get(&b->in[par][3][0][lane], seq, v3) &
                                      coop_get(&b->in[par][4][0][lane], seq, v4);
                     if (__all(got)) break;
+#if !FAN_POLL_FETCH
                     continue;
+#endif
                 }
                 if ((it & 7) == 7 && coop_load(bt.coop_finished + fan_widx) != 0u) { owner = -1; break; }  // the owner is done (or carries on alone)
                 __builtin_amdgcn_s_sleep(2);
@@ -504,19 +513,53 @@ DEVFN void helper_body(const DevBatch &bt, CfgPtr cfg, HarmPtr htab, ColPtr cols
 #ifdef NYX_COOP_FAN
         bool fan_ok = true;
         if (sub == 0) {
-            // the lead: the sums of the parts 1.., in part order (what coop_fallback adds up when the owner walks the parts itself)
+            // the lead: the sums of the parts 1.., in part order (what coop_fallback adds up when the owner walks the parts itself).
+            // Four parts per batch: their thirty-two granules are requested together and the tags checked afterwards - one uncached round
+            // trip per batch where a part at a time cost one each (seven in a row for eight parts, ~8 k cycles on the job's turnaround,
+            // which bounds the owner's period in this mode: round 6, GPU call 26).  The additions stay in part order.
             const int64_t tl = (int64_t)__builtin_amdgcn_s_memrealtime();
-            for (int pq = 1; pq < fan_parts && fan_ok; ++pq) {
-                const uint64_t *o2 = &bt.coop_out2[owner * fan_parts + pq].out[par][0][0][0];
-                double x = 0.0, y = 0.0, z = 0.0, w = 0.0;
+            for (int p0 = 1; p0 < fan_parts && fan_ok; p0 += 4) {
+                uint64_t raw[4][8];
+                bool pend[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    pend[q] = p0 + q < fan_parts;  // (uniform)
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) raw[q][r] = 0;
+                }
                 for (;;) {
-                    const bool got = coop_get(o2 + 0 * 2 * DEV_LANES + lane, seq, x) & coop_get(o2 + 1 * 2 * DEV_LANES + lane, seq, y) &
-                                     coop_get(o2 + 2 * 2 * DEV_LANES + lane, seq, z) & coop_get(o2 + 3 * 2 * DEV_LANES + lane, seq, w);
-                    if (__all(got)) break;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (pend[q]) {
+                            const uint64_t *o2 = &bt.coop_out2[owner * fan_parts + p0 + q].out[par][0][0][0] + lane;
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) raw[q][r] = coop_loadu(o2 + (r >> 1) * 2 * DEV_LANES + (r & 1) * DEV_LANES);
+                        }
+                    }
+                    bool any = false;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (pend[q]) {
+                            bool got = true;
+#pragma unroll
+                            for (int r = 0; r < 8; ++r) got = got && (uint32_t)(raw[q][r] >> 32) == seq;
+                            if (__all(got)) pend[q] = false; else any = true;
+                        }
+                    }
+                    if (!any) break;
                     if ((int64_t)__builtin_amdgcn_s_memrealtime() - tl > COOP_TIMEOUT_TICKS) { fan_ok = false; break; }  // (the owner gives up at the same age)
                     __builtin_amdgcn_s_sleep(2);
                 }
-                o[0] += x; o[1] += y; o[2] += z; o[3] += w;
+                if (fan_ok) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (p0 + q < fan_parts) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k)
+                                o[k] += __longlong_as_double((long long)((raw[q][2 * k] & 0xffffffffull) | (raw[q][2 * k + 1] << 32)));
+                        }
+                    }
+                }
             }
         }
         if (fan_ok) {

@@ -526,7 +526,7 @@ static __device__ __attribute__((noinline)) IxStep integ_step(uint32_t lds_v, ui
 //         or, when that window is the last of a chained attempt,  y + sum_{j<i} (h b_j) k_j[0..2] + (h b_i) v_i)
 // - the terms j <= i - 2 at once (their k rows were complete before the barrier this window starts behind), the term j = i - 1 when
 // the integrator's phase C of stage i - 1 has written k_{i-1} (ctl[6], raised by integ_back), the velocity term when integ_front has
-// stored v_i (ctl[4]) - and leaves the six values in LdsMap.sums, which the integrator reads behind the stage barrier, in front of the
+// stored v_i (ctl[4]) - and leaves the six values in the drag rows of the two perturbation buffers, which the integrator reads behind the stage barrier, in front of the
 // next integ_front.  The same additions in the same order as the inline sums: bit-identical results.  Every spin is bounded; a wait
 // that expires leaves NaNs, which end the step as NYX_HIP_ERR_NAN.
 static __device__ __attribute__((noinline)) void fan_sums(uint32_t lds_v, uint64_t cfg_u, int i_v, int lane, int flags_v, int kdone_v) {
@@ -535,7 +535,9 @@ static __device__ __attribute__((noinline)) void fan_sums(uint32_t lds_v, uint64
     const bool spec = cfg->spec != 0;
     const LdsPtr kb0 = ix_rows(L.kbuf, lane);
     const LdsPtr ysb = ix_rows((i & 1) ? L.ys2 : L.ys, lane);
-    const LdsPtr out = ix_rows(L.sums, lane);
+    // (no LDS of its own: W in rows 6..8 of the even stages' perturbation buffer, P in those of the odd stages' - the drag rows, which
+    //  nothing touches in a configuration without drag; the host names a sums wave only then)
+    const LdsPtr out_w = ix_rows(L.pert + 6 * DEV_LANES, lane), out_p = ix_rows(L.pert2 + 6 * DEV_LANES, lane);
     const bool need_w = i + 1 < stages, need_p = i + 2 < stages, need_b = !need_p && i + 2 == stages && spec;  // (uniform)
     // the tableau from its LDS copy (uniform addresses: broadcast reads that queue with the k rows; scalar loads would drain the LDS queue
     // at every wait): rows i + 1 and i + 2 of A, or h b for the last window of a chained attempt
@@ -617,7 +619,7 @@ static __device__ __attribute__((noinline)) void fan_sums(uint32_t lds_v, uint64
         for (int e = 0; e < 3; ++e) { w[e] = qn; p[e] = qn; }
     }
 #pragma unroll
-    for (int e = 0; e < 3; ++e) { out[e * DEV_LANES] = w[e]; out[(3 + e) * DEV_LANES] = p[e]; }
+    for (int e = 0; e < 3; ++e) { out_w[e * DEV_LANES] = w[e]; out_p[e * DEV_LANES] = p[e]; }
 }
 #endif
 #endif  // INTEG_OOL

@@ -88,7 +88,6 @@ struct LdsMap {
     // pipelined stage loop (non-STM): buffers of odd stages
     double *ys2, *inb2, *pert2;
     double *ixs;    // [4][64]  s, t, u, (mu / r) / R_eq of the ODD stages (the even ones: wave 0's slot of `part`), see INTEG_OOL
-    double *sums;   // [6][64]  fan-out mode: the velocity part of the next stage's sum and the position part of the one after, formed by the sums wave (fan_sums)
     // epoch data carried between attempts (cfg->ed_reuse fields per lane), behind the ephemeris records
     double *ed0;         // [ed_reuse][64]  stage-0 data of the current attempt (what a rejected attempt starts from again)
     long long *ed0_ep;   // [64]            its epoch
@@ -129,15 +128,11 @@ DEVFN LdsMap carve_lds(char *smem, int n_waves, bool stm, int rec_lds_doubles, i
     }
     m.ys2 = m.ys; m.inb2 = m.inb; m.pert2 = m.pert;
     m.ixs = m.part;
-    m.sums = m.part;
     if (!stm) {
         m.ys2 = p; p += 6 * DEV_LANES;
         m.inb2 = p; p += NIN * DEV_LANES;
         m.pert2 = p; p += 9 * DEV_LANES;
         m.ixs = p; p += 4 * DEV_LANES;
-#if FAN_SUMS
-        m.sums = p; p += 6 * DEV_LANES;
-#endif
     } else if (quad) {  // pipelined stage loop of the quad layout: second set of the dual buffers
         m.ys2 = p; p += 6 * DEV_LANES;
         m.inb2 = p; p += 10 * DEV_LANES;
@@ -161,7 +156,7 @@ size_t nyx_kernel_lds_bytes(int n_waves, int rec_doubles, int stm, int reuse_fie
     size_t d = (size_t)DEV_MAX_STAGES * 6 * (quad ? DEV_LANES / 4 : DEV_LANES) + DEV_MAX_STAGES * DEV_MAX_STAGES + 3 * DEV_MAX_STAGES + 6 * DEV_LANES +
                2 * ED_FIELDS * DEV_LANES + 2 * DEV_LANES + CS_FIELDS * DEV_LANES + (size_t)(quad ? DEV_MAX_WAVES * QSLOT : DEV_MAX_WAVES * 4 * DEV_LANES) + DEV_MAX_ALM * DEV_LANES +
                DEV_LANES + 8 + (size_t)rec_doubles;
-    d += quad ? (size_t)(10 + 15 + 6 + QPRE_ROWS + 6 + 10 + 15) * DEV_LANES : (stm ? (size_t)(20 + 27 + 12) * DEV_LANES : (size_t)(NIN + 9 + 6 + NIN + 9 + 4 + (FAN_SUMS ? 6 : 0)) * DEV_LANES);
+    d += quad ? (size_t)(10 + 15 + 6 + QPRE_ROWS + 6 + 10 + 15) * DEV_LANES : (stm ? (size_t)(20 + 27 + 12) * DEV_LANES : (size_t)(NIN + 9 + 6 + NIN + 9 + 4) * DEV_LANES);
     (void)n_waves;
     if (reuse_fields > 0) d += (size_t)reuse_fields * DEV_LANES + 2 * DEV_LANES + DEV_LANES / 2;
     return d * sizeof(double) + 64;

@@ -306,6 +306,9 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
 
     auto begin_attempt = [&](ColdState &c) __attribute__((always_inline)) { begin_attempt_fn(L, lane, c); };
     double h_next = 0.0;  // (chained attempts: the step of the attempt step control has just opened)
+#if defined(NYX_COOP_FAN) && FAN_SKIP
+    const bool rows_primary = cfg->sched[DEV_SCHED_PRIMARY].n_ranges[wave] > 0, rows_solo = cfg->sched[DEV_SCHED_SOLO].n_ranges[wave] > 0;  // (uniform)
+#endif
 
     for (;;) {  // one iteration = one RK attempt for every live lane (derive(), instance.rs:368-414)
         double h = h_next;
@@ -775,7 +778,7 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 const bool pub = i + 1 < stages || spec;
                 if (sums_on && i > 0) {  // the two sums the sums wave formed in the previous window (behind the stage barrier: complete)
 #pragma unroll
-                    for (int e = 0; e < 3; ++e) { wpre[3 + e] = L.sums[e * DEV_LANES + lane]; pre_wr[e] = L.sums[(3 + e) * DEV_LANES + lane]; }
+                    for (int e = 0; e < 3; ++e) { wpre[3 + e] = L.pert[(6 + e) * DEV_LANES + lane]; pre_wr[e] = L.pert2[(6 + e) * DEV_LANES + lane]; }
                 }
                 uint32_t sq = 0;
                 if (pub && coop_on) sq = ++coop_seq;
@@ -980,7 +983,13 @@ DEVFN void role_loop(const DevBatch &bt, CfgPtr cfg, const DevCfg *cfg_g, HarmPt
                 const int sched = LCTL[1] ? DEV_SCHED_PRIMARY : DEV_SCHED_SOLO;
                 const double *const inbw = (pipe && (i & 1)) ? L.inb2 : L.inb;
                 Partial4 pr = {0.0, 0.0, 0.0, 0.0};
+#if defined(NYX_COOP_FAN) && FAN_SKIP
+                // (fan-out mode: the owner's waves hold next to no columns, and the walk of a wave WITHOUT columns - five LDS reads, a call,
+                //  the schedule lookup through the scalar cache - is ~2 k cycles per stage on the almanac wave, which bounds the period there)
+                if (!(pipe && INTEG) && (sched == DEV_SCHED_PRIMARY ? rows_primary : rows_solo)) {
+#else
                 if (!(pipe && INTEG)) {
+#endif
                     const double v0 = inbw[0 * DEV_LANES + lane], v1 = inbw[1 * DEV_LANES + lane], v2 = inbw[2 * DEV_LANES + lane],
                                  v3 = inbw[3 * DEV_LANES + lane], v4 = inbw[4 * DEV_LANES + lane];
                     pr = (cfg->harm_feed & 1) ? harmonics_stream((uint64_t)cfg, (uint64_t)cols, wave, sched, v0, v1, v2, v3, v4)
